@@ -1,0 +1,140 @@
+"""ctypes mirror of include/hbvx.h and a thin handle around a loaded library.
+
+This is the binding a maintainer of the reference would add to call the C ABI
+from Python.  Struct layouts are verified against the
+library's own `hbvx_sizeof()` at load time.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+ABI_VERSION = 1
+MAX_PARAM = 16
+NSTATE = 5
+MAX_FLUX = 12
+UH_MAXLEN = 15
+
+# enum hbvx_model
+MODEL_HBV10, MODEL_HBV11P, MODEL_HBV20 = 0, 1, 2
+
+# enum hbvx_flux
+(F_QSIM, F_Q0, F_Q1, F_Q2, F_AET, F_SWE, F_RECHARGE, F_EXCS, F_EVAPFACTOR, F_TOSOIL, F_PERC,
+ F_CAPILLARY) = range(12)
+
+PARAM_SLOTS = ["parBETA", "parFC", "parK0", "parK1", "parK2", "parLP", "parPERC", "parUZL",
+               "parTT", "parCFMAX", "parCFR", "parCWH", "parBETAET", "parC", "parRT", "parAC"]
+
+_fp = C.c_void_p  # every float*/uint8_t* travels as an address
+
+
+class ParamSrc(C.Structure):
+    _fields_ = [("dyn", _fp), ("sta", _fp), ("drop", _fp),
+                ("dyn_t_stride", C.c_int64), ("dyn_b_stride", C.c_int64),
+                ("sta_b_stride", C.c_int64), ("lo", C.c_float), ("hi", C.c_float)]
+
+
+class ParamGrad(C.Structure):
+    _fields_ = [("dyn", _fp), ("sta", _fp),
+                ("dyn_t_stride", C.c_int64), ("dyn_b_stride", C.c_int64),
+                ("sta_b_stride", C.c_int64)]
+
+
+class Desc(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("model", C.c_int32), ("T", C.c_int32),
+                ("B", C.c_int32), ("M", C.c_int32), ("n_param", C.c_int32),
+                ("raw_sigmoid", C.c_int32), ("ch_prcp", C.c_int32), ("ch_tmean", C.c_int32),
+                ("ch_pet", C.c_int32), ("nearzero", C.c_float), ("reserved0", C.c_int32),
+                ("x", _fp), ("x_t_stride", C.c_int64), ("x_b_stride", C.c_int64),
+                ("ac", _fp), ("elev", _fp), ("muwts", _fp),
+                ("mu_t_stride", C.c_int64), ("mu_b_stride", C.c_int64),
+                ("state_in", _fp), ("p", ParamSrc * MAX_PARAM)]
+
+
+class FwdOut(C.Structure):
+    _fields_ = [("flux", _fp), ("state_out", _fp), ("traj", _fp), ("aux", _fp),
+                ("n_flux", C.c_int32), ("reserved0", C.c_int32)]
+
+
+class BwdIO(C.Structure):
+    _fields_ = [("traj", _fp), ("aux", _fp), ("grad_flux", _fp), ("grad_x", _fp),
+                ("grad_muwts", _fp), ("grad_state_in", _fp),
+                ("n_flux", C.c_int32), ("reserved0", C.c_int32),
+                ("g", ParamGrad * MAX_PARAM)]
+
+
+class RouteDesc(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("T", C.c_int32), ("B", C.c_int32),
+                ("S", C.c_int32), ("L", C.c_int32), ("raw_sigmoid", C.c_int32),
+                ("ra", _fp), ("rb", _fp), ("r_stride", C.c_int64),
+                ("a_lo", C.c_float), ("a_hi", C.c_float), ("b_lo", C.c_float),
+                ("b_hi", C.c_float)]
+
+
+EXPORTS = ["hbvx_version", "hbvx_last_error", "hbvx_backend", "hbvx_sizeof", "hbvx_forward",
+           "hbvx_backward", "hbvx_route_forward", "hbvx_route_backward"]
+
+
+class HbvxError(RuntimeError):
+    pass
+
+
+class Library:
+    """A loaded implementation of include/hbvx.h."""
+
+    def __init__(self, path: str):
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        self.path = path
+        self.dll = C.CDLL(path)
+        d = self.dll
+        for name in EXPORTS:
+            if not hasattr(d, name):
+                raise HbvxError(f"{path}: missing export {name}")
+        d.hbvx_version.restype = C.c_int
+        d.hbvx_last_error.restype = C.c_char_p
+        d.hbvx_backend.restype = C.c_char_p
+        d.hbvx_sizeof.restype = C.c_uint64
+        d.hbvx_sizeof.argtypes = [C.c_int]
+        d.hbvx_forward.restype = C.c_int
+        d.hbvx_forward.argtypes = [C.POINTER(Desc), C.POINTER(FwdOut), C.c_void_p]
+        d.hbvx_backward.restype = C.c_int
+        d.hbvx_backward.argtypes = [C.POINTER(Desc), C.POINTER(BwdIO), C.c_void_p]
+        d.hbvx_route_forward.restype = C.c_int
+        d.hbvx_route_forward.argtypes = [C.POINTER(RouteDesc), _fp, _fp, _fp, C.c_void_p]
+        d.hbvx_route_backward.restype = C.c_int
+        d.hbvx_route_backward.argtypes = [C.POINTER(RouteDesc), _fp, _fp, _fp, _fp, _fp, _fp,
+                                          C.c_void_p]
+        if d.hbvx_version() != ABI_VERSION:
+            raise HbvxError(f"{path}: ABI version {d.hbvx_version()} != {ABI_VERSION}")
+        for which, st in enumerate([Desc, FwdOut, BwdIO, RouteDesc, ParamSrc, ParamGrad]):
+            if d.hbvx_sizeof(which) != C.sizeof(st):
+                raise HbvxError(f"{path}: layout mismatch for {st.__name__}: "
+                                f"{d.hbvx_sizeof(which)} != {C.sizeof(st)}")
+        self.backend = d.hbvx_backend().decode()
+
+    @property
+    def is_device(self) -> bool:
+        return self.backend.startswith("hip")
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            msg = self.dll.hbvx_last_error().decode(errors="replace")
+            raise HbvxError(f"{what} failed ({rc}): {msg}")
+
+    def forward(self, desc: Desc, out: FwdOut, stream: int):
+        self._check(self.dll.hbvx_forward(C.byref(desc), C.byref(out), C.c_void_p(stream)),
+                    "hbvx_forward")
+
+    def backward(self, desc: Desc, io: BwdIO, stream: int):
+        self._check(self.dll.hbvx_backward(C.byref(desc), C.byref(io), C.c_void_p(stream)),
+                    "hbvx_backward")
+
+    def route_forward(self, r: RouteDesc, q: int, uh: int, q_rout: int, stream: int):
+        self._check(self.dll.hbvx_route_forward(C.byref(r), q, uh, q_rout, C.c_void_p(stream)),
+                    "hbvx_route_forward")
+
+    def route_backward(self, r: RouteDesc, q: int, uh: int, gqr: int, gq: int, gra, grb,
+                       stream: int):
+        self._check(self.dll.hbvx_route_backward(C.byref(r), q, uh, gqr, gq, gra, grb,
+                                                 C.c_void_p(stream)), "hbvx_route_backward")

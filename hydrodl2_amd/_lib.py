@@ -1,0 +1,49 @@
+"""Locate and load libhbvx.so (the HIP implementation of include/hbvx.h).
+
+The product has exactly one compute path: the HIP library built in-tree by
+`__graft_entry__.build()` (hipcc --offload-arch=gfx950).  There is no CPU
+fallback: if the library is missing, or a tensor is not on the GPU, the call
+fails loudly.
+
+`_use_library_for_testing()` exists so that tests/ can drive the *host-side*
+logic of this package (parameter unpacking, warm-up orchestration, autograd
+plumbing) against the CPU oracle on machines without a GPU.  It is never
+called from the package itself and there is no environment switch for it.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+from ._abi import Library
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libhbvx.so")
+
+_lib: Optional[Library] = None
+_testing_override = False
+
+
+def get_library() -> Library:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"hydrodl2_amd: HIP library not built ({LIB_PATH} missing). "
+                "Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950) first. There is no CPU fallback."
+            )
+        lib = Library(LIB_PATH)
+        if not lib.is_device:
+            raise RuntimeError(f"{LIB_PATH}: backend {lib.backend!r} is not a HIP build")
+        _lib = lib
+    return _lib
+
+
+def _use_library_for_testing(path: Optional[str]) -> None:
+    """tests/ only: route calls to another implementation of the ABI (the oracle)."""
+    global _lib, _testing_override
+    if path is None:
+        _lib, _testing_override = None, False
+    else:
+        _lib, _testing_override = Library(path), True

@@ -1,0 +1,274 @@
+"""Host-side mirror of the reference's HBV plug-in interface.
+
+The classes built on `HbvModule` keep the reference's constructor, attribute,
+`forward(x_dict, parameters)`, `get_states()` / `load_states()` contract
+(reference: src/hydrodl2/models/hbv/hbv.py:37-361) so that they are drop-ins for
+`hydrodl2.load_model('hbv')` in a dMG-style caller.  What differs is where the
+work happens: nothing is unpacked, repeated or looped over in Python -- the raw
+NN output, the forcings and the states go straight to the HIP library
+(`hydrodl2_amd.ops.HbvPath`) as pointers + strides.
+"""
+from __future__ import annotations
+
+from typing import Any, Optional, Union
+
+import torch
+
+from .. import _abi
+from ..ops import HbvPath, ParamSource, RouteSource, StepConfig
+
+
+class HbvModule(torch.nn.Module):
+    """Shared implementation of HBV 1.0 / 1.1p (single raw `parameters` tensor)."""
+
+    # subclasses set these
+    _model_id = _abi.MODEL_HBV10
+    _display_name = "HBV 1.0"
+    _extra_bounds: dict = {}
+    _has_capillary = False
+    _default_routing = True
+
+    def __init__(self, config: Optional[dict[str, Any]] = None,
+                 device: Optional[torch.device] = None) -> None:
+        super().__init__()
+        # reference: hbv.py:43-59
+        self.name = self._display_name
+        self.config = config
+        self.initialize = False
+        self.warm_up = 0
+        self.pred_cutoff = 0
+        self.warm_up_states = True
+        self.dynamic_params = []
+        self.dy_drop = 0.0
+        self.variables = ['prcp', 'tmean', 'pet']
+        self.routing = self._default_routing
+        self.comprout = False
+        self.nearzero = 1e-5
+        self.nmul = 1
+        self.cache_states = False
+        self.device = device
+        self.muwts = None
+
+        self.states, self._states_cache = None, None
+
+        self.state_names = ['SNOWPACK', 'MELTWATER', 'SM', 'SUZ', 'SLZ']  # hbv.py:61-67
+        self.flux_names = [  # hbv.py:68-86
+            'streamflow', 'srflow', 'ssflow', 'gwflow', 'AET_hydro', 'PET_hydro', 'SWE',
+            'streamflow_no_rout', 'srflow_no_rout', 'ssflow_no_rout', 'gwflow_no_rout',
+            'recharge', 'excs', 'evapfactor', 'tosoil', 'percolation',
+        ]
+        if self._has_capillary:
+            self.flux_names.append('capillary')  # hbv_1_1p.py:83
+        self.flux_names.append('BFI')
+
+        self.parameter_bounds = {  # hbv.py:88-101
+            'parBETA': [1.0, 6.0], 'parFC': [50, 1000], 'parK0': [0.05, 0.9],
+            'parK1': [0.01, 0.5], 'parK2': [0.001, 0.2], 'parLP': [0.2, 1],
+            'parPERC': [0, 10], 'parUZL': [0, 100], 'parTT': [-2.5, 2.5],
+            'parCFMAX': [0.5, 10], 'parCFR': [0, 0.1], 'parCWH': [0, 0.2],
+        }
+        self.parameter_bounds.update(self._extra_bounds)
+        self.routing_parameter_bounds = {'route_a': [0, 2.9], 'route_b': [0, 6.5]}  # :102-105
+
+        if not device:
+            self.device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
+
+        if config is not None:
+            self._read_config(config)
+        self._set_parameters()
+
+    # -- configuration --------------------------------------------------
+    def _read_config(self, config: dict) -> None:
+        """hbv.py:110-125 (same keys, same defaults, `dynamic_params` keyed by class name)."""
+        self.warm_up = config.get('warm_up', self.warm_up)
+        self.warm_up_states = config.get('warm_up_states', self.warm_up_states)
+        self.dy_drop = config.get('dy_drop', self.dy_drop)
+        self.dynamic_params = config['dynamic_params'].get(
+            self.__class__.__name__, self.dynamic_params)
+        self.variables = config.get('variables', self.variables)
+        self.routing = config.get('routing', self.routing)
+        self.comprout = config.get('comprout', self.comprout)
+        self.nearzero = config.get('nearzero', self.nearzero)
+        self.nmul = config.get('nmul', self.nmul)
+        self.cache_states = config.get('cache_states', False)
+        if self._model_id == _abi.MODEL_HBV10 and 'parBETAET' in self.dynamic_params:
+            self.parameter_bounds['parBETAET'] = [0.3, 5]  # hbv.py:124-125
+
+    def _set_parameters(self) -> None:
+        """hbv.py:170-180."""
+        self.phy_param_names = self.parameter_bounds.keys()
+        if self.routing:
+            self.routing_param_names = self.routing_parameter_bounds.keys()
+        else:
+            self.routing_param_names = []
+        self.learnable_param_count = len(self.phy_param_names) * self.nmul + len(
+            self.routing_param_names)
+
+    # -- state API (hbv.py:128-168) --------------------------------------
+    def _init_states(self, ngrid: int):
+        """None = let the kernel start every storage at 0.001 (hbv.py:128-136)."""
+        return None
+
+    def get_states(self) -> Optional[tuple[torch.Tensor, ...]]:
+        return self._states_cache
+
+    def load_states(self, states: tuple[torch.Tensor, ...]) -> None:
+        for state in states:
+            if not isinstance(state, torch.Tensor):
+                raise ValueError("Each element in `states` must be a tensor.")
+        nstates = len(self.state_names)
+        if not (isinstance(states, tuple) and len(states) == nstates):
+            raise ValueError(f"`states` must be a tuple of {nstates} tensors.")
+        self.states = tuple(s.detach().to(self.device, dtype=torch.float32) for s in states)
+
+    # -- helpers ---------------------------------------------------------
+    def _channels(self):
+        return (self.variables.index('prcp'), self.variables.index('tmean'),
+                self.variables.index('pet'))
+
+    def _n_flux(self) -> int:
+        return 12 if self._has_capillary else 11
+
+    def _draw_drop_mask(self, ngrid: int, device) -> torch.Tensor:
+        """One Bernoulli(dy_drop) draw per basin from the CPU global RNG, exactly as the
+        reference consumes it (hbv.py:240,245) -- also when dy_drop == 0."""
+        pmat = torch.ones([1, ngrid, 1]) * self.dy_drop
+        drmask = torch.bernoulli(pmat)
+        return drmask.reshape(ngrid).to(torch.uint8).to(device)
+
+    def _stack_states(self, states, ngrid: int, device):
+        if states is None:
+            return None
+        st = torch.stack([s.to(device=device, dtype=torch.float32).reshape(ngrid, self.nmul)
+                          for s in states])
+        return st.contiguous()
+
+    def _expand_muwts(self, muwts, T: int, B: int):
+        if muwts is None:
+            return None
+        return muwts.to(torch.float32).expand(T, B, self.nmul).contiguous()
+
+    def _param_sources(self, T_total: int, B: int, ny: int, t_first: int, sta_row: int,
+                       dy_list, device):
+        """Addressing of every physical parameter inside raw `parameters[T,B,ny]`:
+        column i*nmul + j (hbv.py:201-208); static value = row `sta_row` (hbv.py:242)."""
+        M = self.nmul
+        srcs = []
+        for i, name in enumerate(self.parameter_bounds.keys()):
+            lo, hi = self.parameter_bounds[name]
+            slot = _abi.PARAM_SLOTS.index(name)
+            ps = ParamSource(slot=slot, lo=float(lo), hi=float(hi), tensor_idx=0,
+                             sta_off=sta_row * B * ny + i * M, sta_bs=ny)
+            if name in dy_list:
+                ps.dyn_tensor_idx = 0
+                ps.dyn_off = t_first * B * ny + i * M
+                ps.dyn_ts, ps.dyn_bs = B * ny, ny
+                ps.drop = self._draw_drop_mask(B, device)
+            srcs.append(ps)
+        return srcs
+
+    # -- forward ---------------------------------------------------------
+    def forward(self, x_dict: dict[str, torch.Tensor], parameters: torch.Tensor
+                ) -> Union[tuple, dict[str, torch.Tensor]]:
+        """Reference: hbv.py:284-361 (orchestration) + :363-596 (`_PBM`)."""
+        x = x_dict['x_phy']
+        self.muwts = x_dict.get('muwts', None)
+        T_total, ngrid = x.shape[0], x.shape[1]
+        M = self.nmul
+        n = len(self.parameter_bounds)
+        if not parameters.is_contiguous():
+            parameters = parameters.contiguous()
+        ny = parameters.shape[2]
+        if ny < n * M + (2 if self.routing else 0):
+            raise ValueError(f"parameters has {ny} columns, need {n * M + 2}")
+        if self.comprout and M != 1:
+            # reference: uh_conv's grouped conv has `ngrid` groups but ngrid*nmul channels
+            # (hbv.py:516-530) -> RuntimeError there as well.
+            raise RuntimeError("comprout=True is only consistent for nmul == 1")
+
+        # hbv.py:314-319
+        if self.warm_up_states:
+            warm_up = self.warm_up
+        else:
+            self.pred_cutoff = self.warm_up
+            warm_up = 0
+
+        # hbv.py:321-324
+        if (not self.states) or (not self.cache_states):
+            state_in = self._init_states(ngrid)
+        else:
+            state_in = self._stack_states(self.states, ngrid, x.device)
+
+        base = dict(model=self._model_id, n_param=n, n_flux=self._n_flux(), B=ngrid, M=M,
+                    raw_sigmoid=True, channels=self._channels(), nearzero=float(self.nearzero))
+
+        # hbv.py:327-346: state warm-up, all parameters static from row warm_up-1, no grad
+        if warm_up > 0:
+            with torch.no_grad():
+                cfg_w = StepConfig(T=warm_up, t0=0, want_flux=False, **base)
+                cfg_w.params = self._param_sources(T_total, ngrid, ny, 0, warm_up - 1, [],
+                                                   x.device)
+                _, _, state_in, _ = HbvPath.apply(cfg_w, x, state_in, None, None, None,
+                                                  parameters.detach())
+
+        # hbv.py:349-353
+        T = T_total - warm_up
+        cfg = StepConfig(T=T, t0=warm_up, **base)
+        cfg.params = self._param_sources(T_total, ngrid, ny, warm_up, T_total - 1,
+                                         self.dynamic_params, x.device)
+        if self.routing:
+            off = (T_total - 1) * ngrid * ny + n * M  # hbv.py:212-214: last row only
+            cfg.route = RouteSource(0, off, off + 1, ny,
+                                    self.routing_parameter_bounds['route_a'],
+                                    self.routing_parameter_bounds['route_b'])
+        muwts = self._expand_muwts(self.muwts, T_total, ngrid)
+        flux, routed, state_out, _ = HbvPath.apply(cfg, x, state_in, muwts, None, None,
+                                                   parameters)
+
+        # hbv.py:356-359
+        self._states_cache = [s for s in state_out.detach().unbind(0)]
+        if self.cache_states:
+            self.states = self._states_cache
+
+        if self.initialize:
+            return tuple(self._states_cache)
+        return self._assemble(flux, routed, x, warm_up)
+
+    def _assemble(self, flux, routed, x, t0) -> dict[str, torch.Tensor]:
+        """hbv.py:555-596: flux dictionary, BFI and the optional prediction cut-off."""
+        F = _abi
+
+        def col(t):
+            return t.unsqueeze(-1)
+
+        if routed is not None:
+            Qs, Q0r, Q1r, Q2r = (col(routed[k]) for k in range(4))
+        else:
+            # The reference's Hbv crashes here (hbv.py:550-567); follow Hbv_2's
+            # handling of routing=False instead (hbv_2.py:620-626).
+            Qs, Q0r, Q1r, Q2r = (col(flux[k]) for k in (F.F_QSIM, F.F_Q0, F.F_Q1, F.F_Q2))
+        BFI = 100 * (torch.sum(Q2r, dim=0) / (torch.sum(Qs, dim=0) + self.nearzero))[:, 0]
+        pet = x[t0:, :, self.variables.index('pet')]
+        out = {
+            'streamflow': Qs, 'srflow': Q0r, 'ssflow': Q1r, 'gwflow': Q2r,
+            'AET_hydro': col(flux[F.F_AET]),
+            'PET_hydro': col(pet),
+            'SWE': col(flux[F.F_SWE]),
+            'streamflow_no_rout': col(flux[F.F_QSIM]),
+            'srflow_no_rout': col(flux[F.F_Q0]),
+            'ssflow_no_rout': col(flux[F.F_Q1]),
+            'gwflow_no_rout': col(flux[F.F_Q2]),
+            'recharge': col(flux[F.F_RECHARGE]),
+            'excs': col(flux[F.F_EXCS]),
+            'evapfactor': col(flux[F.F_EVAPFACTOR]),
+            'tosoil': col(flux[F.F_TOSOIL]),
+            'percolation': col(flux[F.F_PERC]),
+        }
+        if self._has_capillary:
+            out['capillary'] = col(flux[F.F_CAPILLARY])
+        out['BFI'] = BFI
+        if not self.warm_up_states:
+            for key in out.keys():
+                if key != 'BFI':
+                    out[key] = out[key][self.pred_cutoff:, :, :]
+        return out

@@ -1,0 +1,123 @@
+"""HBV 2.0 (multi-scale) on the MI355X-native time-stepper.
+
+Drop-in for `hydrodl2.load_model('hbv_2')`
+(src/hydrodl2/models/hbv/hbv_2.py:8-670): `parameters` is the tuple
+(dynamic [T,B,n_dy*nmul], static [B,n_st*nmul(+2)]) already in [0,1]; needs
+`x_dict['ac_all']` and `x_dict['elev_all']`; returns the flux dictionary and
+caches the full state series.
+"""
+from typing import Any, Optional
+
+import torch
+
+from hydrodl2_amd import _abi
+from hydrodl2_amd.core.hbv_module import HbvModule
+from hydrodl2_amd.ops import HbvPath, ParamSource, RouteSource, StepConfig
+
+
+class Hbv_2(HbvModule):
+    """HBV 2.0: 16 physical parameters x nmul (hbv_2.py:90-107), routing off by default."""
+
+    _model_id = _abi.MODEL_HBV20
+    _display_name = 'HBV 2.0'
+    _extra_bounds = {'parBETAET': [0.3, 5], 'parC': [0, 1], 'parRT': [0, 20],
+                     'parAC': [0, 2500]}
+    _has_capillary = True
+    _default_routing = False  # hbv_2.py:51
+
+    def __init__(self, config: Optional[dict[str, Any]] = None,
+                 device: Optional[torch.device] = None) -> None:
+        self.lenF = 15  # hbv_2.py:52
+        super().__init__(config, device)
+        self._state_cache = None
+
+    def _read_config(self, config: dict) -> None:
+        super()._read_config(config)
+        self.cache_states = config.get('cache_states', self.cache_states)  # hbv_2.py:129
+
+    def _set_parameters(self) -> None:
+        """hbv_2.py:174-188."""
+        self.phy_param_names = self.parameter_bounds.keys()
+        if self.routing:
+            self.routing_param_names = self.routing_parameter_bounds.keys()
+        else:
+            self.routing_param_names = []
+        self.learnable_param_count1 = len(self.dynamic_params) * self.nmul
+        self.learnable_param_count2 = (
+            len(self.phy_param_names) - len(self.dynamic_params)
+        ) * self.nmul + len(self.routing_param_names)
+        self.learnable_param_count = self.learnable_param_count1 + self.learnable_param_count2
+
+    def get_states(self):
+        return self._state_cache  # hbv_2.py:142-150
+
+    def forward(self, x_dict: dict[str, torch.Tensor], parameters):
+        """Reference: hbv_2.py:324-390 + `_PBM` :392-670."""
+        x = x_dict['x_phy']
+        ac = x_dict['ac_all'].to(torch.float32).contiguous()
+        elev = x_dict['elev_all'].to(torch.float32).contiguous()
+        self.muwts = x_dict.get('muwts', None)
+        T, ngrid = x.shape[0], x.shape[1]
+        M = self.nmul
+        p_dyn, p_sta = parameters[0], parameters[1]
+        if not p_dyn.is_contiguous():
+            p_dyn = p_dyn.contiguous()
+        if not p_sta.is_contiguous():
+            p_sta = p_sta.contiguous()
+        n = len(self.parameter_bounds)
+        dy = list(self.dynamic_params)
+        n_dy = len(dy)
+        wd, ws = p_dyn.shape[-1], p_sta.shape[-1]
+        if wd != n_dy * M:
+            raise ValueError(f"dynamic parameters have {wd} columns, need {n_dy * M}")
+        if ws < (n - n_dy) * M + (2 if self.routing else 0):
+            raise ValueError(f"static parameters have {ws} columns")
+
+        # hbv_2.py:258: dynamic parameters are indexed in the ORDER OF THE CONFIG LIST,
+        # with a Bernoulli drop mask per entry; static ones in table order (hbv_2.py:363-367).
+        srcs = []
+        drops = {name: self._draw_drop_mask(ngrid, x.device) for name in dy}
+        stat_list = [name for name in self.parameter_bounds if name not in dy]
+        for name in self.parameter_bounds:
+            lo, hi = self.parameter_bounds[name]
+            slot = _abi.PARAM_SLOTS.index(name)
+            if name in dy:
+                i = dy.index(name)
+                srcs.append(ParamSource(
+                    slot=slot, lo=float(lo), hi=float(hi),
+                    tensor_idx=0, sta_off=(T - 1) * ngrid * wd + i * M, sta_bs=wd,  # :259
+                    dyn_tensor_idx=0, dyn_off=i * M, dyn_ts=ngrid * wd, dyn_bs=wd,
+                    drop=drops[name]))
+            else:
+                i = stat_list.index(name)
+                srcs.append(ParamSource(slot=slot, lo=float(lo), hi=float(hi), tensor_idx=1,
+                                        sta_off=i * M, sta_bs=ws))
+
+        # hbv_2.py:370-373
+        if (not self.states) or (not self.cache_states):
+            state_in = None
+        else:
+            state_in = self._stack_states(self.states, ngrid, x.device)
+
+        cfg = StepConfig(model=self._model_id, n_param=n, n_flux=12, T=T, t0=0, B=ngrid, M=M,
+                         raw_sigmoid=False, channels=self._channels(),
+                         nearzero=float(self.nearzero), params=srcs,
+                         want_flux=not self.initialize, want_traj=True)
+        if self.routing:
+            off = (n - n_dy) * M  # hbv_2.py:228
+            cfg.route = RouteSource(1, off, off + 1, ws,
+                                    self.routing_parameter_bounds['route_a'],
+                                    self.routing_parameter_bounds['route_b'])
+        muwts = self._expand_muwts(self.muwts, T, ngrid)
+        flux, routed, state_out, traj = HbvPath.apply(cfg, x, state_in, muwts, ac, elev,
+                                                      p_dyn, p_sta)
+
+        # hbv_2.py:385-388,628: the state cache is the full series [T,B,nmul] x 5
+        series = traj.detach()[:, 1:, :].reshape(5, T, ngrid, M)
+        self._state_cache = tuple(series[k] for k in range(5))
+        if self.cache_states:
+            self.states = tuple(s[-1].detach() for s in self._state_cache)
+
+        if self.initialize:
+            return {}
+        return self._assemble(flux, routed, x, 0)

@@ -1,0 +1,248 @@
+"""torch.autograd shim over the C ABI (include/hbvx.h).
+
+One autograd.Function covers the whole hot path of one `_PBM` call
+(reference: hbv.py:363-553): parameter prep + daily recurrence + ensemble mean
+(`hbvx_forward`) followed by unit-hydrograph routing of the four runoff series
+(`hbvx_route_forward`).  Keeping both stages in one Function means the
+gradient w.r.t. the raw NN output is written into ONE buffer (the routing
+columns and the physical columns live in the same `parameters` tensor).
+
+PyTorch is used for device memory, the current stream and autograd plumbing
+only; every arithmetic step of the path runs in the HIP library.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _abi
+from ._lib import get_library
+
+
+@dataclass
+class ParamSource:
+    """Where physical-parameter slot `slot` lives inside the input tensors.
+
+    Offsets/strides are in float32 elements relative to tensor `tensor_idx`'s
+    first element; `dyn_off` addresses (t=0 of this call, b=0, j=0).
+    """
+    slot: int
+    lo: float
+    hi: float
+    tensor_idx: int
+    sta_off: int
+    sta_bs: int
+    dyn_tensor_idx: int = -1
+    dyn_off: int = -1          # -1: static parameter
+    dyn_ts: int = 0
+    dyn_bs: int = 0
+    drop: Optional[torch.Tensor] = None  # uint8 [B] on the compute device
+
+
+@dataclass
+class RouteSource:
+    tensor_idx: int
+    a_off: int
+    b_off: int
+    stride: int
+    a_bounds: Sequence[float]
+    b_bounds: Sequence[float]
+
+
+@dataclass
+class StepConfig:
+    model: int
+    n_param: int
+    n_flux: int
+    T: int                     # steps of this call
+    t0: int                    # first row of x used by this call
+    B: int
+    M: int
+    raw_sigmoid: bool
+    channels: Sequence[int]    # (prcp, tmean, pet) channel indices in x
+    nearzero: float
+    params: List[ParamSource] = field(default_factory=list)
+    route: Optional[RouteSource] = None
+    want_flux: bool = True
+    want_traj: bool = False    # keep the state trajectory even without autograd
+
+
+def _ptr(t: Optional[torch.Tensor], off: int = 0) -> Optional[int]:
+    if t is None:
+        return None
+    return t.data_ptr() + 4 * off
+
+
+def _stream_of(lib, t: torch.Tensor) -> int:
+    if lib.is_device:
+        return torch.cuda.current_stream(t.device).cuda_stream
+    return 0
+
+
+def _check_tensor(lib, t: torch.Tensor, name: str):
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    if lib.is_device and not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU (got {t.device}); "
+                           "hydrodl2_amd has no CPU path")
+    if not lib.is_device and t.is_cuda:
+        raise RuntimeError(f"{name}: test library expects host tensors")
+
+
+def _fill_desc(cfg: StepConfig, x, state_in, muwts, ac, elev, ptensors) -> _abi.Desc:
+    d = _abi.Desc()
+    d.abi_version = _abi.ABI_VERSION
+    d.model = cfg.model
+    d.T, d.B, d.M = cfg.T, cfg.B, cfg.M
+    d.n_param = cfg.n_param
+    d.raw_sigmoid = 1 if cfg.raw_sigmoid else 0
+    d.ch_prcp, d.ch_tmean, d.ch_pet = cfg.channels
+    d.nearzero = cfg.nearzero
+    d.x = _ptr(x, cfg.t0 * x.stride(0))
+    d.x_t_stride, d.x_b_stride = x.stride(0), x.stride(1)
+    d.ac = _ptr(ac)
+    d.elev = _ptr(elev)
+    if muwts is not None:  # full [Tx,B,M] contiguous (the module expands broadcasts)
+        d.muwts = _ptr(muwts, cfg.t0 * cfg.B * cfg.M)
+        d.mu_t_stride, d.mu_b_stride = cfg.B * cfg.M, cfg.M
+    d.state_in = _ptr(state_in)
+    for ps in cfg.params:
+        s = d.p[ps.slot]
+        s.sta = _ptr(ptensors[ps.tensor_idx], ps.sta_off)
+        s.sta_b_stride = ps.sta_bs
+        if ps.dyn_off >= 0:
+            s.dyn = _ptr(ptensors[ps.dyn_tensor_idx], ps.dyn_off)
+            s.dyn_t_stride, s.dyn_b_stride = ps.dyn_ts, ps.dyn_bs
+            if ps.drop is not None:
+                s.drop = ps.drop.data_ptr()
+        s.lo, s.hi = ps.lo, ps.hi
+    return d
+
+
+def _route_desc(cfg: StepConfig, ptensors) -> _abi.RouteDesc:
+    r = _abi.RouteDesc()
+    rs = cfg.route
+    r.abi_version = _abi.ABI_VERSION
+    r.T, r.B, r.S = cfg.T, cfg.B, 4
+    r.L = min(cfg.T, _abi.UH_MAXLEN)
+    r.raw_sigmoid = 1 if cfg.raw_sigmoid else 0
+    r.ra = _ptr(ptensors[rs.tensor_idx], rs.a_off)
+    r.rb = _ptr(ptensors[rs.tensor_idx], rs.b_off)
+    r.r_stride = rs.stride
+    r.a_lo, r.a_hi = rs.a_bounds
+    r.b_lo, r.b_hi = rs.b_bounds
+    return r
+
+
+class HbvPath(torch.autograd.Function):
+    """flux, routed, state_out, traj = HbvPath.apply(cfg, x, state_in, muwts, ac, elev, *ptensors)
+
+    flux   [n_flux, T, B]  ensemble means (enum hbvx_flux order)
+    routed [4, T, B]       UH-routed Qsim, Q0, Q1, Q2 (None when cfg.route is None)
+    state_out [5, B, M]; traj [5, T+1, B*M] or None.
+    """
+
+    @staticmethod
+    def forward(ctx, cfg: StepConfig, x, state_in, muwts, ac, elev, *ptensors):
+        lib = get_library()
+        _check_tensor(lib, x, "x_phy")
+        for i, p in enumerate(ptensors):
+            _check_tensor(lib, p, f"parameters[{i}]")
+            if not p.is_contiguous():
+                raise ValueError("parameter tensors must be contiguous")
+        if x.stride(2) != 1:
+            raise ValueError("x_phy must have unit stride on the forcing axis")
+        if muwts is not None:
+            _check_tensor(lib, muwts, "muwts")
+            if not muwts.is_contiguous() or tuple(muwts.shape[1:]) != (cfg.B, cfg.M):
+                raise ValueError("muwts must be a contiguous [T,B,nmul] tensor")
+        dev = x.device
+        T, B, M = cfg.T, cfg.B, cfg.M
+        needs_grad = any(ctx.needs_input_grad)
+        keep = needs_grad or cfg.want_traj
+        stream = _stream_of(lib, x)
+
+        out = _abi.FwdOut()
+        flux = torch.empty((cfg.n_flux, T, B), dtype=torch.float32, device=dev) \
+            if cfg.want_flux else None
+        state_out = torch.empty((5, B, M), dtype=torch.float32, device=dev)
+        traj = torch.empty((5, T + 1, B * M), dtype=torch.float32, device=dev) if keep else None
+        aux = torch.empty((2, T, B * M), dtype=torch.float32, device=dev) if needs_grad else None
+        out.flux, out.state_out = _ptr(flux), _ptr(state_out)
+        out.traj, out.aux = _ptr(traj), _ptr(aux)
+        out.n_flux = cfg.n_flux
+        desc = _fill_desc(cfg, x, state_in, muwts, ac, elev, ptensors)
+        lib.forward(desc, out, stream)
+
+        routed = uh = None
+        if cfg.route is not None and cfg.want_flux:
+            r = _route_desc(cfg, ptensors)
+            routed = torch.empty((4, T, B), dtype=torch.float32, device=dev)
+            uh = torch.empty((B, r.L), dtype=torch.float32, device=dev)
+            lib.route_forward(r, _ptr(flux), _ptr(uh), _ptr(routed), stream)
+
+        ctx.cfg = cfg
+        ctx.n_ptensors = len(ptensors)
+        if needs_grad:
+            ctx.save_for_backward(x, state_in, muwts, ac, elev, traj, aux, flux, uh, *ptensors)
+        nondiff = [state_out]
+        if traj is not None:
+            nondiff.append(traj)
+        ctx.mark_non_differentiable(*nondiff)
+        return flux, routed, state_out, traj
+
+    @staticmethod
+    def backward(ctx, g_flux, g_routed, _g_state, _g_traj):
+        lib = get_library()
+        cfg: StepConfig = ctx.cfg
+        saved = ctx.saved_tensors
+        x, state_in, muwts, ac, elev, traj, aux, flux, uh = saved[:9]
+        ptensors = saved[9:]
+        dev = x.device
+        T, B, M = cfg.T, cfg.B, cfg.M
+        stream = _stream_of(lib, x)
+
+        if g_flux is None:
+            g_flux = torch.zeros((cfg.n_flux, T, B), dtype=torch.float32, device=dev)
+        else:
+            g_flux = g_flux.contiguous().clone() if g_routed is not None else g_flux.contiguous()
+
+        gp = [torch.zeros_like(p) if ctx.needs_input_grad[6 + i] else None
+              for i, p in enumerate(ptensors)]
+
+        if g_routed is not None and cfg.route is not None:
+            r = _route_desc(cfg, ptensors)
+            gq = torch.empty((4, T, B), dtype=torch.float32, device=dev)
+            rs = cfg.route
+            gt = gp[rs.tensor_idx]
+            lib.route_backward(r, _ptr(flux), _ptr(uh), _ptr(g_routed.contiguous()), _ptr(gq),
+                               _ptr(gt, rs.a_off), _ptr(gt, rs.b_off), stream)
+            g_flux[0:4] += gq
+
+        io = _abi.BwdIO()
+        io.traj, io.aux, io.grad_flux = _ptr(traj), _ptr(aux), _ptr(g_flux)
+        io.n_flux = cfg.n_flux
+        gx = gmu = None
+        if ctx.needs_input_grad[1]:
+            gx = torch.zeros_like(x)
+            if gx.stride() != x.stride():
+                raise ValueError("x_phy must be dense for a forcing gradient")
+            io.grad_x = _ptr(gx, cfg.t0 * x.stride(0))
+        if muwts is not None and ctx.needs_input_grad[3]:
+            gmu = torch.zeros_like(muwts)
+            io.grad_muwts = _ptr(gmu, cfg.t0 * B * M)
+        for ps in cfg.params:
+            g = io.g[ps.slot]
+            gs = gp[ps.tensor_idx]
+            if gs is not None:
+                g.sta = _ptr(gs, ps.sta_off)
+                g.sta_b_stride = ps.sta_bs
+            if ps.dyn_off >= 0 and gp[ps.dyn_tensor_idx] is not None:
+                g.dyn = _ptr(gp[ps.dyn_tensor_idx], ps.dyn_off)
+                g.dyn_t_stride, g.dyn_b_stride = ps.dyn_ts, ps.dyn_bs
+        desc = _fill_desc(cfg, x, state_in, muwts, ac, elev, ptensors)
+        lib.backward(desc, io, stream)
+
+        return (None, gx, None, gmu, None, None, *gp)

@@ -1,0 +1,185 @@
+/*
+ * hbvx.h -- C ABI of the MI355X-native HBV time-stepper (libhbvx.so).
+ *
+ * The reference (mhpi/hydrodl2) has no FFI of its own: its plug-in contract is
+ * the Python class `Hbv(config, device).forward(x_dict, parameters)`
+ * (src/hydrodl2/models/hbv/hbv.py:284-361).  This header declares the entry
+ * points a binding for that path needs; each one names the reference code it
+ * replaces.  Plain pointers and sizes only -- no torch types.
+ *
+ *   hbvx_forward         replaces the `for t in range(nsteps)` recurrence and the
+ *                        ensemble mean: hbv.py:423-511, hbv_1_1p.py:422-521,
+ *                        hbv_2.py:464-581, fused with the parameter prep
+ *                        (sigmoid, static-row pick, dy_drop blend, de-scaling:
+ *                        hbv.py:201-208,236-256, core/calc/utils.py:9-24).
+ *   hbvx_backward        replaces the autograd tape of the same lines
+ *                        (SURVEY.md §3.4 / §8 a11): hand-written adjoint.
+ *   hbvx_route_forward   replaces uh_gamma + uh_conv on the ensemble means:
+ *                        core/calc/uh_routing.py:5-57, called at hbv.py:523-538.
+ *   hbvx_route_backward  replaces conv1d/lgamma/pow autograd of those lines.
+ *
+ * Ownership: the caller allocates and owns every buffer; the library keeps no
+ * state between calls and allocates nothing persistent.  All device work is
+ * enqueued on `stream` (a hipStream_t passed as void*); no call synchronises.
+ * Errors: 0 on success, a negative HBVX_E_* otherwise; hbvx_last_error() returns
+ * a thread-local message.  Nothing throws across the ABI.
+ *
+ * The CPU oracle (oracle/hbv_oracle.c) implements the same ABI on host memory
+ * (stream ignored) so that tests can drive both with identical descriptors.
+ */
+#ifndef HBVX_H
+#define HBVX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HBVX_ABI_VERSION 1
+#define HBVX_MAX_PARAM 16
+#define HBVX_NSTATE 5   /* SNOWPACK, MELTWATER, SM, SUZ, SLZ  (hbv.py:61-67) */
+#define HBVX_MAX_FLUX 12
+#define HBVX_UH_MAXLEN 15 /* lenF (hbv.py:526, hbv_2.py:52) */
+
+/* Parameter slots: the order of `parameter_bounds` in every variant
+ * (hbv.py:88-101,124-125; hbv_1_1p.py:87-102; hbv_2.py:90-107). */
+enum hbvx_param_slot {
+    HBVX_P_BETA = 0, HBVX_P_FC, HBVX_P_K0, HBVX_P_K1, HBVX_P_K2, HBVX_P_LP,
+    HBVX_P_PERC, HBVX_P_UZL, HBVX_P_TT, HBVX_P_CFMAX, HBVX_P_CFR, HBVX_P_CWH,
+    HBVX_P_BETAET, HBVX_P_C, HBVX_P_RT, HBVX_P_AC
+};
+
+enum hbvx_model {
+    HBVX_MODEL_HBV10 = 0,  /* n_param 12, or 13 when parBETAET is present */
+    HBVX_MODEL_HBV11P = 1, /* n_param 14: + parBETAET always, capillary rise */
+    HBVX_MODEL_HBV20 = 2   /* n_param 16: + elevation TT switch, lateral flow */
+};
+
+/* Ensemble-mean series written by hbvx_forward, flux[k][t][b]
+ * (the buffers of hbv.py:402-420 after mean(-1): hbv.py:509,575-588). */
+enum hbvx_flux {
+    HBVX_F_QSIM = 0, /* Q0+Q1+Q2; weighted by muwts when given (hbv.py:508-511) */
+    HBVX_F_Q0, HBVX_F_Q1, HBVX_F_Q2, HBVX_F_AET, HBVX_F_SWE, HBVX_F_RECHARGE,
+    HBVX_F_EXCS, HBVX_F_EVAPFACTOR, HBVX_F_TOSOIL, HBVX_F_PERC,
+    HBVX_F_CAPILLARY /* 1.1p / 2.0 only */
+};
+
+enum hbvx_error {
+    HBVX_OK = 0,
+    HBVX_E_NULL = -1,        /* required pointer missing */
+    HBVX_E_SHAPE = -2,       /* T/B/M/n_param out of range */
+    HBVX_E_UNSUPPORTED = -3, /* variant / option not built */
+    HBVX_E_ABI = -4,         /* abi_version mismatch */
+    HBVX_E_DEVICE = -5       /* HIP runtime error (message has the hipError) */
+};
+
+/* Where one physical parameter comes from.  Values are "unit" parameters
+ * u in [0,1] (after the optional sigmoid); physical value = u*(hi-lo)+lo. */
+typedef struct hbvx_param_src {
+    const float *dyn;     /* per-step values or NULL (static parameter):
+                             (t,b,j) at dyn[t*dyn_t_stride + b*dyn_b_stride + j] */
+    const float *sta;     /* static values, required: (b,j) at sta[b*sta_b_stride + j]
+                             (the reference's "last row": hbv.py:242) */
+    const uint8_t *drop;  /* optional [B]; 1 = basin uses the static value although
+                             the parameter is dynamic (dy_drop mask, hbv.py:245-246) */
+    int64_t dyn_t_stride;
+    int64_t dyn_b_stride;
+    int64_t sta_b_stride;
+    float lo, hi;         /* bounds (parameter_bounds) */
+} hbvx_param_src;
+
+/* Where the gradient w.r.t. the *input* values (raw if raw_sigmoid, else unit)
+ * goes; same addressing as hbvx_param_src.  `dyn` rows are overwritten for
+ * every (t,b,j) of the call; `sta` is accumulated into (+=) after the dyn rows,
+ * so both may alias the same tensor (the reference's static row T-1 lies inside
+ * the dynamic tensor).  NULL pointers skip that gradient. */
+typedef struct hbvx_param_grad {
+    float *dyn;
+    float *sta;
+    int64_t dyn_t_stride;
+    int64_t dyn_b_stride;
+    int64_t sta_b_stride;
+} hbvx_param_grad;
+
+typedef struct hbvx_desc {
+    int32_t abi_version;  /* HBVX_ABI_VERSION */
+    int32_t model;        /* enum hbvx_model */
+    int32_t T;            /* steps in this call */
+    int32_t B;            /* basins */
+    int32_t M;            /* ensemble members per basin (nmul), 1..64 */
+    int32_t n_param;      /* 12, 13, 14 or 16 */
+    int32_t raw_sigmoid;  /* 1: inputs are raw NN outputs, apply sigmoid first
+                             (hbv.py:201); 0: inputs already in [0,1] (hbv_2.py:211) */
+    int32_t ch_prcp, ch_tmean, ch_pet; /* channel of each forcing (hbv.py:388-390) */
+    float nearzero;       /* hbv.py:54 */
+    int32_t reserved0;
+    const float *x;       /* forcings: (t,b,c) at x[t*x_t_stride + b*x_b_stride + c] */
+    int64_t x_t_stride, x_b_stride;
+    const float *ac;      /* [B] HBV 2.0 `ac_all`  (hbv_2.py:345), else NULL */
+    const float *elev;    /* [B] HBV 2.0 `elev_all` (hbv_2.py:346), else NULL */
+    const float *muwts;   /* optional ensemble weights (t,b,j) at
+                             muwts[t*mu_t_stride + b*mu_b_stride + j] (strides may be 0) */
+    int64_t mu_t_stride, mu_b_stride;
+    const float *state_in; /* [5,B,M] or NULL = every storage 0.001 (hbv.py:128-136) */
+    hbvx_param_src p[HBVX_MAX_PARAM];
+} hbvx_desc;
+
+typedef struct hbvx_fwd_out {
+    float *flux;      /* [n_flux,T,B] or NULL (state warm-up: hbv.py:557-559) */
+    float *state_out; /* [5,B,M] storages after the last step, required */
+    float *traj;      /* optional [5,T+1,B*M]: storages entering step t; row T = final.
+                         Needed by hbvx_backward; rows 1..T are HBV 2.0's state series
+                         (hbv_2.py:571-575) */
+    float *aux;       /* optional [2,T,B*M]: (SM/FC)^BETA and the evap factor before
+                         their clamps; saved for hbvx_backward */
+    int32_t n_flux;   /* 11 (HBV 1.0) or 12 */
+    int32_t reserved0;
+} hbvx_fwd_out;
+
+typedef struct hbvx_bwd_io {
+    const float *traj;       /* from hbvx_forward, required */
+    const float *aux;        /* from hbvx_forward, required */
+    const float *grad_flux;  /* [n_flux,T,B] dL/d(flux series), required */
+    float *grad_x;           /* optional, addressed like desc->x (overwritten) */
+    float *grad_muwts;       /* optional [T,B,M] contiguous (overwritten) */
+    float *grad_state_in;    /* optional [5,B,M] (overwritten) */
+    int32_t n_flux;
+    int32_t reserved0;
+    hbvx_param_grad g[HBVX_MAX_PARAM];
+} hbvx_bwd_io;
+
+/* Unit-hydrograph routing of S series that share one UH per basin. */
+typedef struct hbvx_route_desc {
+    int32_t abi_version;
+    int32_t T, B, S;      /* steps, basins, series (4: Qsim,Q0,Q1,Q2 at hbv.py:530-538) */
+    int32_t L;            /* UH length = min(T, 15) (uh_routing.py:8) */
+    int32_t raw_sigmoid;  /* routing parameters are raw (hbv.py:212) or unit (hbv_2.py:228) */
+    const float *ra;      /* route_a input of basin b at ra[b*r_stride] */
+    const float *rb;      /* route_b input of basin b at rb[b*r_stride] */
+    int64_t r_stride;
+    float a_lo, a_hi, b_lo, b_hi; /* routing_parameter_bounds (hbv.py:102-105) */
+} hbvx_route_desc;
+
+int hbvx_version(void);                 /* HBVX_ABI_VERSION */
+const char *hbvx_last_error(void);
+const char *hbvx_backend(void);         /* "hip:gfx950" or "cpu-oracle" */
+uint64_t hbvx_sizeof(int which);        /* 0 desc, 1 fwd_out, 2 bwd_io, 3 route_desc,
+                                           4 param_src, 5 param_grad: layout check */
+
+int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream);
+int hbvx_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *stream);
+
+/* q [S,T,B] -> uh [B,L] (normalised gamma UH) and q_rout [S,T,B]. */
+int hbvx_route_forward(const hbvx_route_desc *r, const float *q, float *uh, float *q_rout,
+                       void *stream);
+/* grad_q_rout [S,T,B] -> grad_q [S,T,B] (overwritten) and the gradient w.r.t. the
+ * routing inputs, accumulated (+=) at grad_ra[b*r_stride], grad_rb[b*r_stride]. */
+int hbvx_route_backward(const hbvx_route_desc *r, const float *q, const float *uh,
+                        const float *grad_q_rout, float *grad_q, float *grad_ra,
+                        float *grad_rb, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HBVX_H */

@@ -1,0 +1,756 @@
+/*
+ * hbv_oracle.c -- CPU ORACLE for the HBV time-stepper.  TEST INFRASTRUCTURE ONLY.
+ *
+ * A plain-C, scalar, fp32 restatement of the reference algorithm
+ * (mhpi/hydrodl2, src/hydrodl2/models/hbv/{hbv,hbv_1_1p,hbv_2}.py and
+ * src/hydrodl2/core/calc/{utils,uh_routing}.py), implementing the ABI of
+ * include/hbvx.h on host memory.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load it; the product (hydrodl2_amd/) never does.
+ *
+ * Parity status: PINNED.  tests/test_oracle_golden.py checks this file against
+ * outputs and autograd gradients of the reference itself (tests/golden/NAME.npz,
+ * produced by tests/golden/make_golden.py in the authoring container).
+ *
+ * Build: oracle/Makefile  (gcc -O2 -ffp-contract=off -fopenmp).  No FMA
+ * contraction: the reference evaluates one rounded ATen op per Python operator.
+ *
+ * Every function cites the reference lines it restates.  The backward pass is a
+ * hand-derived adjoint that reproduces PyTorch autograd's conventions
+ * (SURVEY.md §8 a11): minimum() ties send grad/2 to each argument,
+ * clamp(min=m) passes the gradient where x >= m (inclusive), clamp(0,1) where
+ * 0 <= x <= 1, comparison masks carry no gradient.
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/hbvx.h"
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+static __thread char g_err[256] = "";
+
+static int fail(int code, const char *msg)
+{
+    snprintf(g_err, sizeof g_err, "%s", msg);
+    return code;
+}
+
+int hbvx_version(void) { return HBVX_ABI_VERSION; }
+const char *hbvx_last_error(void) { return g_err; }
+const char *hbvx_backend(void) { return "cpu-oracle"; }
+
+uint64_t hbvx_sizeof(int which)
+{
+    switch (which) {
+    case 0: return sizeof(hbvx_desc);
+    case 1: return sizeof(hbvx_fwd_out);
+    case 2: return sizeof(hbvx_bwd_io);
+    case 3: return sizeof(hbvx_route_desc);
+    case 4: return sizeof(hbvx_param_src);
+    case 5: return sizeof(hbvx_param_grad);
+    default: return 0;
+    }
+}
+
+int hbvo_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* ------------------------------------------------------------------ */
+/* parameter prep: hbv.py:201-208 (sigmoid), :242-246 (static row, dy_drop
+ * blend), core/calc/utils.py:24 (p*(hi-lo)+lo, multiply THEN add).     */
+
+static inline float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+typedef struct {
+    float u;      /* unit value actually used (after sigmoid + blend) */
+    int from_dyn; /* 1: came from the per-step tensor, 0: static row */
+} unit_t;
+
+static inline unit_t fetch_unit(const hbvx_desc *d, int i, int t, int b, int j)
+{
+    const hbvx_param_src *s = &d->p[i];
+    unit_t r;
+    float v;
+    if (s->dyn && !(s->drop && s->drop[b])) {
+        v = s->dyn[(int64_t)t * s->dyn_t_stride + (int64_t)b * s->dyn_b_stride + j];
+        r.from_dyn = 1;
+    } else {
+        v = s->sta[(int64_t)b * s->sta_b_stride + j];
+        r.from_dyn = 0;
+    }
+    r.u = d->raw_sigmoid ? sigmoidf_(v) : v;
+    return r;
+}
+
+static inline float descale(float u, float lo, float hi) { return u * (hi - lo) + lo; }
+
+/* ------------------------------------------------------------------ */
+/* one explicit daily step, all intermediates kept for the adjoint.     */
+
+typedef struct {
+    /* inputs */
+    float SP, MW, SM, SUZ, SLZ;
+    float P, Tf, PET;
+    /* snow */
+    float TTe, mlo; /* effective threshold; d(TTe)/d(TT) */
+    float m_rain, m_snow, RAIN, SNOW, SP1, dT, mp, mpc, melt, MW1, SP2;
+    float cc, dT2, rp, rpc, refr, SP3, MW2, cwsp, ts0, tosoil, MW3;
+    /* soil */
+    float r, sw0, sw, rt, rech, SM1, e0, exc, SM2, lpfc, q, ef0, ef, pe, ET, dd, SM3;
+    /* capillary (1.1p, 2.0) */
+    float x1, rc, cs, om, capp, cap, smc, SM4, slc, SLZ0;
+    /* groundwater */
+    float SUZ1, PERC, SUZ2, u0, u0c, Q0, SUZ3, Q1, SUZ4, SLZ1, SLZ1p, Q2, SLZ2, Q;
+    /* lateral flow (2.0) */
+    float a0, a1, m1, m2, ee, LF, sl;
+} step_t;
+
+static inline float clamp01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
+
+/* hbv.py:428-494 ; hbv_1_1p.py:427-506 ; hbv_2.py:471-556 */
+static void step_fwd(int model, int has_betaet, float nz, const float *p, float ac, float elev,
+                     step_t *s)
+{
+    const float BETA = p[HBVX_P_BETA], FC = p[HBVX_P_FC], K0 = p[HBVX_P_K0], K1 = p[HBVX_P_K1],
+                K2 = p[HBVX_P_K2], LP = p[HBVX_P_LP], PERCp = p[HBVX_P_PERC],
+                UZL = p[HBVX_P_UZL], TT = p[HBVX_P_TT], CFMAX = p[HBVX_P_CFMAX],
+                CFR = p[HBVX_P_CFR], CWH = p[HBVX_P_CWH];
+    /* hbv_2.py:473-475: parTT_new = (Elev>=2000)*4.0 + (Elev<2000)*parTT */
+    if (model == HBVX_MODEL_HBV20) {
+        float mhi = (elev >= 2000.0f) ? 1.0f : 0.0f;
+        s->mlo = (elev < 2000.0f) ? 1.0f : 0.0f;
+        s->TTe = mhi * 4.0f + s->mlo * TT;
+    } else {
+        s->mlo = 1.0f;
+        s->TTe = TT;
+    }
+    /* hbv.py:429-435 */
+    s->m_rain = (s->Tf >= s->TTe) ? 1.0f : 0.0f;
+    s->m_snow = (s->Tf < s->TTe) ? 1.0f : 0.0f;
+    s->RAIN = s->P * s->m_rain;
+    s->SNOW = s->P * s->m_snow;
+    /* hbv.py:438-445 */
+    s->SP1 = s->SP + s->SNOW;
+    s->dT = s->Tf - s->TTe;
+    s->mp = CFMAX * s->dT;
+    s->mpc = fmaxf(s->mp, 0.0f);
+    s->melt = fminf(s->mpc, s->SP1);
+    s->MW1 = s->MW + s->melt;
+    s->SP2 = s->SP1 - s->melt;
+    /* hbv.py:446-456 */
+    s->cc = CFR * CFMAX;
+    s->dT2 = s->TTe - s->Tf;
+    s->rp = s->cc * s->dT2;
+    s->rpc = fmaxf(s->rp, 0.0f);
+    s->refr = fminf(s->rpc, s->MW1);
+    s->SP3 = s->SP2 + s->refr;
+    s->MW2 = s->MW1 - s->refr;
+    /* hbv.py:457-459 */
+    s->cwsp = CWH * s->SP3;
+    s->ts0 = s->MW2 - s->cwsp;
+    s->tosoil = fmaxf(s->ts0, 0.0f);
+    s->MW3 = s->MW2 - s->tosoil;
+    /* hbv.py:462-472 */
+    s->r = s->SM / FC;
+    s->sw0 = powf(s->r, BETA);
+    s->sw = clamp01(s->sw0);
+    s->rt = s->RAIN + s->tosoil;
+    s->rech = s->rt * s->sw;
+    s->SM1 = ((s->SM + s->RAIN) + s->tosoil) - s->rech;
+    s->e0 = s->SM1 - FC;
+    s->exc = fmaxf(s->e0, 0.0f);
+    s->SM2 = s->SM1 - s->exc;
+    /* hbv.py:474-480 ; hbv_1_1p.py:473-480 */
+    s->lpfc = LP * FC;
+    s->q = s->SM2 / s->lpfc;
+    s->ef0 = has_betaet ? powf(s->q, p[HBVX_P_BETAET]) : s->q;
+    s->ef = clamp01(s->ef0);
+    s->pe = s->PET * s->ef;
+    s->ET = fminf(s->SM2, s->pe);
+    s->dd = s->SM2 - s->ET;
+    s->SM3 = fmaxf(s->dd, nz);
+    /* hbv_1_1p.py:482-490 ; hbv_2.py:525-533 */
+    if (model != HBVX_MODEL_HBV10) {
+        const float C = p[HBVX_P_C];
+        s->x1 = s->SM3 / FC;
+        s->rc = fminf(s->x1, 1.0f);
+        s->cs = C * s->SLZ;
+        s->om = 1.0f - s->rc;
+        s->capp = s->cs * s->om;
+        s->cap = fminf(s->SLZ, s->capp);
+        s->smc = s->SM3 + s->cap;
+        s->SM4 = fmaxf(s->smc, nz);
+        s->slc = s->SLZ - s->cap;
+        s->SLZ0 = fmaxf(s->slc, nz);
+    } else {
+        s->cap = 0.0f;
+        s->SM4 = s->SM3;
+        s->SLZ0 = s->SLZ;
+    }
+    /* hbv.py:483-492 */
+    s->SUZ1 = (s->SUZ + s->rech) + s->exc;
+    s->PERC = fminf(s->SUZ1, PERCp);
+    s->SUZ2 = s->SUZ1 - s->PERC;
+    s->u0 = s->SUZ2 - UZL;
+    s->u0c = fmaxf(s->u0, 0.0f);
+    s->Q0 = K0 * s->u0c;
+    s->SUZ3 = s->SUZ2 - s->Q0;
+    s->Q1 = K1 * s->SUZ3;
+    s->SUZ4 = s->SUZ3 - s->Q1;
+    s->SLZ1 = s->SLZ0 + s->PERC;
+    /* hbv_2.py:545-550 */
+    if (model == HBVX_MODEL_HBV20) {
+        const float RT = p[HBVX_P_RT], AC = p[HBVX_P_AC];
+        s->m1 = (ac < 2500.0f) ? 1.0f : 0.0f;
+        s->m2 = (ac >= 2500.0f) ? 1.0f : 0.0f;
+        s->a0 = (ac - AC) / 1000.0f;
+        s->a1 = fminf(fmaxf(s->a0, -1.0f), 1.0f);
+        float e0 = -(ac - 2500.0f) / 50.0f;
+        float e1 = fminf(fmaxf(e0, -10.0f), 0.0f);
+        s->ee = expf(e1);
+        s->LF = (s->a1 * RT) * s->m1 + (s->ee * RT) * s->m2;
+        s->sl = s->SLZ1 + s->LF;
+        s->SLZ1p = fmaxf(s->sl, 0.0f);
+    } else {
+        s->SLZ1p = s->SLZ1;
+    }
+    s->Q2 = K2 * s->SLZ1p;
+    s->SLZ2 = s->SLZ1p - s->Q2;
+    /* hbv.py:494 */
+    s->Q = (s->Q0 + s->Q1) + s->Q2;
+}
+
+/* torch.minimum backward: ties split. */
+static inline void minw(float a, float b, float *wa, float *wb)
+{
+    if (a < b) { *wa = 1.0f; *wb = 0.0f; }
+    else if (a > b) { *wa = 0.0f; *wb = 1.0f; }
+    else { *wa = 0.5f; *wb = 0.5f; }
+}
+
+/* x**y backward (torch pow_backward_self / pow_backward_exponent). */
+static inline float pow_dx(float x, float y) { return (y == 0.0f) ? 0.0f : y * powf(x, y - 1.0f); }
+static inline float pow_dy(float x, float y, float res)
+{
+    return (x == 0.0f && y >= 0.0f) ? 0.0f : res * logf(x);
+}
+
+typedef struct {
+    float gQ, gQ0, gQ1, gQ2, gET, gSWE, grech, gexc, gef, gtosoil, gPERC, gcap;
+} fluxgrad_t;
+
+/* Adjoint of step_fwd.  a[5] holds dL/d(new states) on entry and dL/d(old states)
+ * on exit; gp[] accumulates dL/d(physical parameters); gx[3] = dL/d(P,T,PET). */
+static void step_bwd(int model, int has_betaet, float nz, const float *p, const step_t *s,
+                     const fluxgrad_t *g, float *a, float *gp, float *gx)
+{
+    const float BETA = p[HBVX_P_BETA], FC = p[HBVX_P_FC], K0 = p[HBVX_P_K0], K1 = p[HBVX_P_K1],
+                K2 = p[HBVX_P_K2], LP = p[HBVX_P_LP], PERCp = p[HBVX_P_PERC],
+                CFMAX = p[HBVX_P_CFMAX], CFR = p[HBVX_P_CFR], CWH = p[HBVX_P_CWH];
+    float wa, wb;
+    float aSP3 = a[0] + g->gSWE, aMW3 = a[1], aSMn = a[2], aSUZ4 = a[3], aSLZ2 = a[4];
+    float aQ0 = g->gQ0 + g->gQ, aQ1 = g->gQ1 + g->gQ, aQ2 = g->gQ2 + g->gQ;
+
+    /* SLZ2 = SLZ1p - Q2 ; Q2 = K2*SLZ1p */
+    aQ2 -= aSLZ2;
+    float aSLZ1p = aSLZ2 + aQ2 * K2;
+    gp[HBVX_P_K2] += aQ2 * s->SLZ1p;
+    float aSLZ1 = aSLZ1p;
+    if (model == HBVX_MODEL_HBV20) {
+        const float RT = p[HBVX_P_RT];
+        float as = (s->sl >= 0.0f) ? aSLZ1p : 0.0f;
+        aSLZ1 = as;
+        float at1 = as * s->m1; /* adjoint of (a1*RT) */
+        float at2 = as * s->m2; /* adjoint of (ee*RT) */
+        gp[HBVX_P_RT] += at1 * s->a1 + at2 * s->ee;
+        float aa1 = at1 * RT;
+        float aa0 = (s->a0 >= -1.0f && s->a0 <= 1.0f) ? aa1 : 0.0f;
+        gp[HBVX_P_AC] += -(aa0 / 1000.0f);
+    }
+    /* SLZ1 = SLZ0 + PERC */
+    float aSLZ0 = aSLZ1;
+    float aPERC = g->gPERC + aSLZ1;
+    /* SUZ4 = SUZ3 - Q1 ; Q1 = K1*SUZ3 */
+    aQ1 -= aSUZ4;
+    float aSUZ3 = aSUZ4 + aQ1 * K1;
+    gp[HBVX_P_K1] += aQ1 * s->SUZ3;
+    /* SUZ3 = SUZ2 - Q0 ; Q0 = K0*max(u0,0) ; u0 = SUZ2 - UZL */
+    aQ0 -= aSUZ3;
+    float aSUZ2 = aSUZ3;
+    gp[HBVX_P_K0] += aQ0 * s->u0c;
+    float au0 = (s->u0 >= 0.0f) ? aQ0 * K0 : 0.0f;
+    aSUZ2 += au0;
+    gp[HBVX_P_UZL] -= au0;
+    /* SUZ2 = SUZ1 - PERC ; PERC = min(SUZ1, PERCp) */
+    aPERC -= aSUZ2;
+    float aSUZ1 = aSUZ2;
+    minw(s->SUZ1, PERCp, &wa, &wb);
+    aSUZ1 += aPERC * wa;
+    gp[HBVX_P_PERC] += aPERC * wb;
+    /* SUZ1 = (SUZ + rech) + exc */
+    float aSUZ = aSUZ1;
+    float arech = g->grech + aSUZ1;
+    float aexc = g->gexc + aSUZ1;
+
+    float aSLZ, aSM3;
+    if (model != HBVX_MODEL_HBV10) {
+        const float C = p[HBVX_P_C];
+        /* SLZ0 = max(SLZ - cap, nz) ; SM4 = max(SM3 + cap, nz) */
+        float az = (s->slc >= nz) ? aSLZ0 : 0.0f;
+        aSLZ = az;
+        float acap = g->gcap - az;
+        float ay = (s->smc >= nz) ? aSMn : 0.0f;
+        aSM3 = ay;
+        acap += ay;
+        /* cap = min(SLZ, capp) */
+        minw(s->SLZ, s->capp, &wa, &wb);
+        aSLZ += acap * wa;
+        float acapp = acap * wb;
+        /* capp = (C*SLZ) * (1 - rc) */
+        float acs = acapp * s->om;
+        float arc = -(acapp * s->cs);
+        gp[HBVX_P_C] += acs * s->SLZ;
+        aSLZ += acs * C;
+        /* rc = clamp(x1, max=1) ; x1 = SM3/FC */
+        float ax1 = (s->x1 <= 1.0f) ? arc : 0.0f;
+        aSM3 += ax1 / FC;
+        gp[HBVX_P_FC] += -ax1 * ((s->SM3 / FC) / FC);
+    } else {
+        aSLZ = aSLZ0;
+        aSM3 = aSMn;
+    }
+    /* SM3 = max(dd, nz) ; dd = SM2 - ET */
+    float add = (s->dd >= nz) ? aSM3 : 0.0f;
+    float aSM2 = add;
+    float aET = g->gET - add;
+    /* ET = min(SM2, pe) ; pe = PET*ef */
+    minw(s->SM2, s->pe, &wa, &wb);
+    aSM2 += aET * wa;
+    float ape = aET * wb;
+    float aef = g->gef + ape * s->PET;
+    gx[2] = ape * s->ef;
+    /* ef = clamp(ef0, 0, 1) */
+    float aef0 = (s->ef0 >= 0.0f && s->ef0 <= 1.0f) ? aef : 0.0f;
+    float aq;
+    if (has_betaet) {
+        const float BE = p[HBVX_P_BETAET];
+        aq = aef0 * pow_dx(s->q, BE);
+        gp[HBVX_P_BETAET] += aef0 * pow_dy(s->q, BE, s->ef0);
+    } else {
+        aq = aef0;
+    }
+    /* q = SM2 / (LP*FC) */
+    aSM2 += aq / s->lpfc;
+    float alpfc = -aq * ((s->SM2 / s->lpfc) / s->lpfc);
+    gp[HBVX_P_LP] += alpfc * FC;
+    gp[HBVX_P_FC] += alpfc * LP;
+    /* SM2 = SM1 - exc ; exc = max(e0,0) ; e0 = SM1 - FC */
+    float aSM1 = aSM2;
+    aexc -= aSM2;
+    float ae0 = (s->e0 >= 0.0f) ? aexc : 0.0f;
+    aSM1 += ae0;
+    gp[HBVX_P_FC] -= ae0;
+    /* SM1 = ((SM + RAIN) + tosoil) - rech */
+    float aSM = aSM1;
+    float aRAIN = aSM1;
+    float atosoil = g->gtosoil + aSM1;
+    arech -= aSM1;
+    /* rech = rt*sw ; rt = RAIN + tosoil */
+    float art = arech * s->sw;
+    float asw = arech * s->rt;
+    aRAIN += art;
+    atosoil += art;
+    /* sw = clamp(sw0,0,1) ; sw0 = r**BETA ; r = SM/FC */
+    float asw0 = (s->sw0 >= 0.0f && s->sw0 <= 1.0f) ? asw : 0.0f;
+    float ar = asw0 * pow_dx(s->r, BETA);
+    gp[HBVX_P_BETA] += asw0 * pow_dy(s->r, BETA, s->sw0);
+    aSM += ar / FC;
+    gp[HBVX_P_FC] += -ar * ((s->SM / FC) / FC);
+    /* MW3 = MW2 - tosoil ; tosoil = max(ts0,0) ; ts0 = MW2 - CWH*SP3 */
+    float aMW2 = aMW3;
+    atosoil -= aMW3;
+    float ats0 = (s->ts0 >= 0.0f) ? atosoil : 0.0f;
+    aMW2 += ats0;
+    gp[HBVX_P_CWH] -= ats0 * s->SP3;
+    aSP3 -= ats0 * CWH;
+    /* SP3 = SP2 + refr ; MW2 = MW1 - refr */
+    float aSP2 = aSP3;
+    float arefr = aSP3 - aMW2;
+    float aMW1 = aMW2;
+    /* refr = min(rpc, MW1) ; rpc = max(rp,0) ; rp = (CFR*CFMAX)*(TTe - T) */
+    minw(s->rpc, s->MW1, &wa, &wb);
+    float arpc = arefr * wa;
+    aMW1 += arefr * wb;
+    float arp = (s->rp >= 0.0f) ? arpc : 0.0f;
+    float acc = arp * s->dT2;
+    gp[HBVX_P_CFR] += acc * CFMAX;
+    gp[HBVX_P_CFMAX] += acc * CFR;
+    float aTTe = arp * s->cc;
+    float aTf = -(arp * s->cc);
+    /* MW1 = MW + melt ; SP2 = SP1 - melt */
+    float aMW = aMW1;
+    float amelt = aMW1 - aSP2;
+    float aSP1 = aSP2;
+    /* melt = min(mpc, SP1) ; mpc = max(mp,0) ; mp = CFMAX*(T - TTe) */
+    minw(s->mpc, s->SP1, &wa, &wb);
+    float ampc = amelt * wa;
+    aSP1 += amelt * wb;
+    float amp = (s->mp >= 0.0f) ? ampc : 0.0f;
+    gp[HBVX_P_CFMAX] += amp * s->dT;
+    aTTe -= amp * CFMAX;
+    aTf += amp * CFMAX;
+    /* SP1 = SP + SNOW ; SNOW = P*[T<TTe] ; RAIN = P*[T>=TTe] */
+    float aSP = aSP1;
+    gx[0] = aSP1 * s->m_snow + aRAIN * s->m_rain;
+    gx[1] = aTf;
+    gp[HBVX_P_TT] += aTTe * s->mlo;
+
+    a[0] = aSP; a[1] = aMW; a[2] = aSM; a[3] = aSUZ; a[4] = aSLZ;
+}
+
+/* ------------------------------------------------------------------ */
+
+static int check_desc(const hbvx_desc *d)
+{
+    if (!d) return fail(HBVX_E_NULL, "desc is NULL");
+    if (d->abi_version != HBVX_ABI_VERSION) return fail(HBVX_E_ABI, "abi_version mismatch");
+    if (d->T < 0 || d->B <= 0 || d->M <= 0 || d->M > 64) return fail(HBVX_E_SHAPE, "bad T/B/M");
+    int ok = 0;
+    if (d->model == HBVX_MODEL_HBV10) ok = (d->n_param == 12 || d->n_param == 13);
+    else if (d->model == HBVX_MODEL_HBV11P) ok = (d->n_param == 14);
+    else if (d->model == HBVX_MODEL_HBV20) ok = (d->n_param == 16);
+    else return fail(HBVX_E_UNSUPPORTED, "unknown model");
+    if (!ok) return fail(HBVX_E_SHAPE, "n_param does not match model");
+    if (!d->x) return fail(HBVX_E_NULL, "forcing pointer is NULL");
+    if (d->model == HBVX_MODEL_HBV20 && (!d->ac || !d->elev))
+        return fail(HBVX_E_NULL, "HBV 2.0 needs ac and elev");
+    for (int i = 0; i < d->n_param; i++)
+        if (!d->p[i].sta) return fail(HBVX_E_NULL, "static parameter pointer is NULL");
+    return HBVX_OK;
+}
+
+static inline int has_betaet_(const hbvx_desc *d)
+{
+    return d->model != HBVX_MODEL_HBV10 || d->n_param == 13;
+}
+
+static inline void load_step_inputs(const hbvx_desc *d, int t, int b, int j, float *p,
+                                    unit_t *u, step_t *s)
+{
+    for (int i = 0; i < d->n_param; i++) {
+        u[i] = fetch_unit(d, i, t, b, j);
+        p[i] = descale(u[i].u, d->p[i].lo, d->p[i].hi);
+    }
+    const float *xr = d->x + (int64_t)t * d->x_t_stride + (int64_t)b * d->x_b_stride;
+    s->P = xr[d->ch_prcp];
+    s->Tf = xr[d->ch_tmean];
+    s->PET = xr[d->ch_pet];
+}
+
+/* hbv.py:423-511 with the parameter prep fused (see include/hbvx.h). */
+int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream)
+{
+    (void)stream;
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!out || !out->state_out) return fail(HBVX_E_NULL, "state_out is NULL");
+    const int T = d->T, B = d->B, M = d->M;
+    const int64_t N = (int64_t)B * M;
+    const int nf = out->n_flux;
+    const int want_nf = (d->model == HBVX_MODEL_HBV10) ? 11 : 12;
+    if (out->flux && nf != want_nf) return fail(HBVX_E_SHAPE, "n_flux does not match model");
+    const int betaet = has_betaet_(d);
+
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int b = 0; b < B; b++) {
+        float *acc = NULL;
+        if (out->flux) acc = (float *)calloc((size_t)T * nf, sizeof(float));
+        const float ac = d->ac ? d->ac[b] : 0.0f, elev = d->elev ? d->elev[b] : 0.0f;
+        for (int j = 0; j < M; j++) {
+            const int64_t n = (int64_t)b * M + j;
+            float st[5];
+            for (int k = 0; k < 5; k++)
+                st[k] = d->state_in ? d->state_in[k * N + n] : 0.001f; /* hbv.py:131-134 */
+            for (int t = 0; t < T; t++) {
+                float p[HBVX_MAX_PARAM];
+                unit_t u[HBVX_MAX_PARAM];
+                step_t s;
+                s.SP = st[0]; s.MW = st[1]; s.SM = st[2]; s.SUZ = st[3]; s.SLZ = st[4];
+                load_step_inputs(d, t, b, j, p, u, &s);
+                step_fwd(d->model, betaet, d->nearzero, p, ac, elev, &s);
+                if (out->traj)
+                    for (int k = 0; k < 5; k++) out->traj[((int64_t)k * (T + 1) + t) * N + n] = st[k];
+                if (out->aux) {
+                    out->aux[((int64_t)0 * T + t) * N + n] = s.sw0;
+                    out->aux[((int64_t)1 * T + t) * N + n] = s.ef0;
+                }
+                st[0] = s.SP3; st[1] = s.MW3; st[2] = s.SM4; st[3] = s.SUZ4; st[4] = s.SLZ2;
+                if (acc) {
+                    float *a = acc + (size_t)t * nf;
+                    float wq = 1.0f;
+                    if (d->muwts) /* hbv.py:511 (Qsimmu * muwts).sum(-1) */
+                        wq = d->muwts[(int64_t)t * d->mu_t_stride + (int64_t)b * d->mu_b_stride + j];
+                    a[HBVX_F_QSIM] += d->muwts ? s.Q * wq : s.Q;
+                    a[HBVX_F_Q0] += s.Q0;
+                    a[HBVX_F_Q1] += s.Q1;
+                    a[HBVX_F_Q2] += s.Q2;
+                    a[HBVX_F_AET] += s.ET;
+                    a[HBVX_F_SWE] += s.SP3; /* hbv.py:499 stores the updated SNOWPACK */
+                    a[HBVX_F_RECHARGE] += s.rech;
+                    a[HBVX_F_EXCS] += s.exc;
+                    a[HBVX_F_EVAPFACTOR] += s.ef;
+                    a[HBVX_F_TOSOIL] += s.tosoil;
+                    a[HBVX_F_PERC] += s.PERC;
+                    if (nf > HBVX_F_CAPILLARY) a[HBVX_F_CAPILLARY] += s.cap;
+                }
+            }
+            for (int k = 0; k < 5; k++) {
+                out->state_out[k * N + n] = st[k];
+                if (out->traj) out->traj[((int64_t)k * (T + 1) + T) * N + n] = st[k];
+            }
+        }
+        if (acc) {
+            for (int t = 0; t < T; t++)
+                for (int k = 0; k < nf; k++) {
+                    float v = acc[(size_t)t * nf + k];
+                    /* hbv.py:509 mean(-1); the muwts form is a plain sum (hbv.py:511) */
+                    if (!(k == HBVX_F_QSIM && d->muwts)) v = v / (float)M;
+                    out->flux[((int64_t)k * T + t) * B + b] = v;
+                }
+            free(acc);
+        }
+    }
+    return HBVX_OK;
+}
+
+/* The autograd tape of the same lines, by hand. */
+int hbvx_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *stream)
+{
+    (void)stream;
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!io || !io->traj || !io->grad_flux) return fail(HBVX_E_NULL, "traj/grad_flux is NULL");
+    const int T = d->T, B = d->B, M = d->M;
+    const int64_t N = (int64_t)B * M;
+    const int nf = io->n_flux;
+    const int betaet = has_betaet_(d);
+    const float invM = 1.0f / (float)M;
+
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int b = 0; b < B; b++) {
+        const float ac = d->ac ? d->ac[b] : 0.0f, elev = d->elev ? d->elev[b] : 0.0f;
+        float *gxacc = NULL;
+        if (io->grad_x) gxacc = (float *)calloc((size_t)T * 3, sizeof(float));
+        for (int j = 0; j < M; j++) {
+            const int64_t n = (int64_t)b * M + j;
+            float a[5] = {0, 0, 0, 0, 0};
+            float gsta[HBVX_MAX_PARAM]; /* dL/d(unit static value), summed over t */
+            float usta[HBVX_MAX_PARAM];
+            for (int i = 0; i < HBVX_MAX_PARAM; i++) gsta[i] = 0.0f, usta[i] = 0.0f;
+            for (int t = T - 1; t >= 0; t--) {
+                float p[HBVX_MAX_PARAM], gp[HBVX_MAX_PARAM], gx[3];
+                unit_t u[HBVX_MAX_PARAM];
+                step_t s;
+                s.SP = io->traj[((int64_t)0 * (T + 1) + t) * N + n];
+                s.MW = io->traj[((int64_t)1 * (T + 1) + t) * N + n];
+                s.SM = io->traj[((int64_t)2 * (T + 1) + t) * N + n];
+                s.SUZ = io->traj[((int64_t)3 * (T + 1) + t) * N + n];
+                s.SLZ = io->traj[((int64_t)4 * (T + 1) + t) * N + n];
+                load_step_inputs(d, t, b, j, p, u, &s);
+                step_fwd(d->model, betaet, d->nearzero, p, ac, elev, &s);
+                for (int i = 0; i < HBVX_MAX_PARAM; i++) gp[i] = 0.0f;
+                fluxgrad_t g;
+                const float *gf = io->grad_flux;
+#define GF(k) (gf[((int64_t)(k) * T + t) * B + b])
+                float wq = invM; /* mean(-1) backward: grad / M */
+                if (d->muwts)
+                    wq = d->muwts[(int64_t)t * d->mu_t_stride + (int64_t)b * d->mu_b_stride + j];
+                g.gQ = GF(HBVX_F_QSIM) * wq;
+                g.gQ0 = GF(HBVX_F_Q0) * invM;
+                g.gQ1 = GF(HBVX_F_Q1) * invM;
+                g.gQ2 = GF(HBVX_F_Q2) * invM;
+                g.gET = GF(HBVX_F_AET) * invM;
+                g.gSWE = GF(HBVX_F_SWE) * invM;
+                g.grech = GF(HBVX_F_RECHARGE) * invM;
+                g.gexc = GF(HBVX_F_EXCS) * invM;
+                g.gef = GF(HBVX_F_EVAPFACTOR) * invM;
+                g.gtosoil = GF(HBVX_F_TOSOIL) * invM;
+                g.gPERC = GF(HBVX_F_PERC) * invM;
+                g.gcap = (nf > HBVX_F_CAPILLARY) ? GF(HBVX_F_CAPILLARY) * invM : 0.0f;
+                if (io->grad_muwts)
+                    io->grad_muwts[((int64_t)t * B + b) * M + j] = GF(HBVX_F_QSIM) * s.Q;
+#undef GF
+                step_bwd(d->model, betaet, d->nearzero, p, &s, &g, a, gp, gx);
+                if (gxacc) {
+                    gxacc[t * 3 + 0] += gx[0];
+                    gxacc[t * 3 + 1] += gx[1];
+                    gxacc[t * 3 + 2] += gx[2];
+                }
+                /* de-scaling and sigmoid backward; dynamic rows are written, the
+                 * static row's contributions are summed over time. */
+                for (int i = 0; i < d->n_param; i++) {
+                    float gu = gp[i] * (d->p[i].hi - d->p[i].lo);
+                    if (u[i].from_dyn) {
+                        float gr = d->raw_sigmoid ? gu * (u[i].u * (1.0f - u[i].u)) : gu;
+                        if (io->g[i].dyn)
+                            io->g[i].dyn[(int64_t)t * io->g[i].dyn_t_stride +
+                                         (int64_t)b * io->g[i].dyn_b_stride + j] = gr;
+                    } else {
+                        gsta[i] += gu;
+                        usta[i] = u[i].u;
+                        if (d->p[i].dyn && io->g[i].dyn) /* dropped basin: zero dyn grad */
+                            io->g[i].dyn[(int64_t)t * io->g[i].dyn_t_stride +
+                                         (int64_t)b * io->g[i].dyn_b_stride + j] = 0.0f;
+                    }
+                }
+            }
+            for (int i = 0; i < d->n_param; i++) {
+                if (!io->g[i].sta) continue;
+                float gr = d->raw_sigmoid ? gsta[i] * (usta[i] * (1.0f - usta[i])) : gsta[i];
+                io->g[i].sta[(int64_t)b * io->g[i].sta_b_stride + j] += gr;
+            }
+            if (io->grad_state_in)
+                for (int k = 0; k < 5; k++) io->grad_state_in[k * N + n] = a[k];
+        }
+        if (gxacc) {
+            for (int t = 0; t < T; t++) {
+                float *gr = io->grad_x + (int64_t)t * d->x_t_stride + (int64_t)b * d->x_b_stride;
+                gr[d->ch_prcp] = gxacc[t * 3 + 0];
+                gr[d->ch_tmean] = gxacc[t * 3 + 1];
+                gr[d->ch_pet] = gxacc[t * 3 + 2];
+            }
+            free(gxacc);
+        }
+    }
+    return HBVX_OK;
+}
+
+/* ------------------------------------------------------------------ */
+/* routing: core/calc/uh_routing.py:5-57                               */
+
+static int check_route(const hbvx_route_desc *r)
+{
+    if (!r) return fail(HBVX_E_NULL, "route desc is NULL");
+    if (r->abi_version != HBVX_ABI_VERSION) return fail(HBVX_E_ABI, "abi_version mismatch");
+    if (r->T <= 0 || r->B <= 0 || r->S <= 0) return fail(HBVX_E_SHAPE, "bad T/B/S");
+    int L = r->T < HBVX_UH_MAXLEN ? r->T : HBVX_UH_MAXLEN;
+    if (r->L != L) return fail(HBVX_E_SHAPE, "L must be min(T, 15)");
+    if (!r->ra || !r->rb) return fail(HBVX_E_NULL, "routing parameter pointer is NULL");
+    return HBVX_OK;
+}
+
+/* uh_routing.py:5-22 for one basin. */
+static void uh_gamma_one(const hbvx_route_desc *r, int b, float *w, float *ua, float *ub)
+{
+    float va = r->ra[(int64_t)b * r->r_stride], vb = r->rb[(int64_t)b * r->r_stride];
+    *ua = r->raw_sigmoid ? sigmoidf_(va) : va;
+    *ub = r->raw_sigmoid ? sigmoidf_(vb) : vb;
+    float a = descale(*ua, r->a_lo, r->a_hi), bb = descale(*ub, r->b_lo, r->b_hi);
+    float aa = fmaxf(a, 0.0f) + 0.1f;     /* :11-13 */
+    float theta = fmaxf(bb, 0.0f) + 0.5f; /* :14 */
+    float denom = expf(lgammaf(aa)) * powf(theta, aa); /* :17 */
+    float sum = 0.0f;
+    for (int k = 0; k < r->L; k++) {
+        float t = (float)k + 0.5f;        /* :15 */
+        float mid = powf(t, aa - 1.0f);   /* :18 */
+        float right = expf(-t / theta);   /* :19 */
+        w[k] = 1.0f / denom * mid * right; /* :20 */
+        sum += w[k];
+    }
+    for (int k = 0; k < r->L; k++) w[k] = w[k] / sum; /* :21 */
+}
+
+int hbvx_route_forward(const hbvx_route_desc *r, const float *q, float *uh, float *q_rout,
+                       void *stream)
+{
+    (void)stream;
+    int rc = check_route(r);
+    if (rc) return rc;
+    if (!q || !uh || !q_rout) return fail(HBVX_E_NULL, "route buffer is NULL");
+    const int T = r->T, B = r->B, L = r->L;
+#pragma omp parallel for
+    for (int b = 0; b < B; b++) {
+        float w[HBVX_UH_MAXLEN], ua, ub;
+        uh_gamma_one(r, b, w, &ua, &ub);
+        for (int k = 0; k < L; k++) uh[(int64_t)b * L + k] = w[k];
+        /* uh_routing.py:44-57: y[t] = sum_k UH[k] * x[t-k], zero history */
+        for (int s = 0; s < r->S; s++)
+            for (int t = 0; t < T; t++) {
+                float y = 0.0f;
+                for (int k = 0; k < L && k <= t; k++)
+                    y += w[k] * q[((int64_t)s * T + (t - k)) * B + b];
+                q_rout[((int64_t)s * T + t) * B + b] = y;
+            }
+    }
+    return HBVX_OK;
+}
+
+int hbvx_route_backward(const hbvx_route_desc *r, const float *q, const float *uh,
+                        const float *grad_q_rout, float *grad_q, float *grad_ra, float *grad_rb,
+                        void *stream)
+{
+    (void)stream;
+    int rc = check_route(r);
+    if (rc) return rc;
+    if (!q || !uh || !grad_q_rout || !grad_q) return fail(HBVX_E_NULL, "route buffer is NULL");
+    const int T = r->T, B = r->B, L = r->L;
+#pragma omp parallel for
+    for (int b = 0; b < B; b++) {
+        const float *w = uh + (int64_t)b * L;
+        double gw[HBVX_UH_MAXLEN];
+        for (int k = 0; k < L; k++) gw[k] = 0.0;
+        for (int s = 0; s < r->S; s++)
+            for (int t = 0; t < T; t++) {
+                /* conv1d backward w.r.t. the input: correlation with the UH */
+                float gx = 0.0f;
+                for (int k = 0; k < L && t + k < T; k++)
+                    gx += w[k] * grad_q_rout[((int64_t)s * T + (t + k)) * B + b];
+                grad_q[((int64_t)s * T + t) * B + b] = gx;
+                /* ... and w.r.t. the UH taps */
+                float gy = grad_q_rout[((int64_t)s * T + t) * B + b];
+                for (int k = 0; k < L && k <= t; k++)
+                    gw[k] += (double)gy * (double)q[((int64_t)s * T + (t - k)) * B + b];
+            }
+        if (!grad_ra && !grad_rb) continue;
+        /* w_k = u_k / sum(u), u_k = t_k^(aa-1) exp(-t_k/theta) / (Gamma(aa) theta^aa):
+         * the Gamma and theta^aa factors cancel in the normalisation (uh_routing.py:17-21),
+         * so dw_k/daa = w_k (ln t_k - sum_j w_j ln t_j),
+         *    dw_k/dtheta = w_k (t_k - sum_j w_j t_j) / theta^2. */
+        float va = r->ra[(int64_t)b * r->r_stride], vb = r->rb[(int64_t)b * r->r_stride];
+        float ua = r->raw_sigmoid ? sigmoidf_(va) : va, ub = r->raw_sigmoid ? sigmoidf_(vb) : vb;
+        float a = descale(ua, r->a_lo, r->a_hi), bb = descale(ub, r->b_lo, r->b_hi);
+        double theta = (double)(fmaxf(bb, 0.0f) + 0.5f);
+        double mlt = 0.0, mt = 0.0;
+        for (int k = 0; k < L; k++) {
+            double tk = k + 0.5;
+            mlt += w[k] * log(tk);
+            mt += w[k] * tk;
+        }
+        double gaa = 0.0, gth = 0.0;
+        for (int k = 0; k < L; k++) {
+            double tk = k + 0.5;
+            gaa += gw[k] * w[k] * (log(tk) - mlt);
+            gth += gw[k] * w[k] * (tk - mt) / (theta * theta);
+        }
+        double ga = (a > 0.0f) ? gaa : 0.0;  /* relu backward */
+        double gb = (bb > 0.0f) ? gth : 0.0;
+        double gua = ga * (double)(r->a_hi - r->a_lo), gub = gb * (double)(r->b_hi - r->b_lo);
+        if (r->raw_sigmoid) {
+            gua *= (double)ua * (1.0 - (double)ua);
+            gub *= (double)ub * (1.0 - (double)ub);
+        }
+        if (grad_ra) grad_ra[(int64_t)b * r->r_stride] += (float)gua;
+        if (grad_rb) grad_rb[(int64_t)b * r->r_stride] += (float)gub;
+    }
+    return HBVX_OK;
+}

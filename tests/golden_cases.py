@@ -1,0 +1,155 @@
+"""Golden-case catalogue shared by tests/golden/make_golden.py and the tests.
+
+A case names a reference model class, its config, the synthetic input recipe
+(tests/synth.py) and the scalar loss whose gradient is recorded.  The
+generator runs the *reference* on these inputs (authoring container only) and
+stores outputs + gradients in tests/golden/<name>.npz; the tests rebuild the
+same inputs bit-for-bit and compare the oracle / the HIP path against the
+stored arrays.  (SURVEY.md §8c lists the cases this catalogue covers.)
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import synth
+
+PHY_NAMES = {
+    "Hbv": ["parBETA", "parFC", "parK0", "parK1", "parK2", "parLP", "parPERC",
+            "parUZL", "parTT", "parCFMAX", "parCFR", "parCWH"],
+    "Hbv_1_1p": ["parBETA", "parFC", "parK0", "parK1", "parK2", "parLP", "parPERC",
+                 "parUZL", "parTT", "parCFMAX", "parCFR", "parCWH", "parBETAET", "parC"],
+    "Hbv_2": ["parBETA", "parFC", "parK0", "parK1", "parK2", "parLP", "parPERC",
+              "parUZL", "parTT", "parCFMAX", "parCFR", "parCWH", "parBETAET", "parC",
+              "parRT", "parAC"],
+}
+
+
+def _cfg(cls, nmul=1, dyn=(), **kw):
+    c = {"nmul": nmul, "dynamic_params": {cls: list(dyn)}}
+    c.update(kw)
+    return c
+
+
+# name -> spec.  T/B are kept small: the fixtures are committed.
+CASES = {
+    # BASELINE config 1 exactly: Hbv(None), 10 basins x 365 d x 1 member, forward only.
+    "cfg1_hbv_default": dict(model="Hbv", config=None, T=365, B=10, seed=11, loss="none"),
+    # static parameters, 16 members, every flux key in the loss.
+    "hbv_static_m16": dict(model="Hbv", config=_cfg("Hbv", 16), T=96, B=6, seed=12, loss="all"),
+    "hbv_static_m16_sf": dict(model="Hbv", config=_cfg("Hbv", 16), T=96, B=6, seed=13,
+                              loss="streamflow"),
+    # warm-up variants.
+    "hbv_warmup_states": dict(model="Hbv", config=_cfg("Hbv", 16, warm_up=30), T=96, B=6,
+                              seed=14, loss="all"),
+    "hbv_warmup_nostates": dict(model="Hbv",
+                                config=_cfg("Hbv", 16, warm_up=30, warm_up_states=False),
+                                T=96, B=6, seed=15, loss="all"),
+    # dynamic parBETA + parBETAET (the common dMG setting, tests/config.yaml:48-49).
+    "hbv_dyn2": dict(model="Hbv", config=_cfg("Hbv", 16, ("parBETA", "parBETAET"), warm_up=20),
+                     T=80, B=5, seed=16, loss="all"),
+    "hbv_dyn2_drop": dict(model="Hbv",
+                          config=_cfg("Hbv", 16, ("parBETA", "parBETAET"), dy_drop=0.5),
+                          T=64, B=12, seed=17, loss="all", torch_seed=1234),
+    # non power-of-two ensemble, gradient w.r.t. the forcings too.
+    "hbv_m3_xgrad": dict(model="Hbv", config=_cfg("Hbv", 3, ("parK0",)), T=64, B=7, seed=18,
+                         loss="all", x_grad=True),
+    # learned ensemble weights.
+    "hbv_muwts": dict(model="Hbv", config=_cfg("Hbv", 4), T=64, B=5, seed=19, loss="all",
+                      muwts=True),
+    # cold dry start: melt = SNOWPACK = 0 ties, SM hitting FC, SUZ < PERC.
+    "hbv_ties": dict(model="Hbv", config=_cfg("Hbv", 2), T=48, B=9, seed=20, loss="all",
+                     cold=True, raw_scale=2.5),
+    # forcing channels remapped.
+    "hbv_variables": dict(model="Hbv", config=_cfg("Hbv", 2, variables=["tmean", "pet", "prcp"]),
+                          T=40, B=4, seed=21, loss="streamflow"),
+    # T' < 15 shortens the unit hydrograph.
+    "hbv_short": dict(model="Hbv", config=_cfg("Hbv", 2), T=9, B=3, seed=22, loss="all"),
+    # state continuation across two calls.
+    "hbv_cache_states": dict(model="Hbv", config=_cfg("Hbv", 4, cache_states=True), T=60, B=4,
+                             seed=23, loss="none", two_call=True),
+    # HBV 1.1p, all 14 parameters dynamic (BASELINE config 3 shape).
+    "hbv11p_dyn_all": dict(model="Hbv_1_1p",
+                           config=_cfg("Hbv_1_1p", 16, PHY_NAMES["Hbv_1_1p"]), T=64, B=5,
+                           seed=24, loss="all"),
+    "hbv11p_static": dict(model="Hbv_1_1p", config=_cfg("Hbv_1_1p", 4, warm_up=10), T=72, B=6,
+                          seed=25, loss="all", cold=True),
+    # HBV 2.0 tuple parameters, elevation / area switches on both sides.
+    "hbv2_dyn3": dict(model="Hbv_2",
+                      config=_cfg("Hbv_2", 16, ("parBETA", "parK0", "parBETAET")), T=64, B=8,
+                      seed=26, loss="all"),
+    "hbv2_dyn3_routing": dict(model="Hbv_2",
+                              config=_cfg("Hbv_2", 4, ("parBETA", "parK0", "parBETAET"),
+                                          routing=True, dy_drop=0.3),
+                              T=64, B=8, seed=27, loss="all", torch_seed=77),
+    "hbv2_static": dict(model="Hbv_2", config=_cfg("Hbv_2", 2), T=48, B=6, seed=28, loss="all",
+                        cold=True),
+}
+
+FLUX_KEYS_BASE = [
+    "streamflow", "srflow", "ssflow", "gwflow", "AET_hydro", "PET_hydro", "SWE",
+    "streamflow_no_rout", "srflow_no_rout", "ssflow_no_rout", "gwflow_no_rout",
+    "recharge", "excs", "evapfactor", "tosoil", "percolation",
+]
+
+
+def flux_keys(model: str):
+    keys = list(FLUX_KEYS_BASE)
+    if model in ("Hbv_1_1p", "Hbv_2"):
+        keys.append("capillary")
+    keys.append("BFI")
+    return keys
+
+
+def n_phy(spec) -> int:
+    model = spec["model"]
+    n = len(PHY_NAMES[model])
+    if model == "Hbv" and spec["config"] is not None:
+        if "parBETAET" in spec["config"]["dynamic_params"].get("Hbv", []):
+            n += 1
+    return n
+
+
+def build_inputs(name: str) -> dict:
+    """All numpy inputs of a case (float32), bit-reproducible."""
+    spec = CASES[name]
+    cfg = spec["config"] or {}
+    model = spec["model"]
+    T, B, seed = spec["T"], spec["B"], spec["seed"]
+    nmul = cfg.get("nmul", 1)
+    out = {}
+    x = synth.forcing(T, B, seed, cold=spec.get("cold", False))
+    variables = cfg.get("variables", ["prcp", "tmean", "pet"])
+    order = [["prcp", "tmean", "pet"].index(v) for v in variables]
+    out["x_phy"] = np.ascontiguousarray(x[:, :, order])
+    n = n_phy(spec)
+    routing = cfg.get("routing", model != "Hbv_2")
+    if model == "Hbv_2":
+        dyn = cfg["dynamic_params"].get("Hbv_2", [])
+        n_dy = len(dyn)
+        out["p_dyn"] = synth.unit_parameters((T, B, n_dy * nmul), seed, 4)
+        out["p_sta"] = synth.unit_parameters((B, (n - n_dy) * nmul + (2 if routing else 0)),
+                                             seed, 6)
+        out["ac_all"] = (synth.uniform((B,), seed, 7) * np.float32(5000.0)).astype(np.float32)
+        out["elev_all"] = (synth.uniform((B,), seed, 8) * np.float32(3000.0)).astype(np.float32)
+    else:
+        ny = n * nmul + 2
+        out["parameters"] = synth.raw_parameters(T, B, ny, seed, spec.get("raw_scale", 1.0))
+    if spec.get("muwts"):
+        u = synth.uniform((T, B, nmul), seed, 9).astype(np.float64) + 0.25
+        out["muwts"] = (u / u.sum(-1, keepdims=True)).astype(np.float32)
+    return out
+
+
+def loss_weight(name: str, key: str, shape) -> np.ndarray:
+    spec = CASES[name]
+    k = flux_keys(spec["model"]).index(key)
+    return synth.loss_weights(tuple(shape), spec["seed"], 20 + k)
+
+
+def loss_keys(name: str):
+    spec = CASES[name]
+    if spec["loss"] == "none":
+        return []
+    if spec["loss"] == "streamflow":
+        return ["streamflow"]
+    return flux_keys(spec["model"])

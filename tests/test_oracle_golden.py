@@ -1,0 +1,33 @@
+"""CPU tier: the oracle (and this package's host logic driving it) against the
+golden vectors produced by the reference itself (tests/golden/make_golden.py).
+
+This is what pins the oracle (the reference's own tests hold no numerical
+vectors).  Runs without a GPU.
+"""
+import numpy as np
+import pytest
+
+from . import golden_cases as gc
+from .helpers import compare, load_golden, run_case
+
+
+@pytest.mark.parametrize("name", list(gc.CASES))
+def test_case_matches_reference(name, oracle_backend):
+    ref = load_golden(name)
+    res = run_case(name, "cpu")
+    compare(name, res, ref)
+
+
+def test_static_gradient_lands_in_last_row_only(oracle_backend):
+    """static parameters receive gradient only in row T-1."""
+    res = run_case("hbv_static_m16", "cpu")
+    g = res["grad/parameters"]
+    assert np.abs(g[:-1]).max() == 0.0
+    assert np.abs(g[-1]).max() > 0.0
+
+
+def test_warmup_rows_get_no_gradient(oracle_backend):
+    res = run_case("hbv_dyn2", "cpu")
+    g = res["grad/parameters"]
+    wu = gc.CASES["hbv_dyn2"]["config"]["warm_up"]
+    assert np.abs(g[:wu]).max() == 0.0
