@@ -1,0 +1,333 @@
+// hbv_step.h -- one explicit HBV day and its adjoint, per lane (basin x member).
+//
+// Device math of the MI355X time-stepper.  Restates, in registers, the body of
+// the reference's `for t in range(nsteps)` loop:
+//   HBV 1.0   src/hydrodl2/models/hbv/hbv.py:428-494
+//   HBV 1.1p  src/hydrodl2/models/hbv/hbv_1_1p.py:427-506   (+ parBETAET, capillary rise)
+//   HBV 2.0   src/hydrodl2/models/hbv/hbv_2.py:471-556      (+ elevation TT switch, lateral flow)
+// with the reference's association order and, in the adjoint,
+// PyTorch autograd's sub-gradient conventions: minimum() ties
+// split the gradient, clamp bounds are inclusive, comparison masks are constants.
+//
+// Everything is `static inline` on plain floats so the very same code compiles
+// for gfx950 (hipcc) and for the host (tests/hosttest builds it with g++ to check
+// the math against the oracle without a GPU).  Build with -ffp-contract=off:
+// the reference rounds after every operator and thresholds such as T >= TT or
+// min/clamp branch on those roundings.
+#pragma once
+
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define HBVX_HD __host__ __device__ __forceinline__
+#define HBVX_HDM __host__ __device__ __forceinline__
+#else
+#define HBVX_HD static inline
+#define HBVX_HDM inline
+#endif
+
+namespace hbvx {
+
+enum : int { MODEL_HBV10 = 0, MODEL_HBV11P = 1, MODEL_HBV20 = 2 };
+enum : int {
+    P_BETA = 0, P_FC, P_K0, P_K1, P_K2, P_LP, P_PERC, P_UZL, P_TT, P_CFMAX, P_CFR, P_CWH,
+    P_BETAET, P_C, P_RT, P_AC, NPARAM_MAX
+};
+
+HBVX_HD float fmax_(float a, float b) { return fmaxf(a, b); } // v_max_f32
+HBVX_HD float fmin_(float a, float b) { return fminf(a, b); } // v_min_f32
+
+// torch.sigmoid: 1/(1+exp(-x))  (hbv.py:201)
+HBVX_HD float sigmoid_(float v) { return 1.0f / (1.0f + expf(-v)); }
+// core/calc/utils.py:24: multiply, then add (no FMA)
+HBVX_HD float descale_(float u, float lo, float hi) { return u * (hi - lo) + lo; }
+
+// torch.minimum backward weights (ties: 1/2 each)
+HBVX_HD void minw_(float a, float b, float &wa, float &wb)
+{
+    wa = (a < b) ? 1.0f : ((a > b) ? 0.0f : 0.5f);
+    wb = 1.0f - wa;
+}
+
+// Incoming flux-series gradients of one lane (already scaled by 1/M or muwts).
+struct FluxGrad {
+    float gQ, gQ0, gQ1, gQ2, gET, gSWE, grech, gexc, gef, gtosoil, gPERC, gcap;
+};
+
+// All intermediates of one step.  The compiler keeps what is live in VGPRs.
+template <int MODEL, bool BETAET>
+struct Step {
+    // inputs
+    float SP, MW, SM, SUZ, SLZ;
+    float P, Tf, PET;
+    // snow
+    float TTe, mlo, m_rain, m_snow, RAIN, SP1, dT, mp, mpc, melt, MW1, SP2;
+    float cc, dT2, rp, rpc, refr, SP3, MW2, ts0, tosoil, MW3;
+    // soil
+    float r, sw0, sw, rt, rech, SM1, e0, exc, SM2, lpfc, q, ef0, ef, pe, ET, dd, SM3;
+    // capillary
+    float x1, cs, om, capp, cap, smc, SM4, slc, SLZ0;
+    // groundwater
+    float SUZ1, PERC, SUZ2, u0, u0c, Q0, SUZ3, Q1, SUZ4, SLZ1, SLZ1p, Q2, SLZ2, Q;
+    // lateral flow
+    float a0, a1, m1, m2, ee, sl;
+
+    // USE_AUX: (SM/FC)^BETA and the pre-clamp evaporation factor come from the
+    // forward pass (hbvx_fwd_out.aux) instead of two powf calls.
+    template <bool USE_AUX>
+    HBVX_HDM void fwd(const float *p, float nz, float ac, float elev, float aux_sw0, float aux_ef0)
+    {
+        const float BETA = p[P_BETA], FC = p[P_FC], K0 = p[P_K0], K1 = p[P_K1], K2 = p[P_K2],
+                    LP = p[P_LP], PERCp = p[P_PERC], UZL = p[P_UZL], TT = p[P_TT],
+                    CFMAX = p[P_CFMAX], CFR = p[P_CFR], CWH = p[P_CWH];
+        if (MODEL == MODEL_HBV20) { // hbv_2.py:473-475
+            float mhi = (elev >= 2000.0f) ? 1.0f : 0.0f;
+            mlo = (elev < 2000.0f) ? 1.0f : 0.0f;
+            TTe = mhi * 4.0f + mlo * TT;
+        } else {
+            mlo = 1.0f;
+            TTe = TT;
+        }
+        // hbv.py:429-445
+        m_rain = (Tf >= TTe) ? 1.0f : 0.0f;
+        m_snow = (Tf < TTe) ? 1.0f : 0.0f;
+        RAIN = P * m_rain;
+        float SNOW = P * m_snow;
+        SP1 = SP + SNOW;
+        dT = Tf - TTe;
+        mp = CFMAX * dT;
+        mpc = fmax_(mp, 0.0f);
+        melt = fmin_(mpc, SP1);
+        MW1 = MW + melt;
+        SP2 = SP1 - melt;
+        // hbv.py:446-459
+        cc = CFR * CFMAX;
+        dT2 = TTe - Tf;
+        rp = cc * dT2;
+        rpc = fmax_(rp, 0.0f);
+        refr = fmin_(rpc, MW1);
+        SP3 = SP2 + refr;
+        MW2 = MW1 - refr;
+        ts0 = MW2 - CWH * SP3;
+        tosoil = fmax_(ts0, 0.0f);
+        MW3 = MW2 - tosoil;
+        // hbv.py:462-472
+        r = SM / FC;
+        sw0 = USE_AUX ? aux_sw0 : powf(r, BETA);
+        sw = fmin_(fmax_(sw0, 0.0f), 1.0f);
+        rt = RAIN + tosoil;
+        rech = rt * sw;
+        SM1 = ((SM + RAIN) + tosoil) - rech;
+        e0 = SM1 - FC;
+        exc = fmax_(e0, 0.0f);
+        SM2 = SM1 - exc;
+        // hbv.py:474-480 ; hbv_1_1p.py:473-480
+        lpfc = LP * FC;
+        q = SM2 / lpfc;
+        if (BETAET) ef0 = USE_AUX ? aux_ef0 : powf(q, p[P_BETAET]);
+        else ef0 = q;
+        ef = fmin_(fmax_(ef0, 0.0f), 1.0f);
+        pe = PET * ef;
+        ET = fmin_(SM2, pe);
+        dd = SM2 - ET;
+        SM3 = fmax_(dd, nz);
+        // hbv_1_1p.py:482-490
+        if (MODEL != MODEL_HBV10) {
+            const float C = p[P_C];
+            x1 = SM3 / FC;
+            float rc = fmin_(x1, 1.0f);
+            cs = C * SLZ;
+            om = 1.0f - rc;
+            capp = cs * om;
+            cap = fmin_(SLZ, capp);
+            smc = SM3 + cap;
+            SM4 = fmax_(smc, nz);
+            slc = SLZ - cap;
+            SLZ0 = fmax_(slc, nz);
+        } else {
+            cap = 0.0f;
+            SM4 = SM3;
+            SLZ0 = SLZ;
+        }
+        // hbv.py:483-492
+        SUZ1 = (SUZ + rech) + exc;
+        PERC = fmin_(SUZ1, PERCp);
+        SUZ2 = SUZ1 - PERC;
+        u0 = SUZ2 - UZL;
+        u0c = fmax_(u0, 0.0f);
+        Q0 = K0 * u0c;
+        SUZ3 = SUZ2 - Q0;
+        Q1 = K1 * SUZ3;
+        SUZ4 = SUZ3 - Q1;
+        SLZ1 = SLZ0 + PERC;
+        if (MODEL == MODEL_HBV20) { // hbv_2.py:545-550
+            const float RT = p[P_RT], AC = p[P_AC];
+            m1 = (ac < 2500.0f) ? 1.0f : 0.0f;
+            m2 = (ac >= 2500.0f) ? 1.0f : 0.0f;
+            a0 = (ac - AC) / 1000.0f;
+            a1 = fmin_(fmax_(a0, -1.0f), 1.0f);
+            float e0_ = -(ac - 2500.0f) / 50.0f;
+            float e1_ = fmin_(fmax_(e0_, -10.0f), 0.0f);
+            ee = expf(e1_);
+            float LF = (a1 * RT) * m1 + (ee * RT) * m2;
+            sl = SLZ1 + LF;
+            SLZ1p = fmax_(sl, 0.0f);
+        } else {
+            SLZ1p = SLZ1;
+        }
+        Q2 = K2 * SLZ1p;
+        SLZ2 = SLZ1p - Q2;
+        Q = (Q0 + Q1) + Q2; // hbv.py:494
+    }
+
+    // Adjoint of fwd().  a[5]: dL/d(new states) in, dL/d(old states) out.
+    // gp[]: += dL/d(physical parameter).  gx[3] = dL/d(P, T, PET).
+    HBVX_HDM void bwd(const float *p, float nz, const FluxGrad &g, float *a, float *gp,
+                     float *gx) const
+    {
+        const float BETA = p[P_BETA], FC = p[P_FC], K0 = p[P_K0], K1 = p[P_K1], K2 = p[P_K2],
+                    LP = p[P_LP], PERCp = p[P_PERC], CFMAX = p[P_CFMAX], CFR = p[P_CFR],
+                    CWH = p[P_CWH];
+        float wa, wb;
+        float aSP3 = a[0] + g.gSWE, aMW3 = a[1], aSMn = a[2], aSUZ4 = a[3], aSLZ2 = a[4];
+        float aQ0 = g.gQ0 + g.gQ, aQ1 = g.gQ1 + g.gQ, aQ2 = g.gQ2 + g.gQ;
+
+        aQ2 -= aSLZ2;
+        float aSLZ1p = aSLZ2 + aQ2 * K2;
+        gp[P_K2] += aQ2 * SLZ1p;
+        float aSLZ1 = aSLZ1p;
+        if (MODEL == MODEL_HBV20) {
+            const float RT = p[P_RT];
+            float as = (sl >= 0.0f) ? aSLZ1p : 0.0f;
+            aSLZ1 = as;
+            float at1 = as * m1, at2 = as * m2;
+            gp[P_RT] += at1 * a1 + at2 * ee;
+            float aa1 = at1 * RT;
+            float aa0 = (a0 >= -1.0f && a0 <= 1.0f) ? aa1 : 0.0f;
+            gp[P_AC] += -(aa0 / 1000.0f);
+        }
+        float aSLZ0 = aSLZ1;
+        float aPERC = g.gPERC + aSLZ1;
+        aQ1 -= aSUZ4;
+        float aSUZ3 = aSUZ4 + aQ1 * K1;
+        gp[P_K1] += aQ1 * SUZ3;
+        aQ0 -= aSUZ3;
+        float aSUZ2 = aSUZ3;
+        gp[P_K0] += aQ0 * u0c;
+        float au0 = (u0 >= 0.0f) ? aQ0 * K0 : 0.0f;
+        aSUZ2 += au0;
+        gp[P_UZL] -= au0;
+        aPERC -= aSUZ2;
+        float aSUZ1 = aSUZ2;
+        minw_(SUZ1, PERCp, wa, wb);
+        aSUZ1 += aPERC * wa;
+        gp[P_PERC] += aPERC * wb;
+        float aSUZ = aSUZ1;
+        float arech = g.grech + aSUZ1;
+        float aexc = g.gexc + aSUZ1;
+
+        float aSLZ, aSM3;
+        if (MODEL != MODEL_HBV10) {
+            const float C = p[P_C];
+            float az = (slc >= nz) ? aSLZ0 : 0.0f;
+            aSLZ = az;
+            float acap = g.gcap - az;
+            float ay = (smc >= nz) ? aSMn : 0.0f;
+            aSM3 = ay;
+            acap += ay;
+            minw_(SLZ, capp, wa, wb);
+            aSLZ += acap * wa;
+            float acapp = acap * wb;
+            float acs = acapp * om;
+            float arc = -(acapp * cs);
+            gp[P_C] += acs * SLZ;
+            aSLZ += acs * C;
+            float ax1 = (x1 <= 1.0f) ? arc : 0.0f;
+            aSM3 += ax1 / FC;
+            gp[P_FC] += -ax1 * (x1 / FC);
+        } else {
+            aSLZ = aSLZ0;
+            aSM3 = aSMn;
+        }
+        float add = (dd >= nz) ? aSM3 : 0.0f;
+        float aSM2 = add;
+        float aET = g.gET - add;
+        minw_(SM2, pe, wa, wb);
+        aSM2 += aET * wa;
+        float ape = aET * wb;
+        float aef = g.gef + ape * PET;
+        gx[2] = ape * ef;
+        float aef0 = (ef0 >= 0.0f && ef0 <= 1.0f) ? aef : 0.0f;
+        float aq;
+        if (BETAET) {
+            // d/dq q^b = b q^(b-1) = b * ef0 / q ; d/db = ef0 ln q   (q > 0: SM2 > 0)
+            const float BE = p[P_BETAET];
+            float dq = (q > 0.0f) ? BE * (ef0 / q) : 0.0f;
+            float db = (q > 0.0f) ? ef0 * logf(q) : 0.0f;
+            aq = aef0 * dq;
+            gp[P_BETAET] += aef0 * db;
+        } else {
+            aq = aef0;
+        }
+        aSM2 += aq / lpfc;
+        float alpfc = -aq * (q / lpfc);
+        gp[P_LP] += alpfc * FC;
+        gp[P_FC] += alpfc * LP;
+        float aSM1 = aSM2;
+        aexc -= aSM2;
+        float ae0 = (e0 >= 0.0f) ? aexc : 0.0f;
+        aSM1 += ae0;
+        gp[P_FC] -= ae0;
+        float aSM = aSM1;
+        float aRAIN = aSM1;
+        float atosoil = g.gtosoil + aSM1;
+        arech -= aSM1;
+        float art = arech * sw;
+        float asw = arech * rt;
+        aRAIN += art;
+        atosoil += art;
+        float asw0 = (sw0 >= 0.0f && sw0 <= 1.0f) ? asw : 0.0f;
+        float dr = (r > 0.0f) ? BETA * (sw0 / r) : 0.0f;
+        float db_ = (r > 0.0f) ? sw0 * logf(r) : 0.0f;
+        float ar = asw0 * dr;
+        gp[P_BETA] += asw0 * db_;
+        aSM += ar / FC;
+        gp[P_FC] += -ar * (r / FC);
+        float aMW2 = aMW3;
+        atosoil -= aMW3;
+        float ats0 = (ts0 >= 0.0f) ? atosoil : 0.0f;
+        aMW2 += ats0;
+        gp[P_CWH] -= ats0 * SP3;
+        aSP3 -= ats0 * CWH;
+        float aSP2 = aSP3;
+        float arefr = aSP3 - aMW2;
+        float aMW1 = aMW2;
+        minw_(rpc, MW1, wa, wb);
+        float arpc = arefr * wa;
+        aMW1 += arefr * wb;
+        float arp = (rp >= 0.0f) ? arpc : 0.0f;
+        float acc = arp * dT2;
+        gp[P_CFR] += acc * CFMAX;
+        gp[P_CFMAX] += acc * CFR;
+        float aTTe = arp * cc;
+        float aTf = -(arp * cc);
+        float aMW = aMW1;
+        float amelt = aMW1 - aSP2;
+        float aSP1 = aSP2;
+        minw_(mpc, SP1, wa, wb);
+        float ampc = amelt * wa;
+        aSP1 += amelt * wb;
+        float amp = (mp >= 0.0f) ? ampc : 0.0f;
+        gp[P_CFMAX] += amp * dT;
+        aTTe -= amp * CFMAX;
+        aTf += amp * CFMAX;
+        float aSP = aSP1;
+        gx[0] = aSP1 * m_snow + aRAIN * m_rain;
+        gx[1] = aTf;
+        gp[P_TT] += aTTe * mlo;
+
+        a[0] = aSP; a[1] = aMW; a[2] = aSM; a[3] = aSUZ; a[4] = aSLZ;
+    }
+};
+
+} // namespace hbvx

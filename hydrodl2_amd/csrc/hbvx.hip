@@ -1,0 +1,620 @@
+// hbvx.hip -- libhbvx.so: HIP implementation of include/hbvx.h for gfx950 (MI355X).
+//
+// Lane mapping (all kernels): one wavefront lane per (basin, ensemble member).
+// A 64-lane wave holds 64/Mp basins x Mp members, Mp = next power of two >= M,
+// so one basin's ensemble sits in Mp adjacent lanes and the ensemble mean
+// (reference hbv.py:507-511) is an intra-wave butterfly, never memory traffic.
+// The time axis is strictly serial per lane (explicit Euler recurrence).
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/hbvx.h"
+#include "hbv_step.h"
+
+using namespace hbvx;
+
+// ---------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *msg)
+{
+    snprintf(g_err, sizeof g_err, "%s", msg);
+    return code;
+}
+
+static int hip_fail(hipError_t e, const char *what)
+{
+    snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
+    return HBVX_E_DEVICE;
+}
+
+extern "C" int hbvx_version(void) { return HBVX_ABI_VERSION; }
+extern "C" const char *hbvx_last_error(void) { return g_err; }
+extern "C" const char *hbvx_backend(void) { return "hip:gfx950"; }
+extern "C" uint64_t hbvx_sizeof(int which)
+{
+    switch (which) {
+    case 0: return sizeof(hbvx_desc);
+    case 1: return sizeof(hbvx_fwd_out);
+    case 2: return sizeof(hbvx_bwd_io);
+    case 3: return sizeof(hbvx_route_desc);
+    case 4: return sizeof(hbvx_param_src);
+    case 5: return sizeof(hbvx_param_grad);
+    default: return 0;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// shared device helpers
+// ---------------------------------------------------------------------------
+template <int MODEL, bool BETAET>
+struct NParam {
+    static constexpr int value = MODEL == MODEL_HBV10 ? (BETAET ? 13 : 12)
+                               : MODEL == MODEL_HBV11P ? 14 : 16;
+};
+
+struct LaneId {
+    int jm, b, j;   // padded member index, basin (clamped), member (clamped)
+    bool active;    // lane maps to a real (basin, member)
+    bool leader;    // first lane of a real basin
+    int64_t n;      // b*M + j
+};
+
+__device__ __forceinline__ LaneId lane_id(const hbvx_desc &d, int lgMp)
+{
+    LaneId L;
+    const int lane = threadIdx.x & 63;
+    const int Mp = 1 << lgMp;
+    L.jm = lane & (Mp - 1);
+    int b = blockIdx.x * (64 >> lgMp) + (lane >> lgMp);
+    L.active = (b < d.B) && (L.jm < d.M);
+    L.leader = (b < d.B) && (L.jm == 0);
+    L.b = b < d.B ? b : d.B - 1;
+    L.j = L.jm < d.M ? L.jm : d.M - 1;
+    L.n = (int64_t)L.b * d.M + L.j;
+    return L;
+}
+
+// sum over the Mp lanes of one basin (xor butterfly; every lane gets the sum)
+__device__ __forceinline__ float ens_sum(float v, int lgMp)
+{
+    for (int s = 0; s < lgMp; s++) v += __shfl_xor(v, 1 << s, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// forward recurrence (reference hbv.py:423-511 + parameter prep hbv.py:201-256)
+// ---------------------------------------------------------------------------
+struct FwdArgs {
+    hbvx_desc d;
+    hbvx_fwd_out o;
+    int lgMp;
+};
+
+template <int MODEL, bool BETAET>
+__global__ void __launch_bounds__(64) k_fwd(const FwdArgs A)
+{
+    constexpr int NP = NParam<MODEL, BETAET>::value;
+    const hbvx_desc &d = A.d;
+    const hbvx_fwd_out &o = A.o;
+    const int lgMp = A.lgMp;
+    const LaneId L = lane_id(d, lgMp);
+    const int T = d.T;
+    const int64_t N = (int64_t)d.B * d.M;
+    const bool raw = d.raw_sigmoid != 0;
+    const float nz = d.nearzero;
+    const float ac = (MODEL == MODEL_HBV20) ? d.ac[L.b] : 0.0f;
+    const float elev = (MODEL == MODEL_HBV20) ? d.elev[L.b] : 0.0f;
+
+    float p[NPARAM_MAX];
+    const float *dynp[NP];
+    bool use_dyn[NP];
+    unsigned dmask = 0;
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        const hbvx_param_src &s = d.p[i];
+        float v = s.sta[(int64_t)L.b * s.sta_b_stride + L.j];
+        v = raw ? sigmoid_(v) : v;
+        p[i] = descale_(v, s.lo, s.hi);
+        dynp[i] = s.dyn ? s.dyn + (int64_t)L.b * s.dyn_b_stride + L.j : s.sta;
+        use_dyn[i] = s.dyn && !(s.drop && s.drop[L.b]);
+        if (s.dyn) dmask |= 1u << i;
+    }
+#pragma unroll
+    for (int i = NP; i < NPARAM_MAX; i++) p[i] = 0.0f;
+
+    float st[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) st[k] = d.state_in ? d.state_in[k * N + L.n] : 0.001f;
+
+    const float *xb = d.x + (int64_t)L.b * d.x_b_stride;
+    const float *mu = d.muwts ? d.muwts + (int64_t)L.b * d.mu_b_stride + L.j : nullptr;
+    const float invM = 1.0f / (float)d.M;
+    const int nf = o.n_flux;
+
+    // one-step-ahead register prefetch of the per-step inputs
+    float nxf[3], nxd[NP];
+    {
+        const float *xr = xb;
+        nxf[0] = T > 0 ? xr[d.ch_prcp] : 0.f;
+        nxf[1] = T > 0 ? xr[d.ch_tmean] : 0.f;
+        nxf[2] = T > 0 ? xr[d.ch_pet] : 0.f;
+#pragma unroll
+        for (int i = 0; i < NP; i++) nxd[i] = ((dmask >> i) & 1) && T > 0 ? dynp[i][0] : 0.f;
+    }
+
+    for (int t = 0; t < T; t++) {
+        Step<MODEL, BETAET> s;
+        s.P = nxf[0]; s.Tf = nxf[1]; s.PET = nxf[2];
+        float cur[NP];
+#pragma unroll
+        for (int i = 0; i < NP; i++) cur[i] = nxd[i];
+        {
+            const int tn = t + 1 < T ? t + 1 : t;
+            const float *xr = xb + (int64_t)tn * d.x_t_stride;
+            nxf[0] = xr[d.ch_prcp]; nxf[1] = xr[d.ch_tmean]; nxf[2] = xr[d.ch_pet];
+#pragma unroll
+            for (int i = 0; i < NP; i++)
+                if ((dmask >> i) & 1) nxd[i] = dynp[i][(int64_t)tn * d.p[i].dyn_t_stride];
+        }
+#pragma unroll
+        for (int i = 0; i < NP; i++)
+            if ((dmask >> i) & 1) {
+                float v = raw ? sigmoid_(cur[i]) : cur[i];
+                float pv = descale_(v, d.p[i].lo, d.p[i].hi);
+                if (use_dyn[i]) p[i] = pv;
+            }
+        s.SP = st[0]; s.MW = st[1]; s.SM = st[2]; s.SUZ = st[3]; s.SLZ = st[4];
+        s.template fwd<false>(p, nz, ac, elev, 0.f, 0.f);
+
+        if (o.traj && L.active) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) o.traj[((int64_t)k * (T + 1) + t) * N + L.n] = st[k];
+        }
+        if (o.aux && L.active) {
+            o.aux[((int64_t)0 * T + t) * N + L.n] = s.sw0;
+            o.aux[((int64_t)1 * T + t) * N + L.n] = s.ef0;
+        }
+        st[0] = s.SP3; st[1] = s.MW3; st[2] = s.SM4; st[3] = s.SUZ4; st[4] = s.SLZ2;
+
+        if (o.flux) {
+            const float act = L.active ? 1.0f : 0.0f;
+            float wq = mu ? mu[(int64_t)t * d.mu_t_stride] : 1.0f;
+            float f[HBVX_MAX_FLUX];
+            f[HBVX_F_QSIM] = (mu ? s.Q * wq : s.Q) * act;
+            f[HBVX_F_Q0] = s.Q0 * act;
+            f[HBVX_F_Q1] = s.Q1 * act;
+            f[HBVX_F_Q2] = s.Q2 * act;
+            f[HBVX_F_AET] = s.ET * act;
+            f[HBVX_F_SWE] = s.SP3 * act;
+            f[HBVX_F_RECHARGE] = s.rech * act;
+            f[HBVX_F_EXCS] = s.exc * act;
+            f[HBVX_F_EVAPFACTOR] = s.ef * act;
+            f[HBVX_F_TOSOIL] = s.tosoil * act;
+            f[HBVX_F_PERC] = s.PERC * act;
+            f[HBVX_F_CAPILLARY] = s.cap * act;
+#pragma unroll
+            for (int k = 0; k < HBVX_MAX_FLUX; k++) {
+                if (k < nf) {
+                    float v = ens_sum(f[k], lgMp);
+                    if (!(k == HBVX_F_QSIM && mu)) v = v * invM;
+                    if (L.leader) o.flux[((int64_t)k * T + t) * d.B + L.b] = v;
+                }
+            }
+        }
+    }
+    if (L.active) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            o.state_out[k * N + L.n] = st[k];
+            if (o.traj) o.traj[((int64_t)k * (T + 1) + T) * N + L.n] = st[k];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// adjoint recurrence (the autograd tape of the same lines)
+// ---------------------------------------------------------------------------
+struct BwdArgs {
+    hbvx_desc d;
+    hbvx_bwd_io io;
+    int lgMp;
+};
+
+template <int MODEL, bool BETAET>
+__global__ void __launch_bounds__(64) k_bwd(const BwdArgs A)
+{
+    constexpr int NP = NParam<MODEL, BETAET>::value;
+    const hbvx_desc &d = A.d;
+    const hbvx_bwd_io &io = A.io;
+    const int lgMp = A.lgMp;
+    const LaneId L = lane_id(d, lgMp);
+    const int T = d.T;
+    const int64_t N = (int64_t)d.B * d.M;
+    const bool raw = d.raw_sigmoid != 0;
+    const float nz = d.nearzero;
+    const float ac = (MODEL == MODEL_HBV20) ? d.ac[L.b] : 0.0f;
+    const float elev = (MODEL == MODEL_HBV20) ? d.elev[L.b] : 0.0f;
+    const int nf = io.n_flux;
+
+    float p[NPARAM_MAX], usta[NP], gsta[NP];
+    const float *dynp[NP];
+    float *gdyn[NP];
+    bool use_dyn[NP];
+    unsigned dmask = 0;
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        const hbvx_param_src &s = d.p[i];
+        float v = s.sta[(int64_t)L.b * s.sta_b_stride + L.j];
+        usta[i] = raw ? sigmoid_(v) : v;
+        p[i] = descale_(usta[i], s.lo, s.hi);
+        dynp[i] = s.dyn ? s.dyn + (int64_t)L.b * s.dyn_b_stride + L.j : s.sta;
+        gdyn[i] = io.g[i].dyn ? io.g[i].dyn + (int64_t)L.b * io.g[i].dyn_b_stride + L.j : nullptr;
+        use_dyn[i] = s.dyn && !(s.drop && s.drop[L.b]);
+        gsta[i] = 0.0f;
+        if (s.dyn) dmask |= 1u << i;
+    }
+#pragma unroll
+    for (int i = NP; i < NPARAM_MAX; i++) p[i] = 0.0f;
+
+    const float *xb = d.x + (int64_t)L.b * d.x_b_stride;
+    const float *mu = d.muwts ? d.muwts + (int64_t)L.b * d.mu_b_stride + L.j : nullptr;
+    const float invM = 1.0f / (float)d.M;
+    float a[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+
+    for (int t = T - 1; t >= 0; t--) {
+        Step<MODEL, BETAET> s;
+        const float *xr = xb + (int64_t)t * d.x_t_stride;
+        s.P = xr[d.ch_prcp]; s.Tf = xr[d.ch_tmean]; s.PET = xr[d.ch_pet];
+        s.SP = io.traj[((int64_t)0 * (T + 1) + t) * N + L.n];
+        s.MW = io.traj[((int64_t)1 * (T + 1) + t) * N + L.n];
+        s.SM = io.traj[((int64_t)2 * (T + 1) + t) * N + L.n];
+        s.SUZ = io.traj[((int64_t)3 * (T + 1) + t) * N + L.n];
+        s.SLZ = io.traj[((int64_t)4 * (T + 1) + t) * N + L.n];
+        const float sw0 = io.aux[((int64_t)0 * T + t) * N + L.n];
+        const float ef0 = io.aux[((int64_t)1 * T + t) * N + L.n];
+        float ud[NP];
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            ud[i] = usta[i];
+            if ((dmask >> i) & 1) {
+                float v = dynp[i][(int64_t)t * d.p[i].dyn_t_stride];
+                v = raw ? sigmoid_(v) : v;
+                if (use_dyn[i]) {
+                    ud[i] = v;
+                    p[i] = descale_(v, d.p[i].lo, d.p[i].hi);
+                }
+            }
+        }
+        s.template fwd<true>(p, nz, ac, elev, sw0, ef0);
+
+        FluxGrad g;
+        const float *gf = io.grad_flux + (int64_t)t * d.B + L.b;
+        const int64_t fs = (int64_t)T * d.B;
+        const float gq = gf[HBVX_F_QSIM * fs];
+        const float wq = mu ? mu[(int64_t)t * d.mu_t_stride] : invM;
+        g.gQ = gq * wq;
+        g.gQ0 = gf[HBVX_F_Q0 * fs] * invM;
+        g.gQ1 = gf[HBVX_F_Q1 * fs] * invM;
+        g.gQ2 = gf[HBVX_F_Q2 * fs] * invM;
+        g.gET = gf[HBVX_F_AET * fs] * invM;
+        g.gSWE = gf[HBVX_F_SWE * fs] * invM;
+        g.grech = gf[HBVX_F_RECHARGE * fs] * invM;
+        g.gexc = gf[HBVX_F_EXCS * fs] * invM;
+        g.gef = gf[HBVX_F_EVAPFACTOR * fs] * invM;
+        g.gtosoil = gf[HBVX_F_TOSOIL * fs] * invM;
+        g.gPERC = gf[HBVX_F_PERC * fs] * invM;
+        g.gcap = (nf > HBVX_F_CAPILLARY) ? gf[HBVX_F_CAPILLARY * fs] * invM : 0.0f;
+        if (io.grad_muwts && L.active) io.grad_muwts[((int64_t)t * d.B + L.b) * d.M + L.j] = gq * s.Q;
+
+        float gp[NPARAM_MAX], gx[3];
+#pragma unroll
+        for (int i = 0; i < NPARAM_MAX; i++) gp[i] = 0.0f;
+        s.bwd(p, nz, g, a, gp, gx);
+
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            float gu = gp[i] * (d.p[i].hi - d.p[i].lo);
+            if ((dmask >> i) & 1) {
+                float gr = raw ? gu * (ud[i] * (1.0f - ud[i])) : gu;
+                if (gdyn[i] && L.active)
+                    gdyn[i][(int64_t)t * io.g[i].dyn_t_stride] = use_dyn[i] ? gr : 0.0f;
+                gsta[i] += use_dyn[i] ? 0.0f : gu;
+            } else {
+                gsta[i] += gu;
+            }
+        }
+        if (io.grad_x) {
+            const float act = L.active ? 1.0f : 0.0f;
+            float g0 = ens_sum(gx[0] * act, lgMp), g1 = ens_sum(gx[1] * act, lgMp),
+                  g2 = ens_sum(gx[2] * act, lgMp);
+            if (L.leader) {
+                float *gr = io.grad_x + (int64_t)t * d.x_t_stride + (int64_t)L.b * d.x_b_stride;
+                gr[d.ch_prcp] = g0; gr[d.ch_tmean] = g1; gr[d.ch_pet] = g2;
+            }
+        }
+    }
+    if (L.active) {
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            if (!io.g[i].sta) continue;
+            float gr = raw ? gsta[i] * (usta[i] * (1.0f - usta[i])) : gsta[i];
+            float *dst = io.g[i].sta + (int64_t)L.b * io.g[i].sta_b_stride + L.j;
+            *dst += gr;
+        }
+        if (io.grad_state_in) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) io.grad_state_in[k * N + L.n] = a[k];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// unit-hydrograph routing (reference core/calc/uh_routing.py:5-57)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void route_ab(const hbvx_route_desc &r, int b, float &ua, float &ub,
+                                         float &a, float &bb)
+{
+    float va = r.ra[(int64_t)b * r.r_stride], vb = r.rb[(int64_t)b * r.r_stride];
+    ua = r.raw_sigmoid ? sigmoid_(va) : va;
+    ub = r.raw_sigmoid ? sigmoid_(vb) : vb;
+    a = descale_(ua, r.a_lo, r.a_hi);
+    bb = descale_(ub, r.b_lo, r.b_hi);
+}
+
+// uh_gamma (uh_routing.py:5-22): one thread per basin
+__global__ void k_uh_gamma(const hbvx_route_desc r, float *__restrict__ uh)
+{
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= r.B) return;
+    float ua, ub, a, bb;
+    route_ab(r, b, ua, ub, a, bb);
+    float aa = fmaxf(a, 0.0f) + 0.1f;
+    float theta = fmaxf(bb, 0.0f) + 0.5f;
+    float denom = expf(lgammaf(aa)) * powf(theta, aa);
+    float w[HBVX_UH_MAXLEN];
+    float sum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < HBVX_UH_MAXLEN; k++) {
+        float t = (float)k + 0.5f;
+        float mid = powf(t, aa - 1.0f);
+        float right = expf(-t / theta);
+        w[k] = (k < r.L) ? 1.0f / denom * mid * right : 0.0f;
+        sum += w[k];
+    }
+#pragma unroll
+    for (int k = 0; k < HBVX_UH_MAXLEN; k++)
+        if (k < r.L) uh[(int64_t)b * r.L + k] = w[k] / sum;
+}
+
+// uh_conv (uh_routing.py:25-57): y[s,t,b] = sum_k UH[b,k] * q[s,t-k,b]; thread per (s,t,b)
+__global__ void k_route_fwd(int T, int B, int S, int L, const float *__restrict__ q,
+                            const float *__restrict__ uh, float *__restrict__ y)
+{
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t total = (int64_t)S * T * B;
+    if (idx >= total) return;
+    int b = (int)(idx % B);
+    int t = (int)((idx / B) % T);
+    const float *w = uh + (int64_t)b * L;
+    float acc = 0.0f;
+    for (int k = 0; k < L && k <= t; k++) acc += w[k] * q[idx - (int64_t)k * B];
+    y[idx] = acc;
+}
+
+// conv backward w.r.t. the input: gq[s,t,b] = sum_k UH[b,k] * gy[s,t+k,b]
+__global__ void k_route_bwd_q(int T, int B, int S, int L, const float *__restrict__ gy,
+                              const float *__restrict__ uh, float *__restrict__ gq)
+{
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t total = (int64_t)S * T * B;
+    if (idx >= total) return;
+    int b = (int)(idx % B);
+    int t = (int)((idx / B) % T);
+    const float *w = uh + (int64_t)b * L;
+    float acc = 0.0f;
+    for (int k = 0; k < L && t + k < T; k++) acc += w[k] * gy[idx + (int64_t)k * B];
+    gq[idx] = acc;
+}
+
+// conv backward w.r.t. the taps, then through the normalised gamma UH to the
+// routing inputs.  Block = 32 basins x 8 time slices; LDS tree over the slices.
+// d w_k / d aa    = w_k (ln t_k - sum_j w_j ln t_j)      (Gamma(aa) and theta^aa cancel
+// d w_k / d theta = w_k (t_k - sum_j w_j t_j) / theta^2    in the normalisation)
+__global__ void __launch_bounds__(256) k_route_bwd_uh(const hbvx_route_desc r,
+                                                      const float *__restrict__ q,
+                                                      const float *__restrict__ uh,
+                                                      const float *__restrict__ gy,
+                                                      float *grad_ra, float *grad_rb)
+{
+    __shared__ float red[8][HBVX_UH_MAXLEN][33];
+    const int bl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int b = blockIdx.x * 32 + bl;
+    const int T = r.T, B = r.B, L = r.L;
+    float gw[HBVX_UH_MAXLEN];
+#pragma unroll
+    for (int k = 0; k < HBVX_UH_MAXLEN; k++) gw[k] = 0.0f;
+    if (b < B) {
+        for (int s = 0; s < r.S; s++)
+            for (int t = sl; t < T; t += 8) {
+                const int64_t base = ((int64_t)s * T + t) * B + b;
+                const float g = gy[base];
+#pragma unroll
+                for (int k = 0; k < HBVX_UH_MAXLEN; k++)
+                    if (k < L && k <= t) gw[k] += g * q[base - (int64_t)k * B];
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < HBVX_UH_MAXLEN; k++) red[sl][k][bl] = gw[k];
+    __syncthreads();
+    if (sl == 0 && b < B) {
+        float ua, ub, a, bb;
+        route_ab(r, b, ua, ub, a, bb);
+        const float theta = fmaxf(bb, 0.0f) + 0.5f;
+        float w[HBVX_UH_MAXLEN];
+        float mlt = 0.0f, mt = 0.0f;
+#pragma unroll
+        for (int k = 0; k < HBVX_UH_MAXLEN; k++) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int s2 = 0; s2 < 8; s2++) acc += red[s2][k][bl];
+            gw[k] = acc;
+            w[k] = (k < L) ? uh[(int64_t)b * L + k] : 0.0f;
+            const float tk = (float)k + 0.5f;
+            mlt += w[k] * logf(tk);
+            mt += w[k] * tk;
+        }
+        float gaa = 0.0f, gth = 0.0f;
+#pragma unroll
+        for (int k = 0; k < HBVX_UH_MAXLEN; k++) {
+            const float tk = (float)k + 0.5f;
+            gaa += gw[k] * w[k] * (logf(tk) - mlt);
+            gth += gw[k] * w[k] * ((tk - mt) / (theta * theta));
+        }
+        float ga = (a > 0.0f) ? gaa : 0.0f;   // relu backward (uh_routing.py:11-14)
+        float gb = (bb > 0.0f) ? gth : 0.0f;
+        float gua = ga * (r.a_hi - r.a_lo), gub = gb * (r.b_hi - r.b_lo);
+        if (r.raw_sigmoid) {
+            gua *= ua * (1.0f - ua);
+            gub *= ub * (1.0f - ub);
+        }
+        if (grad_ra) grad_ra[(int64_t)b * r.r_stride] += gua;
+        if (grad_rb) grad_rb[(int64_t)b * r.r_stride] += gub;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host side of the C ABI
+// ---------------------------------------------------------------------------
+static int check_desc(const hbvx_desc *d)
+{
+    if (!d) return fail(HBVX_E_NULL, "desc is NULL");
+    if (d->abi_version != HBVX_ABI_VERSION) return fail(HBVX_E_ABI, "abi_version mismatch");
+    if (d->T < 0 || d->B <= 0 || d->M <= 0 || d->M > 64) return fail(HBVX_E_SHAPE, "bad T/B/M");
+    bool ok = false;
+    if (d->model == HBVX_MODEL_HBV10) ok = (d->n_param == 12 || d->n_param == 13);
+    else if (d->model == HBVX_MODEL_HBV11P) ok = (d->n_param == 14);
+    else if (d->model == HBVX_MODEL_HBV20) ok = (d->n_param == 16);
+    else return fail(HBVX_E_UNSUPPORTED, "unknown model");
+    if (!ok) return fail(HBVX_E_SHAPE, "n_param does not match model");
+    if (!d->x) return fail(HBVX_E_NULL, "forcing pointer is NULL");
+    if (d->ch_prcp < 0 || d->ch_tmean < 0 || d->ch_pet < 0)
+        return fail(HBVX_E_SHAPE, "negative forcing channel");
+    if (d->model == HBVX_MODEL_HBV20 && (!d->ac || !d->elev))
+        return fail(HBVX_E_NULL, "HBV 2.0 needs ac and elev");
+    for (int i = 0; i < d->n_param; i++)
+        if (!d->p[i].sta) return fail(HBVX_E_NULL, "static parameter pointer is NULL");
+    return HBVX_OK;
+}
+
+static int lg_members(int M)
+{
+    int lg = 0;
+    while ((1 << lg) < M) lg++;
+    return lg;
+}
+
+template <typename Args, typename K0, typename K1, typename K2, typename K3>
+static hipError_t launch_variant(const hbvx_desc *d, const Args &a, dim3 grid, hipStream_t st,
+                                 K0 k0, K1 k1, K2 k2, K3 k3)
+{
+    if (d->model == HBVX_MODEL_HBV10 && d->n_param == 12) hipLaunchKernelGGL(k0, grid, dim3(64), 0, st, a);
+    else if (d->model == HBVX_MODEL_HBV10) hipLaunchKernelGGL(k1, grid, dim3(64), 0, st, a);
+    else if (d->model == HBVX_MODEL_HBV11P) hipLaunchKernelGGL(k2, grid, dim3(64), 0, st, a);
+    else hipLaunchKernelGGL(k3, grid, dim3(64), 0, st, a);
+    return hipGetLastError();
+}
+
+extern "C" int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream)
+{
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!out || !out->state_out) return fail(HBVX_E_NULL, "state_out is NULL");
+    const int want_nf = (d->model == HBVX_MODEL_HBV10) ? 11 : 12;
+    if (out->flux && out->n_flux != want_nf) return fail(HBVX_E_SHAPE, "n_flux does not match model");
+    FwdArgs a;
+    a.d = *d;
+    a.o = *out;
+    a.lgMp = lg_members(d->M);
+    const int bpw = 64 >> a.lgMp;
+    dim3 grid((d->B + bpw - 1) / bpw);
+    hipError_t e = launch_variant(d, a, grid, (hipStream_t)stream,
+                                  k_fwd<MODEL_HBV10, false>, k_fwd<MODEL_HBV10, true>,
+                                  k_fwd<MODEL_HBV11P, true>, k_fwd<MODEL_HBV20, true>);
+    if (e != hipSuccess) return hip_fail(e, "hbvx_forward launch");
+    return HBVX_OK;
+}
+
+extern "C" int hbvx_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *stream)
+{
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!io || !io->traj || !io->aux || !io->grad_flux)
+        return fail(HBVX_E_NULL, "traj/aux/grad_flux is NULL");
+    const int want_nf = (d->model == HBVX_MODEL_HBV10) ? 11 : 12;
+    if (io->n_flux != want_nf) return fail(HBVX_E_SHAPE, "n_flux does not match model");
+    if (d->T == 0) return HBVX_OK;
+    BwdArgs a;
+    a.d = *d;
+    a.io = *io;
+    a.lgMp = lg_members(d->M);
+    const int bpw = 64 >> a.lgMp;
+    dim3 grid((d->B + bpw - 1) / bpw);
+    hipError_t e = launch_variant(d, a, grid, (hipStream_t)stream,
+                                  k_bwd<MODEL_HBV10, false>, k_bwd<MODEL_HBV10, true>,
+                                  k_bwd<MODEL_HBV11P, true>, k_bwd<MODEL_HBV20, true>);
+    if (e != hipSuccess) return hip_fail(e, "hbvx_backward launch");
+    return HBVX_OK;
+}
+
+static int check_route(const hbvx_route_desc *r)
+{
+    if (!r) return fail(HBVX_E_NULL, "route desc is NULL");
+    if (r->abi_version != HBVX_ABI_VERSION) return fail(HBVX_E_ABI, "abi_version mismatch");
+    if (r->T <= 0 || r->B <= 0 || r->S <= 0) return fail(HBVX_E_SHAPE, "bad T/B/S");
+    const int L = r->T < HBVX_UH_MAXLEN ? r->T : HBVX_UH_MAXLEN;
+    if (r->L != L) return fail(HBVX_E_SHAPE, "L must be min(T, 15)");
+    if (!r->ra || !r->rb) return fail(HBVX_E_NULL, "routing parameter pointer is NULL");
+    return HBVX_OK;
+}
+
+extern "C" int hbvx_route_forward(const hbvx_route_desc *r, const float *q, float *uh,
+                                  float *q_rout, void *stream)
+{
+    int rc = check_route(r);
+    if (rc) return rc;
+    if (!q || !uh || !q_rout) return fail(HBVX_E_NULL, "route buffer is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_uh_gamma, dim3((r->B + 63) / 64), dim3(64), 0, st, *r, uh);
+    const int64_t total = (int64_t)r->S * r->T * r->B;
+    hipLaunchKernelGGL(k_route_fwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, r->T,
+                       r->B, r->S, r->L, q, uh, q_rout);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "hbvx_route_forward launch");
+    return HBVX_OK;
+}
+
+extern "C" int hbvx_route_backward(const hbvx_route_desc *r, const float *q, const float *uh,
+                                   const float *grad_q_rout, float *grad_q, float *grad_ra,
+                                   float *grad_rb, void *stream)
+{
+    int rc = check_route(r);
+    if (rc) return rc;
+    if (!q || !uh || !grad_q_rout || !grad_q) return fail(HBVX_E_NULL, "route buffer is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t total = (int64_t)r->S * r->T * r->B;
+    hipLaunchKernelGGL(k_route_bwd_q, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       r->T, r->B, r->S, r->L, grad_q_rout, uh, grad_q);
+    if (grad_ra || grad_rb)
+        hipLaunchKernelGGL(k_route_bwd_uh, dim3((r->B + 31) / 32), dim3(256), 0, st, *r, q, uh,
+                           grad_q_rout, grad_ra, grad_rb);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "hbvx_route_backward launch");
+    return HBVX_OK;
+}

@@ -69,6 +69,22 @@ class StepConfig:
     want_traj: bool = False    # keep the state trajectory even without autograd
 
 
+# bench.py sets this to a list to collect (abi_call, start_event, end_event) per launch,
+# recorded on the stream the kernels are enqueued on.
+KERNEL_EVENTS = None
+
+
+def _call(lib, name, fn, *args):
+    if KERNEL_EVENTS is None or not lib.is_device:
+        return fn(*args)
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn(*args)
+    e1.record()
+    KERNEL_EVENTS.append((name, e0, e1))
+
+
 def _ptr(t: Optional[torch.Tensor], off: int = 0) -> Optional[int]:
     if t is None:
         return None
@@ -174,14 +190,14 @@ class HbvPath(torch.autograd.Function):
         out.traj, out.aux = _ptr(traj), _ptr(aux)
         out.n_flux = cfg.n_flux
         desc = _fill_desc(cfg, x, state_in, muwts, ac, elev, ptensors)
-        lib.forward(desc, out, stream)
+        _call(lib, 'hbvx_forward', lib.forward, desc, out, stream)
 
         routed = uh = None
         if cfg.route is not None and cfg.want_flux:
             r = _route_desc(cfg, ptensors)
             routed = torch.empty((4, T, B), dtype=torch.float32, device=dev)
             uh = torch.empty((B, r.L), dtype=torch.float32, device=dev)
-            lib.route_forward(r, _ptr(flux), _ptr(uh), _ptr(routed), stream)
+            _call(lib, 'hbvx_route_forward', lib.route_forward, r, _ptr(flux), _ptr(uh), _ptr(routed), stream)
 
         ctx.cfg = cfg
         ctx.n_ptensors = len(ptensors)
@@ -217,8 +233,9 @@ class HbvPath(torch.autograd.Function):
             gq = torch.empty((4, T, B), dtype=torch.float32, device=dev)
             rs = cfg.route
             gt = gp[rs.tensor_idx]
-            lib.route_backward(r, _ptr(flux), _ptr(uh), _ptr(g_routed.contiguous()), _ptr(gq),
-                               _ptr(gt, rs.a_off), _ptr(gt, rs.b_off), stream)
+            _call(lib, 'hbvx_route_backward', lib.route_backward, r, _ptr(flux), _ptr(uh),
+                  _ptr(g_routed.contiguous()), _ptr(gq), _ptr(gt, rs.a_off), _ptr(gt, rs.b_off),
+                  stream)
             g_flux[0:4] += gq
 
         io = _abi.BwdIO()
@@ -243,6 +260,6 @@ class HbvPath(torch.autograd.Function):
                 g.dyn = _ptr(gp[ps.dyn_tensor_idx], ps.dyn_off)
                 g.dyn_t_stride, g.dyn_b_stride = ps.dyn_ts, ps.dyn_bs
         desc = _fill_desc(cfg, x, state_in, muwts, ac, elev, ptensors)
-        lib.backward(desc, io, stream)
+        _call(lib, 'hbvx_backward', lib.backward, desc, io, stream)
 
         return (None, gx, None, gmu, None, None, *gp)

@@ -1,0 +1,116 @@
+"""Drive HbvPath (recurrence only or with routing) with synthetic inputs under a chosen
+implementation of the ABI; used to compare implementations on identical descriptors."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from hydrodl2_amd import _abi, _lib
+from hydrodl2_amd.ops import HbvPath, ParamSource, RouteSource, StepConfig
+
+from . import synth
+from .golden_cases import PHY_NAMES
+
+BOUNDS = {
+    'parBETA': [1.0, 6.0], 'parFC': [50, 1000], 'parK0': [0.05, 0.9], 'parK1': [0.01, 0.5],
+    'parK2': [0.001, 0.2], 'parLP': [0.2, 1], 'parPERC': [0, 10], 'parUZL': [0, 100],
+    'parTT': [-2.5, 2.5], 'parCFMAX': [0.5, 10], 'parCFR': [0, 0.1], 'parCWH': [0, 0.2],
+    'parBETAET': [0.3, 5], 'parC': [0, 1], 'parRT': [0, 20], 'parAC': [0, 2500],
+}
+MODEL_ID = {"Hbv": _abi.MODEL_HBV10, "Hbv_1_1p": _abi.MODEL_HBV11P, "Hbv_2": _abi.MODEL_HBV20}
+
+
+def make_problem(model="Hbv", T=40, B=5, M=4, dyn=(), betaet=False, drop_frac=0.0, seed=1,
+                 routing=True, muwts=False, cold=False, raw_scale=1.0):
+    """numpy inputs + a builder of (cfg, tensors) for a raw [T,B,ny] parameter tensor."""
+    names = list(PHY_NAMES[model])
+    if model == "Hbv" and (betaet or "parBETAET" in dyn):
+        names.append("parBETAET")
+    n = len(names)
+    ny = n * M + 2
+    prob = dict(model=model, T=T, B=B, M=M, names=names, n=n, ny=ny, dyn=list(dyn),
+                routing=routing)
+    prob["x"] = synth.forcing(T, B, seed, cold=cold)
+    prob["params"] = synth.raw_parameters(T, B, ny, seed, raw_scale)
+    prob["gflux"] = synth.loss_weights((12 if model != "Hbv" else 11, T, B), seed, 40)
+    prob["grouted"] = synth.loss_weights((4, T, B), seed, 41)
+    if model == "Hbv_2":
+        prob["ac"] = (synth.uniform((B,), seed, 7) * np.float32(5000.0)).astype(np.float32)
+        prob["elev"] = (synth.uniform((B,), seed, 8) * np.float32(3000.0)).astype(np.float32)
+    if muwts:
+        u = synth.uniform((T, B, M), seed, 9).astype(np.float64) + 0.25
+        prob["muwts"] = (u / u.sum(-1, keepdims=True)).astype(np.float32)
+    if drop_frac > 0:
+        prob["drop"] = (synth.uniform((len(dyn), B), seed, 12) < drop_frac).astype(np.uint8)
+    return prob
+
+
+def run_problem(prob, lib_path, device="cpu", x_grad=False, backward=True, t0=0):
+    """Run forward (+backward with fixed output gradients) under `lib_path` (None = product)."""
+    _lib._use_library_for_testing(lib_path)
+    try:
+        dev = torch.device(device)
+        T, B, M, n, ny = prob["T"], prob["B"], prob["M"], prob["n"], prob["ny"]
+        x = torch.from_numpy(prob["x"]).to(dev)
+        if x_grad:
+            x.requires_grad_(True)
+        p = torch.from_numpy(prob["params"]).to(dev).requires_grad_(backward)
+        mu = torch.from_numpy(prob["muwts"]).to(dev) if "muwts" in prob else None
+        if mu is not None and backward:
+            mu.requires_grad_(True)
+        ac = torch.from_numpy(prob["ac"]).to(dev) if "ac" in prob else None
+        elev = torch.from_numpy(prob["elev"]).to(dev) if "elev" in prob else None
+        srcs = []
+        Tc = T - t0
+        for i, name in enumerate(prob["names"]):
+            lo, hi = BOUNDS[name]
+            ps = ParamSource(slot=_abi.PARAM_SLOTS.index(name), lo=float(lo), hi=float(hi),
+                             tensor_idx=0, sta_off=(T - 1) * B * ny + i * M, sta_bs=ny)
+            if name in prob["dyn"]:
+                ps.dyn_tensor_idx, ps.dyn_off = 0, t0 * B * ny + i * M
+                ps.dyn_ts, ps.dyn_bs = B * ny, ny
+                if "drop" in prob:
+                    ps.drop = torch.from_numpy(prob["drop"][prob["dyn"].index(name)]).to(dev)
+            srcs.append(ps)
+        nf = 11 if prob["model"] == "Hbv" else 12
+        cfg = StepConfig(model=MODEL_ID[prob["model"]], n_param=n, n_flux=nf, T=Tc, t0=t0, B=B,
+                         M=M, raw_sigmoid=True, channels=(0, 1, 2), nearzero=1e-5, params=srcs)
+        if prob["routing"]:
+            off = (T - 1) * B * ny + n * M
+            cfg.route = RouteSource(0, off, off + 1, ny, [0, 2.9], [0, 6.5])
+        flux, routed, state_out, traj = HbvPath.apply(cfg, x, None, mu, ac, elev, p)
+        res = {"flux": flux.detach().cpu().numpy(), "state_out": state_out.cpu().numpy()}
+        if routed is not None:
+            res["routed"] = routed.detach().cpu().numpy()
+        if traj is not None:
+            res["traj"] = traj.cpu().numpy()
+        if backward:
+            gf = torch.from_numpy(prob["gflux"][:, t0:]).to(dev)
+            loss = (flux * gf).sum()
+            if routed is not None:
+                loss = loss + (routed * torch.from_numpy(prob["grouted"][:, t0:]).to(dev)).sum()
+            loss.backward()
+            res["g_params"] = p.grad.cpu().numpy()
+            if x_grad:
+                res["g_x"] = x.grad.cpu().numpy()
+            if mu is not None:
+                res["g_muwts"] = mu.grad.cpu().numpy()
+        return res
+    finally:
+        _lib._use_library_for_testing(None)
+
+
+def assert_close(name, a, b, rtol, atol_rel):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, f"{name}: {a.shape} vs {b.shape}"
+    if a.size == 0:
+        return
+    scale = max(float(np.abs(b).max()), 1e-30)
+    tol = atol_rel * scale + rtol * np.abs(b)
+    err = np.abs(a - b)
+    bad = err > tol
+    if bad.any():
+        i = np.unravel_index(np.argmax(err - tol), err.shape)
+        raise AssertionError(f"{name}: {int(bad.sum())}/{a.size} outside tol (rtol {rtol}, "
+                             f"atol {atol_rel}*{scale:.3g}); worst at {i}: {a[i]!r} vs {b[i]!r}")

@@ -1,0 +1,196 @@
+// hbvx_host.cpp -- TEST HARNESS: runs the product's device math (hydrodl2_amd/csrc/hbv_step.h)
+// on the host behind the same C ABI, so the re-typed step/adjoint can be checked against the
+// golden fixtures without a GPU.  Lives under tests/, is built only by
+// tests/test_step_math_host.py and is never shipped or loaded by the package.  Routing is not
+// part of hbv_step.h and is not provided here.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/hbvx.h"
+#include "../../hydrodl2_amd/csrc/hbv_step.h"
+
+using namespace hbvx;
+
+static thread_local char g_err[256] = "";
+extern "C" int hbvx_version(void) { return HBVX_ABI_VERSION; }
+extern "C" const char *hbvx_last_error(void) { return g_err; }
+extern "C" const char *hbvx_backend(void) { return "cpu-steptest"; }
+extern "C" uint64_t hbvx_sizeof(int w)
+{
+    switch (w) {
+    case 0: return sizeof(hbvx_desc);
+    case 1: return sizeof(hbvx_fwd_out);
+    case 2: return sizeof(hbvx_bwd_io);
+    case 3: return sizeof(hbvx_route_desc);
+    case 4: return sizeof(hbvx_param_src);
+    case 5: return sizeof(hbvx_param_grad);
+    }
+    return 0;
+}
+
+template <int MODEL, bool BETAET>
+static void run_fwd(const hbvx_desc &d, const hbvx_fwd_out &o)
+{
+    const int T = d.T, B = d.B, M = d.M, NP = d.n_param;
+    const int64_t N = (int64_t)B * M;
+    std::vector<float> acc;
+    for (int b = 0; b < B; b++) {
+        if (o.flux) acc.assign((size_t)T * o.n_flux, 0.0f);
+        for (int j = 0; j < M; j++) {
+            const int64_t n = (int64_t)b * M + j;
+            float st[5], p[NPARAM_MAX] = {0};
+            for (int k = 0; k < 5; k++) st[k] = d.state_in ? d.state_in[k * N + n] : 0.001f;
+            for (int t = 0; t < T; t++) {
+                for (int i = 0; i < NP; i++) {
+                    const hbvx_param_src &s = d.p[i];
+                    bool ud = s.dyn && !(s.drop && s.drop[b]);
+                    float v = ud ? s.dyn[(int64_t)t * s.dyn_t_stride + (int64_t)b * s.dyn_b_stride + j]
+                                 : s.sta[(int64_t)b * s.sta_b_stride + j];
+                    v = d.raw_sigmoid ? sigmoid_(v) : v;
+                    p[i] = descale_(v, s.lo, s.hi);
+                }
+                Step<MODEL, BETAET> s;
+                const float *xr = d.x + (int64_t)t * d.x_t_stride + (int64_t)b * d.x_b_stride;
+                s.P = xr[d.ch_prcp]; s.Tf = xr[d.ch_tmean]; s.PET = xr[d.ch_pet];
+                s.SP = st[0]; s.MW = st[1]; s.SM = st[2]; s.SUZ = st[3]; s.SLZ = st[4];
+                s.template fwd<false>(p, d.nearzero, d.ac ? d.ac[b] : 0.f, d.elev ? d.elev[b] : 0.f,
+                                      0.f, 0.f);
+                if (o.traj)
+                    for (int k = 0; k < 5; k++) o.traj[((int64_t)k * (T + 1) + t) * N + n] = st[k];
+                if (o.aux) {
+                    o.aux[((int64_t)0 * T + t) * N + n] = s.sw0;
+                    o.aux[((int64_t)1 * T + t) * N + n] = s.ef0;
+                }
+                st[0] = s.SP3; st[1] = s.MW3; st[2] = s.SM4; st[3] = s.SUZ4; st[4] = s.SLZ2;
+                if (o.flux) {
+                    float *a = &acc[(size_t)t * o.n_flux];
+                    float wq = d.muwts ? d.muwts[(int64_t)t * d.mu_t_stride + (int64_t)b * d.mu_b_stride + j] : 1.f;
+                    a[HBVX_F_QSIM] += d.muwts ? s.Q * wq : s.Q;
+                    a[HBVX_F_Q0] += s.Q0; a[HBVX_F_Q1] += s.Q1; a[HBVX_F_Q2] += s.Q2;
+                    a[HBVX_F_AET] += s.ET; a[HBVX_F_SWE] += s.SP3; a[HBVX_F_RECHARGE] += s.rech;
+                    a[HBVX_F_EXCS] += s.exc; a[HBVX_F_EVAPFACTOR] += s.ef; a[HBVX_F_TOSOIL] += s.tosoil;
+                    a[HBVX_F_PERC] += s.PERC;
+                    if (o.n_flux > HBVX_F_CAPILLARY) a[HBVX_F_CAPILLARY] += s.cap;
+                }
+            }
+            for (int k = 0; k < 5; k++) {
+                o.state_out[k * N + n] = st[k];
+                if (o.traj) o.traj[((int64_t)k * (T + 1) + T) * N + n] = st[k];
+            }
+        }
+        if (o.flux)
+            for (int t = 0; t < T; t++)
+                for (int k = 0; k < o.n_flux; k++) {
+                    float v = acc[(size_t)t * o.n_flux + k];
+                    if (!(k == HBVX_F_QSIM && d.muwts)) v = v * (1.0f / (float)M);
+                    o.flux[((int64_t)k * T + t) * B + b] = v;
+                }
+    }
+}
+
+template <int MODEL, bool BETAET>
+static void run_bwd(const hbvx_desc &d, const hbvx_bwd_io &io)
+{
+    const int T = d.T, B = d.B, M = d.M, NP = d.n_param, nf = io.n_flux;
+    const int64_t N = (int64_t)B * M;
+    const float invM = 1.0f / (float)M;
+    const int64_t fs = (int64_t)T * B;
+    std::vector<float> gxa;
+    for (int b = 0; b < B; b++) {
+        if (io.grad_x) gxa.assign((size_t)T * 3, 0.f);
+        for (int j = 0; j < M; j++) {
+            const int64_t n = (int64_t)b * M + j;
+            float a[5] = {0, 0, 0, 0, 0}, gsta[NPARAM_MAX] = {0}, usta[NPARAM_MAX] = {0};
+            for (int t = T - 1; t >= 0; t--) {
+                float p[NPARAM_MAX] = {0}, u[NPARAM_MAX] = {0};
+                bool ud[NPARAM_MAX] = {false};
+                for (int i = 0; i < NP; i++) {
+                    const hbvx_param_src &s = d.p[i];
+                    ud[i] = s.dyn && !(s.drop && s.drop[b]);
+                    float v = ud[i] ? s.dyn[(int64_t)t * s.dyn_t_stride + (int64_t)b * s.dyn_b_stride + j]
+                                    : s.sta[(int64_t)b * s.sta_b_stride + j];
+                    u[i] = d.raw_sigmoid ? sigmoid_(v) : v;
+                    p[i] = descale_(u[i], s.lo, s.hi);
+                }
+                Step<MODEL, BETAET> s;
+                const float *xr = d.x + (int64_t)t * d.x_t_stride + (int64_t)b * d.x_b_stride;
+                s.P = xr[d.ch_prcp]; s.Tf = xr[d.ch_tmean]; s.PET = xr[d.ch_pet];
+                s.SP = io.traj[((int64_t)0 * (T + 1) + t) * N + n];
+                s.MW = io.traj[((int64_t)1 * (T + 1) + t) * N + n];
+                s.SM = io.traj[((int64_t)2 * (T + 1) + t) * N + n];
+                s.SUZ = io.traj[((int64_t)3 * (T + 1) + t) * N + n];
+                s.SLZ = io.traj[((int64_t)4 * (T + 1) + t) * N + n];
+                s.template fwd<true>(p, d.nearzero, d.ac ? d.ac[b] : 0.f, d.elev ? d.elev[b] : 0.f,
+                                     io.aux[((int64_t)0 * T + t) * N + n],
+                                     io.aux[((int64_t)1 * T + t) * N + n]);
+                const float *gf = io.grad_flux + (int64_t)t * B + b;
+                FluxGrad g;
+                float wq = d.muwts ? d.muwts[(int64_t)t * d.mu_t_stride + (int64_t)b * d.mu_b_stride + j] : invM;
+                g.gQ = gf[HBVX_F_QSIM * fs] * wq;
+                g.gQ0 = gf[HBVX_F_Q0 * fs] * invM; g.gQ1 = gf[HBVX_F_Q1 * fs] * invM;
+                g.gQ2 = gf[HBVX_F_Q2 * fs] * invM; g.gET = gf[HBVX_F_AET * fs] * invM;
+                g.gSWE = gf[HBVX_F_SWE * fs] * invM; g.grech = gf[HBVX_F_RECHARGE * fs] * invM;
+                g.gexc = gf[HBVX_F_EXCS * fs] * invM; g.gef = gf[HBVX_F_EVAPFACTOR * fs] * invM;
+                g.gtosoil = gf[HBVX_F_TOSOIL * fs] * invM; g.gPERC = gf[HBVX_F_PERC * fs] * invM;
+                g.gcap = nf > HBVX_F_CAPILLARY ? gf[HBVX_F_CAPILLARY * fs] * invM : 0.f;
+                if (io.grad_muwts) io.grad_muwts[((int64_t)t * B + b) * M + j] = gf[HBVX_F_QSIM * fs] * s.Q;
+                float gp[NPARAM_MAX] = {0}, gx[3];
+                s.bwd(p, d.nearzero, g, a, gp, gx);
+                if (io.grad_x) { gxa[t * 3] += gx[0]; gxa[t * 3 + 1] += gx[1]; gxa[t * 3 + 2] += gx[2]; }
+                for (int i = 0; i < NP; i++) {
+                    float gu = gp[i] * (d.p[i].hi - d.p[i].lo);
+                    if (d.p[i].dyn) {
+                        float gr = d.raw_sigmoid ? gu * (u[i] * (1.0f - u[i])) : gu;
+                        if (io.g[i].dyn)
+                            io.g[i].dyn[(int64_t)t * io.g[i].dyn_t_stride + (int64_t)b * io.g[i].dyn_b_stride + j] =
+                                ud[i] ? gr : 0.0f;
+                        if (!ud[i]) { gsta[i] += gu; usta[i] = u[i]; }
+                    } else {
+                        gsta[i] += gu; usta[i] = u[i];
+                    }
+                }
+            }
+            for (int i = 0; i < NP; i++) {
+                if (!io.g[i].sta) continue;
+                float gr = d.raw_sigmoid ? gsta[i] * (usta[i] * (1.0f - usta[i])) : gsta[i];
+                io.g[i].sta[(int64_t)b * io.g[i].sta_b_stride + j] += gr;
+            }
+            if (io.grad_state_in) for (int k = 0; k < 5; k++) io.grad_state_in[k * N + n] = a[k];
+        }
+        if (io.grad_x)
+            for (int t = 0; t < T; t++) {
+                float *gr = io.grad_x + (int64_t)t * d.x_t_stride + (int64_t)b * d.x_b_stride;
+                gr[d.ch_prcp] = gxa[t * 3]; gr[d.ch_tmean] = gxa[t * 3 + 1]; gr[d.ch_pet] = gxa[t * 3 + 2];
+            }
+    }
+}
+
+#define DISPATCH(fn, ...)                                                                       \
+    if (d->model == HBVX_MODEL_HBV10 && d->n_param == 12) fn<MODEL_HBV10, false>(__VA_ARGS__);   \
+    else if (d->model == HBVX_MODEL_HBV10) fn<MODEL_HBV10, true>(__VA_ARGS__);                  \
+    else if (d->model == HBVX_MODEL_HBV11P) fn<MODEL_HBV11P, true>(__VA_ARGS__);                \
+    else fn<MODEL_HBV20, true>(__VA_ARGS__);
+
+extern "C" int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *o, void *)
+{
+    DISPATCH(run_fwd, *d, *o);
+    return 0;
+}
+extern "C" int hbvx_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *)
+{
+    DISPATCH(run_bwd, *d, *io);
+    return 0;
+}
+extern "C" int hbvx_route_forward(const hbvx_route_desc *, const float *, float *, float *, void *)
+{
+    snprintf(g_err, sizeof g_err, "routing is not part of the step-math harness");
+    return HBVX_E_UNSUPPORTED;
+}
+extern "C" int hbvx_route_backward(const hbvx_route_desc *, const float *, const float *,
+                                   const float *, float *, float *, float *, void *)
+{
+    snprintf(g_err, sizeof g_err, "routing is not part of the step-math harness");
+    return HBVX_E_UNSUPPORTED;
+}
