@@ -12,8 +12,11 @@
 #include <cstdio>
 #include <cstring>
 
+#include <cstdlib>
+
 #include "../../include/hbvx.h"
 #include "hbv_step.h"
+#include "hbv_tiled.h"
 
 using namespace hbvx;
 
@@ -531,6 +534,104 @@ static hipError_t launch_variant(const hbvx_desc *d, const Args &a, dim3 grid, h
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// tile geometry + launch of the wave-specialised kernels (hbv_tiled.h)
+// ---------------------------------------------------------------------------
+static const int LDS_BUDGET = 160 * 1024 - 512; // gfx950: 160 KiB per CU, one workgroup may take it all
+
+static int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+// HBVX_KERNEL=simple selects the one-wave kernels (kept for very large grids and as a
+// cross-check); default is the tiled, wave-specialised path.
+static bool use_tiled(const hbvx_desc *d)
+{
+    const char *v = getenv("HBVX_KERNEL");
+    if (v && !strcmp(v, "simple")) return false;
+    return d->T > 0;
+}
+
+static int count_dyn(const hbvx_desc *d)
+{
+    int nd = 0;
+    for (int i = 0; i < d->n_param; i++) nd += d->p[i].dyn ? 1 : 0;
+    return nd;
+}
+
+static bool geom_fwd(const hbvx_desc *d, const hbvx_fwd_out *o, TileGeom &g)
+{
+    g = TileGeom{};
+    g.lgMp = lg_members(d->M);
+    g.ND = count_dyn(d);
+    g.NDm = g.ND + (d->muwts ? 1 : 0);
+    const int NF = (d->model == HBVX_MODEL_HBV10) ? 11 : 12;
+    const int ktmax = env_int("HBVX_KT", 16);
+    for (int Kt = 16; Kt >= 1; Kt >>= 1) {
+        if (Kt > ktmax) continue;
+        g.Kt = Kt;
+        g.off_pin = Kt * 256;
+        g.in_sz = Kt * (256 + g.NDm * 64);
+        g.off_tout = Kt * 64 * (o->flux ? NF : 0);
+        g.out_sz = g.off_tout + Kt * 64 * (o->traj ? 7 : 0);
+        if (g.out_sz == 0) g.out_sz = 4;
+        if (2 * (g.in_sz + g.out_sz) * 4 <= LDS_BUDGET) return true;
+    }
+    return false;
+}
+
+static bool geom_bwd(const hbvx_desc *d, const hbvx_bwd_io *io, TileGeom &g)
+{
+    g = TileGeom{};
+    g.lgMp = lg_members(d->M);
+    g.ND = count_dyn(d);
+    g.NDm = g.ND + (d->muwts ? 1 : 0);
+    const int NF = (d->model == HBVX_MODEL_HBV10) ? 11 : 12;
+    const int bpw = 64 >> g.lgMp;
+    const int ktmax = env_int("HBVX_KT", 16);
+    for (int Kt = 16; Kt >= 1; Kt >>= 1) {
+        if (Kt > ktmax) continue;
+        g.Kt = Kt;
+        g.off_pin = Kt * 256;
+        g.off_tin = g.off_pin + Kt * g.NDm * 64;
+        g.off_gin = g.off_tin + Kt * 7 * 64;
+        g.in_sz = (g.off_gin + Kt * NF * bpw + 3) & ~3;
+        g.off_xout = Kt * 64 * g.ND;
+        g.off_mout = g.off_xout + Kt * 64 * (io->grad_x ? 3 : 0);
+        g.out_sz = g.off_mout + Kt * 64 * (io->grad_muwts ? 1 : 0);
+        if (g.out_sz == 0) g.out_sz = 4;
+        if (2 * (g.in_sz + g.out_sz) * 4 <= LDS_BUDGET) return true;
+    }
+    return false;
+}
+
+template <typename Args, typename K>
+static hipError_t launch_tiled_one(K kern, const Args &a, dim3 grid, int threads, size_t lds,
+                                   hipStream_t st)
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, grid, dim3(threads), lds, st, a);
+    return hipGetLastError();
+}
+
+template <typename Args, typename K0, typename K1, typename K2, typename K3>
+static hipError_t launch_tiled(const hbvx_desc *d, const Args &a, dim3 grid, size_t lds,
+                               hipStream_t st, K0 k0, K1 k1, K2 k2, K3 k3)
+{
+    int nh = env_int("HBVX_NH", 7);
+    if (nh < 1) nh = 1;
+    if (nh > 7) nh = 7;
+    const int threads = 64 * (1 + nh);
+    if (d->model == HBVX_MODEL_HBV10 && d->n_param == 12) return launch_tiled_one(k0, a, grid, threads, lds, st);
+    if (d->model == HBVX_MODEL_HBV10) return launch_tiled_one(k1, a, grid, threads, lds, st);
+    if (d->model == HBVX_MODEL_HBV11P) return launch_tiled_one(k2, a, grid, threads, lds, st);
+    return launch_tiled_one(k3, a, grid, threads, lds, st);
+}
+
 extern "C" int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream)
 {
     int rc = check_desc(d);
@@ -538,6 +639,21 @@ extern "C" int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *s
     if (!out || !out->state_out) return fail(HBVX_E_NULL, "state_out is NULL");
     const int want_nf = (d->model == HBVX_MODEL_HBV10) ? 11 : 12;
     if (out->flux && out->n_flux != want_nf) return fail(HBVX_E_SHAPE, "n_flux does not match model");
+    {
+        FwdTArgs ta;
+        if (use_tiled(d) && geom_fwd(d, out, ta.g)) {
+            ta.d = *d;
+            ta.o = *out;
+            const int bpw_t = 64 >> ta.g.lgMp;
+            dim3 grid_t((d->B + bpw_t - 1) / bpw_t);
+            const size_t lds = (size_t)2 * (ta.g.in_sz + ta.g.out_sz) * 4;
+            hipError_t e = launch_tiled(d, ta, grid_t, lds, (hipStream_t)stream,
+                                        k_fwd_tiled<MODEL_HBV10, false>, k_fwd_tiled<MODEL_HBV10, true>,
+                                        k_fwd_tiled<MODEL_HBV11P, true>, k_fwd_tiled<MODEL_HBV20, true>);
+            if (e != hipSuccess) return hip_fail(e, "hbvx_forward (tiled) launch");
+            return HBVX_OK;
+        }
+    }
     FwdArgs a;
     a.d = *d;
     a.o = *out;
@@ -560,6 +676,21 @@ extern "C" int hbvx_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *st
     const int want_nf = (d->model == HBVX_MODEL_HBV10) ? 11 : 12;
     if (io->n_flux != want_nf) return fail(HBVX_E_SHAPE, "n_flux does not match model");
     if (d->T == 0) return HBVX_OK;
+    {
+        BwdTArgs ta;
+        if (use_tiled(d) && geom_bwd(d, io, ta.g)) {
+            ta.d = *d;
+            ta.io = *io;
+            const int bpw_t = 64 >> ta.g.lgMp;
+            dim3 grid_t((d->B + bpw_t - 1) / bpw_t);
+            const size_t lds = (size_t)2 * (ta.g.in_sz + ta.g.out_sz) * 4;
+            hipError_t e = launch_tiled(d, ta, grid_t, lds, (hipStream_t)stream,
+                                        k_bwd_tiled<MODEL_HBV10, false>, k_bwd_tiled<MODEL_HBV10, true>,
+                                        k_bwd_tiled<MODEL_HBV11P, true>, k_bwd_tiled<MODEL_HBV20, true>);
+            if (e != hipSuccess) return hip_fail(e, "hbvx_backward (tiled) launch");
+            return HBVX_OK;
+        }
+    }
     BwdArgs a;
     a.d = *d;
     a.io = *io;

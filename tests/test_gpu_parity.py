@@ -43,6 +43,27 @@ def test_hip_matches_oracle(kw, hip_backend, oracle_path):
         assert_close(k, got[k], want[k], 1e-3, 1e-5)
 
 
+@pytest.mark.parametrize("env", [
+    {"HBVX_KERNEL": "simple"},
+    {"HBVX_KT": "2", "HBVX_NH": "1"},
+    {"HBVX_KT": "4", "HBVX_NH": "3"},
+    {"HBVX_KT": "1", "HBVX_NH": "7"},
+], ids=lambda e: "-".join(f"{k[5:]}{v}" for k, v in e.items()))
+@pytest.mark.parametrize("kw", [ORACLE_CASES[1], ORACLE_CASES[3], ORACLE_CASES[6]],
+                         ids=lambda k: f"{k['model']}-M{k['M']}")
+def test_kernel_variants_and_tile_shapes(kw, env, hip_backend, oracle_path, monkeypatch):
+    """The one-wave kernels and odd tile geometries (tile edges, 1..7 helper waves)."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    prob = make_problem(seed=11, **dict(kw, T=kw["T"] // 2 + 3))
+    got = run_problem(prob, None, device="cuda:0", x_grad=True)
+    want = run_problem(prob, oracle_path, device="cpu", x_grad=True)
+    for k in ("flux", "routed", "state_out", "traj"):
+        assert_close(k, got[k], want[k], 1e-4, 1e-5)
+    for k in ("g_params", "g_x") + (("g_muwts",) if "g_muwts" in want else ()):
+        assert_close(k, got[k], want[k], 1e-3, 1e-5)
+
+
 def test_warmup_offset_call(hip_backend, oracle_path):
     """t0 > 0: the main run reads rows t0.. of x / parameters in place."""
     prob = make_problem(model="Hbv", T=90, B=11, M=16, dyn=("parBETA",), seed=9)
