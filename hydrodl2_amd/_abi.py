@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_PARAM = 16
 NSTATE = 5
 MAX_FLUX = 12
@@ -57,7 +57,8 @@ class FwdOut(C.Structure):
 
 
 class BwdIO(C.Structure):
-    _fields_ = [("traj", _fp), ("aux", _fp), ("grad_flux", _fp), ("grad_x", _fp),
+    _fields_ = [("traj", _fp), ("aux", _fp), ("grad_flux", _fp), ("grad_flux4", _fp),
+                ("grad_x", _fp),
                 ("grad_muwts", _fp), ("grad_state_in", _fp),
                 ("n_flux", C.c_int32), ("reserved0", C.c_int32),
                 ("g", ParamGrad * MAX_PARAM)]
@@ -72,7 +73,8 @@ class RouteDesc(C.Structure):
 
 
 EXPORTS = ["hbvx_version", "hbvx_last_error", "hbvx_backend", "hbvx_sizeof", "hbvx_forward",
-           "hbvx_backward", "hbvx_route_forward", "hbvx_route_backward"]
+           "hbvx_backward", "hbvx_route_forward", "hbvx_route_workspace_bytes",
+           "hbvx_route_backward"]
 
 
 class HbvxError(RuntimeError):
@@ -103,8 +105,10 @@ class Library:
         d.hbvx_route_forward.restype = C.c_int
         d.hbvx_route_forward.argtypes = [C.POINTER(RouteDesc), _fp, _fp, _fp, C.c_void_p]
         d.hbvx_route_backward.restype = C.c_int
+        d.hbvx_route_workspace_bytes.restype = C.c_uint64
+        d.hbvx_route_workspace_bytes.argtypes = [C.POINTER(RouteDesc)]
         d.hbvx_route_backward.argtypes = [C.POINTER(RouteDesc), _fp, _fp, _fp, _fp, _fp, _fp,
-                                          C.c_void_p]
+                                          _fp, C.c_uint64, C.c_void_p]
         if d.hbvx_version() != ABI_VERSION:
             raise HbvxError(f"{path}: ABI version {d.hbvx_version()} != {ABI_VERSION}")
         for which, st in enumerate([Desc, FwdOut, BwdIO, RouteDesc, ParamSrc, ParamGrad]):
@@ -134,7 +138,11 @@ class Library:
         self._check(self.dll.hbvx_route_forward(C.byref(r), q, uh, q_rout, C.c_void_p(stream)),
                     "hbvx_route_forward")
 
+    def route_workspace_bytes(self, r: RouteDesc) -> int:
+        return int(self.dll.hbvx_route_workspace_bytes(C.byref(r)))
+
     def route_backward(self, r: RouteDesc, q: int, uh: int, gqr: int, gq: int, gra, grb,
-                       stream: int):
-        self._check(self.dll.hbvx_route_backward(C.byref(r), q, uh, gqr, gq, gra, grb,
-                                                 C.c_void_p(stream)), "hbvx_route_backward")
+                       ws, ws_bytes: int, stream: int):
+        self._check(self.dll.hbvx_route_backward(C.byref(r), q, uh, gqr, gq, gra, grb, ws,
+                                                 C.c_uint64(ws_bytes), C.c_void_p(stream)),
+                    "hbvx_route_backward")

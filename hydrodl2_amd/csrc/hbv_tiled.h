@@ -89,7 +89,9 @@ struct FwdTArgs {
     TileGeom g;
 };
 
-template <int MODEL, bool BETAET>
+// DYN = false: all parameters static and no muwts -- the specialisation the all-static
+// configuration runs; every dynamic-parameter scalar drops out of the stepper loop.
+template <int MODEL, bool BETAET, bool DYN>
 __global__ void __launch_bounds__(512) k_fwd_tiled(const FwdTArgs A)
 {
     constexpr int NP = NParamT<MODEL, BETAET>::value;
@@ -107,12 +109,14 @@ __global__ void __launch_bounds__(512) k_fwd_tiled(const FwdTArgs A)
     const int64_t N = (int64_t)d.B * d.M;
     const bool raw = d.raw_sigmoid != 0;
     const bool has_flux = o.flux != nullptr, has_traj = o.traj != nullptr, has_aux = o.aux != nullptr;
-    const bool has_mu = d.muwts != nullptr;
+    const bool has_mu = DYN && d.muwts != nullptr;
 
     unsigned dmask = 0;
+    if (DYN) {
 #pragma unroll
-    for (int i = 0; i < NP; i++)
-        if (d.p[i].dyn) dmask |= 1u << i;
+        for (int i = 0; i < NP; i++)
+            if (d.p[i].dyn) dmask |= 1u << i;
+    }
 
     float psta[NP];
 #pragma unroll
@@ -307,7 +311,7 @@ struct BwdTArgs {
     TileGeom g;
 };
 
-template <int MODEL, bool BETAET>
+template <int MODEL, bool BETAET, bool DYN>
 __global__ void __launch_bounds__(512) k_bwd_tiled(const BwdTArgs A)
 {
     constexpr int NP = NParamT<MODEL, BETAET>::value;
@@ -324,15 +328,17 @@ __global__ void __launch_bounds__(512) k_bwd_tiled(const BwdTArgs A)
     const int nT = (T + Kt - 1) / Kt;
     const int64_t N = (int64_t)d.B * d.M;
     const bool raw = d.raw_sigmoid != 0;
-    const bool has_mu = d.muwts != nullptr;
-    const bool has_gx = io.grad_x != nullptr, has_gmu = io.grad_muwts != nullptr;
+    const bool has_mu = DYN && d.muwts != nullptr;
+    const bool has_gx = io.grad_x != nullptr, has_gmu = DYN && io.grad_muwts != nullptr;
     const int lgMp = G.lgMp, Mp = 1 << lgMp, bpw = 64 >> lgMp;
     const float invM = 1.0f / (float)d.M;
 
     unsigned dmask = 0;
+    if (DYN) {
 #pragma unroll
-    for (int i = 0; i < NP; i++)
-        if (d.p[i].dyn) dmask |= 1u << i;
+        for (int i = 0; i < NP; i++)
+            if (d.p[i].dyn) dmask |= 1u << i;
+    }
 
     float psta[NP], usta[NP];
     bool use_dyn[NP];
@@ -493,7 +499,9 @@ __global__ void __launch_bounds__(512) k_bwd_tiled(const BwdTArgs A)
                 const int r = e >> (6 - lgMp);
                 const int kk = r % NF, tt = r / NF;
                 const int bb = min(b0 + bl, d.B - 1);
-                float v = io.grad_flux[((int64_t)kk * T + (t0 + tt)) * d.B + bb];
+                const int64_t gi = ((int64_t)kk * T + (t0 + tt)) * d.B + bb;
+                float v = io.grad_flux ? io.grad_flux[gi] : 0.0f;
+                if (io.grad_flux4 && kk < 4) v += io.grad_flux4[gi];
                 gin[(tt * NF + kk) * bpw + bl] = (kk == HBVX_F_QSIM) ? v : v * invM;
             }
         };

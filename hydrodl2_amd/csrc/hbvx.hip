@@ -298,22 +298,27 @@ __global__ void __launch_bounds__(64) k_bwd(const BwdArgs A)
         s.template fwd<true>(p, nz, ac, elev, sw0, ef0);
 
         FluxGrad g;
-        const float *gf = io.grad_flux + (int64_t)t * d.B + L.b;
         const int64_t fs = (int64_t)T * d.B;
-        const float gq = gf[HBVX_F_QSIM * fs];
+        const int64_t go = (int64_t)t * d.B + L.b;
+        auto GF = [&](int k) -> float {
+            float v = io.grad_flux ? io.grad_flux[k * fs + go] : 0.0f;
+            if (io.grad_flux4 && k < 4) v += io.grad_flux4[k * fs + go];
+            return v;
+        };
+        const float gq = GF(HBVX_F_QSIM);
         const float wq = mu ? mu[(int64_t)t * d.mu_t_stride] : invM;
         g.gQ = gq * wq;
-        g.gQ0 = gf[HBVX_F_Q0 * fs] * invM;
-        g.gQ1 = gf[HBVX_F_Q1 * fs] * invM;
-        g.gQ2 = gf[HBVX_F_Q2 * fs] * invM;
-        g.gET = gf[HBVX_F_AET * fs] * invM;
-        g.gSWE = gf[HBVX_F_SWE * fs] * invM;
-        g.grech = gf[HBVX_F_RECHARGE * fs] * invM;
-        g.gexc = gf[HBVX_F_EXCS * fs] * invM;
-        g.gef = gf[HBVX_F_EVAPFACTOR * fs] * invM;
-        g.gtosoil = gf[HBVX_F_TOSOIL * fs] * invM;
-        g.gPERC = gf[HBVX_F_PERC * fs] * invM;
-        g.gcap = (nf > HBVX_F_CAPILLARY) ? gf[HBVX_F_CAPILLARY * fs] * invM : 0.0f;
+        g.gQ0 = GF(HBVX_F_Q0) * invM;
+        g.gQ1 = GF(HBVX_F_Q1) * invM;
+        g.gQ2 = GF(HBVX_F_Q2) * invM;
+        g.gET = GF(HBVX_F_AET) * invM;
+        g.gSWE = GF(HBVX_F_SWE) * invM;
+        g.grech = GF(HBVX_F_RECHARGE) * invM;
+        g.gexc = GF(HBVX_F_EXCS) * invM;
+        g.gef = GF(HBVX_F_EVAPFACTOR) * invM;
+        g.gtosoil = GF(HBVX_F_TOSOIL) * invM;
+        g.gPERC = GF(HBVX_F_PERC) * invM;
+        g.gcap = (nf > HBVX_F_CAPILLARY) ? GF(HBVX_F_CAPILLARY) * invM : 0.0f;
         if (io.grad_muwts && L.active) io.grad_muwts[((int64_t)t * d.B + L.b) * d.M + L.j] = gq * s.Q;
 
         float gp[NPARAM_MAX], gx[3];
@@ -426,70 +431,92 @@ __global__ void k_route_bwd_q(int T, int B, int S, int L, const float *__restric
     gq[idx] = acc;
 }
 
-// conv backward w.r.t. the taps, then through the normalised gamma UH to the
-// routing inputs.  Block = 32 basins x 8 time slices; LDS tree over the slices.
-// d w_k / d aa    = w_k (ln t_k - sum_j w_j ln t_j)      (Gamma(aa) and theta^aa cancel
-// d w_k / d theta = w_k (t_k - sum_j w_j t_j) / theta^2    in the normalisation)
-__global__ void __launch_bounds__(256) k_route_bwd_uh(const hbvx_route_desc r,
-                                                      const float *__restrict__ q,
-                                                      const float *__restrict__ uh,
-                                                      const float *__restrict__ gy,
-                                                      float *grad_ra, float *grad_rb)
+// conv backward w.r.t. the taps, stage 1: partial tap gradients per time chunk.
+// thread = (basin, chunk of ROUTE_CHUNK days); lanes run over basins (coalesced);
+// ws[(chunk*L + k)*B + b] = sum_{s, t in chunk} gy[s,t,b] * q[s,t-k,b]
+#define ROUTE_CHUNK 32
+__global__ void __launch_bounds__(256) k_route_bwd_taps(int T, int B, int S, int L,
+                                                        const float *__restrict__ q,
+                                                        const float *__restrict__ gy,
+                                                        float *__restrict__ ws)
 {
-    __shared__ float red[8][HBVX_UH_MAXLEN][33];
-    const int bl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int b = blockIdx.x * 32 + bl;
-    const int T = r.T, B = r.B, L = r.L;
+    const int b = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int chunk = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int t0 = chunk * ROUTE_CHUNK;
+    if (b >= B || t0 >= T) return;
+    const int t1 = min(T, t0 + ROUTE_CHUNK);
     float gw[HBVX_UH_MAXLEN];
 #pragma unroll
     for (int k = 0; k < HBVX_UH_MAXLEN; k++) gw[k] = 0.0f;
-    if (b < B) {
-        for (int s = 0; s < r.S; s++)
-            for (int t = sl; t < T; t += 8) {
-                const int64_t base = ((int64_t)s * T + t) * B + b;
-                const float g = gy[base];
+    for (int s = 0; s < S; s++) {
+        const float *qs = q + (int64_t)s * T * B + b;
+        const float *gs = gy + (int64_t)s * T * B + b;
+        // sliding window of the last 15 inputs in registers
+        float win[HBVX_UH_MAXLEN];
 #pragma unroll
-                for (int k = 0; k < HBVX_UH_MAXLEN; k++)
-                    if (k < L && k <= t) gw[k] += g * q[base - (int64_t)k * B];
-            }
+        for (int k = 1; k < HBVX_UH_MAXLEN; k++) win[k] = (t0 - k >= 0) ? qs[(int64_t)(t0 - k) * B] : 0.0f;
+        for (int t = t0; t < t1; t++) {
+            win[0] = qs[(int64_t)t * B];
+            const float g = gs[(int64_t)t * B];
+#pragma unroll
+            for (int k = 0; k < HBVX_UH_MAXLEN; k++) gw[k] += g * win[k];
+#pragma unroll
+            for (int k = HBVX_UH_MAXLEN - 1; k > 0; k--) win[k] = win[k - 1];
+        }
     }
 #pragma unroll
-    for (int k = 0; k < HBVX_UH_MAXLEN; k++) red[sl][k][bl] = gw[k];
-    __syncthreads();
-    if (sl == 0 && b < B) {
-        float ua, ub, a, bb;
-        route_ab(r, b, ua, ub, a, bb);
-        const float theta = fmaxf(bb, 0.0f) + 0.5f;
-        float w[HBVX_UH_MAXLEN];
-        float mlt = 0.0f, mt = 0.0f;
+    for (int k = 0; k < HBVX_UH_MAXLEN; k++)
+        if (k < L) ws[((int64_t)chunk * L + k) * B + b] = gw[k];
+}
+
+// stage 2: reduce the chunks (fixed order: deterministic) and go through the normalised
+// gamma UH to the routing inputs.
+// d w_k / d aa    = w_k (ln t_k - sum_j w_j ln t_j)      (Gamma(aa) and theta^aa cancel
+// d w_k / d theta = w_k (t_k - sum_j w_j t_j) / theta^2    in the normalisation)
+__global__ void __launch_bounds__(64) k_route_bwd_params(const hbvx_route_desc r, int nchunk,
+                                                         const float *__restrict__ uh,
+                                                         const float *__restrict__ ws,
+                                                         float *grad_ra, float *grad_rb)
+{
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    const int B = r.B, L = r.L;
+    if (b >= B) return;
+    float gw[HBVX_UH_MAXLEN];
 #pragma unroll
-        for (int k = 0; k < HBVX_UH_MAXLEN; k++) {
-            float acc = 0.0f;
+    for (int k = 0; k < HBVX_UH_MAXLEN; k++) gw[k] = 0.0f;
+    for (int c = 0; c < nchunk; c++) {
 #pragma unroll
-            for (int s2 = 0; s2 < 8; s2++) acc += red[s2][k][bl];
-            gw[k] = acc;
-            w[k] = (k < L) ? uh[(int64_t)b * L + k] : 0.0f;
-            const float tk = (float)k + 0.5f;
-            mlt += w[k] * logf(tk);
-            mt += w[k] * tk;
-        }
-        float gaa = 0.0f, gth = 0.0f;
-#pragma unroll
-        for (int k = 0; k < HBVX_UH_MAXLEN; k++) {
-            const float tk = (float)k + 0.5f;
-            gaa += gw[k] * w[k] * (logf(tk) - mlt);
-            gth += gw[k] * w[k] * ((tk - mt) / (theta * theta));
-        }
-        float ga = (a > 0.0f) ? gaa : 0.0f;   // relu backward (uh_routing.py:11-14)
-        float gb = (bb > 0.0f) ? gth : 0.0f;
-        float gua = ga * (r.a_hi - r.a_lo), gub = gb * (r.b_hi - r.b_lo);
-        if (r.raw_sigmoid) {
-            gua *= ua * (1.0f - ua);
-            gub *= ub * (1.0f - ub);
-        }
-        if (grad_ra) grad_ra[(int64_t)b * r.r_stride] += gua;
-        if (grad_rb) grad_rb[(int64_t)b * r.r_stride] += gub;
+        for (int k = 0; k < HBVX_UH_MAXLEN; k++)
+            if (k < L) gw[k] += ws[((int64_t)c * L + k) * B + b];
     }
+    float ua, ub, a, bb;
+    route_ab(r, b, ua, ub, a, bb);
+    const float theta = fmaxf(bb, 0.0f) + 0.5f;
+    float w[HBVX_UH_MAXLEN];
+    float mlt = 0.0f, mt = 0.0f;
+#pragma unroll
+    for (int k = 0; k < HBVX_UH_MAXLEN; k++) {
+        w[k] = (k < L) ? uh[(int64_t)b * L + k] : 0.0f;
+        const float tk = (float)k + 0.5f;
+        mlt += w[k] * logf(tk);
+        mt += w[k] * tk;
+    }
+    float gaa = 0.0f, gth = 0.0f;
+#pragma unroll
+    for (int k = 0; k < HBVX_UH_MAXLEN; k++) {
+        const float tk = (float)k + 0.5f;
+        gaa += gw[k] * w[k] * (logf(tk) - mlt);
+        gth += gw[k] * w[k] * ((tk - mt) / (theta * theta));
+    }
+    float ga = (a > 0.0f) ? gaa : 0.0f;   // relu backward (uh_routing.py:11-14)
+    float gb = (bb > 0.0f) ? gth : 0.0f;
+    float gua = ga * (r.a_hi - r.a_lo), gub = gb * (r.b_hi - r.b_lo);
+    if (r.raw_sigmoid) {
+        gua *= ua * (1.0f - ua);
+        gub *= ub * (1.0f - ub);
+    }
+    if (grad_ra) grad_ra[(int64_t)b * r.r_stride] += gua;
+    if (grad_rb) grad_rb[(int64_t)b * r.r_stride] += gub;
 }
 
 // ---------------------------------------------------------------------------
@@ -618,19 +645,24 @@ static hipError_t launch_tiled_one(K kern, const Args &a, dim3 grid, int threads
     return hipGetLastError();
 }
 
-template <typename Args, typename K0, typename K1, typename K2, typename K3>
-static hipError_t launch_tiled(const hbvx_desc *d, const Args &a, dim3 grid, size_t lds,
-                               hipStream_t st, K0 k0, K1 k1, K2 k2, K3 k3)
-{
-    int nh = env_int("HBVX_NH", 7);
-    if (nh < 1) nh = 1;
-    if (nh > 7) nh = 7;
-    const int threads = 64 * (1 + nh);
-    if (d->model == HBVX_MODEL_HBV10 && d->n_param == 12) return launch_tiled_one(k0, a, grid, threads, lds, st);
-    if (d->model == HBVX_MODEL_HBV10) return launch_tiled_one(k1, a, grid, threads, lds, st);
-    if (d->model == HBVX_MODEL_HBV11P) return launch_tiled_one(k2, a, grid, threads, lds, st);
-    return launch_tiled_one(k3, a, grid, threads, lds, st);
-}
+#define LAUNCH_TILED(KERN, d, a, grid, lds, st, dyn)                                              \
+    ([&]() -> hipError_t {                                                                        \
+        int nh = env_int("HBVX_NH", 7);                                                           \
+        nh = nh < 1 ? 1 : (nh > 7 ? 7 : nh);                                                      \
+        const int threads = 64 * (1 + nh);                                                        \
+        const int m = (d)->model;                                                                 \
+        const bool be = (d)->n_param == 13;                                                       \
+        if (dyn) {                                                                                \
+            if (m == HBVX_MODEL_HBV10 && !be) return launch_tiled_one(KERN<MODEL_HBV10, false, true>, a, grid, threads, lds, st); \
+            if (m == HBVX_MODEL_HBV10) return launch_tiled_one(KERN<MODEL_HBV10, true, true>, a, grid, threads, lds, st);         \
+            if (m == HBVX_MODEL_HBV11P) return launch_tiled_one(KERN<MODEL_HBV11P, true, true>, a, grid, threads, lds, st);       \
+            return launch_tiled_one(KERN<MODEL_HBV20, true, true>, a, grid, threads, lds, st);    \
+        }                                                                                         \
+        if (m == HBVX_MODEL_HBV10 && !be) return launch_tiled_one(KERN<MODEL_HBV10, false, false>, a, grid, threads, lds, st);    \
+        if (m == HBVX_MODEL_HBV10) return launch_tiled_one(KERN<MODEL_HBV10, true, false>, a, grid, threads, lds, st);            \
+        if (m == HBVX_MODEL_HBV11P) return launch_tiled_one(KERN<MODEL_HBV11P, true, false>, a, grid, threads, lds, st);          \
+        return launch_tiled_one(KERN<MODEL_HBV20, true, false>, a, grid, threads, lds, st);       \
+    })()
 
 extern "C" int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream)
 {
@@ -647,9 +679,8 @@ extern "C" int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *s
             const int bpw_t = 64 >> ta.g.lgMp;
             dim3 grid_t((d->B + bpw_t - 1) / bpw_t);
             const size_t lds = (size_t)2 * (ta.g.in_sz + ta.g.out_sz) * 4;
-            hipError_t e = launch_tiled(d, ta, grid_t, lds, (hipStream_t)stream,
-                                        k_fwd_tiled<MODEL_HBV10, false>, k_fwd_tiled<MODEL_HBV10, true>,
-                                        k_fwd_tiled<MODEL_HBV11P, true>, k_fwd_tiled<MODEL_HBV20, true>);
+            const bool dyn = ta.g.NDm > 0;
+            hipError_t e = LAUNCH_TILED(k_fwd_tiled, d, ta, grid_t, lds, (hipStream_t)stream, dyn);
             if (e != hipSuccess) return hip_fail(e, "hbvx_forward (tiled) launch");
             return HBVX_OK;
         }
@@ -671,8 +702,7 @@ extern "C" int hbvx_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *st
 {
     int rc = check_desc(d);
     if (rc) return rc;
-    if (!io || !io->traj || !io->aux || !io->grad_flux)
-        return fail(HBVX_E_NULL, "traj/aux/grad_flux is NULL");
+    if (!io || !io->traj || !io->aux) return fail(HBVX_E_NULL, "traj/aux is NULL");
     const int want_nf = (d->model == HBVX_MODEL_HBV10) ? 11 : 12;
     if (io->n_flux != want_nf) return fail(HBVX_E_SHAPE, "n_flux does not match model");
     if (d->T == 0) return HBVX_OK;
@@ -684,9 +714,8 @@ extern "C" int hbvx_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *st
             const int bpw_t = 64 >> ta.g.lgMp;
             dim3 grid_t((d->B + bpw_t - 1) / bpw_t);
             const size_t lds = (size_t)2 * (ta.g.in_sz + ta.g.out_sz) * 4;
-            hipError_t e = launch_tiled(d, ta, grid_t, lds, (hipStream_t)stream,
-                                        k_bwd_tiled<MODEL_HBV10, false>, k_bwd_tiled<MODEL_HBV10, true>,
-                                        k_bwd_tiled<MODEL_HBV11P, true>, k_bwd_tiled<MODEL_HBV20, true>);
+            const bool dyn = ta.g.NDm > 0;
+            hipError_t e = LAUNCH_TILED(k_bwd_tiled, d, ta, grid_t, lds, (hipStream_t)stream, dyn);
             if (e != hipSuccess) return hip_fail(e, "hbvx_backward (tiled) launch");
             return HBVX_OK;
         }
@@ -731,9 +760,18 @@ extern "C" int hbvx_route_forward(const hbvx_route_desc *r, const float *q, floa
     return HBVX_OK;
 }
 
+static int route_chunks(const hbvx_route_desc *r) { return (r->T + ROUTE_CHUNK - 1) / ROUTE_CHUNK; }
+
+extern "C" uint64_t hbvx_route_workspace_bytes(const hbvx_route_desc *r)
+{
+    if (!r || r->T <= 0 || r->B <= 0) return 0;
+    return (uint64_t)route_chunks(r) * (uint64_t)r->L * (uint64_t)r->B * sizeof(float);
+}
+
 extern "C" int hbvx_route_backward(const hbvx_route_desc *r, const float *q, const float *uh,
                                    const float *grad_q_rout, float *grad_q, float *grad_ra,
-                                   float *grad_rb, void *stream)
+                                   float *grad_rb, void *workspace, uint64_t workspace_bytes,
+                                   void *stream)
 {
     int rc = check_route(r);
     if (rc) return rc;
@@ -742,10 +780,35 @@ extern "C" int hbvx_route_backward(const hbvx_route_desc *r, const float *q, con
     const int64_t total = (int64_t)r->S * r->T * r->B;
     hipLaunchKernelGGL(k_route_bwd_q, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                        r->T, r->B, r->S, r->L, grad_q_rout, uh, grad_q);
-    if (grad_ra || grad_rb)
-        hipLaunchKernelGGL(k_route_bwd_uh, dim3((r->B + 31) / 32), dim3(256), 0, st, *r, q, uh,
-                           grad_q_rout, grad_ra, grad_rb);
+    if (grad_ra || grad_rb) {
+        if (!workspace || workspace_bytes < hbvx_route_workspace_bytes(r))
+            return fail(HBVX_E_NULL, "route workspace missing or too small");
+        const int nchunk = route_chunks(r);
+        hipLaunchKernelGGL(k_route_bwd_taps, dim3((r->B + 63) / 64, (nchunk + 3) / 4), dim3(256), 0,
+                           st, r->T, r->B, r->S, r->L, q, grad_q_rout, (float *)workspace);
+        hipLaunchKernelGGL(k_route_bwd_params, dim3((r->B + 63) / 64), dim3(64), 0, st, *r, nchunk,
+                           uh, (const float *)workspace, grad_ra, grad_rb);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "hbvx_route_backward launch");
+    return HBVX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// diagnostics: device-side accuracy probe of hbvx::pow_pos_ (tests only)
+// ---------------------------------------------------------------------------
+__global__ void k_selftest_pow(const float *x, const float *y, float *out, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = pow_pos_(x[i], y[i]);
+}
+
+extern "C" int hbvx_selftest_pow(const float *x, const float *y, float *out, int n, void *stream)
+{
+    if (!x || !y || !out || n <= 0) return fail(HBVX_E_NULL, "selftest_pow: bad arguments");
+    hipLaunchKernelGGL(k_selftest_pow, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, y,
+                       out, n);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "selftest_pow launch");
     return HBVX_OK;
 }

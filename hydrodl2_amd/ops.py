@@ -200,7 +200,7 @@ class HbvPath(torch.autograd.Function):
             _call(lib, 'hbvx_route_forward', lib.route_forward, r, _ptr(flux), _ptr(uh), _ptr(routed), stream)
 
         ctx.cfg = cfg
-        ctx.n_ptensors = len(ptensors)
+        ctx.set_materialize_grads(False)
         if needs_grad:
             ctx.save_for_backward(x, state_in, muwts, ac, elev, traj, aux, flux, uh, *ptensors)
         nondiff = [state_out]
@@ -220,26 +220,26 @@ class HbvPath(torch.autograd.Function):
         T, B, M = cfg.T, cfg.B, cfg.M
         stream = _stream_of(lib, x)
 
-        if g_flux is None:
-            g_flux = torch.zeros((cfg.n_flux, T, B), dtype=torch.float32, device=dev)
-        else:
-            g_flux = g_flux.contiguous().clone() if g_routed is not None else g_flux.contiguous()
-
         gp = [torch.zeros_like(p) if ctx.needs_input_grad[6 + i] else None
               for i, p in enumerate(ptensors)]
 
+        gq = None
         if g_routed is not None and cfg.route is not None:
             r = _route_desc(cfg, ptensors)
             gq = torch.empty((4, T, B), dtype=torch.float32, device=dev)
             rs = cfg.route
             gt = gp[rs.tensor_idx]
+            ws_bytes = lib.route_workspace_bytes(r)
+            ws = torch.empty((max(ws_bytes, 4) + 3) // 4, dtype=torch.float32, device=dev)
             _call(lib, 'hbvx_route_backward', lib.route_backward, r, _ptr(flux), _ptr(uh),
                   _ptr(g_routed.contiguous()), _ptr(gq), _ptr(gt, rs.a_off), _ptr(gt, rs.b_off),
-                  stream)
-            g_flux[0:4] += gq
+                  _ptr(ws), ws_bytes, stream)
+        if g_flux is not None:
+            g_flux = g_flux.contiguous()
 
         io = _abi.BwdIO()
-        io.traj, io.aux, io.grad_flux = _ptr(traj), _ptr(aux), _ptr(g_flux)
+        io.traj, io.aux = _ptr(traj), _ptr(aux)
+        io.grad_flux, io.grad_flux4 = _ptr(g_flux), _ptr(gq)
         io.n_flux = cfg.n_flux
         gx = gmu = None
         if ctx.needs_input_grad[1]:

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define HBVX_ABI_VERSION 1
+#define HBVX_ABI_VERSION 2
 #define HBVX_MAX_PARAM 16
 #define HBVX_NSTATE 5   /* SNOWPACK, MELTWATER, SM, SUZ, SLZ  (hbv.py:61-67) */
 #define HBVX_MAX_FLUX 12
@@ -140,7 +140,9 @@ typedef struct hbvx_fwd_out {
 typedef struct hbvx_bwd_io {
     const float *traj;       /* from hbvx_forward, required */
     const float *aux;        /* from hbvx_forward, required */
-    const float *grad_flux;  /* [n_flux,T,B] dL/d(flux series), required */
+    const float *grad_flux;  /* [n_flux,T,B] dL/d(flux series) or NULL (= zeros) */
+    const float *grad_flux4; /* optional [4,T,B]: extra gradient of series 0..3 (Qsim,Q0,Q1,Q2),
+                                i.e. grad_q of hbvx_route_backward; added to grad_flux */
     float *grad_x;           /* optional, addressed like desc->x (overwritten) */
     float *grad_muwts;       /* optional [T,B,M] contiguous (overwritten) */
     float *grad_state_in;    /* optional [5,B,M] (overwritten) */
@@ -173,11 +175,18 @@ int hbvx_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *stream);
 /* q [S,T,B] -> uh [B,L] (normalised gamma UH) and q_rout [S,T,B]. */
 int hbvx_route_forward(const hbvx_route_desc *r, const float *q, float *uh, float *q_rout,
                        void *stream);
+/* Scratch bytes hbvx_route_backward needs (per-time-chunk partial tap gradients). */
+uint64_t hbvx_route_workspace_bytes(const hbvx_route_desc *r);
 /* grad_q_rout [S,T,B] -> grad_q [S,T,B] (overwritten) and the gradient w.r.t. the
- * routing inputs, accumulated (+=) at grad_ra[b*r_stride], grad_rb[b*r_stride]. */
+ * routing inputs, accumulated (+=) at grad_ra[b*r_stride], grad_rb[b*r_stride].
+ * `workspace` is caller-owned scratch of at least hbvx_route_workspace_bytes(r). */
 int hbvx_route_backward(const hbvx_route_desc *r, const float *q, const float *uh,
                         const float *grad_q_rout, float *grad_q, float *grad_ra,
-                        float *grad_rb, void *stream);
+                        float *grad_rb, void *workspace, uint64_t workspace_bytes,
+                        void *stream);
+
+/* Diagnostics (tests only): out[i] = the device pow used for (SM/FC)**BETA on x[i], y[i]. */
+int hbvx_selftest_pow(const float *x, const float *y, float *out, int n, void *stream);
 
 #ifdef __cplusplus
 }

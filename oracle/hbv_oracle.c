@@ -539,7 +539,7 @@ int hbvx_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *stream)
     (void)stream;
     int rc = check_desc(d);
     if (rc) return rc;
-    if (!io || !io->traj || !io->grad_flux) return fail(HBVX_E_NULL, "traj/grad_flux is NULL");
+    if (!io || !io->traj) return fail(HBVX_E_NULL, "traj is NULL");
     const int T = d->T, B = d->B, M = d->M;
     const int64_t N = (int64_t)B * M;
     const int nf = io->n_flux;
@@ -571,7 +571,9 @@ int hbvx_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *stream)
                 for (int i = 0; i < HBVX_MAX_PARAM; i++) gp[i] = 0.0f;
                 fluxgrad_t g;
                 const float *gf = io->grad_flux;
-#define GF(k) (gf[((int64_t)(k) * T + t) * B + b])
+                const float *gf4 = io->grad_flux4;
+#define GF(k) ((gf ? gf[((int64_t)(k) * T + t) * B + b] : 0.0f) + \
+               ((gf4 && (k) < 4) ? gf4[((int64_t)(k) * T + t) * B + b] : 0.0f))
                 float wq = invM; /* mean(-1) backward: grad / M */
                 if (d->muwts)
                     wq = d->muwts[(int64_t)t * d->mu_t_stride + (int64_t)b * d->mu_b_stride + j];
@@ -695,11 +697,17 @@ int hbvx_route_forward(const hbvx_route_desc *r, const float *q, float *uh, floa
     return HBVX_OK;
 }
 
+uint64_t hbvx_route_workspace_bytes(const hbvx_route_desc *r)
+{
+    (void)r;
+    return 0; /* the oracle reduces in place */
+}
+
 int hbvx_route_backward(const hbvx_route_desc *r, const float *q, const float *uh,
                         const float *grad_q_rout, float *grad_q, float *grad_ra, float *grad_rb,
-                        void *stream)
+                        void *workspace, uint64_t workspace_bytes, void *stream)
 {
-    (void)stream;
+    (void)stream; (void)workspace; (void)workspace_bytes;
     int rc = check_route(r);
     if (rc) return rc;
     if (!q || !uh || !grad_q_rout || !grad_q) return fail(HBVX_E_NULL, "route buffer is NULL");
@@ -752,5 +760,13 @@ int hbvx_route_backward(const hbvx_route_desc *r, const float *q, const float *u
         if (grad_ra) grad_ra[(int64_t)b * r->r_stride] += (float)gua;
         if (grad_rb) grad_rb[(int64_t)b * r->r_stride] += (float)gub;
     }
+    return HBVX_OK;
+}
+
+/* diagnostics entry of the ABI: the oracle's pow is libm's powf */
+int hbvx_selftest_pow(const float *x, const float *y, float *out, int n, void *stream)
+{
+    (void)stream;
+    for (int i = 0; i < n; i++) out[i] = powf(x[i], y[i]);
     return HBVX_OK;
 }

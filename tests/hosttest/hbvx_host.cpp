@@ -125,17 +125,21 @@ static void run_bwd(const hbvx_desc &d, const hbvx_bwd_io &io)
                 s.template fwd<true>(p, d.nearzero, d.ac ? d.ac[b] : 0.f, d.elev ? d.elev[b] : 0.f,
                                      io.aux[((int64_t)0 * T + t) * N + n],
                                      io.aux[((int64_t)1 * T + t) * N + n]);
-                const float *gf = io.grad_flux + (int64_t)t * B + b;
+                float gfv[HBVX_MAX_FLUX];
+                for (int k = 0; k < nf; k++) {
+                    gfv[k] = io.grad_flux ? io.grad_flux[(int64_t)k * fs + (int64_t)t * B + b] : 0.f;
+                    if (io.grad_flux4 && k < 4) gfv[k] += io.grad_flux4[(int64_t)k * fs + (int64_t)t * B + b];
+                }
                 FluxGrad g;
                 float wq = d.muwts ? d.muwts[(int64_t)t * d.mu_t_stride + (int64_t)b * d.mu_b_stride + j] : invM;
-                g.gQ = gf[HBVX_F_QSIM * fs] * wq;
-                g.gQ0 = gf[HBVX_F_Q0 * fs] * invM; g.gQ1 = gf[HBVX_F_Q1 * fs] * invM;
-                g.gQ2 = gf[HBVX_F_Q2 * fs] * invM; g.gET = gf[HBVX_F_AET * fs] * invM;
-                g.gSWE = gf[HBVX_F_SWE * fs] * invM; g.grech = gf[HBVX_F_RECHARGE * fs] * invM;
-                g.gexc = gf[HBVX_F_EXCS * fs] * invM; g.gef = gf[HBVX_F_EVAPFACTOR * fs] * invM;
-                g.gtosoil = gf[HBVX_F_TOSOIL * fs] * invM; g.gPERC = gf[HBVX_F_PERC * fs] * invM;
-                g.gcap = nf > HBVX_F_CAPILLARY ? gf[HBVX_F_CAPILLARY * fs] * invM : 0.f;
-                if (io.grad_muwts) io.grad_muwts[((int64_t)t * B + b) * M + j] = gf[HBVX_F_QSIM * fs] * s.Q;
+                g.gQ = gfv[HBVX_F_QSIM] * wq;
+                g.gQ0 = gfv[HBVX_F_Q0] * invM; g.gQ1 = gfv[HBVX_F_Q1] * invM;
+                g.gQ2 = gfv[HBVX_F_Q2] * invM; g.gET = gfv[HBVX_F_AET] * invM;
+                g.gSWE = gfv[HBVX_F_SWE] * invM; g.grech = gfv[HBVX_F_RECHARGE] * invM;
+                g.gexc = gfv[HBVX_F_EXCS] * invM; g.gef = gfv[HBVX_F_EVAPFACTOR] * invM;
+                g.gtosoil = gfv[HBVX_F_TOSOIL] * invM; g.gPERC = gfv[HBVX_F_PERC] * invM;
+                g.gcap = nf > HBVX_F_CAPILLARY ? gfv[HBVX_F_CAPILLARY] * invM : 0.f;
+                if (io.grad_muwts) io.grad_muwts[((int64_t)t * B + b) * M + j] = gfv[HBVX_F_QSIM] * s.Q;
                 float gp[NPARAM_MAX] = {0}, gx[3];
                 s.bwd(p, d.nearzero, g, a, gp, gx);
                 if (io.grad_x) { gxa[t * 3] += gx[0]; gxa[t * 3 + 1] += gx[1]; gxa[t * 3 + 2] += gx[2]; }
@@ -188,9 +192,17 @@ extern "C" int hbvx_route_forward(const hbvx_route_desc *, const float *, float 
     snprintf(g_err, sizeof g_err, "routing is not part of the step-math harness");
     return HBVX_E_UNSUPPORTED;
 }
+extern "C" uint64_t hbvx_route_workspace_bytes(const hbvx_route_desc *) { return 0; }
 extern "C" int hbvx_route_backward(const hbvx_route_desc *, const float *, const float *,
-                                   const float *, float *, float *, float *, void *)
+                                   const float *, float *, float *, float *, void *, uint64_t,
+                                   void *)
 {
     snprintf(g_err, sizeof g_err, "routing is not part of the step-math harness");
     return HBVX_E_UNSUPPORTED;
+}
+
+// accuracy probe for hbvx::pow_pos_ (host build of the same source)
+extern "C" void hbvx_test_pow(const float *x, const float *y, float *out, int n)
+{
+    for (int i = 0; i < n; i++) out[i] = pow_pos_(x[i], y[i]);
 }

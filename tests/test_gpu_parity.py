@@ -81,3 +81,20 @@ def test_product_refuses_cpu_tensors(hip_backend):
     m = Hbv(None, torch.device("cpu"))
     with pytest.raises(RuntimeError, match="no CPU path"):
         m({"x_phy": torch.rand(10, 3, 3)}, torch.randn(10, 3, 14))
+
+
+def test_pow_on_gpu(hip_backend):
+    """The device pow (fp64 polynomials, v_rcp_f64 path) stays within 1 ulp of exact x**y."""
+    import ctypes as C
+    import torch
+    from .test_step_math_host import _pow_inputs, pow_error_ulps
+    x, y = _pow_inputs()
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    out = torch.empty_like(xd)
+    fn = hip_backend.dll.hbvx_selftest_pow
+    fn.restype = C.c_int
+    rc = fn(C.c_void_p(xd.data_ptr()), C.c_void_p(yd.data_ptr()), C.c_void_p(out.data_ptr()),
+            C.c_int(x.size), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    err = pow_error_ulps(out.cpu().numpy(), x, y)
+    assert err.max() <= 0.75, f"max error {err.max():.3f} ulp"

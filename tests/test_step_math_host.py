@@ -42,3 +42,42 @@ def test_step_math_matches_oracle(kw, steptest_lib, oracle_path):
     assert_close("traj", a["traj"], b["traj"], 1e-5, 1e-6)
     for k in ("g_params", "g_x") + (("g_muwts",) if "g_muwts" in b else ()):
         assert_close(k, a[k], b[k], 2e-4, 2e-6)
+
+
+def _pow_inputs():
+    import numpy as np
+    from . import synth
+    n = 400000
+    u = synth.uniform((n,), 77, 1).astype(np.float64)
+    v = synth.uniform((n,), 77, 2).astype(np.float64)
+    # bases spanning SM/FC in [1e-8, 1] and the evap ratio up to ~5; exponents in [0.3, 6]
+    x = np.where(u < 0.7, 10.0 ** (-8.0 * synth.uniform((n,), 77, 3).astype(np.float64)),
+                 5.0 * synth.uniform((n,), 77, 4).astype(np.float64) + 1e-3)
+    y = 0.3 + 5.7 * v
+    x[:8] = [1.0, 0.5, 2.0, 1e-38, 3.0e38, 1.0000001, 0.9999999, 1e-45]
+    y[:8] = [3.3, 2.0, 0.5, 0.3, 0.3, 6.0, 6.0, 1.0]
+    return x.astype(np.float32), y.astype(np.float32)
+
+
+def pow_error_ulps(got, x, y):
+    import numpy as np
+    exact = np.power(x.astype(np.float64), y.astype(np.float64))
+    ref32 = exact.astype(np.float32)
+    ok = np.isfinite(ref32) & (ref32 > 1e-37)      # normal range
+    ulp = np.spacing(np.abs(ref32[ok]))
+    return np.abs(got[ok].astype(np.float64) - exact[ok]) / ulp
+
+
+def test_pow_accuracy(steptest_lib):
+    """hbvx::pow_pos_ stays within 1 ulp of the exact x**y (as libm/ATen powf does)."""
+    import ctypes as C
+    import numpy as np
+    lib = C.CDLL(steptest_lib)
+    x, y = _pow_inputs()
+    out = np.empty_like(x)
+    lib.hbvx_test_pow(x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p),
+                      out.ctypes.data_as(C.c_void_p), C.c_int(x.size))
+    err = pow_error_ulps(out, x, y)
+    assert err.max() <= 0.75, f"max error {err.max():.3f} ulp"
+    # underflow / overflow ends behave like powf
+    assert out[3] == np.float32(np.power(np.float64(np.float32(1e-38)), np.float64(np.float32(0.3))))
