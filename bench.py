@@ -138,7 +138,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     import hydrodl2_amd
-    from hydrodl2_amd import ops
+    from hydrodl2_amd import ops, sharding
     B, M, T = args.basins, args.nmul, args.days
     Hbv = hydrodl2_amd.load_model("hbv", "Hbv")
     model = Hbv({"nmul": M, "dynamic_params": {"Hbv": []}}, dev)
@@ -155,8 +155,7 @@ def main():
         # what a shared parameterisation network would receive: basin-summed last-row gradient
         bucket[:ny] = params.grad[-1].sum(0)
         bucket[ny] = loss.detach()
-        if world > 1:
-            dist.all_reduce(bucket)
+        sharding.all_reduce_sum_([bucket])   # the path's only collective (RCCL over xGMI)
         return loss
 
     for _ in range(args.warmup):

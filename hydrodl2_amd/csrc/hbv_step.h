@@ -50,7 +50,8 @@ HBVX_HD float descale_(float u, float lo, float hi) { return u * (hi - lo) + lo;
 // atanh series after frexp, exp2 via Taylor after rint; relative error < 1e-9 before the
 // final rounding, i.e. within 1 ulp (fp32) of the exact result like libm/ATen's powf
 // (tests/test_step_math_host.py::test_pow_accuracy, tests/test_gpu_parity.py::test_pow_on_gpu).
-// x <= 0, NaN and Inf fall back to powf (never reached on the hot path: SM >= nearzero > 0).
+// Special bases are patched branch-free after the polynomial: 0**y, inf**y as powf; NaN or a
+// negative base give NaN (the reference can only reach x < 0 with nearzero < 0).
 HBVX_HD double rcp64_(double v)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -64,7 +65,6 @@ HBVX_HD double rcp64_(double v)
 
 HBVX_HD float pow_pos_(float x, float y)
 {
-    if (!(x > 0.0f) || !(x < 3.0e38f) || !(y == y) || !(fabsf(y) < 3.0e38f)) return powf(x, y);
     const double xd = (double)x;
 #if defined(__HIP_DEVICE_COMPILE__)
     double m = __builtin_amdgcn_frexp_mant(xd);   // [0.5, 1)
@@ -102,7 +102,12 @@ HBVX_HD float pow_pos_(float x, float y)
     e = __builtin_fma(e, f, 2.4022650695910071e-01); // ln2^2/2!
     e = __builtin_fma(e, f, 6.9314718055994531e-01); // ln2
     e = __builtin_fma(e, f, 1.0);
-    return ldexpf((float)e, (int)n);
+    float r = ldexpf((float)e, (int)n);
+    const float inf = __builtin_inff();
+    r = (x == 0.0f) ? (y > 0.0f ? 0.0f : (y == 0.0f ? 1.0f : inf)) : r;
+    r = (x == inf) ? (y > 0.0f ? inf : (y == 0.0f ? 1.0f : 0.0f)) : r;
+    r = (x < 0.0f || x != x || y != y) ? __builtin_nanf("") : r;
+    return r;
 }
 
 // natural log for the adjoint's d(x**y)/dy = x**y ln x: gradients are compared at rtol 1e-3,

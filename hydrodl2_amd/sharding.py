@@ -1,0 +1,85 @@
+"""Basin sharding across GPUs: one process per GPU, torch.distributed (backend "nccl" = RCCL).
+
+The HBV path has no term that couples basins (every operation in the reference's loop is
+element-wise over [basin, member]; routing is per basin: hbv.py:423-553, uh_routing.py:47-50),
+so the data path needs NO collective: each rank runs the kernels on its contiguous block of
+basins.  The only exchange is one level up -- summing, across ranks, the loss and whatever
+gradient a shared parameterisation network receives -- and, optionally, gathering outputs on
+the basin axis.  This module provides exactly that and nothing more.
+"""
+from __future__ import annotations
+
+from typing import Iterable, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def basin_range(n_basins: int, world: int, rank: int) -> tuple[int, int]:
+    """Contiguous block [b0, b1) of basins owned by `rank` (ceil split; last blocks may be short)."""
+    per = (n_basins + world - 1) // world
+    b0 = min(rank * per, n_basins)
+    return b0, min(b0 + per, n_basins)
+
+
+def shard_inputs(x_dict: dict, parameters, world: int, rank: int):
+    """Slice the basin axis of an `x_dict` / `parameters` pair as the reference lays them out:
+    x_phy [T,B,3], muwts [T,B,nmul], ac_all/elev_all [B]; parameters [T,B,ny] or the HBV 2.0
+    tuple ([T,B,*], [B,*])."""
+    B = x_dict['x_phy'].shape[1]
+    b0, b1 = basin_range(B, world, rank)
+    xs = {}
+    for k, v in x_dict.items():
+        if not torch.is_tensor(v):
+            xs[k] = v
+        elif v.dim() >= 2 and v.shape[1] == B and k not in ('ac_all', 'elev_all'):
+            xs[k] = v[:, b0:b1].contiguous()
+        elif v.dim() >= 1 and v.shape[0] == B:
+            xs[k] = v[b0:b1].contiguous()
+        else:
+            xs[k] = v
+    if isinstance(parameters, (tuple, list)):
+        ps = (parameters[0][:, b0:b1].contiguous(), parameters[1][b0:b1].contiguous())
+    else:
+        ps = parameters[:, b0:b1].contiguous()
+    return xs, ps
+
+
+def all_reduce_sum_(tensors: Sequence[torch.Tensor], group=None) -> None:
+    """Sum `tensors` over ranks in ONE bucketed all-reduce (flatten -> all_reduce -> scatter back).
+
+    xGMI is point-to-point and a ring all-reduce of a small bucket is latency-bound, so the
+    loss scalar(s) and the shared-network gradient travel together in a single collective."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    flat = torch.cat([t.reshape(-1) for t in tensors])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    off = 0
+    for t in tensors:
+        n = t.numel()
+        t.copy_(flat[off:off + n].view_as(t))
+        off += n
+
+
+def gather_basins(local: torch.Tensor, n_basins: int, dim: int, group=None) -> torch.Tensor:
+    """All-gather a per-shard tensor along its basin axis (shards may be uneven)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    per = (n_basins + world - 1) // world
+    pad_shape = list(local.shape)
+    pad_shape[dim] = per
+    padded = local.new_zeros(pad_shape)
+    padded.narrow(dim, 0, local.shape[dim]).copy_(local)
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded.contiguous(), group=group)
+    out = []
+    for r, p in enumerate(parts):
+        b0, b1 = basin_range(n_basins, world, r)
+        out.append(p.narrow(dim, 0, b1 - b0))
+    return torch.cat(out, dim=dim)
+
+
+def gather_flux_dict(flux: dict, n_basins: int, group=None) -> dict:
+    """Gather a flux dictionary ([T,b,1] series, BFI [b]) to full-basin tensors on every rank."""
+    return {k: gather_basins(v, n_basins, 0 if v.dim() == 1 else 1, group) for k, v in flux.items()}

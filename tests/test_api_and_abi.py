@@ -1,0 +1,118 @@
+"""CPU tier: the plug-in API mirrors the reference's (tests/test_methods.py there), the C-ABI
+library loads and exports every symbol include/hbvx.h declares, and host-side validation."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+from torch.nn import Module
+
+import hydrodl2_amd
+from hydrodl2_amd import _abi, available_models, load_model
+from hydrodl2_amd.api.methods import _list_available_models
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# --- the reference's own API tests, restated for this package (tests/test_methods.py:16-47) ---
+def test_available_models():
+    models = available_models()
+    assert isinstance(models, dict)
+    assert all(isinstance(v, list) for v in models.values())
+    assert all(isinstance(v, str) for v in models.keys())
+    assert len(models) > 0
+
+
+@pytest.mark.parametrize('model', _list_available_models())
+def test_load_model(model):
+    loaded_model = load_model(model)
+    assert loaded_model is not None, f"Failed to load '{model}'."
+    assert isinstance(loaded_model, type), f"Loaded '{model}' is not a class."
+    assert issubclass(loaded_model, Module)
+
+
+@pytest.mark.parametrize("model, ver_name", [("hbv", "Hbv"), ("hbv_1_1p", "Hbv_1_1p"),
+                                             ("hbv_2", "Hbv_2"), ("Hbv_2", "Hbv_2")])
+def test_load_model_with_version(model, ver_name):
+    cls = load_model(model, ver_name=ver_name)
+    assert isinstance(cls, type) and cls.__name__ == ver_name
+
+
+def test_load_model_unknown():
+    with pytest.raises(ImportError):
+        load_model("does_not_exist")
+    with pytest.raises(NotImplementedError):
+        hydrodl2_amd.load_module()
+
+
+# --- constructor / attribute contract (hbv.py:37-126,170-180) ---
+def test_defaults_and_param_counts():
+    Hbv = load_model("hbv", "Hbv")
+    m = Hbv(None, torch.device("cpu"))
+    assert (m.nmul, m.warm_up, m.routing, m.nearzero, m.dy_drop) == (1, 0, True, 1e-5, 0.0)
+    assert m.learnable_param_count == 14 and m.variables == ['prcp', 'tmean', 'pet']
+    assert list(m.parameter_bounds)[:3] == ['parBETA', 'parFC', 'parK0'] and 'BFI' in m.flux_names
+    m = Hbv({"nmul": 16, "dynamic_params": {"Hbv": ["parBETA", "parBETAET"]}}, torch.device("cpu"))
+    assert m.learnable_param_count == 13 * 16 + 2 and m.parameter_bounds['parBETAET'] == [0.3, 5]
+    with pytest.raises(KeyError):  # config without dynamic_params: same failure as the reference
+        Hbv({"nmul": 2}, torch.device("cpu"))
+    H11 = load_model("hbv_1_1p", "Hbv_1_1p")
+    assert H11({"nmul": 16, "dynamic_params": {}}, torch.device("cpu")).learnable_param_count == 226
+    H2 = load_model("hbv_2", "Hbv_2")
+    m2 = H2({"nmul": 4, "dynamic_params": {"Hbv_2": ["parBETA", "parK0"]}}, torch.device("cpu"))
+    assert (m2.learnable_param_count1, m2.learnable_param_count2, m2.routing) == (8, 56, False)
+
+
+def test_load_states_validation():
+    m = load_model("hbv", "Hbv")(None, torch.device("cpu"))
+    with pytest.raises(ValueError):
+        m.load_states((torch.zeros(2, 1),) * 4)
+    with pytest.raises(ValueError):
+        m.load_states([torch.zeros(2, 1)] * 5)
+    with pytest.raises(ValueError):
+        m.load_states((1, 2, 3, 4, 5))
+    m.load_states(tuple(torch.zeros(2, 1, dtype=torch.float64) for _ in range(5)))
+    assert all(s.dtype == torch.float32 for s in m.states) and m.get_states() is None
+
+
+# --- the C ABI library itself (no compute: there is no GPU here) ---
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "hbvx.h")).read()
+    return sorted(set(re.findall(r"\b(hbvx_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported_by_the_hip_library():
+    import __graft_entry__ as ge
+    lib_path = ge.build_hip()
+    dll = C.CDLL(lib_path)
+    for sym in _declared_symbols():
+        assert hasattr(dll, sym), f"{sym} declared in include/hbvx.h but not exported"
+    lib = _abi.Library(lib_path)           # version + struct layout checks
+    assert lib.backend == "hip:gfx950"
+
+
+def test_hip_library_rejects_bad_descriptors():
+    """Validation happens on the host before any launch, so it is testable without a GPU."""
+    import __graft_entry__ as ge
+    lib = _abi.Library(ge.build_hip())
+    d, o = _abi.Desc(), _abi.FwdOut()
+    with pytest.raises(_abi.HbvxError, match="abi_version"):
+        lib.forward(d, o, 0)
+    d.abi_version, d.model, d.T, d.B, d.M, d.n_param = _abi.ABI_VERSION, 0, 4, 2, 65, 12
+    with pytest.raises(_abi.HbvxError, match="T/B/M"):
+        lib.forward(d, o, 0)
+    d.M, d.n_param = 4, 14
+    with pytest.raises(_abi.HbvxError, match="n_param"):
+        lib.forward(d, o, 0)
+    d.n_param = 12
+    with pytest.raises(_abi.HbvxError, match="forcing"):
+        lib.forward(d, o, 0)
+
+
+def test_product_fails_loudly_without_gpu_tensors():
+    from hydrodl2_amd import _lib
+    _lib._use_library_for_testing(None)
+    m = load_model("hbv", "Hbv")(None, torch.device("cpu"))
+    with pytest.raises(RuntimeError, match="GPU|HIP"):
+        m({"x_phy": torch.rand(6, 2, 3)}, torch.randn(6, 2, 14))
