@@ -186,10 +186,12 @@ def main():
         kt.setdefault(name, []).append(e0.elapsed_time(e1))
     kavg = {k: sum(v) / len(v) for k, v in kt.items()}
 
-    # Algorithmic HBM bytes per launch of the dominant kernel (DESIGN.md "bytes per lane-step").
+    # Algorithmic HBM bytes per launch ("bytes per lane-step", fp32):
+    #   forward : forcings 12/M + 11 mean series 4*11/M + saved trajectory/aux 28   = 31.5  B
+    #   adjoint : forcings 12/M + trajectory/aux 28 + routed-Q gradients 4*4/M       = 29.75 B
     n_flux = 11
-    bytes_fwd = lane_steps * (12.0 / M + 4.0 * n_flux / M + 28.0)   # forcing + mean series + traj/aux
-    bytes_bwd = lane_steps * (12.0 / M + 4.0 * n_flux / M + 28.0)   # forcing + grad series + traj/aux
+    bytes_fwd = lane_steps * (12.0 / M + 4.0 * n_flux / M + 28.0)
+    bytes_bwd = lane_steps * (12.0 / M + 28.0 + 4.0 * 4 / M)
     dom = max((k for k in kavg if k in ("hbvx_forward", "hbvx_backward")), key=lambda k: kavg[k])
     dom_bytes = bytes_bwd if dom == "hbvx_backward" else bytes_fwd
     achieved = dom_bytes / (kavg[dom] * 1e-3) / 1e9
@@ -197,7 +199,7 @@ def main():
     tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tj):
         try:
-            traffic = json.load(open(tj)).get(dom)
+            traffic = json.load(open(tj)).get(dom, {}).get("hbm_bytes_raw")
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2),
