@@ -271,8 +271,8 @@ __global__ void __launch_bounds__(512) k_fwd_tiled(const FwdTArgs A)
                 }
             }
             if (has_flux) {
-                // ensemble mean: item e -> (day tt, series kk, basin bl); member reads rotated
-                // by the item index to spread LDS banks.
+                // ensemble mean: item e -> (day tt, series kk, basin bl); the member loop starts at
+                // a series-dependent member to spread LDS banks.
                 const int items = nt * NF * bpw;
                 for (int e = hid; e < items; e += nhid) {
                     const int bl = e & (bpw - 1);
@@ -280,7 +280,8 @@ __global__ void __launch_bounds__(512) k_fwd_tiled(const FwdTArgs A)
                     const int kk = r % NF, tt = r / NF;
                     const float *src = out + (tt * NF + kk) * 64 + bl * Mp;
                     float acc = 0.0f;
-                    int m = e % d.M;
+                    int m = kk % d.M; // start member depends on the series only: results do not depend on
+                                      // tile alignment or on where a basin sits in its wave
                     for (int c = 0; c < d.M; c++) {
                         acc += src[m];
                         m = (m + 1 == d.M) ? 0 : m + 1;
@@ -540,7 +541,7 @@ __global__ void __launch_bounds__(512) k_bwd_tiled(const BwdTArgs A)
                     const int c = r % 3, tt = r / 3;
                     const float *src = out + G.off_xout + (tt * 3 + c) * 64 + bl * Mp;
                     float acc = 0.0f;
-                    int m = e % d.M;
+                    int m = c % d.M;
                     for (int q = 0; q < d.M; q++) {
                         acc += src[m];
                         m = (m + 1 == d.M) ? 0 : m + 1;

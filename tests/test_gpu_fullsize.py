@@ -1,0 +1,157 @@
+"""GPU tier: BASELINE.json's full sizes, checked through size-independent properties
+(the oracle cannot run 7.8e7 lane-days in seconds, so it checks a basin subset):
+
+ * basins are independent: a subset of basins run alone gives bit-identical outputs/gradients;
+ * oracle spot-check: a few basins at the full 7300 days against the CPU oracle;
+ * time continuation: two half-length calls with carried states == one call (un-routed fluxes);
+ * gradient structure: static parameters only receive gradient in the last row.
+"""
+import numpy as np
+import pytest
+import torch
+
+from .abi_util import assert_close, make_problem, run_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def _gen(T, B, ny, seed, dev):
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    day = torch.arange(T, device=dev, dtype=torch.float32)[:, None]
+    season = torch.sin(2 * torch.pi * day / 365.0)
+    P = torch.clamp((torch.rand((T, B), generator=g, device=dev) - 0.7) * 60.0, min=0.0)
+    Tm = 10.0 * season + 5.0 * torch.randn((T, B), generator=g, device=dev) \
+        + (torch.rand((1, B), generator=g, device=dev) * 25.0 - 10.0)
+    PET = torch.clamp(3.0 + 2.5 * season, min=0.0).expand(T, B)
+    x = torch.stack([P, Tm, PET], dim=-1).contiguous()
+    p = torch.randn((T, B, ny), generator=g, device=dev)
+    w = torch.randn((T, B, 1), generator=g, device=dev)
+    return x, p, w
+
+
+def _fwd_bwd(model, x, p, w, keys=("streamflow",)):
+    p = p.detach().clone().requires_grad_(True)
+    out = model({"x_phy": x}, p)
+    loss = sum((out[k] * w[-out[k].shape[0]:]).sum() for k in keys)
+    loss.backward()
+    return out, p.grad
+
+
+def test_cfg2_full_size_properties(hip_backend, oracle_path):
+    """hbv, 671 basins x 16 members x 7300 days, static parameters, fwd+bwd."""
+    import hydrodl2_amd
+    dev = torch.device("cuda:0")
+    T, B, M = 7300, 671, 16
+    Hbv = hydrodl2_amd.load_model("hbv", "Hbv")
+    model = Hbv({"nmul": M, "dynamic_params": {"Hbv": []}}, dev)
+    ny = model.learnable_param_count
+    x, p, w = _gen(T, B, ny, 5, dev)
+    out, grad = _fwd_bwd(model, x, p, w, keys=("streamflow", "AET_hydro", "SWE"))
+    assert all(torch.isfinite(v).all() for v in out.values())
+    assert torch.isfinite(grad).all()
+    # static parameters: gradient only in the last row
+    assert float(grad[:-1].abs().max()) == 0.0 and float(grad[-1].abs().max()) > 0.0
+
+    # (1) basin independence, including a block that straddles wave boundaries and the tail
+    sel = torch.tensor([0, 1, 2, 3, 4, 333, 334, 335, 668, 669, 670], device=dev)
+    out_s, grad_s = _fwd_bwd(model, x[:, sel].contiguous(), p[:, sel].contiguous(),
+                             w[:, sel].contiguous(), keys=("streamflow", "AET_hydro", "SWE"))
+    for k in out:
+        if k == "BFI":  # torch.sum glue: its reduction order depends on the tensor shape
+            torch.testing.assert_close(out[k][sel], out_s[k], rtol=1e-5, atol=1e-5)
+            continue
+        assert torch.equal(out[k][:, sel], out_s[k]), k
+    assert torch.equal(grad[-1, sel], grad_s[-1])
+
+    # (2) oracle spot-check of 3 basins over the full 7300 days (through the ABI)
+    pick = [0, 335, 670]
+    prob = make_problem(model="Hbv", T=T, B=len(pick), M=M, dyn=(), seed=1)
+    prob["x"] = x[:, pick].cpu().numpy()
+    prob["params"] = p[:, pick].cpu().numpy()
+    prob["gflux"] = np.zeros((11, T, len(pick)), np.float32)
+    prob["grouted"] = np.zeros((4, T, len(pick)), np.float32)
+    prob["grouted"][0] = w[:, pick, 0].cpu().numpy()
+    want = run_problem(prob, oracle_path, device="cpu")
+    got = run_problem(prob, None, device="cuda:0")
+    assert_close("routed", got["routed"], want["routed"], 1e-4, 1e-5)
+    assert_close("flux", got["flux"], want["flux"], 1e-4, 1e-5)
+    assert_close("g_params", got["g_params"][-1], want["g_params"][-1], 1e-3, 1e-5)
+    assert_close("module streamflow", out["streamflow"][:, pick, 0].detach().cpu().numpy(),
+                 want["routed"][0], 1e-4, 1e-5)
+
+    # (3) time continuation with cache_states (un-routed fluxes are bit-identical)
+    m2 = Hbv({"nmul": M, "dynamic_params": {"Hbv": []}, "cache_states": True}, dev)
+    h = T // 2
+    with torch.no_grad():
+        p1 = torch.cat([p[:h - 1], p[-1:]], 0)
+        o1 = m2({"x_phy": x[:h]}, p1)
+        o2 = m2({"x_phy": x[h:]}, p[h:])
+        for k in ("streamflow_no_rout", "SWE", "AET_hydro", "percolation"):
+            assert torch.equal(torch.cat([o1[k], o2[k]], 0), out[k].detach()), k
+
+
+def test_cfg3_full_size_dynamic_parameters(hip_backend, oracle_path):
+    """hbv_1_1p, all 14 parameters dynamic, 671 x 16 x 7300: 4.4 GB of streamed parameters."""
+    import hydrodl2_amd
+    dev = torch.device("cuda:0")
+    T, B, M = 7300, 671, 16
+    H = hydrodl2_amd.load_model("hbv_1_1p", "Hbv_1_1p")
+    names = list(H(None, dev).parameter_bounds)
+    model = H({"nmul": M, "dynamic_params": {"Hbv_1_1p": names}}, dev)
+    ny = model.learnable_param_count
+    x, p, w = _gen(T, B, ny, 6, dev)
+    out, grad = _fwd_bwd(model, x, p, w)
+    assert all(torch.isfinite(v).all() for v in out.values()) and torch.isfinite(grad).all()
+    assert float(grad[:, :, :14 * M].abs().sum(dim=(1, 2)).min()) > 0.0   # every day gets gradient
+
+    sel = torch.tensor([5, 6, 7, 400, 670], device=dev)
+    out_s, grad_s = _fwd_bwd(model, x[:, sel].contiguous(), p[:, sel].contiguous(),
+                             w[:, sel].contiguous())
+    assert torch.equal(out["streamflow"][:, sel], out_s["streamflow"])
+    assert torch.equal(grad[:, sel], grad_s)
+
+    pick = [5, 670]
+    prob = make_problem(model="Hbv_1_1p", T=T, B=len(pick), M=M, dyn=tuple(names), seed=1)
+    prob["x"] = x[:, pick].cpu().numpy()
+    prob["params"] = p[:, pick].cpu().numpy()
+    prob["gflux"] = np.zeros((12, T, len(pick)), np.float32)
+    prob["grouted"] = np.zeros((4, T, len(pick)), np.float32)
+    prob["grouted"][0] = w[:, pick, 0].cpu().numpy()
+    want = run_problem(prob, oracle_path, device="cpu")
+    assert_close("streamflow", out["streamflow"][:, pick, 0].detach().cpu().numpy(),
+                 want["routed"][0], 1e-4, 1e-5)
+    assert_close("g_params", grad[:, pick].cpu().numpy(), want["g_params"], 1e-3, 1e-5)
+
+
+def test_hbv2_many_basins(hip_backend):
+    """hbv_2, 40k basins x 16 members x 365 days (one GPU's share of a 100k+-basin run):
+    basin independence across 10 000 workgroups and the state series."""
+    import hydrodl2_amd
+    dev = torch.device("cuda:0")
+    T, B, M = 365, 40000, 16
+    H2 = hydrodl2_amd.load_model("hbv_2", "Hbv_2")
+    dyn = ["parBETA", "parK0", "parBETAET"]
+    model = H2({"nmul": M, "dynamic_params": {"Hbv_2": dyn}}, dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(9)
+    x, _, w = _gen(T, B, 1, 9, dev)
+    pd = torch.rand((T, B, 3 * M), generator=g, device=dev).requires_grad_(True)
+    ps = torch.rand((B, 13 * M), generator=g, device=dev).requires_grad_(True)
+    xd = {"x_phy": x, "ac_all": torch.rand(B, generator=g, device=dev) * 5000,
+          "elev_all": torch.rand(B, generator=g, device=dev) * 3000}
+    out = model(xd, (pd, ps))
+    (out["streamflow"] * w).sum().backward()
+    st = model.get_states()
+    assert len(st) == 5 and st[0].shape == (T, B, M)
+    assert torch.isfinite(out["streamflow"]).all() and torch.isfinite(pd.grad).all()
+    sel = torch.tensor([0, 3, 4, 19999, 39996, 39999], device=dev)
+    pd2 = pd.detach()[:, sel].contiguous().requires_grad_(True)
+    ps2 = ps.detach()[sel].contiguous().requires_grad_(True)
+    xd2 = {"x_phy": x[:, sel].contiguous(), "ac_all": xd["ac_all"][sel], "elev_all": xd["elev_all"][sel]}
+    m2 = H2({"nmul": M, "dynamic_params": {"Hbv_2": dyn}}, dev)
+    out2 = m2(xd2, (pd2, ps2))
+    (out2["streamflow"] * w[:, sel]).sum().backward()
+    assert torch.equal(out["streamflow"][:, sel], out2["streamflow"])
+    assert torch.equal(pd.grad[:, sel], pd2.grad) and torch.equal(ps.grad[sel], ps2.grad)
+    assert torch.equal(st[2][:, sel], m2.get_states()[2])
