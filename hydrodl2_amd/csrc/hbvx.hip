@@ -401,112 +401,147 @@ __global__ void k_uh_gamma(const hbvx_route_desc r, float *__restrict__ uh)
         if (k < r.L) uh[(int64_t)b * r.L + k] = w[k] / sum;
 }
 
-// uh_conv (uh_routing.py:25-57): y[s,t,b] = sum_k UH[b,k] * q[s,t-k,b]; thread per (s,t,b)
-__global__ void k_route_fwd(int T, int B, int S, int L, const float *__restrict__ q,
-                            const float *__restrict__ uh, float *__restrict__ y)
-{
-    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t total = (int64_t)S * T * B;
-    if (idx >= total) return;
-    int b = (int)(idx % B);
-    int t = (int)((idx / B) % T);
-    const float *w = uh + (int64_t)b * L;
-    float acc = 0.0f;
-    for (int k = 0; k < L && k <= t; k++) acc += w[k] * q[idx - (int64_t)k * B];
-    y[idx] = acc;
-}
-
-// conv backward w.r.t. the input: gq[s,t,b] = sum_k UH[b,k] * gy[s,t+k,b]
-__global__ void k_route_bwd_q(int T, int B, int S, int L, const float *__restrict__ gy,
-                              const float *__restrict__ uh, float *__restrict__ gq)
-{
-    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t total = (int64_t)S * T * B;
-    if (idx >= total) return;
-    int b = (int)(idx % B);
-    int t = (int)((idx / B) % T);
-    const float *w = uh + (int64_t)b * L;
-    float acc = 0.0f;
-    for (int k = 0; k < L && t + k < T; k++) acc += w[k] * gy[idx + (int64_t)k * B];
-    gq[idx] = acc;
-}
-
-// conv backward w.r.t. the taps, stage 1: partial tap gradients per time chunk.
-// thread = (basin, chunk of ROUTE_CHUNK days); lanes run over basins (coalesced);
-// ws[(chunk*L + k)*B + b] = sum_{s, t in chunk} gy[s,t,b] * q[s,t-k,b]
+// Routing kernels: thread = (basin, chunk of ROUTE_CHUNK days); the 64 lanes of a wave are 64
+// consecutive basins (256-byte coalesced accesses), the 15-tap window slides through registers,
+// so every input element is read once (plus a 14-day halo per chunk).
 #define ROUTE_CHUNK 32
-__global__ void __launch_bounds__(256) k_route_bwd_taps(int T, int B, int S, int L,
-                                                        const float *__restrict__ q,
-                                                        const float *__restrict__ gy,
-                                                        float *__restrict__ ws)
+
+__device__ __forceinline__ void load_uh(const float *__restrict__ uh, int b, int L, float *w)
+{
+#pragma unroll
+    for (int k = 0; k < HBVX_UH_MAXLEN; k++) w[k] = (k < L) ? uh[(int64_t)b * L + k] : 0.0f;
+}
+
+// uh_conv (uh_routing.py:25-57): y[s,t,b] = sum_k UH[b,k] * q[s,t-k,b], zero history
+__global__ void __launch_bounds__(256) k_route_fwd(int T, int B, int S, int L,
+                                                   const float *__restrict__ q,
+                                                   const float *__restrict__ uh,
+                                                   float *__restrict__ y)
 {
     const int b = blockIdx.x * 64 + (threadIdx.x & 63);
     const int chunk = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int t0 = chunk * ROUTE_CHUNK;
     if (b >= B || t0 >= T) return;
     const int t1 = min(T, t0 + ROUTE_CHUNK);
-    float gw[HBVX_UH_MAXLEN];
-#pragma unroll
-    for (int k = 0; k < HBVX_UH_MAXLEN; k++) gw[k] = 0.0f;
+    float w[HBVX_UH_MAXLEN];
+    load_uh(uh, b, L, w);
     for (int s = 0; s < S; s++) {
         const float *qs = q + (int64_t)s * T * B + b;
-        const float *gs = gy + (int64_t)s * T * B + b;
-        // sliding window of the last 15 inputs in registers
+        float *ys = y + (int64_t)s * T * B + b;
         float win[HBVX_UH_MAXLEN];
 #pragma unroll
         for (int k = 1; k < HBVX_UH_MAXLEN; k++) win[k] = (t0 - k >= 0) ? qs[(int64_t)(t0 - k) * B] : 0.0f;
         for (int t = t0; t < t1; t++) {
             win[0] = qs[(int64_t)t * B];
-            const float g = gs[(int64_t)t * B];
+            float acc = 0.0f;
 #pragma unroll
-            for (int k = 0; k < HBVX_UH_MAXLEN; k++) gw[k] += g * win[k];
+            for (int k = 0; k < HBVX_UH_MAXLEN; k++) acc += w[k] * win[k];
+            ys[(int64_t)t * B] = acc;
 #pragma unroll
             for (int k = HBVX_UH_MAXLEN - 1; k > 0; k--) win[k] = win[k - 1];
         }
     }
+}
+
+// conv1d backward in one pass over the chunk:
+//   gq[s,t,b] = sum_k UH[b,k] * gy[s,t+k,b]                      (w.r.t. the input)
+//   ws[(chunk*L+k)*B + b] = sum_{s, t in chunk} gy[s,t,b] * q[s,t-k,b]   (partial tap gradients)
+__global__ void __launch_bounds__(256) k_route_bwd(int T, int B, int S, int L,
+                                                   const float *__restrict__ q,
+                                                   const float *__restrict__ uh,
+                                                   const float *__restrict__ gy,
+                                                   float *__restrict__ gq, float *__restrict__ ws)
+{
+    const int b = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int chunk = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int t0 = chunk * ROUTE_CHUNK;
+    if (b >= B || t0 >= T) return;
+    const int t1 = min(T, t0 + ROUTE_CHUNK);
+    float w[HBVX_UH_MAXLEN], gw[HBVX_UH_MAXLEN];
+    load_uh(uh, b, L, w);
 #pragma unroll
-    for (int k = 0; k < HBVX_UH_MAXLEN; k++)
-        if (k < L) ws[((int64_t)chunk * L + k) * B + b] = gw[k];
+    for (int k = 0; k < HBVX_UH_MAXLEN; k++) gw[k] = 0.0f;
+    for (int s = 0; s < S; s++) {
+        const float *qs = q + (int64_t)s * T * B + b;
+        const float *gs = gy + (int64_t)s * T * B + b;
+        float *gqs = gq + (int64_t)s * T * B + b;
+        float qwin[HBVX_UH_MAXLEN], gwin[HBVX_UH_MAXLEN]; // q[t-k], gy[t+k]
+#pragma unroll
+        for (int k = 1; k < HBVX_UH_MAXLEN; k++) qwin[k] = (t0 - k >= 0) ? qs[(int64_t)(t0 - k) * B] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < HBVX_UH_MAXLEN - 1; k++) gwin[k + 1] = (t0 + k < T) ? gs[(int64_t)(t0 + k) * B] : 0.0f;
+        for (int t = t0; t < t1; t++) {
+#pragma unroll
+            for (int k = 0; k < HBVX_UH_MAXLEN - 1; k++) gwin[k] = gwin[k + 1];
+            gwin[HBVX_UH_MAXLEN - 1] = (t + HBVX_UH_MAXLEN - 1 < T) ? gs[(int64_t)(t + HBVX_UH_MAXLEN - 1) * B] : 0.0f;
+            qwin[0] = qs[(int64_t)t * B];
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < HBVX_UH_MAXLEN; k++) {
+                acc += w[k] * gwin[k];
+                gw[k] += gwin[0] * qwin[k];
+            }
+            gqs[(int64_t)t * B] = acc;
+#pragma unroll
+            for (int k = HBVX_UH_MAXLEN - 1; k > 0; k--) qwin[k] = qwin[k - 1];
+        }
+    }
+    if (ws) {
+#pragma unroll
+        for (int k = 0; k < HBVX_UH_MAXLEN; k++)
+            if (k < L) ws[((int64_t)chunk * L + k) * B + b] = gw[k];
+    }
 }
 
 // stage 2: reduce the chunks (fixed order: deterministic) and go through the normalised
-// gamma UH to the routing inputs.
+// gamma UH to the routing inputs.  Block = 64 basins x 16 tap-threads: thread (bl, k) sums tap
+// k over all chunks (coalesced along basins), then the k == 0 threads finish per basin.
 // d w_k / d aa    = w_k (ln t_k - sum_j w_j ln t_j)      (Gamma(aa) and theta^aa cancel
 // d w_k / d theta = w_k (t_k - sum_j w_j t_j) / theta^2    in the normalisation)
-__global__ void __launch_bounds__(64) k_route_bwd_params(const hbvx_route_desc r, int nchunk,
-                                                         const float *__restrict__ uh,
-                                                         const float *__restrict__ ws,
-                                                         float *grad_ra, float *grad_rb)
+__global__ void __launch_bounds__(1024) k_route_bwd_params(const hbvx_route_desc r, int nchunk,
+                                                           const float *__restrict__ uh,
+                                                           const float *__restrict__ ws,
+                                                           float *grad_ra, float *grad_rb)
 {
-    const int b = blockIdx.x * 64 + threadIdx.x;
+    __shared__ float red[16][64];
+    const int bl = threadIdx.x & 63, k = threadIdx.x >> 6;
+    const int b = blockIdx.x * 64 + bl;
     const int B = r.B, L = r.L;
-    if (b >= B) return;
-    float gw[HBVX_UH_MAXLEN];
-#pragma unroll
-    for (int k = 0; k < HBVX_UH_MAXLEN; k++) gw[k] = 0.0f;
-    for (int c = 0; c < nchunk; c++) {
-#pragma unroll
-        for (int k = 0; k < HBVX_UH_MAXLEN; k++)
-            if (k < L) gw[k] += ws[((int64_t)c * L + k) * B + b];
+    float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;
+    if (b < B && k < L) {
+        const float *src = ws + (int64_t)k * B + b;
+        const int64_t cs = (int64_t)L * B;
+        int c = 0;
+        for (; c + 3 < nchunk; c += 4) {
+            acc0 += src[(int64_t)c * cs];
+            acc1 += src[(int64_t)(c + 1) * cs];
+            acc2 += src[(int64_t)(c + 2) * cs];
+            acc3 += src[(int64_t)(c + 3) * cs];
+        }
+        for (; c < nchunk; c++) acc0 += src[(int64_t)c * cs];
     }
+    red[k][bl] = (acc0 + acc1) + (acc2 + acc3);
+    __syncthreads();
+    if (k != 0 || b >= B) return;
     float ua, ub, a, bb;
     route_ab(r, b, ua, ub, a, bb);
     const float theta = fmaxf(bb, 0.0f) + 0.5f;
-    float w[HBVX_UH_MAXLEN];
+    float w[HBVX_UH_MAXLEN], gw[HBVX_UH_MAXLEN];
     float mlt = 0.0f, mt = 0.0f;
 #pragma unroll
-    for (int k = 0; k < HBVX_UH_MAXLEN; k++) {
-        w[k] = (k < L) ? uh[(int64_t)b * L + k] : 0.0f;
-        const float tk = (float)k + 0.5f;
-        mlt += w[k] * logf(tk);
-        mt += w[k] * tk;
+    for (int j = 0; j < HBVX_UH_MAXLEN; j++) {
+        gw[j] = (j < L) ? red[j][bl] : 0.0f;
+        w[j] = (j < L) ? uh[(int64_t)b * L + j] : 0.0f;
+        const float tk = (float)j + 0.5f;
+        mlt += w[j] * logf(tk);
+        mt += w[j] * tk;
     }
     float gaa = 0.0f, gth = 0.0f;
 #pragma unroll
-    for (int k = 0; k < HBVX_UH_MAXLEN; k++) {
-        const float tk = (float)k + 0.5f;
-        gaa += gw[k] * w[k] * (logf(tk) - mlt);
-        gth += gw[k] * w[k] * ((tk - mt) / (theta * theta));
+    for (int j = 0; j < HBVX_UH_MAXLEN; j++) {
+        const float tk = (float)j + 0.5f;
+        gaa += gw[j] * w[j] * (logf(tk) - mlt);
+        gth += gw[j] * w[j] * ((tk - mt) / (theta * theta));
     }
     float ga = (a > 0.0f) ? gaa : 0.0f;   // relu backward (uh_routing.py:11-14)
     float gb = (bb > 0.0f) ? gth : 0.0f;
@@ -752,8 +787,8 @@ extern "C" int hbvx_route_forward(const hbvx_route_desc *r, const float *q, floa
     if (!q || !uh || !q_rout) return fail(HBVX_E_NULL, "route buffer is NULL");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_uh_gamma, dim3((r->B + 63) / 64), dim3(64), 0, st, *r, uh);
-    const int64_t total = (int64_t)r->S * r->T * r->B;
-    hipLaunchKernelGGL(k_route_fwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, r->T,
+    const int nchunk = (r->T + ROUTE_CHUNK - 1) / ROUTE_CHUNK;
+    hipLaunchKernelGGL(k_route_fwd, dim3((r->B + 63) / 64, (nchunk + 3) / 4), dim3(256), 0, st, r->T,
                        r->B, r->S, r->L, q, uh, q_rout);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "hbvx_route_forward launch");
@@ -777,18 +812,15 @@ extern "C" int hbvx_route_backward(const hbvx_route_desc *r, const float *q, con
     if (rc) return rc;
     if (!q || !uh || !grad_q_rout || !grad_q) return fail(HBVX_E_NULL, "route buffer is NULL");
     hipStream_t st = (hipStream_t)stream;
-    const int64_t total = (int64_t)r->S * r->T * r->B;
-    hipLaunchKernelGGL(k_route_bwd_q, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                       r->T, r->B, r->S, r->L, grad_q_rout, uh, grad_q);
-    if (grad_ra || grad_rb) {
-        if (!workspace || workspace_bytes < hbvx_route_workspace_bytes(r))
-            return fail(HBVX_E_NULL, "route workspace missing or too small");
-        const int nchunk = route_chunks(r);
-        hipLaunchKernelGGL(k_route_bwd_taps, dim3((r->B + 63) / 64, (nchunk + 3) / 4), dim3(256), 0,
-                           st, r->T, r->B, r->S, r->L, q, grad_q_rout, (float *)workspace);
-        hipLaunchKernelGGL(k_route_bwd_params, dim3((r->B + 63) / 64), dim3(64), 0, st, *r, nchunk,
+    const bool want_p = grad_ra || grad_rb;
+    if (want_p && (!workspace || workspace_bytes < hbvx_route_workspace_bytes(r)))
+        return fail(HBVX_E_NULL, "route workspace missing or too small");
+    const int nchunk = route_chunks(r);
+    hipLaunchKernelGGL(k_route_bwd, dim3((r->B + 63) / 64, (nchunk + 3) / 4), dim3(256), 0, st, r->T,
+                       r->B, r->S, r->L, q, uh, grad_q_rout, grad_q, want_p ? (float *)workspace : nullptr);
+    if (want_p)
+        hipLaunchKernelGGL(k_route_bwd_params, dim3((r->B + 63) / 64), dim3(1024), 0, st, *r, nchunk,
                            uh, (const float *)workspace, grad_ra, grad_rb);
-    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "hbvx_route_backward launch");
     return HBVX_OK;
