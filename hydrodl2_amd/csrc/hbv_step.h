@@ -37,6 +37,35 @@ enum : int {
 HBVX_HD float fmax_(float a, float b) { return fmaxf(a, b); } // v_max_f32
 HBVX_HD float fmin_(float a, float b) { return fminf(a, b); } // v_min_f32
 
+// a / b for the forward quantities (SM/FC, SM/(LP*FC)).  The compiler's IEEE sequence is ten
+// dependent instructions (div_scale x2, rcp, 4 fma, div_fmas, div_fixup).  On the device use
+// rcp + multiply + two fused corrections: correctly rounded for normal-range operands except in
+// astronomically rare double-rounding cases, and exactly 1.0f when a == b (the inclusive clamp
+// gradients at SM == FC depend on that).  Operands here are O(1e-5 .. 1e3): no scaling needed.
+HBVX_HD float div_(float a, float b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float rc = __builtin_amdgcn_rcpf(b);
+    float q = a * rc;
+    float r = __builtin_fmaf(-b, q, a);
+    q = __builtin_fmaf(r, rc, q);
+    r = __builtin_fmaf(-b, q, a);
+    return __builtin_fmaf(r, rc, q);
+#else
+    return a / b;
+#endif
+}
+
+// a / b inside the adjoint only (gradients are compared at rtol 1e-3): rcp + multiply.
+HBVX_HD float div_approx_(float a, float b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return a * __builtin_amdgcn_rcpf(b);
+#else
+    return a / b;
+#endif
+}
+
 // torch.sigmoid: 1/(1+exp(-x))  (hbv.py:201)
 HBVX_HD float sigmoid_(float v) { return 1.0f / (1.0f + expf(-v)); }
 // core/calc/utils.py:24: multiply, then add (no FMA)
@@ -191,7 +220,7 @@ struct Step {
         tosoil = fmax_(ts0, 0.0f);
         MW3 = MW2 - tosoil;
         // hbv.py:462-472
-        r = SM / FC;
+        r = div_(SM, FC);
         sw0 = USE_AUX ? aux_sw0 : pow_pos_(r, BETA);
         sw = fmin_(fmax_(sw0, 0.0f), 1.0f);
         rt = RAIN + tosoil;
@@ -202,7 +231,7 @@ struct Step {
         SM2 = SM1 - exc;
         // hbv.py:474-480 ; hbv_1_1p.py:473-480
         lpfc = LP * FC;
-        q = SM2 / lpfc;
+        q = div_(SM2, lpfc);
         if (BETAET) ef0 = USE_AUX ? aux_ef0 : pow_pos_(q, p[P_BETAET]);
         else ef0 = q;
         ef = fmin_(fmax_(ef0, 0.0f), 1.0f);
@@ -213,7 +242,7 @@ struct Step {
         // hbv_1_1p.py:482-490
         if (MODEL != MODEL_HBV10) {
             const float C = p[P_C];
-            x1 = SM3 / FC;
+            x1 = div_(SM3, FC);
             float rc = fmin_(x1, 1.0f);
             cs = C * SLZ;
             om = 1.0f - rc;
@@ -322,8 +351,8 @@ struct Step {
             gp[P_C] += acs * SLZ;
             aSLZ += acs * C;
             float ax1 = (x1 <= 1.0f) ? arc : 0.0f;
-            aSM3 += ax1 / FC;
-            gp[P_FC] += -ax1 * (x1 / FC);
+            aSM3 += div_approx_(ax1, FC);
+            gp[P_FC] += -ax1 * div_approx_(x1, FC);
         } else {
             aSLZ = aSLZ0;
             aSM3 = aSMn;
@@ -341,15 +370,15 @@ struct Step {
         if (BETAET) {
             // d/dq q^b = b q^(b-1) = b * ef0 / q ; d/db = ef0 ln q   (q > 0: SM2 > 0)
             const float BE = p[P_BETAET];
-            float dq = (q > 0.0f) ? BE * (ef0 / q) : 0.0f;
+            float dq = (q > 0.0f) ? BE * div_approx_(ef0, q) : 0.0f;
             float db = (q > 0.0f) ? ef0 * log_fast_(q) : 0.0f;
             aq = aef0 * dq;
             gp[P_BETAET] += aef0 * db;
         } else {
             aq = aef0;
         }
-        aSM2 += aq / lpfc;
-        float alpfc = -aq * (q / lpfc);
+        aSM2 += div_approx_(aq, lpfc);
+        float alpfc = -aq * div_approx_(q, lpfc);
         gp[P_LP] += alpfc * FC;
         gp[P_FC] += alpfc * LP;
         float aSM1 = aSM2;
@@ -366,12 +395,12 @@ struct Step {
         aRAIN += art;
         atosoil += art;
         float asw0 = (sw0 >= 0.0f && sw0 <= 1.0f) ? asw : 0.0f;
-        float dr = (r > 0.0f) ? BETA * (sw0 / r) : 0.0f;
+        float dr = (r > 0.0f) ? BETA * div_approx_(sw0, r) : 0.0f;
         float db_ = (r > 0.0f) ? sw0 * log_fast_(r) : 0.0f;
         float ar = asw0 * dr;
         gp[P_BETA] += asw0 * db_;
-        aSM += ar / FC;
-        gp[P_FC] += -ar * (r / FC);
+        aSM += div_approx_(ar, FC);
+        gp[P_FC] += -ar * div_approx_(r, FC);
         float aMW2 = aMW3;
         atosoil -= aMW3;
         float ats0 = (ts0 >= 0.0f) ? atosoil : 0.0f;

@@ -844,3 +844,19 @@ extern "C" int hbvx_selftest_pow(const float *x, const float *y, float *out, int
     if (e != hipSuccess) return hip_fail(e, "selftest_pow launch");
     return HBVX_OK;
 }
+
+__global__ void k_selftest_div(const float *x, const float *y, float *out, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = div_(x[i], y[i]);
+}
+
+extern "C" int hbvx_selftest_div(const float *x, const float *y, float *out, int n, void *stream)
+{
+    if (!x || !y || !out || n <= 0) return fail(HBVX_E_NULL, "selftest_div: bad arguments");
+    hipLaunchKernelGGL(k_selftest_div, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, y,
+                       out, n);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "selftest_div launch");
+    return HBVX_OK;
+}

@@ -187,6 +187,8 @@ int hbvx_route_backward(const hbvx_route_desc *r, const float *q, const float *u
 
 /* Diagnostics (tests only): out[i] = the device pow used for (SM/FC)**BETA on x[i], y[i]. */
 int hbvx_selftest_pow(const float *x, const float *y, float *out, int n, void *stream);
+/* Diagnostics (tests only): out[i] = the device quotient used for SM/FC on x[i] / y[i]. */
+int hbvx_selftest_div(const float *x, const float *y, float *out, int n, void *stream);
 
 #ifdef __cplusplus
 }

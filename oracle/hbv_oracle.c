@@ -770,3 +770,10 @@ int hbvx_selftest_pow(const float *x, const float *y, float *out, int n, void *s
     for (int i = 0; i < n; i++) out[i] = powf(x[i], y[i]);
     return HBVX_OK;
 }
+
+int hbvx_selftest_div(const float *x, const float *y, float *out, int n, void *stream)
+{
+    (void)stream;
+    for (int i = 0; i < n; i++) out[i] = x[i] / y[i];
+    return HBVX_OK;
+}

@@ -98,3 +98,26 @@ def test_pow_on_gpu(hip_backend):
     assert rc == 0
     err = pow_error_ulps(out.cpu().numpy(), x, y)
     assert err.max() <= 0.75, f"max error {err.max():.3f} ulp"
+
+
+def test_div_on_gpu(hip_backend):
+    """The device quotient (rcp + two fused corrections) equals IEEE a/b on the path's operand
+    range, and is exactly 1 for a == b (the clamp gradients at SM == FC rely on it)."""
+    import ctypes as C
+    import torch
+    from . import synth
+    n = 1 << 20
+    a = (10.0 ** (synth.uniform((n,), 91, 1).astype(np.float64) * 8 - 5)).astype(np.float32)
+    b = (10.0 ** (synth.uniform((n,), 91, 2).astype(np.float64) * 3)).astype(np.float32)
+    a[: n // 8] = b[: n // 8]
+    ad, bd = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    out = torch.empty_like(ad)
+    fn = hip_backend.dll.hbvx_selftest_div
+    fn.restype = C.c_int
+    assert fn(C.c_void_p(ad.data_ptr()), C.c_void_p(bd.data_ptr()), C.c_void_p(out.data_ptr()),
+              C.c_int(n), C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    got = out.cpu().numpy()
+    want = a / b
+    assert (got[: n // 8] == 1.0).all()
+    mism = int((got != want).sum())
+    assert mism == 0, f"{mism} of {n} quotients differ from IEEE division"
