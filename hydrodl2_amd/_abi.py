@@ -9,14 +9,14 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_PARAM = 16
 NSTATE = 5
 MAX_FLUX = 12
 UH_MAXLEN = 15
 
 # enum hbvx_model
-MODEL_HBV10, MODEL_HBV11P, MODEL_HBV20 = 0, 1, 2
+MODEL_HBV10, MODEL_HBV11P, MODEL_HBV20, MODEL_HBVADJ = 0, 1, 2, 3
 
 # enum hbvx_flux
 (F_QSIM, F_Q0, F_Q1, F_Q2, F_AET, F_SWE, F_RECHARGE, F_EXCS, F_EVAPFACTOR, F_TOSOIL, F_PERC,
@@ -48,7 +48,8 @@ class Desc(C.Structure):
                 ("x", _fp), ("x_t_stride", C.c_int64), ("x_b_stride", C.c_int64),
                 ("ac", _fp), ("elev", _fp), ("muwts", _fp),
                 ("mu_t_stride", C.c_int64), ("mu_b_stride", C.c_int64),
-                ("state_in", _fp), ("p", ParamSrc * MAX_PARAM)]
+                ("state_in", _fp), ("p", ParamSrc * MAX_PARAM),
+                ("adj_gtol", C.c_float), ("adj_max_iter", C.c_int32)]
 
 
 class FwdOut(C.Structure):
@@ -58,7 +59,7 @@ class FwdOut(C.Structure):
 
 class BwdIO(C.Structure):
     _fields_ = [("traj", _fp), ("aux", _fp), ("grad_flux", _fp), ("grad_flux4", _fp),
-                ("grad_x", _fp),
+                ("grad_state_out", _fp), ("grad_x", _fp),
                 ("grad_muwts", _fp), ("grad_state_in", _fp),
                 ("n_flux", C.c_int32), ("reserved0", C.c_int32),
                 ("g", ParamGrad * MAX_PARAM)]
@@ -74,7 +75,7 @@ class RouteDesc(C.Structure):
 
 EXPORTS = ["hbvx_version", "hbvx_last_error", "hbvx_backend", "hbvx_sizeof", "hbvx_forward",
            "hbvx_backward", "hbvx_route_forward", "hbvx_route_workspace_bytes",
-           "hbvx_route_backward"]
+           "hbvx_route_backward", "hbvx_adj_forward", "hbvx_adj_backward"]
 
 
 class HbvxError(RuntimeError):
@@ -109,6 +110,10 @@ class Library:
         d.hbvx_route_workspace_bytes.argtypes = [C.POINTER(RouteDesc)]
         d.hbvx_route_backward.argtypes = [C.POINTER(RouteDesc), _fp, _fp, _fp, _fp, _fp, _fp,
                                           _fp, C.c_uint64, C.c_void_p]
+        for fn in (d.hbvx_adj_forward, d.hbvx_adj_backward):
+            fn.restype = C.c_int
+        d.hbvx_adj_forward.argtypes = [C.POINTER(Desc), C.POINTER(FwdOut), C.c_void_p]
+        d.hbvx_adj_backward.argtypes = [C.POINTER(Desc), C.POINTER(BwdIO), C.c_void_p]
         if d.hbvx_version() != ABI_VERSION:
             raise HbvxError(f"{path}: ABI version {d.hbvx_version()} != {ABI_VERSION}")
         for which, st in enumerate([Desc, FwdOut, BwdIO, RouteDesc, ParamSrc, ParamGrad]):
@@ -133,6 +138,14 @@ class Library:
     def backward(self, desc: Desc, io: BwdIO, stream: int):
         self._check(self.dll.hbvx_backward(C.byref(desc), C.byref(io), C.c_void_p(stream)),
                     "hbvx_backward")
+
+    def adj_forward(self, desc: Desc, out: FwdOut, stream: int):
+        self._check(self.dll.hbvx_adj_forward(C.byref(desc), C.byref(out), C.c_void_p(stream)),
+                    "hbvx_adj_forward")
+
+    def adj_backward(self, desc: Desc, io: BwdIO, stream: int):
+        self._check(self.dll.hbvx_adj_backward(C.byref(desc), C.byref(io), C.c_void_p(stream)),
+                    "hbvx_adj_backward")
 
     def route_forward(self, r: RouteDesc, q: int, uh: int, q_rout: int, stream: int):
         self._check(self.dll.hbvx_route_forward(C.byref(r), q, uh, q_rout, C.c_void_p(stream)),

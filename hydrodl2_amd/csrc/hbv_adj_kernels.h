@@ -1,0 +1,198 @@
+// hbv_adj_kernels.h -- implicit HBV ("HBV adjoint") forward / backward kernels.
+// One wave per workgroup, lane = (basin, member) as everywhere else; per day a modified Newton
+// solve in registers (hbv_adj_step.h).  First-cut launch geometry (round 1): correctness and
+// parity against the oracle; the wave-specialised tiling of hbv_tiled.h is the next step here.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/hbvx.h"
+#include "hbv_adj_step.h"
+
+namespace hbvx {
+
+struct AdjFwdArgs {
+    hbvx_desc d;
+    hbvx_fwd_out o;
+    int lgMp;
+};
+struct AdjBwdArgs {
+    hbvx_desc d;
+    hbvx_bwd_io io;
+    int lgMp;
+};
+
+struct AdjLane {
+    int jm, b, j;
+    bool active, leader;
+    int64_t n;
+};
+
+__device__ __forceinline__ AdjLane adj_lane(const hbvx_desc &d, int lgMp)
+{
+    AdjLane L;
+    const int lane = threadIdx.x & 63;
+    const int Mp = 1 << lgMp;
+    L.jm = lane & (Mp - 1);
+    int b = blockIdx.x * (64 >> lgMp) + (lane >> lgMp);
+    L.active = (b < d.B) && (L.jm < d.M);
+    L.leader = (b < d.B) && (L.jm == 0);
+    L.b = b < d.B ? b : d.B - 1;
+    L.j = L.jm < d.M ? L.jm : d.M - 1;
+    L.n = (int64_t)L.b * d.M + L.j;
+    return L;
+}
+
+__device__ __forceinline__ float adj_ens_sum(float v, int lgMp)
+{
+    for (int s = 0; s < lgMp; s++) v += __shfl_xor(v, 1 << s, 64);
+    return v;
+}
+
+// per-lane parameter fetch for day t: unit value u[i] and physical p[i]
+template <int NP>
+__device__ __forceinline__ void adj_params(const hbvx_desc &d, const AdjLane &L, int t, bool raw,
+                                           const float *usta, const bool *use_dyn, float *u, float *p)
+{
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        const hbvx_param_src &s = d.p[i];
+        float uv = usta[i];
+        if (s.dyn) {
+            float v = s.dyn[(int64_t)t * s.dyn_t_stride + (int64_t)L.b * s.dyn_b_stride + L.j];
+            v = raw ? sigmoid_(v) : v;
+            uv = use_dyn[i] ? v : uv;
+        }
+        u[i] = uv;
+        p[i] = descale_(uv, s.lo, s.hi);
+    }
+#pragma unroll
+    for (int i = NP; i < NPARAM_MAX; i++) p[i] = 0.0f;
+}
+
+template <bool BETAET>
+__global__ void __launch_bounds__(64) k_adj_fwd(const AdjFwdArgs A)
+{
+    constexpr int NP = BETAET ? 13 : 12;
+    const hbvx_desc &d = A.d;
+    const hbvx_fwd_out &o = A.o;
+    const AdjLane L = adj_lane(d, A.lgMp);
+    const int T = d.T;
+    const int64_t N = (int64_t)d.B * d.M;
+    const bool raw = d.raw_sigmoid != 0;
+    const float invM = 1.0f / (float)d.M;
+    float usta[NP];
+    bool use_dyn[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        const hbvx_param_src &s = d.p[i];
+        float v = s.sta[(int64_t)L.b * s.sta_b_stride + L.j];
+        usta[i] = raw ? sigmoid_(v) : v;
+        use_dyn[i] = s.dyn && !(s.drop && s.drop[L.n]); // per-lane drop (hbv_adj.py:182-189)
+    }
+    float x[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) x[k] = d.state_in ? d.state_in[k * N + L.n] : 0.0f; // :254
+    const float *xb = d.x + (int64_t)L.b * d.x_b_stride;
+    for (int t = 0; t < T; t++) {
+        float u[NP], p[NPARAM_MAX], xn[5];
+        adj_params<NP>(d, L, t, raw, usta, use_dyn, u, p);
+        AdjStep<BETAET> s;
+        const float *xr = xb + (int64_t)t * d.x_t_stride;
+        s.P = xr[d.ch_prcp]; s.Tf = xr[d.ch_tmean]; s.PET = xr[d.ch_pet];
+        if (o.traj && L.active) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) o.traj[((int64_t)k * (T + 1) + t) * N + L.n] = x[k];
+        }
+        adj_newton<BETAET>(s, p, x, 1.0f, d.adj_gtol, d.adj_max_iter, xn);
+#pragma unroll
+        for (int k = 0; k < 5; k++) x[k] = xn[k];
+        if (o.flux) {
+            // hbv_adj.py:309-317: Q = q0+q1+q2 at the solved state, mean over members
+            const float SUZ = fmaxf(x[3], 0.0f), SLZ = fmaxf(x[4], 0.0f);
+            const float q0 = p[P_K0] * fmaxf(SUZ - p[P_UZL], 0.0f);
+            const float q1 = p[P_K1] * SUZ, q2 = p[P_K2] * SLZ;
+            float Q = (q0 + q1) + q2;
+            Q = adj_ens_sum(L.active ? Q : 0.0f, A.lgMp) * invM;
+            if (L.leader) o.flux[(int64_t)t * d.B + L.b] = Q;
+        }
+    }
+    if (L.active) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            o.state_out[k * N + L.n] = x[k];
+            if (o.traj) o.traj[((int64_t)k * (T + 1) + T) * N + L.n] = x[k];
+        }
+    }
+}
+
+template <bool BETAET>
+__global__ void __launch_bounds__(64) k_adj_bwd(const AdjBwdArgs A)
+{
+    constexpr int NP = BETAET ? 13 : 12;
+    const hbvx_desc &d = A.d;
+    const hbvx_bwd_io &io = A.io;
+    const AdjLane L = adj_lane(d, A.lgMp);
+    const int T = d.T;
+    const int64_t N = (int64_t)d.B * d.M;
+    const bool raw = d.raw_sigmoid != 0;
+    const float invM = 1.0f / (float)d.M;
+    float usta[NP], gsta[NP];
+    bool use_dyn[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        const hbvx_param_src &s = d.p[i];
+        float v = s.sta[(int64_t)L.b * s.sta_b_stride + L.j];
+        usta[i] = raw ? sigmoid_(v) : v;
+        use_dyn[i] = s.dyn && !(s.drop && s.drop[L.n]);
+        gsta[i] = 0.0f;
+    }
+    const float *xb = d.x + (int64_t)L.b * d.x_b_stride;
+    float a[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) a[k] = io.grad_state_out ? io.grad_state_out[k * N + L.n] : 0.0f;
+    for (int t = T - 1; t >= 0; t--) {
+        float u[NP], p[NPARAM_MAX], x[5], gp[NPARAM_MAX];
+        adj_params<NP>(d, L, t, raw, usta, use_dyn, u, p);
+        AdjStep<BETAET> s;
+        const float *xr = xb + (int64_t)t * d.x_t_stride;
+        s.P = xr[d.ch_prcp]; s.Tf = xr[d.ch_tmean]; s.PET = xr[d.ch_pet];
+#pragma unroll
+        for (int k = 0; k < 5; k++) x[k] = io.traj[((int64_t)k * (T + 1) + (t + 1)) * N + L.n];
+        const int64_t gi = (int64_t)t * d.B + L.b;
+        float gQ = io.grad_flux ? io.grad_flux[gi] : 0.0f;
+        if (io.grad_flux4) gQ += io.grad_flux4[gi];
+        gQ *= invM;
+#pragma unroll
+        for (int i = 0; i < NPARAM_MAX; i++) gp[i] = 0.0f;
+        adj_backstep<BETAET>(s, p, x, 1.0f, gQ, a, gp);
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            const float gu = gp[i] * (d.p[i].hi - d.p[i].lo);
+            if (d.p[i].dyn) {
+                const float gr = raw ? gu * (u[i] * (1.0f - u[i])) : gu;
+                if (io.g[i].dyn && L.active)
+                    io.g[i].dyn[(int64_t)t * io.g[i].dyn_t_stride + (int64_t)L.b * io.g[i].dyn_b_stride + L.j] =
+                        use_dyn[i] ? gr : 0.0f;
+                gsta[i] += use_dyn[i] ? 0.0f : gu;
+            } else {
+                gsta[i] += gu;
+            }
+        }
+    }
+    if (L.active) {
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            if (!io.g[i].sta) continue;
+            const float gr = raw ? gsta[i] * (usta[i] * (1.0f - usta[i])) : gsta[i];
+            float *dst = io.g[i].sta + (int64_t)L.b * io.g[i].sta_b_stride + L.j;
+            *dst += gr;
+        }
+        if (io.grad_state_in) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) io.grad_state_in[k * N + L.n] = a[k];
+        }
+    }
+}
+
+} // namespace hbvx

@@ -363,7 +363,9 @@ __global__ void __launch_bounds__(512) k_bwd_tiled(const BwdTArgs A)
         for (int i = 0; i < NPARAM_MAX; i++) p[i] = i < NP ? psta[i < NP ? i : 0] : 0.0f;
 #pragma unroll
         for (int i = 0; i < NP; i++) gsta[i] = 0.0f;
-        float a[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        float a[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) a[k] = io.grad_state_out ? io.grad_state_out[k * N + L.n] : 0.0f;
 
         lds_barrier();
         for (int it = 0; it < nT; it++) {

@@ -17,6 +17,7 @@
 #include "../../include/hbvx.h"
 #include "hbv_step.h"
 #include "hbv_tiled.h"
+#include "hbv_adj_kernels.h"
 
 using namespace hbvx;
 
@@ -269,7 +270,9 @@ __global__ void __launch_bounds__(64) k_bwd(const BwdArgs A)
     const float *xb = d.x + (int64_t)L.b * d.x_b_stride;
     const float *mu = d.muwts ? d.muwts + (int64_t)L.b * d.mu_b_stride + L.j : nullptr;
     const float invM = 1.0f / (float)d.M;
-    float a[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    float a[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) a[k] = io.grad_state_out ? io.grad_state_out[k * N + L.n] : 0.0f;
 
     for (int t = T - 1; t >= 0; t--) {
         Step<MODEL, BETAET> s;
@@ -566,6 +569,7 @@ static int check_desc(const hbvx_desc *d)
     if (d->model == HBVX_MODEL_HBV10) ok = (d->n_param == 12 || d->n_param == 13);
     else if (d->model == HBVX_MODEL_HBV11P) ok = (d->n_param == 14);
     else if (d->model == HBVX_MODEL_HBV20) ok = (d->n_param == 16);
+    else if (d->model == HBVX_MODEL_HBVADJ) ok = (d->n_param == 12 || d->n_param == 13);
     else return fail(HBVX_E_UNSUPPORTED, "unknown model");
     if (!ok) return fail(HBVX_E_SHAPE, "n_param does not match model");
     if (!d->x) return fail(HBVX_E_NULL, "forcing pointer is NULL");
@@ -703,6 +707,7 @@ extern "C" int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *s
 {
     int rc = check_desc(d);
     if (rc) return rc;
+    if (d->model == HBVX_MODEL_HBVADJ) return fail(HBVX_E_UNSUPPORTED, "use hbvx_adj_forward for HBVADJ");
     if (!out || !out->state_out) return fail(HBVX_E_NULL, "state_out is NULL");
     const int want_nf = (d->model == HBVX_MODEL_HBV10) ? 11 : 12;
     if (out->flux && out->n_flux != want_nf) return fail(HBVX_E_SHAPE, "n_flux does not match model");
@@ -737,6 +742,7 @@ extern "C" int hbvx_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *st
 {
     int rc = check_desc(d);
     if (rc) return rc;
+    if (d->model == HBVX_MODEL_HBVADJ) return fail(HBVX_E_UNSUPPORTED, "use hbvx_adj_backward for HBVADJ");
     if (!io || !io->traj || !io->aux) return fail(HBVX_E_NULL, "traj/aux is NULL");
     const int want_nf = (d->model == HBVX_MODEL_HBV10) ? 11 : 12;
     if (io->n_flux != want_nf) return fail(HBVX_E_SHAPE, "n_flux does not match model");
@@ -858,5 +864,57 @@ extern "C" int hbvx_selftest_div(const float *x, const float *y, float *out, int
                        out, n);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "selftest_div launch");
+    return HBVX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// implicit HBV ("HBV adjoint", hbv_adj.py)
+// ---------------------------------------------------------------------------
+static int check_adj(const hbvx_desc *d)
+{
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (d->model != HBVX_MODEL_HBVADJ) return fail(HBVX_E_UNSUPPORTED, "hbvx_adj_* needs model HBVADJ");
+    if (!(d->adj_gtol >= 0.0f) || d->adj_max_iter < 0 || d->adj_max_iter > 64)
+        return fail(HBVX_E_SHAPE, "bad Newton policy (adj_gtol / adj_max_iter)");
+    return HBVX_OK;
+}
+
+extern "C" int hbvx_adj_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream)
+{
+    int rc = check_adj(d);
+    if (rc) return rc;
+    if (!out || !out->state_out) return fail(HBVX_E_NULL, "state_out is NULL");
+    if (out->flux && out->n_flux != 1) return fail(HBVX_E_SHAPE, "hbvx_adj_forward writes n_flux = 1");
+    AdjFwdArgs a;
+    a.d = *d;
+    a.o = *out;
+    a.lgMp = lg_members(d->M);
+    const int bpw = 64 >> a.lgMp;
+    dim3 grid((d->B + bpw - 1) / bpw);
+    if (d->n_param == 13) hipLaunchKernelGGL(k_adj_fwd<true>, grid, dim3(64), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_adj_fwd<false>, grid, dim3(64), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "hbvx_adj_forward launch");
+    return HBVX_OK;
+}
+
+extern "C" int hbvx_adj_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *stream)
+{
+    int rc = check_adj(d);
+    if (rc) return rc;
+    if (!io || !io->traj) return fail(HBVX_E_NULL, "traj is NULL");
+    if (io->n_flux != 1) return fail(HBVX_E_SHAPE, "hbvx_adj_backward expects n_flux = 1");
+    if (d->T == 0) return HBVX_OK;
+    AdjBwdArgs a;
+    a.d = *d;
+    a.io = *io;
+    a.lgMp = lg_members(d->M);
+    const int bpw = 64 >> a.lgMp;
+    dim3 grid((d->B + bpw - 1) / bpw);
+    if (d->n_param == 13) hipLaunchKernelGGL(k_adj_bwd<true>, grid, dim3(64), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_adj_bwd<false>, grid, dim3(64), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "hbvx_adj_backward launch");
     return HBVX_OK;
 }

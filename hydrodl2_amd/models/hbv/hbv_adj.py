@@ -1,0 +1,137 @@
+"""HBV with an implicit (backward-Euler) time step and an implicit-function adjoint.
+
+Counterpart of the reference's `HbvAdj` (src/hydrodl2/models/hbv/hbv_adj.py:15-330).  The
+reference file cannot be imported (it needs an encrypted dependency and has several defects,
+SURVEY.md §2 #13); this class implements the algorithm that file specifies:
+
+* per day solve  G(x) = (x - x_t)/dt - f(x, theta_t, t) = 0  (hbv_adj.py:669-678) with the
+  flux-form right-hand side of hbv_adj.py:385-431, by modified Newton (<= 4 updates, gtol 1e-3 on
+  |G|_inf, Jacobian refreshed when the residual ratio exceeds 0.2: hbv_adj.py:516-581);
+* streamflow = ensemble mean of q0+q1+q2 at the solved states (hbv_adj.py:309-317), routed with the
+  gamma unit hydrograph (hbv_adj.py:319-325); only `flow_sim` is returned (hbv_adj.py:328-330);
+* backward = implicit-function adjoint (hbv_adj.py:617-633).
+
+Same constructor / config keys / attributes as the reference (`rout_a`, `rout_b` routing names,
+`ad_efficient` accepted and ignored).  Differences, all deliberate:
+  - the Newton stopping rule is per (basin, member), not one maximum over the whole batch;
+  - `parBETAET` is used only when it is listed dynamic (its bounds exist only then,
+    hbv_adj.py:94-95); the reference reads it unconditionally and would raise KeyError;
+  - derivatives are analytic (the reference mixes an autograd Jacobian with float64 finite
+    differences, hbv_adj.py:531,606).
+"""
+from typing import Any, Optional
+
+import torch
+
+from hydrodl2_amd import _abi
+from hydrodl2_amd.ops import HbvAdjPath, ParamSource, RouteSource, StepConfig
+
+
+class HbvAdj(torch.nn.Module):
+    """HBV adjoint: 12 (+parBETAET) physical parameters x nmul, 2 routing parameters."""
+
+    def __init__(self, config: Optional[dict[str, Any]] = None,
+                 device: Optional[torch.device] = None) -> None:
+        super().__init__()
+        # hbv_adj.py:46-76
+        self.name = 'HBV Adjoint'
+        self.config = config
+        self.initialize = False
+        self.warm_up = 0
+        self.dynamic_params = []
+        self.dy_drop = 0.0
+        self.variables = ['prcp', 'tmean', 'pet']
+        self.routing = True
+        self.comprout = False
+        self.nearzero = 1e-5
+        self.nmul = 1
+        self.ad_efficient = True
+        self.device = device
+        self.newton_gtol = 1e-3      # hbv_adj.py:519
+        self.newton_max_iter = 3     # hbv_adj.py:518
+        self.parameter_bounds = {
+            'parBETA': [1.0, 6.0], 'parFC': [50, 1000], 'parK0': [0.05, 0.9],
+            'parK1': [0.01, 0.5], 'parK2': [0.001, 0.2], 'parLP': [0.2, 1],
+            'parPERC': [0, 10], 'parUZL': [0, 100], 'parTT': [-2.5, 2.5],
+            'parCFMAX': [0.5, 10], 'parCFR': [0, 0.1], 'parCWH': [0, 0.2],
+        }
+        self.routing_parameter_bounds = {'rout_a': [0, 2.9], 'rout_b': [0, 6.5]}
+        if not device:
+            self.device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
+        if config is not None:  # hbv_adj.py:81-95
+            self.warm_up = config.get('warm_up', self.warm_up)
+            self.dy_drop = config.get('dy_drop', self.dy_drop)
+            self.dynamic_params = config['dynamic_params'].get(
+                self.__class__.__name__, self.dynamic_params)
+            self.variables = config.get('variables', self.variables)
+            self.routing = config.get('routing', self.routing)
+            self.comprout = config.get('comprout', self.comprout)
+            self.nearzero = config.get('nearzero', self.nearzero)
+            self.nmul = config.get('nmul', self.nmul)
+            self.ad_efficient = config.get('ad_efficient', self.ad_efficient)
+            self.newton_gtol = config.get('newton_gtol', self.newton_gtol)
+            self.newton_max_iter = config.get('newton_max_iter', self.newton_max_iter)
+            if 'parBETAET' in self.dynamic_params:
+                self.parameter_bounds['parBETAET'] = [0.3, 5]
+        self.set_parameters()
+
+    def set_parameters(self) -> None:
+        """hbv_adj.py:99-109."""
+        self.phy_param_names = self.parameter_bounds.keys()
+        self.routing_param_names = self.routing_parameter_bounds.keys() if self.routing else []
+        self.rout_params_name = list(self.routing_parameter_bounds.keys())
+        self.learnable_param_count = len(self.phy_param_names) * self.nmul + len(
+            self.routing_param_names)
+
+    def _lane_drop_mask(self, ngrid: int, device) -> torch.Tensor:
+        """hbv_adj.py:182-189: one Bernoulli(dy_drop) per LANE of the member-major batch
+        (index j*B + b); returned in this package's basin-major lane order (b*M + j)."""
+        pmat = torch.ones([1, ngrid * self.nmul]) * self.dy_drop
+        drmask = torch.bernoulli(pmat)
+        m = drmask.reshape(self.nmul, ngrid).t().contiguous().reshape(-1)
+        return m.to(torch.uint8).to(device)
+
+    def _sources(self, T_total, B, ny, t_first, sta_row, dy_list, device):
+        M = self.nmul
+        srcs = []
+        for i, name in enumerate(self.parameter_bounds.keys()):
+            lo, hi = self.parameter_bounds[name]
+            ps = ParamSource(slot=_abi.PARAM_SLOTS.index(name), lo=float(lo), hi=float(hi),
+                             tensor_idx=0, sta_off=sta_row * B * ny + i * M, sta_bs=ny)
+            if name in dy_list:
+                ps.dyn_tensor_idx, ps.dyn_off = 0, t_first * B * ny + i * M
+                ps.dyn_ts, ps.dyn_bs = B * ny, ny
+                ps.drop = self._lane_drop_mask(B, device)
+            srcs.append(ps)
+        return srcs
+
+    def forward(self, x_dict: dict[str, torch.Tensor], parameters: torch.Tensor):
+        """hbv_adj.py:227-330."""
+        x = x_dict['x_phy']
+        T_total, B = x.shape[0], x.shape[1]
+        M = self.nmul
+        n = len(self.parameter_bounds)
+        if not parameters.is_contiguous():
+            parameters = parameters.contiguous()
+        ny = parameters.shape[2]
+        ch = (self.variables.index('prcp'), self.variables.index('tmean'),
+              self.variables.index('pet'))
+        base = dict(model=_abi.MODEL_HBVADJ, n_param=n, n_flux=1, B=B, M=M, raw_sigmoid=True,
+                    channels=ch, nearzero=float(self.nearzero),
+                    adj_gtol=float(self.newton_gtol), adj_max_iter=int(self.newton_max_iter))
+        state = None  # zeros (hbv_adj.py:254)
+        wu = self.warm_up
+        if wu > 0:  # hbv_adj.py:257-274: static parameters from row warm_up-1, differentiable
+            cfg_w = StepConfig(T=wu, t0=0, want_flux=False, **base)
+            cfg_w.params = self._sources(T_total, B, ny, 0, wu - 1, [], x.device)
+            _, _, state = HbvAdjPath.apply(cfg_w, x, None, parameters)
+        cfg = StepConfig(T=T_total - wu, t0=wu, **base)
+        cfg.params = self._sources(T_total, B, ny, wu, T_total - 1, self.dynamic_params, x.device)
+        if self.routing:
+            off = (T_total - 1) * B * ny + n * M  # hbv_adj.py:151-153: last row only
+            cfg.route = RouteSource(0, off, off + 1, ny,
+                                    self.routing_parameter_bounds['rout_a'],
+                                    self.routing_parameter_bounds['rout_b'])
+        flux, routed, _ = HbvAdjPath.apply(cfg, x, state, parameters)
+        q = routed if routed is not None else flux
+        return {'flow_sim': q[0].unsqueeze(-1)}

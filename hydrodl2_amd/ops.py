@@ -67,6 +67,8 @@ class StepConfig:
     route: Optional[RouteSource] = None
     want_flux: bool = True
     want_traj: bool = False    # keep the state trajectory even without autograd
+    adj_gtol: float = 1e-3     # implicit scheme only (hbv_adj.py:519)
+    adj_max_iter: int = 3      # implicit scheme only (hbv_adj.py:518)
 
 
 # bench.py sets this to a list to collect (abi_call, start_event, end_event) per launch,
@@ -134,14 +136,15 @@ def _fill_desc(cfg: StepConfig, x, state_in, muwts, ac, elev, ptensors) -> _abi.
             if ps.drop is not None:
                 s.drop = ps.drop.data_ptr()
         s.lo, s.hi = ps.lo, ps.hi
+    d.adj_gtol, d.adj_max_iter = cfg.adj_gtol, cfg.adj_max_iter
     return d
 
 
-def _route_desc(cfg: StepConfig, ptensors) -> _abi.RouteDesc:
+def _route_desc(cfg: StepConfig, ptensors, S: int = 4) -> _abi.RouteDesc:
     r = _abi.RouteDesc()
     rs = cfg.route
     r.abi_version = _abi.ABI_VERSION
-    r.T, r.B, r.S = cfg.T, cfg.B, 4
+    r.T, r.B, r.S = cfg.T, cfg.B, S
     r.L = min(cfg.T, _abi.UH_MAXLEN)
     r.raw_sigmoid = 1 if cfg.raw_sigmoid else 0
     r.ra = _ptr(ptensors[rs.tensor_idx], rs.a_off)
@@ -263,3 +266,92 @@ class HbvPath(torch.autograd.Function):
         _call(lib, 'hbvx_backward', lib.backward, desc, io, stream)
 
         return (None, gx, None, gmu, None, None, *gp)
+
+
+class HbvAdjPath(torch.autograd.Function):
+    """flux, routed, state_out = HbvAdjPath.apply(cfg, x, state_in, *ptensors)
+
+    Implicit (backward-Euler) HBV, reference hbv_adj.py:227-330.  flux [1,T,B] = ensemble-mean
+    q0+q1+q2 at the solved states; routed [1,T,B] = its UH routing; state_out [5,B,M] is
+    differentiable so that a warm-up call can be chained in front of the main call (the reference
+    differentiates through its warm-up, hbv_adj.py:257-274)."""
+
+    @staticmethod
+    def forward(ctx, cfg: StepConfig, x, state_in, *ptensors):
+        lib = get_library()
+        _check_tensor(lib, x, "x_phy")
+        for i, p in enumerate(ptensors):
+            _check_tensor(lib, p, f"parameters[{i}]")
+            if not p.is_contiguous():
+                raise ValueError("parameter tensors must be contiguous")
+        dev = x.device
+        T, B, M = cfg.T, cfg.B, cfg.M
+        needs_grad = any(ctx.needs_input_grad)
+        stream = _stream_of(lib, x)
+        out = _abi.FwdOut()
+        flux = torch.empty((1, T, B), dtype=torch.float32, device=dev) if cfg.want_flux else None
+        state_out = torch.empty((5, B, M), dtype=torch.float32, device=dev)
+        traj = torch.empty((5, T + 1, B * M), dtype=torch.float32, device=dev) if needs_grad else None
+        out.flux, out.state_out, out.traj, out.n_flux = _ptr(flux), _ptr(state_out), _ptr(traj), 1
+        if state_in is not None:
+            state_in = state_in.contiguous()
+        desc = _fill_desc(cfg, x, state_in, None, None, None, ptensors)
+        _call(lib, 'hbvx_adj_forward', lib.adj_forward, desc, out, stream)
+        routed = uh = None
+        if cfg.route is not None and cfg.want_flux:
+            r = _route_desc(cfg, ptensors, S=1)
+            routed = torch.empty((1, T, B), dtype=torch.float32, device=dev)
+            uh = torch.empty((B, r.L), dtype=torch.float32, device=dev)
+            _call(lib, 'hbvx_route_forward', lib.route_forward, r, _ptr(flux), _ptr(uh),
+                  _ptr(routed), stream)
+        ctx.cfg = cfg
+        ctx.set_materialize_grads(False)
+        if needs_grad:
+            ctx.save_for_backward(x, state_in, traj, flux, uh, *ptensors)
+        return flux, routed, state_out
+
+    @staticmethod
+    def backward(ctx, g_flux, g_routed, g_state):
+        lib = get_library()
+        cfg: StepConfig = ctx.cfg
+        saved = ctx.saved_tensors
+        x, state_in, traj, flux, uh = saved[:5]
+        ptensors = saved[5:]
+        dev = x.device
+        T, B, M = cfg.T, cfg.B, cfg.M
+        stream = _stream_of(lib, x)
+        gp = [torch.zeros_like(p) if ctx.needs_input_grad[3 + i] else None
+              for i, p in enumerate(ptensors)]
+        gq = None
+        if g_routed is not None and cfg.route is not None:
+            r = _route_desc(cfg, ptensors, S=1)
+            gq = torch.empty((1, T, B), dtype=torch.float32, device=dev)
+            rs = cfg.route
+            gt = gp[rs.tensor_idx]
+            ws_bytes = lib.route_workspace_bytes(r)
+            ws = torch.empty((max(ws_bytes, 4) + 3) // 4, dtype=torch.float32, device=dev)
+            _call(lib, 'hbvx_route_backward', lib.route_backward, r, _ptr(flux), _ptr(uh),
+                  _ptr(g_routed.contiguous()), _ptr(gq), _ptr(gt, rs.a_off), _ptr(gt, rs.b_off),
+                  _ptr(ws), ws_bytes, stream)
+        io = _abi.BwdIO()
+        io.traj = _ptr(traj)
+        io.grad_flux = _ptr(g_flux.contiguous()) if g_flux is not None else None
+        io.grad_flux4 = _ptr(gq)
+        io.grad_state_out = _ptr(g_state.contiguous()) if g_state is not None else None
+        io.n_flux = 1
+        gs_in = None
+        if state_in is not None and ctx.needs_input_grad[2]:
+            gs_in = torch.empty((5, B, M), dtype=torch.float32, device=dev)
+            io.grad_state_in = _ptr(gs_in)
+        for ps in cfg.params:
+            g = io.g[ps.slot]
+            gs = gp[ps.tensor_idx]
+            if gs is not None:
+                g.sta = _ptr(gs, ps.sta_off)
+                g.sta_b_stride = ps.sta_bs
+            if ps.dyn_off >= 0 and gp[ps.dyn_tensor_idx] is not None:
+                g.dyn = _ptr(gp[ps.dyn_tensor_idx], ps.dyn_off)
+                g.dyn_t_stride, g.dyn_b_stride = ps.dyn_ts, ps.dyn_bs
+        desc = _fill_desc(cfg, x, state_in, None, None, None, ptensors)
+        _call(lib, 'hbvx_adj_backward', lib.adj_backward, desc, io, stream)
+        return (None, None, gs_in, *gp)

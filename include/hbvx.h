@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define HBVX_ABI_VERSION 2
+#define HBVX_ABI_VERSION 3
 #define HBVX_MAX_PARAM 16
 #define HBVX_NSTATE 5   /* SNOWPACK, MELTWATER, SM, SUZ, SLZ  (hbv.py:61-67) */
 #define HBVX_MAX_FLUX 12
@@ -53,7 +53,8 @@ enum hbvx_param_slot {
 enum hbvx_model {
     HBVX_MODEL_HBV10 = 0,  /* n_param 12, or 13 when parBETAET is present */
     HBVX_MODEL_HBV11P = 1, /* n_param 14: + parBETAET always, capillary rise */
-    HBVX_MODEL_HBV20 = 2   /* n_param 16: + elevation TT switch, lateral flow */
+    HBVX_MODEL_HBV20 = 2,  /* n_param 16: + elevation TT switch, lateral flow */
+    HBVX_MODEL_HBVADJ = 3  /* implicit (backward-Euler) HBV, hbvx_adj_* only; n_param 12 or 13 */
 };
 
 /* Ensemble-mean series written by hbvx_forward, flux[k][t][b]
@@ -121,8 +122,12 @@ typedef struct hbvx_desc {
     const float *muwts;   /* optional ensemble weights (t,b,j) at
                              muwts[t*mu_t_stride + b*mu_b_stride + j] (strides may be 0) */
     int64_t mu_t_stride, mu_b_stride;
-    const float *state_in; /* [5,B,M] or NULL = every storage 0.001 (hbv.py:128-136) */
+    const float *state_in; /* [5,B,M] or NULL = every storage 0.001 (hbv.py:128-136);
+                              hbvx_adj_*: NULL = 0 (hbv_adj.py:254) */
     hbvx_param_src p[HBVX_MAX_PARAM];
+    /* hbvx_adj_* only (ignored elsewhere): Newton policy of hbv_adj.py:518-519,544 */
+    float adj_gtol;        /* stop when max_i |G_i| <= gtol; reference 1e-3 */
+    int32_t adj_max_iter;  /* updates allowed = max_iter + 1; reference max_iter = 3 */
 } hbvx_desc;
 
 typedef struct hbvx_fwd_out {
@@ -143,6 +148,7 @@ typedef struct hbvx_bwd_io {
     const float *grad_flux;  /* [n_flux,T,B] dL/d(flux series) or NULL (= zeros) */
     const float *grad_flux4; /* optional [4,T,B]: extra gradient of series 0..3 (Qsim,Q0,Q1,Q2),
                                 i.e. grad_q of hbvx_route_backward; added to grad_flux */
+    const float *grad_state_out; /* optional [5,B,M]: dL/d(final storages) (adjoint seed; NULL = 0) */
     float *grad_x;           /* optional, addressed like desc->x (overwritten) */
     float *grad_muwts;       /* optional [T,B,M] contiguous (overwritten) */
     float *grad_state_in;    /* optional [5,B,M] (overwritten) */
@@ -184,6 +190,16 @@ int hbvx_route_backward(const hbvx_route_desc *r, const float *q, const float *u
                         const float *grad_q_rout, float *grad_q, float *grad_ra,
                         float *grad_rb, void *workspace, uint64_t workspace_bytes,
                         void *stream);
+
+/* Implicit HBV ("HBV adjoint", hbv_adj.py): per day solve G(x) = (x - x_t)/dt - f(x, theta_t, t) = 0
+ * (hbv_adj.py:669-687) by modified Newton (hbv_adj.py:507-581) with the analytic 5x5 Jacobian;
+ * flux[0][t][b] = ensemble mean of q0+q1+q2 at the solved state (hbv_adj.py:309-317).
+ * Uses hbvx_desc (model HBVX_MODEL_HBVADJ; `drop` is per LANE [B*M], hbv_adj.py:182-189),
+ * hbvx_fwd_out with n_flux = 1 (traj rows 1..T = solved states; aux unused) and hbvx_bwd_io.
+ * The backward is the implicit-function adjoint the reference intends (hbv_adj.py:617-633):
+ * (dG/dx)^T lambda = dL/dx, dL/dtheta = -lambda^T dG/dtheta, dL/dx_t = lambda/dt. */
+int hbvx_adj_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream);
+int hbvx_adj_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *stream);
 
 /* Diagnostics (tests only): out[i] = the device pow used for (SM/FC)**BETA on x[i], y[i]. */
 int hbvx_selftest_pow(const float *x, const float *y, float *out, int n, void *stream);

@@ -429,6 +429,7 @@ static int check_desc(const hbvx_desc *d)
     if (d->model == HBVX_MODEL_HBV10) ok = (d->n_param == 12 || d->n_param == 13);
     else if (d->model == HBVX_MODEL_HBV11P) ok = (d->n_param == 14);
     else if (d->model == HBVX_MODEL_HBV20) ok = (d->n_param == 16);
+    else if (d->model == HBVX_MODEL_HBVADJ) return fail(HBVX_E_UNSUPPORTED, "the implicit scheme's oracle is oracle/hbv_adj_oracle.py");
     else return fail(HBVX_E_UNSUPPORTED, "unknown model");
     if (!ok) return fail(HBVX_E_SHAPE, "n_param does not match model");
     if (!d->x) return fail(HBVX_E_NULL, "forcing pointer is NULL");
@@ -553,7 +554,8 @@ int hbvx_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *stream)
         if (io->grad_x) gxacc = (float *)calloc((size_t)T * 3, sizeof(float));
         for (int j = 0; j < M; j++) {
             const int64_t n = (int64_t)b * M + j;
-            float a[5] = {0, 0, 0, 0, 0};
+            float a[5];
+            for (int k = 0; k < 5; k++) a[k] = io->grad_state_out ? io->grad_state_out[k * N + n] : 0.0f;
             float gsta[HBVX_MAX_PARAM]; /* dL/d(unit static value), summed over t */
             float usta[HBVX_MAX_PARAM];
             for (int i = 0; i < HBVX_MAX_PARAM; i++) gsta[i] = 0.0f, usta[i] = 0.0f;
@@ -776,4 +778,16 @@ int hbvx_selftest_div(const float *x, const float *y, float *out, int n, void *s
     (void)stream;
     for (int i = 0; i < n; i++) out[i] = x[i] / y[i];
     return HBVX_OK;
+}
+
+/* The implicit scheme (hbv_adj.py) is restated in oracle/hbv_adj_oracle.py (float64, autograd). */
+int hbvx_adj_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream)
+{
+    (void)d; (void)out; (void)stream;
+    return fail(HBVX_E_UNSUPPORTED, "see oracle/hbv_adj_oracle.py");
+}
+int hbvx_adj_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *stream)
+{
+    (void)d; (void)io; (void)stream;
+    return fail(HBVX_E_UNSUPPORTED, "see oracle/hbv_adj_oracle.py");
 }

@@ -9,7 +9,10 @@
 #include <vector>
 
 #include "../../include/hbvx.h"
+#include <dlfcn.h>
+
 #include "../../hydrodl2_amd/csrc/hbv_step.h"
+#include "../../hydrodl2_amd/csrc/hbv_adj_step.h"
 
 using namespace hbvx;
 
@@ -102,7 +105,8 @@ static void run_bwd(const hbvx_desc &d, const hbvx_bwd_io &io)
         if (io.grad_x) gxa.assign((size_t)T * 3, 0.f);
         for (int j = 0; j < M; j++) {
             const int64_t n = (int64_t)b * M + j;
-            float a[5] = {0, 0, 0, 0, 0}, gsta[NPARAM_MAX] = {0}, usta[NPARAM_MAX] = {0};
+            float a[5], gsta[NPARAM_MAX] = {0}, usta[NPARAM_MAX] = {0};
+            for (int k = 0; k < 5; k++) a[k] = io.grad_state_out ? io.grad_state_out[k * N + n] : 0.f;
             for (int t = T - 1; t >= 0; t--) {
                 float p[NPARAM_MAX] = {0}, u[NPARAM_MAX] = {0};
                 bool ud[NPARAM_MAX] = {false};
@@ -187,18 +191,134 @@ extern "C" int hbvx_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *)
     DISPATCH(run_bwd, *d, *io);
     return 0;
 }
-extern "C" int hbvx_route_forward(const hbvx_route_desc *, const float *, float *, float *, void *)
+// routing is not part of the step headers: forward it to the oracle library (HBVX_ORACLE_LIB)
+static void *oracle_sym(const char *name)
 {
-    snprintf(g_err, sizeof g_err, "routing is not part of the step-math harness");
-    return HBVX_E_UNSUPPORTED;
+    static void *h = nullptr;
+    if (!h) {
+        const char *path = getenv("HBVX_ORACLE_LIB");
+        if (path) h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    }
+    return h ? dlsym(h, name) : nullptr;
+}
+extern "C" int hbvx_route_forward(const hbvx_route_desc *r, const float *q, float *uh, float *qr, void *st)
+{
+    typedef int (*fn_t)(const hbvx_route_desc *, const float *, float *, float *, void *);
+    fn_t fn = (fn_t)oracle_sym("hbvx_route_forward");
+    if (!fn) { snprintf(g_err, sizeof g_err, "set HBVX_ORACLE_LIB for routing"); return HBVX_E_UNSUPPORTED; }
+    return fn(r, q, uh, qr, st);
 }
 extern "C" uint64_t hbvx_route_workspace_bytes(const hbvx_route_desc *) { return 0; }
-extern "C" int hbvx_route_backward(const hbvx_route_desc *, const float *, const float *,
-                                   const float *, float *, float *, float *, void *, uint64_t,
-                                   void *)
+extern "C" int hbvx_route_backward(const hbvx_route_desc *r, const float *q, const float *uh,
+                                   const float *gy, float *gq, float *ga, float *gb, void *ws,
+                                   uint64_t wsb, void *st)
 {
-    snprintf(g_err, sizeof g_err, "routing is not part of the step-math harness");
-    return HBVX_E_UNSUPPORTED;
+    typedef int (*fn_t)(const hbvx_route_desc *, const float *, const float *, const float *, float *,
+                        float *, float *, void *, uint64_t, void *);
+    fn_t fn = (fn_t)oracle_sym("hbvx_route_backward");
+    if (!fn) { snprintf(g_err, sizeof g_err, "set HBVX_ORACLE_LIB for routing"); return HBVX_E_UNSUPPORTED; }
+    return fn(r, q, uh, gy, gq, ga, gb, ws, wsb, st);
+}
+
+// implicit scheme through the product header hbv_adj_step.h
+template <bool BETAET>
+static void run_adj_fwd(const hbvx_desc &d, const hbvx_fwd_out &o)
+{
+    const int T = d.T, B = d.B, M = d.M, NP = d.n_param;
+    const int64_t N = (int64_t)B * M;
+    for (int b = 0; b < B; b++) {
+        std::vector<float> acc((size_t)T, 0.f);
+        for (int j = 0; j < M; j++) {
+            const int64_t n = (int64_t)b * M + j;
+            float x[5], xn[5], p[NPARAM_MAX] = {0};
+            for (int k = 0; k < 5; k++) x[k] = d.state_in ? d.state_in[k * N + n] : 0.f;
+            for (int t = 0; t < T; t++) {
+                for (int i = 0; i < NP; i++) {
+                    const hbvx_param_src &s = d.p[i];
+                    bool ud = s.dyn && !(s.drop && s.drop[n]);
+                    float v = ud ? s.dyn[(int64_t)t * s.dyn_t_stride + (int64_t)b * s.dyn_b_stride + j]
+                                 : s.sta[(int64_t)b * s.sta_b_stride + j];
+                    v = d.raw_sigmoid ? sigmoid_(v) : v;
+                    p[i] = descale_(v, s.lo, s.hi);
+                }
+                AdjStep<BETAET> s;
+                const float *xr = d.x + (int64_t)t * d.x_t_stride + (int64_t)b * d.x_b_stride;
+                s.P = xr[d.ch_prcp]; s.Tf = xr[d.ch_tmean]; s.PET = xr[d.ch_pet];
+                if (o.traj) for (int k = 0; k < 5; k++) o.traj[((int64_t)k * (T + 1) + t) * N + n] = x[k];
+                adj_newton<BETAET>(s, p, x, 1.0f, d.adj_gtol, d.adj_max_iter, xn);
+                for (int k = 0; k < 5; k++) x[k] = xn[k];
+                const float SUZ = fmaxf(x[3], 0.f), SLZ = fmaxf(x[4], 0.f);
+                acc[t] += (p[P_K0] * fmaxf(SUZ - p[P_UZL], 0.f) + p[P_K1] * SUZ) + p[P_K2] * SLZ;
+            }
+            for (int k = 0; k < 5; k++) {
+                o.state_out[k * N + n] = x[k];
+                if (o.traj) o.traj[((int64_t)k * (T + 1) + T) * N + n] = x[k];
+            }
+        }
+        if (o.flux) for (int t = 0; t < T; t++) o.flux[(int64_t)t * B + b] = acc[t] * (1.0f / (float)M);
+    }
+}
+
+template <bool BETAET>
+static void run_adj_bwd(const hbvx_desc &d, const hbvx_bwd_io &io)
+{
+    const int T = d.T, B = d.B, M = d.M, NP = d.n_param;
+    const int64_t N = (int64_t)B * M;
+    const float invM = 1.0f / (float)M;
+    for (int b = 0; b < B; b++)
+        for (int j = 0; j < M; j++) {
+            const int64_t n = (int64_t)b * M + j;
+            float a[5], gsta[NPARAM_MAX] = {0}, usta[NPARAM_MAX] = {0};
+            for (int k = 0; k < 5; k++) a[k] = io.grad_state_out ? io.grad_state_out[k * N + n] : 0.f;
+            for (int t = T - 1; t >= 0; t--) {
+                float p[NPARAM_MAX] = {0}, u[NPARAM_MAX] = {0}, x[5], gp[NPARAM_MAX] = {0};
+                bool ud[NPARAM_MAX] = {false};
+                for (int i = 0; i < NP; i++) {
+                    const hbvx_param_src &s = d.p[i];
+                    ud[i] = s.dyn && !(s.drop && s.drop[n]);
+                    float v = ud[i] ? s.dyn[(int64_t)t * s.dyn_t_stride + (int64_t)b * s.dyn_b_stride + j]
+                                    : s.sta[(int64_t)b * s.sta_b_stride + j];
+                    u[i] = d.raw_sigmoid ? sigmoid_(v) : v;
+                    p[i] = descale_(u[i], s.lo, s.hi);
+                }
+                AdjStep<BETAET> s;
+                const float *xr = d.x + (int64_t)t * d.x_t_stride + (int64_t)b * d.x_b_stride;
+                s.P = xr[d.ch_prcp]; s.Tf = xr[d.ch_tmean]; s.PET = xr[d.ch_pet];
+                for (int k = 0; k < 5; k++) x[k] = io.traj[((int64_t)k * (T + 1) + (t + 1)) * N + n];
+                float gQ = io.grad_flux ? io.grad_flux[(int64_t)t * B + b] : 0.f;
+                if (io.grad_flux4) gQ += io.grad_flux4[(int64_t)t * B + b];
+                adj_backstep<BETAET>(s, p, x, 1.0f, gQ * invM, a, gp);
+                for (int i = 0; i < NP; i++) {
+                    float gu = gp[i] * (d.p[i].hi - d.p[i].lo);
+                    if (d.p[i].dyn) {
+                        float gr = d.raw_sigmoid ? gu * (u[i] * (1.0f - u[i])) : gu;
+                        if (io.g[i].dyn)
+                            io.g[i].dyn[(int64_t)t * io.g[i].dyn_t_stride + (int64_t)b * io.g[i].dyn_b_stride + j] =
+                                ud[i] ? gr : 0.0f;
+                        if (!ud[i]) { gsta[i] += gu; usta[i] = u[i]; }
+                    } else {
+                        gsta[i] += gu; usta[i] = u[i];
+                    }
+                }
+            }
+            for (int i = 0; i < NP; i++) {
+                if (!io.g[i].sta) continue;
+                float gr = d.raw_sigmoid ? gsta[i] * (usta[i] * (1.0f - usta[i])) : gsta[i];
+                io.g[i].sta[(int64_t)b * io.g[i].sta_b_stride + j] += gr;
+            }
+            if (io.grad_state_in) for (int k = 0; k < 5; k++) io.grad_state_in[k * N + n] = a[k];
+        }
+}
+
+extern "C" int hbvx_adj_forward(const hbvx_desc *d, const hbvx_fwd_out *o, void *)
+{
+    if (d->n_param == 13) run_adj_fwd<true>(*d, *o); else run_adj_fwd<false>(*d, *o);
+    return 0;
+}
+extern "C" int hbvx_adj_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *)
+{
+    if (d->n_param == 13) run_adj_bwd<true>(*d, *io); else run_adj_bwd<false>(*d, *io);
+    return 0;
 }
 
 // accuracy probe for hbvx::pow_pos_ (host build of the same source)

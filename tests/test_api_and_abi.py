@@ -79,7 +79,8 @@ def test_load_states_validation():
 # --- the C ABI library itself (no compute: there is no GPU here) ---
 def _declared_symbols():
     text = open(os.path.join(ROOT, "include", "hbvx.h")).read()
-    return sorted(set(re.findall(r"\b(hbvx_[a-z_0-9]+)\s*\(", text)))
+    return sorted(set(re.findall(r"^(?:int|uint64_t|const char \*)\s*(hbvx_[a-z_0-9]+)\s*\(", text,
+                                 flags=re.M)))
 
 
 def test_header_symbols_are_exported_by_the_hip_library():

@@ -1,0 +1,175 @@
+"""Implicit HBV ("HBV adjoint").  Parity is UNPINNED by the reference (its file is not
+importable and its own tests skip it); these tests pin the product to the independent float64
+autograd oracle (oracle/hbv_adj_oracle.py) and the oracle to finite differences.
+
+CPU tier: the product's math header compiled for the host (tests/hosttest) driven through the
+package's HbvAdj module.  GPU tier (-m gpu): the HIP kernels."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from . import synth
+from .test_step_math_host import steptest_lib  # noqa: F401  (fixture)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_spec = importlib.util.spec_from_file_location("hbv_adj_oracle",
+                                               os.path.join(ROOT, "oracle", "hbv_adj_oracle.py"))
+adj_oracle = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(adj_oracle)
+
+
+def _inputs(T, B, M, seed, betaet, cold=False, scale=1.0):
+    n = 13 if betaet else 12
+    x = synth.forcing(T, B, seed, cold=cold)
+    p = synth.raw_parameters(T, B, n * M + 2, seed, scale)
+    w = synth.loss_weights((T, B, 1), seed, 70)
+    return torch.from_numpy(x), torch.from_numpy(p), torch.from_numpy(w)
+
+
+def _product(device, x, p, w, cfg):
+    import hydrodl2_amd
+    H = hydrodl2_amd.load_model("hbv_adj", "HbvAdj")
+    m = H(cfg, torch.device(device))
+    pp = p.to(device).clone().requires_grad_(True)
+    out = m({"x_phy": x.to(device)}, pp)["flow_sim"]
+    (out * w[-out.shape[0]:].to(device)).sum().backward()
+    return out.detach().cpu().numpy(), pp.grad.cpu().numpy()
+
+
+def _oracle(x, p, w, cfg, **kw):
+    pp = p.clone().double().requires_grad_(True)
+    out, its = adj_oracle.hbv_adj_forward(
+        x, pp, nmul=cfg["nmul"], warm_up=cfg.get("warm_up", 0),
+        dynamic_params=cfg["dynamic_params"]["HbvAdj"], dy_drop=cfg.get("dy_drop", 0.0),
+        gtol=cfg.get("newton_gtol", 1e-3), max_iter=cfg.get("newton_max_iter", 3), **kw)
+    (out * w[-out.shape[0]:].double()).sum().backward()
+    return out.detach().numpy(), pp.grad.numpy(), its
+
+
+def _close(name, a, b, rtol, atol_rel):
+    scale = max(np.abs(b).max(), 1e-30)
+    err = np.abs(a - b)
+    tol = atol_rel * scale + rtol * np.abs(b)
+    assert (err <= tol).all(), f"{name}: max err {err.max():.3e} (scale {scale:.3e}), " \
+                               f"{int((err > tol).sum())}/{err.size} outside"
+
+
+CASES = [
+    dict(T=40, B=5, M=4, seed=81, cfg=dict(nmul=4, dynamic_params={"HbvAdj": []})),
+    dict(T=50, B=4, M=16, seed=82,
+         cfg=dict(nmul=16, warm_up=10, dynamic_params={"HbvAdj": ["parBETA", "parBETAET"]})),
+    dict(T=36, B=6, M=3, seed=83, cold=True, scale=2.0,
+         cfg=dict(nmul=3, dy_drop=0.5, dynamic_params={"HbvAdj": ["parK0", "parFC", "parBETAET"]})),
+]
+
+
+def _run_case(device, case, tight):
+    cfg = dict(case["cfg"])
+    if tight:
+        cfg.update(newton_gtol=1e-6, newton_max_iter=12)
+    betaet = "parBETAET" in cfg["dynamic_params"]["HbvAdj"]
+    x, p, w = _inputs(case["T"], case["B"], case["M"], case["seed"], betaet,
+                      case.get("cold", False), case.get("scale", 1.0))
+    torch.manual_seed(5)
+    got, ggot = _product(device, x, p, w, cfg)
+    torch.manual_seed(5)
+    want, gwant, its = _oracle(x, p, w, cfg)
+    return got, ggot, want, gwant, its
+
+
+@pytest.fixture()
+def host_math_backend(steptest_lib, oracle_path, monkeypatch):  # noqa: F811
+    from hydrodl2_amd import _lib
+    monkeypatch.setenv("HBVX_ORACLE_LIB", oracle_path)
+    _lib._use_library_for_testing(steptest_lib)
+    yield
+    _lib._use_library_for_testing(None)
+
+
+def test_oracle_gradient_is_the_implicit_function_derivative():
+    """Central finite differences of the oracle's own (tightly converged) forward."""
+    T, B, M = 12, 2, 2
+    x, p, w = _inputs(T, B, M, 80, True)
+    cfg = dict(nmul=M, newton_gtol=1e-11, newton_max_iter=40,
+               dynamic_params={"HbvAdj": ["parBETA", "parBETAET"]})
+    _, g, _ = _oracle(x, p, w, cfg)
+
+    def loss(pv):
+        with torch.no_grad():
+            out, _ = adj_oracle.hbv_adj_forward(x, pv, nmul=M, dynamic_params=["parBETA", "parBETAET"],
+                                                gtol=1e-11, max_iter=40)
+        return float((out * w.double()).sum())
+
+    rng = np.random.default_rng(0)
+    pd = p.double()
+    worst = 0.0
+    for _ in range(12):
+        idx = (int(rng.integers(T)), int(rng.integers(B)), int(rng.integers(p.shape[2])))
+        if abs(g[idx]) < 1e-8:
+            continue
+        e = torch.zeros_like(pd)
+        e[idx] = 1e-5
+        fd = (loss(pd + e) - loss(pd - e)) / 2e-5
+        worst = max(worst, abs(fd - g[idx]) / max(abs(g[idx]), 1e-6))
+    assert worst < 2e-3, worst
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"M{c['M']}-T{c['T']}")
+def test_host_math_matches_oracle_converged(case, host_math_backend):
+    """Tightly converged Newton: the scheme itself (values and implicit-function gradients)."""
+    got, ggot, want, gwant, _ = _run_case("cpu", case, tight=True)
+    _close("flow_sim", got, want, 2e-4, 2e-5)
+    _close("grad", ggot, gwant, 2e-3, 2e-4)
+
+
+@pytest.mark.parametrize("case", CASES[:2], ids=lambda c: f"M{c['M']}-T{c['T']}")
+def test_host_math_matches_oracle_reference_policy(case, host_math_backend):
+    """The reference's Newton policy (gtol 1e-3, <= 4 updates), per-lane stopping."""
+    got, ggot, want, gwant, its = _run_case("cpu", case, tight=False)
+    assert float(its.max()) <= 4
+    _close("flow_sim", got, want, 5e-3, 5e-4)
+    _close("grad", ggot, gwant, 5e-2, 5e-3)
+
+
+def test_global_stopping_rule_differs_only_within_gtol():
+    """What the per-lane rule changes w.r.t. the reference's batch-global maximum."""
+    case = CASES[0]
+    x, p, w = _inputs(case["T"], case["B"], case["M"], case["seed"], False)
+    a, _, _ = _oracle(x, p, w, case["cfg"], stop="lane")
+    b, _, _ = _oracle(x, p, w, case["cfg"], stop="global")
+    assert np.abs(a - b).max() <= 2e-3 * max(1.0, np.abs(b).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"M{c['M']}-T{c['T']}")
+def test_hip_matches_oracle_converged(case, hip_backend):
+    got, ggot, want, gwant, _ = _run_case("cuda:0", case, tight=True)
+    _close("flow_sim", got, want, 2e-4, 2e-5)
+    _close("grad", ggot, gwant, 2e-3, 2e-4)
+
+
+@pytest.mark.gpu
+def test_hip_reference_policy_and_size(hip_backend):
+    got, ggot, want, gwant, its = _run_case("cuda:0", CASES[1], tight=False)
+    _close("flow_sim", got, want, 5e-3, 5e-4)
+    _close("grad", ggot, gwant, 5e-2, 5e-3)
+    # BASELINE config 4 shape: 671 basins x 16 members (365 days here), finite and basin-independent
+    import hydrodl2_amd
+    dev = torch.device("cuda:0")
+    H = hydrodl2_amd.load_model("hbv_adj", "HbvAdj")
+    m = H({"nmul": 16, "dynamic_params": {"HbvAdj": ["parBETAET"]}}, dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    T, B = 365, 671
+    x = torch.from_numpy(synth.forcing(T, B, 90)).to(dev)
+    p = torch.randn((T, B, 13 * 16 + 2), generator=g, device=dev).requires_grad_(True)
+    out = m({"x_phy": x}, p)["flow_sim"]
+    out.sum().backward()
+    assert torch.isfinite(out).all() and torch.isfinite(p.grad).all()
+    sel = torch.tensor([0, 5, 670], device=dev)
+    p2 = p.detach()[:, sel].contiguous().requires_grad_(True)
+    out2 = m({"x_phy": x[:, sel].contiguous()}, p2)["flow_sim"]
+    assert torch.equal(out[:, sel], out2)

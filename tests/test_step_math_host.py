@@ -12,14 +12,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "hosttest", "hbvx_host.cpp")
 LIB = os.path.join(HERE, "hosttest", "libhbvx_steptest.so")
 STEP_H = os.path.join(os.path.dirname(HERE), "hydrodl2_amd", "csrc", "hbv_step.h")
+ADJ_H = os.path.join(os.path.dirname(HERE), "hydrodl2_amd", "csrc", "hbv_adj_step.h")
 
 
 @pytest.fixture(scope="module")
 def steptest_lib():
-    newest = max(os.path.getmtime(SRC), os.path.getmtime(STEP_H))
+    newest = max(os.path.getmtime(SRC), os.path.getmtime(STEP_H), os.path.getmtime(ADJ_H))
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < newest:
         subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-std=c++17",
-                               "-ffp-contract=off", "-o", LIB, SRC])
+                               "-ffp-contract=off", "-o", LIB, SRC, "-ldl"])
     return LIB
 
 
