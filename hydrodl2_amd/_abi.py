@@ -62,7 +62,8 @@ class BwdIO(C.Structure):
                 ("grad_state_out", _fp), ("grad_x", _fp),
                 ("grad_muwts", _fp), ("grad_state_in", _fp),
                 ("n_flux", C.c_int32), ("reserved0", C.c_int32),
-                ("g", ParamGrad * MAX_PARAM)]
+                ("g", ParamGrad * MAX_PARAM),
+                ("workspace", _fp), ("workspace_bytes", C.c_uint64)]
 
 
 class RouteDesc(C.Structure):
@@ -74,7 +75,7 @@ class RouteDesc(C.Structure):
 
 
 EXPORTS = ["hbvx_version", "hbvx_last_error", "hbvx_backend", "hbvx_sizeof", "hbvx_forward",
-           "hbvx_backward", "hbvx_route_forward", "hbvx_route_workspace_bytes",
+           "hbvx_backward", "hbvx_backward_workspace_bytes", "hbvx_route_forward", "hbvx_route_workspace_bytes",
            "hbvx_route_backward", "hbvx_adj_forward", "hbvx_adj_backward"]
 
 
@@ -103,6 +104,8 @@ class Library:
         d.hbvx_forward.argtypes = [C.POINTER(Desc), C.POINTER(FwdOut), C.c_void_p]
         d.hbvx_backward.restype = C.c_int
         d.hbvx_backward.argtypes = [C.POINTER(Desc), C.POINTER(BwdIO), C.c_void_p]
+        d.hbvx_backward_workspace_bytes.restype = C.c_uint64
+        d.hbvx_backward_workspace_bytes.argtypes = [C.POINTER(Desc)]
         d.hbvx_route_forward.restype = C.c_int
         d.hbvx_route_forward.argtypes = [C.POINTER(RouteDesc), _fp, _fp, _fp, C.c_void_p]
         d.hbvx_route_backward.restype = C.c_int
@@ -138,6 +141,9 @@ class Library:
     def backward(self, desc: Desc, io: BwdIO, stream: int):
         self._check(self.dll.hbvx_backward(C.byref(desc), C.byref(io), C.c_void_p(stream)),
                     "hbvx_backward")
+
+    def backward_workspace_bytes(self, desc: Desc) -> int:
+        return int(self.dll.hbvx_backward_workspace_bytes(C.byref(desc)))
 
     def adj_forward(self, desc: Desc, out: FwdOut, stream: int):
         self._check(self.dll.hbvx_adj_forward(C.byref(desc), C.byref(out), C.c_void_p(stream)),

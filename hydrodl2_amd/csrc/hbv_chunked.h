@@ -1,0 +1,382 @@
+// hbv_chunked.h -- time-parallel adjoint of the explicit HBV recurrence.
+//
+// The forward recurrence is nonlinear and strictly serial in time, but its adjoint
+//     a_t = J_t^T a_{t+1} + c_t        (a_t = dL/d(storages entering day t); c_t from dL/d(flux_t))
+// is LINEAR in a, and J_t, c_t depend only on the saved trajectory.  With the trajectory in HBM
+// (hbvx_fwd_out.traj/aux) the 7300-day chain therefore splits into independent chunks:
+//
+//   B1 k_bwd_chunk_phi    per (64 lanes, chunk of C days), all chunks in parallel: sweep the chunk
+//                         backwards propagating the 5 unit adjoints and the offset, i.e. build
+//                         a_{t0} = Phi a_{t1} + phi  (Phi 5x5, phi 5) for the chunk.
+//   B2 k_bwd_chunk_scan   per lane: hop the adjoint across chunk boundaries, last chunk first
+//                         (T/C steps of a 5x5 mat-vec); record the adjoint entering every chunk.
+//   B3 k_bwd_chunk_sweep  per (64 lanes, chunk), all chunks in parallel: the ordinary adjoint
+//                         sweep seeded with the chunk's true incoming adjoint: dynamic-parameter,
+//                         forcing and muwts gradients are written, static-parameter gradients are
+//                         summed per chunk.
+//   B4 k_bwd_chunk_reduce per (parameter, lane): fixed-order sum of the chunk partials (deterministic),
+//                         sigmoid' chain, accumulate into the static-row gradient.
+//
+// ~19 000 independent waves at cfg2 instead of 168 serial ones: the adjoint becomes throughput/HBM
+// bound.  B1 and B3 are plain one-wave-per-block kernels with direct global loads -- there is now
+// enough thread-level parallelism to hide memory latency without LDS staging.
+// Floating point: a_t is obtained through composed maps, so gradients differ from the serial
+// sweep by rounding (1e-6 relative); branch predicates come from the same recomputed forward values.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/hbvx.h"
+#include "hbv_step.h"
+
+namespace hbvx {
+
+struct ChunkArgs {
+    hbvx_desc d;
+    hbvx_bwd_io io;
+    int lgMp;
+    int C;        // days per chunk
+    int nchunk;
+    float *phi;   // [nchunk][30][N]  Phi (5 propagated unit adjoints x 5) then phi (5)
+    float *abnd;  // [nchunk][5][N]   adjoint entering each chunk from the future
+    float *gpart; // [nchunk][NP][N]  per-chunk static-parameter gradient (unit space)
+};
+
+struct ChunkLane {
+    int jm, b, j;
+    bool active, leader;
+    int64_t n;
+};
+
+__device__ __forceinline__ ChunkLane chunk_lane(const hbvx_desc &d, int lgMp)
+{
+    ChunkLane L;
+    const int lane = threadIdx.x & 63;
+    const int Mp = 1 << lgMp;
+    L.jm = lane & (Mp - 1);
+    int b = blockIdx.x * (64 >> lgMp) + (lane >> lgMp);
+    L.active = (b < d.B) && (L.jm < d.M);
+    L.leader = (b < d.B) && (L.jm == 0);
+    L.b = b < d.B ? b : d.B - 1;
+    L.j = L.jm < d.M ? L.jm : d.M - 1;
+    L.n = (int64_t)L.b * d.M + L.j;
+    return L;
+}
+
+template <int MODEL, bool BETAET>
+struct ChunkNP {
+    static constexpr int value = MODEL == MODEL_HBV10 ? (BETAET ? 13 : 12)
+                               : MODEL == MODEL_HBV11P ? 14 : 16;
+};
+
+// Raw per-day loads (issued one day ahead), then the recompute that turns them into a Step.
+template <int NP>
+struct ChunkRaw {
+    float f[3];      // P, T, PET
+    float st[5];     // storages entering the day
+    float sw0, ef0;  // saved pow results
+    float gf[HBVX_MAX_FLUX];
+    float dv[NP];    // raw dynamic-parameter values
+    float mu;
+};
+
+template <int MODEL, bool BETAET, int NP>
+struct ChunkDay {
+    Step<MODEL, BETAET> s;
+    float p[NPARAM_MAX];
+    float ud[NP];   // unit value used (for sigmoid')
+    FluxGrad g;
+    float gq;       // raw dL/dQsim (before the member weight), for the muwts gradient
+};
+
+template <int NP, bool DYN, bool GFULL>
+__device__ __forceinline__ void chunk_issue(const hbvx_desc &d, const hbvx_bwd_io &io,
+                                            const ChunkLane &L, int t, int nf, ChunkRaw<NP> &R)
+{
+    const int T = d.T;
+    const int64_t N = (int64_t)d.B * d.M;
+    const float *xr = d.x + (int64_t)t * d.x_t_stride + (int64_t)L.b * d.x_b_stride;
+    R.f[0] = xr[d.ch_prcp]; R.f[1] = xr[d.ch_tmean]; R.f[2] = xr[d.ch_pet];
+    const float *tp = io.traj + (int64_t)t * N + L.n;
+    const int64_t ks = (int64_t)(T + 1) * N;
+#pragma unroll
+    for (int k = 0; k < 5; k++) R.st[k] = tp[k * ks];
+    const float *ap = io.aux + (int64_t)t * N + L.n;
+    R.sw0 = ap[0];
+    R.ef0 = ap[(int64_t)T * N];
+    const int64_t fs = (int64_t)T * d.B, go = (int64_t)t * d.B + L.b;
+#pragma unroll
+    for (int k = 0; k < HBVX_MAX_FLUX; k++) {
+        float v = 0.0f;
+        if (k < 4 || GFULL) {
+            if (GFULL && k < nf) v = io.grad_flux[k * fs + go];
+            if (k < 4 && io.grad_flux4) v += io.grad_flux4[k * fs + go];
+        }
+        R.gf[k] = v;
+    }
+    R.mu = 0.0f;
+    if (DYN) {
+#pragma unroll
+        for (int i = 0; i < NP; i++)
+            R.dv[i] = d.p[i].dyn ? d.p[i].dyn[(int64_t)t * d.p[i].dyn_t_stride +
+                                              (int64_t)L.b * d.p[i].dyn_b_stride + L.j]
+                                 : 0.0f;
+        if (d.muwts) R.mu = d.muwts[(int64_t)t * d.mu_t_stride + (int64_t)L.b * d.mu_b_stride + L.j];
+    }
+}
+
+template <int MODEL, bool BETAET, int NP, bool DYN, bool GFULL>
+__device__ __forceinline__ void chunk_finish(const hbvx_desc &d, const ChunkRaw<NP> &R, bool raw, float nz,
+                                             float ac, float elev, const float *usta, const float *psta,
+                                             const bool *use_dyn, int nf, float invM,
+                                             ChunkDay<MODEL, BETAET, NP> &D)
+{
+    D.s.P = R.f[0]; D.s.Tf = R.f[1]; D.s.PET = R.f[2];
+    D.s.SP = R.st[0]; D.s.MW = R.st[1]; D.s.SM = R.st[2]; D.s.SUZ = R.st[3]; D.s.SLZ = R.st[4];
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        D.ud[i] = usta[i];
+        D.p[i] = psta[i];
+        if (DYN && d.p[i].dyn) {
+            const float v = raw ? sigmoid_(R.dv[i]) : R.dv[i];
+            if (use_dyn[i]) {
+                D.ud[i] = v;
+                D.p[i] = descale_(v, d.p[i].lo, d.p[i].hi);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = NP; i < NPARAM_MAX; i++) D.p[i] = 0.0f;
+    D.s.template fwd<true>(D.p, nz, ac, elev, R.sw0, R.ef0);
+    D.gq = R.gf[HBVX_F_QSIM];
+    const float wq = (DYN && d.muwts) ? R.mu : invM;
+    D.g.gQ = D.gq * wq;
+    D.g.gQ0 = R.gf[HBVX_F_Q0] * invM;
+    D.g.gQ1 = R.gf[HBVX_F_Q1] * invM;
+    D.g.gQ2 = R.gf[HBVX_F_Q2] * invM;
+    D.g.gET = GFULL ? R.gf[HBVX_F_AET] * invM : 0.0f;
+    D.g.gSWE = GFULL ? R.gf[HBVX_F_SWE] * invM : 0.0f;
+    D.g.grech = GFULL ? R.gf[HBVX_F_RECHARGE] * invM : 0.0f;
+    D.g.gexc = GFULL ? R.gf[HBVX_F_EXCS] * invM : 0.0f;
+    D.g.gef = GFULL ? R.gf[HBVX_F_EVAPFACTOR] * invM : 0.0f;
+    D.g.gtosoil = GFULL ? R.gf[HBVX_F_TOSOIL] * invM : 0.0f;
+    D.g.gPERC = GFULL ? R.gf[HBVX_F_PERC] * invM : 0.0f;
+    D.g.gcap = (GFULL && nf > HBVX_F_CAPILLARY) ? R.gf[HBVX_F_CAPILLARY] * invM : 0.0f;
+}
+
+template <int NP, bool DYN>
+__device__ __forceinline__ void chunk_static(const hbvx_desc &d, const ChunkLane &L, bool raw,
+                                             float *usta, float *psta, bool *use_dyn)
+{
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        const hbvx_param_src &s = d.p[i];
+        float v = s.sta[(int64_t)L.b * s.sta_b_stride + L.j];
+        usta[i] = raw ? sigmoid_(v) : v;
+        psta[i] = descale_(usta[i], s.lo, s.hi);
+        use_dyn[i] = DYN && s.dyn && !(s.drop && s.drop[L.b]);
+    }
+}
+
+// ---- B1 -------------------------------------------------------------------------------------
+template <int MODEL, bool BETAET, bool DYN, bool GFULL>
+__global__ void __launch_bounds__(64) k_bwd_chunk_phi(const ChunkArgs A)
+{
+    constexpr int NP = ChunkNP<MODEL, BETAET>::value;
+    const hbvx_desc &d = A.d;
+    const hbvx_bwd_io &io = A.io;
+    const ChunkLane L = chunk_lane(d, A.lgMp);
+    const int chunk = blockIdx.y;
+    const int t0 = chunk * A.C, t1 = min(d.T, t0 + A.C);
+    const int64_t N = (int64_t)d.B * d.M;
+    const bool raw = d.raw_sigmoid != 0;
+    const float nz = d.nearzero, invM = 1.0f / (float)d.M;
+    const float ac = (MODEL == MODEL_HBV20) ? d.ac[L.b] : 0.0f;
+    const float elev = (MODEL == MODEL_HBV20) ? d.elev[L.b] : 0.0f;
+    float usta[NP], psta[NP];
+    bool use_dyn[NP];
+    chunk_static<NP, DYN>(d, L, raw, usta, psta, use_dyn);
+
+    float Phi[5][5], phi[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        phi[k] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 5; i++) Phi[k][i] = (i == k) ? 1.0f : 0.0f;
+    }
+    FluxGrad g0;
+    g0.gQ = g0.gQ0 = g0.gQ1 = g0.gQ2 = g0.gET = g0.gSWE = g0.grech = g0.gexc = g0.gef = g0.gtosoil =
+        g0.gPERC = g0.gcap = 0.0f;
+    ChunkRaw<NP> Rn;
+    chunk_issue<NP, DYN, GFULL>(d, io, L, t1 - 1, io.n_flux, Rn);
+    for (int t = t1 - 1; t >= t0; t--) {
+        const ChunkRaw<NP> Rc = Rn;
+        if (t > t0) chunk_issue<NP, DYN, GFULL>(d, io, L, t - 1, io.n_flux, Rn); // next day's loads in flight
+        ChunkDay<MODEL, BETAET, NP> D;
+        chunk_finish<MODEL, BETAET, NP, DYN, GFULL>(d, Rc, raw, nz, ac, elev, usta, psta, use_dyn,
+                                                    io.n_flux, invM, D);
+        float gp[NPARAM_MAX], gx[3];
+#pragma unroll
+        for (int i = 0; i < NPARAM_MAX; i++) gp[i] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 5; k++) D.s.bwd(D.p, nz, g0, Phi[k], gp, gx);
+        D.s.bwd(D.p, nz, D.g, phi, gp, gx);
+    }
+    if (L.active) {
+        float *dst = A.phi + ((int64_t)chunk * 30) * N + L.n;
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+#pragma unroll
+            for (int i = 0; i < 5; i++) dst[(int64_t)(k * 5 + i) * N] = Phi[k][i];
+#pragma unroll
+        for (int i = 0; i < 5; i++) dst[(int64_t)(25 + i) * N] = phi[i];
+    }
+}
+
+// ---- B2 -------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_bwd_chunk_scan(const ChunkArgs A)
+{
+    const hbvx_desc &d = A.d;
+    const int64_t N = (int64_t)d.B * d.M;
+    const int64_t n = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (n >= N) return;
+    float a[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) a[k] = A.io.grad_state_out ? A.io.grad_state_out[k * N + n] : 0.0f;
+    // register ring: the maps of the next chunk are loaded while this one is applied
+    float cur[30], nxt[30];
+    {
+        const float *src = A.phi + ((int64_t)(A.nchunk - 1) * 30) * N + n;
+#pragma unroll
+        for (int i = 0; i < 30; i++) nxt[i] = src[(int64_t)i * N];
+    }
+    for (int c = A.nchunk - 1; c >= 0; c--) {
+#pragma unroll
+        for (int i = 0; i < 30; i++) cur[i] = nxt[i];
+        if (c > 0) {
+            const float *src = A.phi + ((int64_t)(c - 1) * 30) * N + n;
+#pragma unroll
+            for (int i = 0; i < 30; i++) nxt[i] = src[(int64_t)i * N];
+        }
+#pragma unroll
+        for (int k = 0; k < 5; k++) A.abnd[((int64_t)c * 5 + k) * N + n] = a[k];
+        float an[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            float v = cur[25 + i];
+#pragma unroll
+            for (int k = 0; k < 5; k++) v += a[k] * cur[k * 5 + i];
+            an[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 5; i++) a[i] = an[i];
+    }
+    if (A.io.grad_state_in) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) A.io.grad_state_in[k * N + n] = a[k];
+    }
+}
+
+// ---- B3 -------------------------------------------------------------------------------------
+__device__ __forceinline__ float chunk_ens_sum(float v, int lgMp)
+{
+    for (int s = 0; s < lgMp; s++) v += __shfl_xor(v, 1 << s, 64);
+    return v;
+}
+
+template <int MODEL, bool BETAET, bool DYN, bool GFULL>
+__global__ void __launch_bounds__(64) k_bwd_chunk_sweep(const ChunkArgs A)
+{
+    constexpr int NP = ChunkNP<MODEL, BETAET>::value;
+    const hbvx_desc &d = A.d;
+    const hbvx_bwd_io &io = A.io;
+    const ChunkLane L = chunk_lane(d, A.lgMp);
+    const int chunk = blockIdx.y;
+    const int t0 = chunk * A.C, t1 = min(d.T, t0 + A.C);
+    const int64_t N = (int64_t)d.B * d.M;
+    const bool raw = d.raw_sigmoid != 0;
+    const float nz = d.nearzero, invM = 1.0f / (float)d.M;
+    const float ac = (MODEL == MODEL_HBV20) ? d.ac[L.b] : 0.0f;
+    const float elev = (MODEL == MODEL_HBV20) ? d.elev[L.b] : 0.0f;
+    float usta[NP], psta[NP], gsta[NP];
+    bool use_dyn[NP];
+    chunk_static<NP, DYN>(d, L, raw, usta, psta, use_dyn);
+#pragma unroll
+    for (int i = 0; i < NP; i++) gsta[i] = 0.0f;
+    float a[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) a[k] = A.abnd[((int64_t)chunk * 5 + k) * N + L.n];
+
+    ChunkRaw<NP> Rn;
+    chunk_issue<NP, DYN, GFULL>(d, io, L, t1 - 1, io.n_flux, Rn);
+    for (int t = t1 - 1; t >= t0; t--) {
+        const ChunkRaw<NP> Rc = Rn;
+        if (t > t0) chunk_issue<NP, DYN, GFULL>(d, io, L, t - 1, io.n_flux, Rn);
+        ChunkDay<MODEL, BETAET, NP> D;
+        chunk_finish<MODEL, BETAET, NP, DYN, GFULL>(d, Rc, raw, nz, ac, elev, usta, psta, use_dyn,
+                                                    io.n_flux, invM, D);
+        if (DYN && io.grad_muwts && L.active) io.grad_muwts[((int64_t)t * d.B + L.b) * d.M + L.j] = D.gq * D.s.Q;
+        float gp[NPARAM_MAX], gx[3];
+#pragma unroll
+        for (int i = 0; i < NPARAM_MAX; i++) gp[i] = 0.0f;
+        D.s.bwd(D.p, nz, D.g, a, gp, gx);
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            const float gu = gp[i] * (d.p[i].hi - d.p[i].lo);
+            if (DYN && d.p[i].dyn) {
+                const float gr = raw ? gu * (D.ud[i] * (1.0f - D.ud[i])) : gu;
+                if (io.g[i].dyn && L.active)
+                    io.g[i].dyn[(int64_t)t * io.g[i].dyn_t_stride + (int64_t)L.b * io.g[i].dyn_b_stride + L.j] =
+                        use_dyn[i] ? gr : 0.0f;
+                gsta[i] += use_dyn[i] ? 0.0f : gu;
+            } else {
+                gsta[i] += gu;
+            }
+        }
+        if (io.grad_x) {
+            const float act = L.active ? 1.0f : 0.0f;
+            const float g0 = chunk_ens_sum(gx[0] * act, A.lgMp), g1 = chunk_ens_sum(gx[1] * act, A.lgMp),
+                        g2 = chunk_ens_sum(gx[2] * act, A.lgMp);
+            if (L.leader) {
+                float *gr = io.grad_x + (int64_t)t * d.x_t_stride + (int64_t)L.b * d.x_b_stride;
+                gr[d.ch_prcp] = g0; gr[d.ch_tmean] = g1; gr[d.ch_pet] = g2;
+            }
+        }
+    }
+    if (L.active) {
+#pragma unroll
+        for (int i = 0; i < NP; i++) A.gpart[((int64_t)chunk * NP + i) * N + L.n] = gsta[i];
+    }
+}
+
+// ---- B4 -------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_bwd_chunk_reduce(const ChunkArgs A, int NP)
+{
+    const hbvx_desc &d = A.d;
+    const hbvx_bwd_io &io = A.io;
+    const int64_t N = (int64_t)d.B * d.M;
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.y;
+    if (n >= N || !io.g[i].sta) return;
+    const float *src = A.gpart + (int64_t)i * N + n;
+    const int64_t cs = (int64_t)NP * N;
+    float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;
+    int c = 0;
+    for (; c + 3 < A.nchunk; c += 4) {
+        acc0 += src[(int64_t)c * cs];
+        acc1 += src[(int64_t)(c + 1) * cs];
+        acc2 += src[(int64_t)(c + 2) * cs];
+        acc3 += src[(int64_t)(c + 3) * cs];
+    }
+    for (; c < A.nchunk; c++) acc0 += src[(int64_t)c * cs];
+    float gsum = (acc0 + acc1) + (acc2 + acc3);
+    const int b = (int)(n / d.M), j = (int)(n % d.M);
+    if (d.raw_sigmoid) {
+        const float u = sigmoid_(d.p[i].sta[(int64_t)b * d.p[i].sta_b_stride + j]);
+        gsum = gsum * (u * (1.0f - u));
+    }
+    float *dst = io.g[i].sta + (int64_t)b * io.g[i].sta_b_stride + j;
+    *dst += gsum;
+}
+
+} // namespace hbvx

@@ -312,7 +312,10 @@ struct BwdTArgs {
     TileGeom g;
 };
 
-template <int MODEL, bool BETAET, bool DYN>
+// GFULL = false: only the runoff series (Qsim, Q0, Q1, Q2) carry gradient (loss on routed or
+// un-routed streamflow): the other flux adjoints are compile-time zero and are neither staged
+// nor added.
+template <int MODEL, bool BETAET, bool DYN, bool GFULL>
 __global__ void __launch_bounds__(512) k_bwd_tiled(const BwdTArgs A)
 {
     constexpr int NP = NParamT<MODEL, BETAET>::value;
@@ -329,6 +332,7 @@ __global__ void __launch_bounds__(512) k_bwd_tiled(const BwdTArgs A)
     const int nT = (T + Kt - 1) / Kt;
     const int64_t N = (int64_t)d.B * d.M;
     const bool raw = d.raw_sigmoid != 0;
+    constexpr int NG = GFULL ? NF : 4; // staged gradient series per day
     const bool has_mu = DYN && d.muwts != nullptr;
     const bool has_gx = io.grad_x != nullptr, has_gmu = DYN && io.grad_muwts != nullptr;
     const int lgMp = G.lgMp, Mp = 1 << lgMp, bpw = 64 >> lgMp;
@@ -388,7 +392,7 @@ __global__ void __launch_bounds__(512) k_bwd_tiled(const BwdTArgs A)
                 const float *tr = tin + tt * 7 * 64 + lane;
                 s.SP = tr[0]; s.MW = tr[64]; s.SM = tr[128]; s.SUZ = tr[192]; s.SLZ = tr[256];
                 const float sw0 = tr[320], ef0 = tr[384];
-                const float *gr = gin + tt * NF * bpw + L.bl;
+                const float *gr = gin + tt * NG * bpw + L.bl;
                 FluxGrad g;
                 const float gq = gr[HBVX_F_QSIM * bpw];
                 const float wq = has_mu ? pr[G.ND * 64] : invM;
@@ -396,14 +400,14 @@ __global__ void __launch_bounds__(512) k_bwd_tiled(const BwdTArgs A)
                 g.gQ0 = gr[HBVX_F_Q0 * bpw];
                 g.gQ1 = gr[HBVX_F_Q1 * bpw];
                 g.gQ2 = gr[HBVX_F_Q2 * bpw];
-                g.gET = gr[HBVX_F_AET * bpw];
-                g.gSWE = gr[HBVX_F_SWE * bpw];
-                g.grech = gr[HBVX_F_RECHARGE * bpw];
-                g.gexc = gr[HBVX_F_EXCS * bpw];
-                g.gef = gr[HBVX_F_EVAPFACTOR * bpw];
-                g.gtosoil = gr[HBVX_F_TOSOIL * bpw];
-                g.gPERC = gr[HBVX_F_PERC * bpw];
-                g.gcap = (NF > HBVX_F_CAPILLARY) ? gr[(NF - 1) * bpw] : 0.0f;
+                g.gET = GFULL ? gr[HBVX_F_AET * bpw] : 0.0f;
+                g.gSWE = GFULL ? gr[HBVX_F_SWE * bpw] : 0.0f;
+                g.grech = GFULL ? gr[HBVX_F_RECHARGE * bpw] : 0.0f;
+                g.gexc = GFULL ? gr[HBVX_F_EXCS * bpw] : 0.0f;
+                g.gef = GFULL ? gr[HBVX_F_EVAPFACTOR * bpw] : 0.0f;
+                g.gtosoil = GFULL ? gr[HBVX_F_TOSOIL * bpw] : 0.0f;
+                g.gPERC = GFULL ? gr[HBVX_F_PERC * bpw] : 0.0f;
+                g.gcap = (GFULL && NF > HBVX_F_CAPILLARY) ? gr[(NF - 1) * bpw] : 0.0f;
                 s.template fwd<true>(p, nz, ac, elev, sw0, ef0);
                 float gp[NPARAM_MAX], gx[3];
 #pragma unroll
@@ -496,16 +500,16 @@ __global__ void __launch_bounds__(512) k_bwd_tiled(const BwdTArgs A)
             }
             // incoming flux-series gradients, compact [tt][k][bl], pre-scaled by 1/M
             // (mean backward) except Qsim, whose per-lane weight the stepper applies.
-            const int items = nt * NF * bpw;
+            const int items = nt * NG * bpw;
             for (int e = hid; e < items; e += nhid) {
                 const int bl = e & (bpw - 1);
                 const int r = e >> (6 - lgMp);
-                const int kk = r % NF, tt = r / NF;
+                const int kk = r % NG, tt = r / NG;
                 const int bb = min(b0 + bl, d.B - 1);
                 const int64_t gi = ((int64_t)kk * T + (t0 + tt)) * d.B + bb;
-                float v = io.grad_flux ? io.grad_flux[gi] : 0.0f;
+                float v = (GFULL && io.grad_flux) ? io.grad_flux[gi] : 0.0f;
                 if (io.grad_flux4 && kk < 4) v += io.grad_flux4[gi];
-                gin[(tt * NF + kk) * bpw + bl] = (kk == HBVX_F_QSIM) ? v : v * invM;
+                gin[(tt * NG + kk) * bpw + bl] = (kk == HBVX_F_QSIM) ? v : v * invM;
             }
         };
 

@@ -18,6 +18,7 @@
 #include "hbv_step.h"
 #include "hbv_tiled.h"
 #include "hbv_adj_kernels.h"
+#include "hbv_chunked.h"
 
 using namespace hbvx;
 
@@ -654,7 +655,7 @@ static bool geom_bwd(const hbvx_desc *d, const hbvx_bwd_io *io, TileGeom &g)
     g.lgMp = lg_members(d->M);
     g.ND = count_dyn(d);
     g.NDm = g.ND + (d->muwts ? 1 : 0);
-    const int NF = (d->model == HBVX_MODEL_HBV10) ? 11 : 12;
+    const int NF = io->grad_flux ? ((d->model == HBVX_MODEL_HBV10) ? 11 : 12) : 4; // staged series
     const int bpw = 64 >> g.lgMp;
     const int ktmax = env_int("HBVX_KT", 16);
     for (int Kt = 16; Kt >= 1; Kt >>= 1) {
@@ -684,23 +685,17 @@ static hipError_t launch_tiled_one(K kern, const Args &a, dim3 grid, int threads
     return hipGetLastError();
 }
 
-#define LAUNCH_TILED(KERN, d, a, grid, lds, st, dyn)                                              \
+#define LAUNCH_TILED_V(K, d, a, grid, lds, st, ...)                                                \
     ([&]() -> hipError_t {                                                                        \
         int nh = env_int("HBVX_NH", 7);                                                           \
         nh = nh < 1 ? 1 : (nh > 7 ? 7 : nh);                                                      \
         const int threads = 64 * (1 + nh);                                                        \
         const int m = (d)->model;                                                                 \
         const bool be = (d)->n_param == 13;                                                       \
-        if (dyn) {                                                                                \
-            if (m == HBVX_MODEL_HBV10 && !be) return launch_tiled_one(KERN<MODEL_HBV10, false, true>, a, grid, threads, lds, st); \
-            if (m == HBVX_MODEL_HBV10) return launch_tiled_one(KERN<MODEL_HBV10, true, true>, a, grid, threads, lds, st);         \
-            if (m == HBVX_MODEL_HBV11P) return launch_tiled_one(KERN<MODEL_HBV11P, true, true>, a, grid, threads, lds, st);       \
-            return launch_tiled_one(KERN<MODEL_HBV20, true, true>, a, grid, threads, lds, st);    \
-        }                                                                                         \
-        if (m == HBVX_MODEL_HBV10 && !be) return launch_tiled_one(KERN<MODEL_HBV10, false, false>, a, grid, threads, lds, st);    \
-        if (m == HBVX_MODEL_HBV10) return launch_tiled_one(KERN<MODEL_HBV10, true, false>, a, grid, threads, lds, st);            \
-        if (m == HBVX_MODEL_HBV11P) return launch_tiled_one(KERN<MODEL_HBV11P, true, false>, a, grid, threads, lds, st);          \
-        return launch_tiled_one(KERN<MODEL_HBV20, true, false>, a, grid, threads, lds, st);       \
+        if (m == HBVX_MODEL_HBV10 && !be) return launch_tiled_one(K<MODEL_HBV10, false, __VA_ARGS__>, a, grid, threads, lds, st); \
+        if (m == HBVX_MODEL_HBV10) return launch_tiled_one(K<MODEL_HBV10, true, __VA_ARGS__>, a, grid, threads, lds, st);         \
+        if (m == HBVX_MODEL_HBV11P) return launch_tiled_one(K<MODEL_HBV11P, true, __VA_ARGS__>, a, grid, threads, lds, st);       \
+        return launch_tiled_one(K<MODEL_HBV20, true, __VA_ARGS__>, a, grid, threads, lds, st);    \
     })()
 
 extern "C" int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream)
@@ -720,7 +715,8 @@ extern "C" int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *s
             dim3 grid_t((d->B + bpw_t - 1) / bpw_t);
             const size_t lds = (size_t)2 * (ta.g.in_sz + ta.g.out_sz) * 4;
             const bool dyn = ta.g.NDm > 0;
-            hipError_t e = LAUNCH_TILED(k_fwd_tiled, d, ta, grid_t, lds, (hipStream_t)stream, dyn);
+            hipError_t e = dyn ? LAUNCH_TILED_V(k_fwd_tiled, d, ta, grid_t, lds, (hipStream_t)stream, true)
+                               : LAUNCH_TILED_V(k_fwd_tiled, d, ta, grid_t, lds, (hipStream_t)stream, false);
             if (e != hipSuccess) return hip_fail(e, "hbvx_forward (tiled) launch");
             return HBVX_OK;
         }
@@ -738,6 +734,70 @@ extern "C" int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *s
     return HBVX_OK;
 }
 
+// ---------------------------------------------------------------------------
+// time-parallel adjoint (hbv_chunked.h)
+// ---------------------------------------------------------------------------
+static int chunk_days() { int c = env_int("HBVX_CHUNK", 64); return c < 2 ? 2 : c; }
+
+static bool chunked_applicable(const hbvx_desc *d)
+{
+    const char *v = getenv("HBVX_BWD");
+    if (v && !strcmp(v, "tiled")) return false;
+    if (d->model == HBVX_MODEL_HBVADJ) return false;
+    return d->T >= 2 * chunk_days();
+}
+
+static int np_of(const hbvx_desc *d) { return d->n_param; }
+
+extern "C" uint64_t hbvx_backward_workspace_bytes(const hbvx_desc *d)
+{
+    if (!d || d->T <= 0 || d->B <= 0 || d->M <= 0 || !chunked_applicable(d)) return 0;
+    const int C = chunk_days();
+    const uint64_t nchunk = (uint64_t)(d->T + C - 1) / C;
+    return nchunk * (uint64_t)d->B * (uint64_t)d->M * (uint64_t)(35 + np_of(d)) * sizeof(float);
+}
+
+template <int MODEL, bool BETAET, bool DYN, bool GFULL>
+static hipError_t launch_chunked_t(const ChunkArgs &a, hipStream_t st)
+{
+    const hbvx_desc &d = a.d;
+    const int bpw = 64 >> a.lgMp;
+    const int64_t N = (int64_t)d.B * d.M;
+    dim3 g2((d.B + bpw - 1) / bpw, a.nchunk);
+    hipLaunchKernelGGL((k_bwd_chunk_phi<MODEL, BETAET, DYN, GFULL>), g2, dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_bwd_chunk_scan, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, st, a);
+    hipLaunchKernelGGL((k_bwd_chunk_sweep<MODEL, BETAET, DYN, GFULL>), g2, dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_bwd_chunk_reduce, dim3((unsigned)((N + 255) / 256), d.n_param), dim3(256), 0, st,
+                       a, d.n_param);
+    return hipGetLastError();
+}
+
+template <bool DYN, bool GFULL>
+static hipError_t launch_chunked_v(const hbvx_desc *d, const ChunkArgs &a, hipStream_t st)
+{
+    if (d->model == HBVX_MODEL_HBV10 && d->n_param == 12) return launch_chunked_t<MODEL_HBV10, false, DYN, GFULL>(a, st);
+    if (d->model == HBVX_MODEL_HBV10) return launch_chunked_t<MODEL_HBV10, true, DYN, GFULL>(a, st);
+    if (d->model == HBVX_MODEL_HBV11P) return launch_chunked_t<MODEL_HBV11P, true, DYN, GFULL>(a, st);
+    return launch_chunked_t<MODEL_HBV20, true, DYN, GFULL>(a, st);
+}
+
+static hipError_t launch_chunked(const hbvx_desc *d, const hbvx_bwd_io *io, hipStream_t st)
+{
+    ChunkArgs a;
+    a.d = *d;
+    a.io = *io;
+    a.lgMp = lg_members(d->M);
+    a.C = chunk_days();
+    a.nchunk = (d->T + a.C - 1) / a.C;
+    const int64_t N = (int64_t)d->B * d->M;
+    a.phi = (float *)io->workspace;
+    a.abnd = a.phi + (int64_t)a.nchunk * 30 * N;
+    a.gpart = a.abnd + (int64_t)a.nchunk * 5 * N;
+    const bool dyn = count_dyn(d) > 0 || d->muwts, gfull = io->grad_flux != nullptr;
+    if (dyn) return gfull ? launch_chunked_v<true, true>(d, a, st) : launch_chunked_v<true, false>(d, a, st);
+    return gfull ? launch_chunked_v<false, true>(d, a, st) : launch_chunked_v<false, false>(d, a, st);
+}
+
 extern "C" int hbvx_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *stream)
 {
     int rc = check_desc(d);
@@ -747,6 +807,12 @@ extern "C" int hbvx_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *st
     const int want_nf = (d->model == HBVX_MODEL_HBV10) ? 11 : 12;
     if (io->n_flux != want_nf) return fail(HBVX_E_SHAPE, "n_flux does not match model");
     if (d->T == 0) return HBVX_OK;
+    if (io->workspace && chunked_applicable(d) &&
+        io->workspace_bytes >= hbvx_backward_workspace_bytes(d)) {
+        hipError_t e = launch_chunked(d, io, (hipStream_t)stream);
+        if (e != hipSuccess) return hip_fail(e, "hbvx_backward (chunked) launch");
+        return HBVX_OK;
+    }
     {
         BwdTArgs ta;
         if (use_tiled(d) && geom_bwd(d, io, ta.g)) {
@@ -755,8 +821,13 @@ extern "C" int hbvx_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *st
             const int bpw_t = 64 >> ta.g.lgMp;
             dim3 grid_t((d->B + bpw_t - 1) / bpw_t);
             const size_t lds = (size_t)2 * (ta.g.in_sz + ta.g.out_sz) * 4;
-            const bool dyn = ta.g.NDm > 0;
-            hipError_t e = LAUNCH_TILED(k_bwd_tiled, d, ta, grid_t, lds, (hipStream_t)stream, dyn);
+            const bool dyn = ta.g.NDm > 0, gfull = io->grad_flux != nullptr;
+            hipStream_t st_ = (hipStream_t)stream;
+            hipError_t e =
+                dyn ? (gfull ? LAUNCH_TILED_V(k_bwd_tiled, d, ta, grid_t, lds, st_, true, true)
+                             : LAUNCH_TILED_V(k_bwd_tiled, d, ta, grid_t, lds, st_, true, false))
+                    : (gfull ? LAUNCH_TILED_V(k_bwd_tiled, d, ta, grid_t, lds, st_, false, true)
+                             : LAUNCH_TILED_V(k_bwd_tiled, d, ta, grid_t, lds, st_, false, false));
             if (e != hipSuccess) return hip_fail(e, "hbvx_backward (tiled) launch");
             return HBVX_OK;
         }

@@ -155,6 +155,9 @@ typedef struct hbvx_bwd_io {
     int32_t n_flux;
     int32_t reserved0;
     hbvx_param_grad g[HBVX_MAX_PARAM];
+    void *workspace;          /* optional caller-owned scratch of hbvx_backward_workspace_bytes();
+                                 enables the time-parallel (chunked) adjoint */
+    uint64_t workspace_bytes;
 } hbvx_bwd_io;
 
 /* Unit-hydrograph routing of S series that share one UH per basin. */
@@ -177,6 +180,8 @@ uint64_t hbvx_sizeof(int which);        /* 0 desc, 1 fwd_out, 2 bwd_io, 3 route_
 
 int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream);
 int hbvx_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *stream);
+/* Scratch bytes the time-parallel adjoint wants for this problem (0: not applicable). */
+uint64_t hbvx_backward_workspace_bytes(const hbvx_desc *d);
 
 /* q [S,T,B] -> uh [B,L] (normalised gamma UH) and q_rout [S,T,B]. */
 int hbvx_route_forward(const hbvx_route_desc *r, const float *q, float *uh, float *q_rout,

@@ -791,3 +791,9 @@ int hbvx_adj_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *stream)
     (void)d; (void)io; (void)stream;
     return fail(HBVX_E_UNSUPPORTED, "see oracle/hbv_adj_oracle.py");
 }
+
+uint64_t hbvx_backward_workspace_bytes(const hbvx_desc *d)
+{
+    (void)d;
+    return 0; /* the oracle sweeps serially */
+}

@@ -186,6 +186,7 @@ extern "C" int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *o, void *)
     DISPATCH(run_fwd, *d, *o);
     return 0;
 }
+extern "C" uint64_t hbvx_backward_workspace_bytes(const hbvx_desc *) { return 0; }
 extern "C" int hbvx_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *)
 {
     DISPATCH(run_bwd, *d, *io);
