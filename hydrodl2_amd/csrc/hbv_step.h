@@ -188,14 +188,14 @@ struct Step {
     // lateral flow
     float a0, a1, m1, m2, ee, sl;
 
-    // USE_AUX: (SM/FC)^BETA and the pre-clamp evaporation factor come from the
-    // forward pass (hbvx_fwd_out.aux) instead of two powf calls.
-    template <bool USE_AUX>
-    HBVX_HDM void fwd(const float *p, float nz, float ac, float elev, float aux_sw0, float aux_ef0)
+    // The day step in its three feed-forward stages (snow -> soil -> groundwater).  fwd() runs
+    // them back to back; the pipelined forward kernel (hbv_pipe.h) runs each stage on its own
+    // wave.  The operations and their order are exactly those of the reference loop body.
+
+    // snow: needs SP, MW, P, Tf; produces RAIN, tosoil, SP3, MW3      (hbv.py:429-459)
+    HBVX_HDM void fwd_snow(const float *p, float elev)
     {
-        const float BETA = p[P_BETA], FC = p[P_FC], K0 = p[P_K0], K1 = p[P_K1], K2 = p[P_K2],
-                    LP = p[P_LP], PERCp = p[P_PERC], UZL = p[P_UZL], TT = p[P_TT],
-                    CFMAX = p[P_CFMAX], CFR = p[P_CFR], CWH = p[P_CWH];
+        const float TT = p[P_TT], CFMAX = p[P_CFMAX], CFR = p[P_CFR], CWH = p[P_CWH];
         if (MODEL == MODEL_HBV20) { // hbv_2.py:473-475
             float mhi = (elev >= 2000.0f) ? 1.0f : 0.0f;
             mlo = (elev < 2000.0f) ? 1.0f : 0.0f;
@@ -204,7 +204,6 @@ struct Step {
             mlo = 1.0f;
             TTe = TT;
         }
-        // hbv.py:429-445
         m_rain = (Tf >= TTe) ? 1.0f : 0.0f;
         m_snow = (Tf < TTe) ? 1.0f : 0.0f;
         RAIN = P * m_rain;
@@ -216,7 +215,6 @@ struct Step {
         melt = fmin_(mpc, SP1);
         MW1 = MW + melt;
         SP2 = SP1 - melt;
-        // hbv.py:446-459
         cc = CFR * CFMAX;
         dT2 = TTe - Tf;
         rp = cc * dT2;
@@ -227,7 +225,15 @@ struct Step {
         ts0 = MW2 - CWH * SP3;
         tosoil = fmax_(ts0, 0.0f);
         MW3 = MW2 - tosoil;
-        // hbv.py:462-472
+    }
+
+    // soil: needs SM, RAIN, tosoil, PET; produces rech, exc, ET, ef, SM3   (hbv.py:462-480)
+    // USE_AUX: (SM/FC)^BETA and the pre-clamp evaporation factor come from the forward pass
+    // (hbvx_fwd_out.aux) instead of two pow calls.
+    template <bool USE_AUX>
+    HBVX_HDM void fwd_soil(const float *p, float nz, float aux_sw0, float aux_ef0)
+    {
+        const float BETA = p[P_BETA], FC = p[P_FC], LP = p[P_LP];
         r = div_(SM, FC);
         sw0 = USE_AUX ? aux_sw0 : pow_pos_(r, BETA);
         sw = fmin_(fmax_(sw0, 0.0f), 1.0f);
@@ -237,7 +243,6 @@ struct Step {
         e0 = SM1 - FC;
         exc = fmax_(e0, 0.0f);
         SM2 = SM1 - exc;
-        // hbv.py:474-480 ; hbv_1_1p.py:473-480
         lpfc = LP * FC;
         q = div_(SM2, lpfc);
         if (BETAET) ef0 = USE_AUX ? aux_ef0 : pow_pos_(q, p[P_BETAET]);
@@ -247,9 +252,13 @@ struct Step {
         ET = fmin_(SM2, pe);
         dd = SM2 - ET;
         SM3 = fmax_(dd, nz);
-        // hbv_1_1p.py:482-490
+    }
+
+    // capillary rise (1.1p / 2.0): couples SM3 and SLZ                 (hbv_1_1p.py:482-490)
+    HBVX_HDM void fwd_cap(const float *p, float nz)
+    {
         if (MODEL != MODEL_HBV10) {
-            const float C = p[P_C];
+            const float C = p[P_C], FC = p[P_FC];
             x1 = div_(SM3, FC);
             float rc = fmin_(x1, 1.0f);
             cs = C * SLZ;
@@ -265,7 +274,12 @@ struct Step {
             SM4 = SM3;
             SLZ0 = SLZ;
         }
-        // hbv.py:483-492
+    }
+
+    // groundwater: needs SUZ, SLZ0, rech, exc; produces PERC, Q0, Q1, Q2, SUZ4, SLZ2   (hbv.py:483-494)
+    HBVX_HDM void fwd_gw(const float *p, float ac)
+    {
+        const float K0 = p[P_K0], K1 = p[P_K1], K2 = p[P_K2], PERCp = p[P_PERC], UZL = p[P_UZL];
         SUZ1 = (SUZ + rech) + exc;
         PERC = fmin_(SUZ1, PERCp);
         SUZ2 = SUZ1 - PERC;
@@ -294,6 +308,15 @@ struct Step {
         Q2 = K2 * SLZ1p;
         SLZ2 = SLZ1p - Q2;
         Q = (Q0 + Q1) + Q2; // hbv.py:494
+    }
+
+    template <bool USE_AUX>
+    HBVX_HDM void fwd(const float *p, float nz, float ac, float elev, float aux_sw0, float aux_ef0)
+    {
+        fwd_snow(p, elev);
+        fwd_soil<USE_AUX>(p, nz, aux_sw0, aux_ef0);
+        fwd_cap(p, nz);
+        fwd_gw(p, ac);
     }
 
     // Adjoint of fwd().  a[5]: dL/d(new states) in, dL/d(old states) out.

@@ -74,6 +74,85 @@ __device__ __forceinline__ LaneT lane_t(const hbvx_desc &d, int lgMp)
     return L;
 }
 
+// Ensemble sum of one basin whose per-member values sit in LDS at src[0..Mp): LPI = max(Mp/4, 1)
+// adjacent lanes cooperate; lane `sub` reads members 4*sub..4*sub+3 with one ds_read_b128 (masked to
+// m < M), then an xor butterfly over the LPI lanes.  Fixed summation tree: independent of tile
+// alignment and of where the basin sits.  All 64 lanes must call it (cross-lane shuffles).
+__device__ __forceinline__ float ens_sum_lds(const float *src, int sub, int M, int lgMp)
+{
+    float s;
+    if (lgMp >= 2) {
+        const float4 v = *reinterpret_cast<const float4 *>(src + 4 * sub);
+        const int m0 = 4 * sub;
+        const float a = ((m0 < M) ? v.x : 0.0f) + ((m0 + 1 < M) ? v.y : 0.0f);
+        const float b = ((m0 + 2 < M) ? v.z : 0.0f) + ((m0 + 3 < M) ? v.w : 0.0f);
+        s = a + b;
+        for (int k = 0; k < lgMp - 2; k++) s += __shfl_xor(s, 1 << k, 64);
+    } else {
+        s = src[0];
+        if (M > 1) s += src[1];
+    }
+    return s;
+}
+
+// Reduce `items` (= nt * NFS * bpw) basin-series of an output tile and hand each sum to `emit`.
+// Item e -> (bl = e % bpw, ks = (e / bpw) % NFS, tt = e / (bpw * NFS)); values of item e live at
+// buf[(tt * NSER + ks) * 64 + bl * Mp ...].  `w`/`nw`: this helper wave's index / number of waves.
+template <int NSER, int NFS, typename Emit>
+__device__ __forceinline__ void ens_reduce_tile(const float *buf, int items, int lane, int w, int nw,
+                                                int M, int lgMp, Emit emit)
+{
+    const int Mp = 1 << lgMp, bpw = 64 >> lgMp;
+    const int lgLPI = lgMp >= 2 ? lgMp - 2 : 0;
+    const int ipp = 64 >> lgLPI;            // items per wave pass
+    const int sub = lane & ((1 << lgLPI) - 1), slot = lane >> lgLPI;
+    // two independent items per lane and pass: the chain ds_read -> add -> 2 shuffles is latency
+    // bound, a second chain in flight nearly halves the time per item
+    for (int base = w * ipp; base < items; base += 2 * nw * ipp) {
+        int e[2], tt[2], ks[2], bl[2];
+        bool valid[2];
+        const float *src[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            e[u] = base + u * nw * ipp + slot;
+            valid[u] = e[u] < items;
+            const int ec = valid[u] ? e[u] : items - 1;
+            bl[u] = ec & (bpw - 1);
+            const int r = ec >> (6 - lgMp);
+            ks[u] = r % NFS;
+            tt[u] = r / NFS;
+            src[u] = buf + (tt[u] * NSER + ks[u]) * 64 + bl[u] * Mp;
+        }
+        float v[2];
+        if (lgMp >= 2) {
+            float4 q[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) q[u] = *reinterpret_cast<const float4 *>(src[u] + 4 * sub);
+            const int m0 = 4 * sub;
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const float a = ((m0 < M) ? q[u].x : 0.0f) + ((m0 + 1 < M) ? q[u].y : 0.0f);
+                const float b = ((m0 + 2 < M) ? q[u].z : 0.0f) + ((m0 + 3 < M) ? q[u].w : 0.0f);
+                v[u] = a + b;
+            }
+            for (int k = 0; k < lgMp - 2; k++) {
+                const float s0 = __shfl_xor(v[0], 1 << k, 64), s1 = __shfl_xor(v[1], 1 << k, 64);
+                v[0] += s0;
+                v[1] += s1;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                v[u] = src[u][0];
+                if (M > 1) v[u] += src[u][1];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+            if (valid[u] && sub == 0) emit(tt[u], ks[u], bl[u], v[u]);
+    }
+}
+
 // index of dynamic slot i among the dynamic slots (wave-uniform)
 __device__ __forceinline__ int dyn_index(unsigned dmask, int i)
 {
@@ -271,24 +350,12 @@ __global__ void __launch_bounds__(512) k_fwd_tiled(const FwdTArgs A)
                 }
             }
             if (has_flux) {
-                // ensemble mean: item e -> (day tt, series kk, basin bl); the member loop starts at
-                // a series-dependent member to spread LDS banks.
-                const int items = nt * NF * bpw;
-                for (int e = hid; e < items; e += nhid) {
-                    const int bl = e & (bpw - 1);
-                    const int r = e >> (6 - lgMp);
-                    const int kk = r % NF, tt = r / NF;
-                    const float *src = out + (tt * NF + kk) * 64 + bl * Mp;
-                    float acc = 0.0f;
-                    int m = kk % d.M; // start member depends on the series only: results do not depend on
-                                      // tile alignment or on where a basin sits in its wave
-                    for (int c = 0; c < d.M; c++) {
-                        acc += src[m];
-                        m = (m + 1 == d.M) ? 0 : m + 1;
-                    }
-                    if (!(kk == HBVX_F_QSIM && has_mu)) acc = acc * invM;
-                    if (b0 + bl < d.B) o.flux[((int64_t)kk * T + (t0 + tt)) * d.B + b0 + bl] = acc;
-                }
+                ens_reduce_tile<NF, NF>(out, nt * NF * bpw, lane, w, NH, d.M, lgMp,
+                                        [&](int tt, int kk, int bl, float acc) {
+                                            if (!(kk == HBVX_F_QSIM && has_mu)) acc = acc * invM;
+                                            if (b0 + bl < d.B)
+                                                o.flux[((int64_t)kk * T + (t0 + tt)) * d.B + b0 + bl] = acc;
+                                        });
             }
         };
 
@@ -540,23 +607,14 @@ __global__ void __launch_bounds__(512) k_bwd_tiled(const BwdTArgs A)
                 }
             }
             if (has_gx) {
-                const int items = nt * 3 * bpw;
-                for (int e = hid; e < items; e += nhid) {
-                    const int bl = e & (bpw - 1);
-                    const int r = e >> (6 - lgMp);
-                    const int c = r % 3, tt = r / 3;
-                    const float *src = out + G.off_xout + (tt * 3 + c) * 64 + bl * Mp;
-                    float acc = 0.0f;
-                    int m = c % d.M;
-                    for (int q = 0; q < d.M; q++) {
-                        acc += src[m];
-                        m = (m + 1 == d.M) ? 0 : m + 1;
-                    }
-                    if (b0 + bl < d.B) {
-                        const int ch = c == 0 ? d.ch_prcp : (c == 1 ? d.ch_tmean : d.ch_pet);
-                        io.grad_x[(int64_t)(t0 + tt) * d.x_t_stride + (int64_t)(b0 + bl) * d.x_b_stride + ch] = acc;
-                    }
-                }
+                ens_reduce_tile<3, 3>(out + G.off_xout, nt * 3 * bpw, lane, w, NH, d.M, lgMp,
+                                      [&](int tt, int c, int bl, float acc) {
+                                          if (b0 + bl < d.B) {
+                                              const int ch = c == 0 ? d.ch_prcp : (c == 1 ? d.ch_tmean : d.ch_pet);
+                                              io.grad_x[(int64_t)(t0 + tt) * d.x_t_stride +
+                                                        (int64_t)(b0 + bl) * d.x_b_stride + ch] = acc;
+                                          }
+                                      });
             }
             if (has_gmu) {
                 for (int tt = w; tt < nt; tt += NH) {

@@ -19,6 +19,7 @@
 #include "hbv_tiled.h"
 #include "hbv_adj_kernels.h"
 #include "hbv_chunked.h"
+#include "hbv_pipe.h"
 
 using namespace hbvx;
 
@@ -706,6 +707,29 @@ extern "C" int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *s
     if (!out || !out->state_out) return fail(HBVX_E_NULL, "state_out is NULL");
     const int want_nf = (d->model == HBVX_MODEL_HBV10) ? 11 : 12;
     if (out->flux && out->n_flux != want_nf) return fail(HBVX_E_SHAPE, "n_flux does not match model");
+    {
+        // HBV 1.0, static parameters, flux requested: three-stage pipelined forward (hbv_pipe.h)
+        const char *fv = getenv("HBVX_FWD");
+        const int Kt = 8;
+        if (use_tiled(d) && !(fv && !strcmp(fv, "tiled")) && d->model == HBVX_MODEL_HBV10 &&
+            count_dyn(d) == 0 && !d->muwts && out->flux && d->T >= 4 * Kt) {
+            PipeArgs pa;
+            pa.d = *d;
+            pa.o = *out;
+            pa.lgMp = lg_members(d->M);
+            pa.Kt = Kt;
+            const int bpw_p = 64 >> pa.lgMp;
+            dim3 grid_p((d->B + bpw_p - 1) / bpw_p);
+            const size_t lds = (size_t)PipeLds(Kt).total * 4;
+            int pthreads = env_int("HBVX_PIPE_THREADS", 1024); // 3 steppers + 2 fillers + drainers
+            pthreads = pthreads < 384 ? 384 : (pthreads > 1024 ? 1024 : (pthreads / 64) * 64);
+            hipError_t e = (d->n_param == 13)
+                               ? launch_tiled_one(k_fwd_pipe<true>, pa, grid_p, pthreads, lds, (hipStream_t)stream)
+                               : launch_tiled_one(k_fwd_pipe<false>, pa, grid_p, pthreads, lds, (hipStream_t)stream);
+            if (e != hipSuccess) return hip_fail(e, "hbvx_forward (pipelined) launch");
+            return HBVX_OK;
+        }
+    }
     {
         FwdTArgs ta;
         if (use_tiled(d) && geom_fwd(d, out, ta.g)) {
