@@ -188,10 +188,12 @@ def main():
 
     # Algorithmic HBM bytes per launch ("bytes per lane-step", fp32):
     #   forward : forcings 12/M + 11 mean series 4*11/M + saved trajectory/aux 28   = 31.5  B
-    #   adjoint : forcings 12/M + trajectory/aux 28 + routed-Q gradients 4*4/M       = 29.75 B
+    #   adjoint : time-parallel, two passes over (forcings 12/M + trajectory/aux 28 + routed-Q
+    #             gradients 4*4/M = 29.75 B) + per-chunk maps/partials (35+12 floats per lane and
+    #             64-day chunk, written and read: 5.9 B)                               = 65.4  B
     n_flux = 11
     bytes_fwd = lane_steps * (12.0 / M + 4.0 * n_flux / M + 28.0)
-    bytes_bwd = lane_steps * (12.0 / M + 28.0 + 4.0 * 4 / M)
+    bytes_bwd = lane_steps * (2.0 * (12.0 / M + 28.0 + 4.0 * 4 / M) + 2.0 * 4.0 * (35 + 12) / 64.0)
     dom = max((k for k in kavg if k in ("hbvx_forward", "hbvx_backward")), key=lambda k: kavg[k])
     dom_bytes = bytes_bwd if dom == "hbvx_backward" else bytes_fwd
     achieved = dom_bytes / (kavg[dom] * 1e-3) / 1e9
@@ -202,7 +204,9 @@ def main():
             traffic = json.load(open(tj)).get(dom, {}).get("hbm_bytes_raw")
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2),
+    hip_kernels = {"hbvx_forward": "k_fwd_pipe (hbv_pipe.h)",
+                   "hbvx_backward": "k_bwd_chunk_phi + _scan + _sweep + _reduce (hbv_chunked.h)"}
+    roofline = {"bound": "hbm", "kernel": dom, "hip_kernels": hip_kernels.get(dom), "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
                 "traffic": traffic, "avg_ms": round(kavg[dom], 4),
                 "kernel_ms": {k: round(v, 4) for k, v in kavg.items()}}
