@@ -76,7 +76,7 @@ class RouteDesc(C.Structure):
 
 EXPORTS = ["hbvx_version", "hbvx_last_error", "hbvx_backend", "hbvx_sizeof", "hbvx_forward",
            "hbvx_backward", "hbvx_backward_workspace_bytes", "hbvx_route_forward", "hbvx_route_workspace_bytes",
-           "hbvx_route_backward", "hbvx_adj_forward", "hbvx_adj_backward"]
+           "hbvx_route_backward", "hbvx_adj_forward", "hbvx_adj_backward", "hbvx_bfi"]
 
 
 class HbvxError(RuntimeError):
@@ -117,6 +117,8 @@ class Library:
             fn.restype = C.c_int
         d.hbvx_adj_forward.argtypes = [C.POINTER(Desc), C.POINTER(FwdOut), C.c_void_p]
         d.hbvx_adj_backward.argtypes = [C.POINTER(Desc), C.POINTER(BwdIO), C.c_void_p]
+        d.hbvx_bfi.restype = C.c_int
+        d.hbvx_bfi.argtypes = [C.c_int32, C.c_int32, _fp, _fp, C.c_float, _fp, C.c_void_p]
         if d.hbvx_version() != ABI_VERSION:
             raise HbvxError(f"{path}: ABI version {d.hbvx_version()} != {ABI_VERSION}")
         for which, st in enumerate([Desc, FwdOut, BwdIO, RouteDesc, ParamSrc, ParamGrad]):
@@ -152,6 +154,10 @@ class Library:
     def adj_backward(self, desc: Desc, io: BwdIO, stream: int):
         self._check(self.dll.hbvx_adj_backward(C.byref(desc), C.byref(io), C.c_void_p(stream)),
                     "hbvx_adj_backward")
+
+    def bfi(self, T: int, B: int, qs: int, q2: int, nearzero: float, out: int, stream: int):
+        self._check(self.dll.hbvx_bfi(T, B, qs, q2, C.c_float(nearzero), out, C.c_void_p(stream)),
+                    "hbvx_bfi")
 
     def route_forward(self, r: RouteDesc, q: int, uh: int, q_rout: int, stream: int):
         self._check(self.dll.hbvx_route_forward(C.byref(r), q, uh, q_rout, C.c_void_p(stream)),

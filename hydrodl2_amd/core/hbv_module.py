@@ -15,7 +15,7 @@ from typing import Any, Optional, Union
 import torch
 
 from .. import _abi
-from ..ops import HbvPath, ParamSource, RouteSource, StepConfig
+from ..ops import Bfi, HbvPath, ParamSource, RouteSource, StepConfig
 
 
 class HbvModule(torch.nn.Module):
@@ -247,7 +247,7 @@ class HbvModule(torch.nn.Module):
             # The reference's Hbv crashes here (hbv.py:550-567); follow Hbv_2's
             # handling of routing=False instead (hbv_2.py:620-626).
             Qs, Q0r, Q1r, Q2r = (col(flux[k]) for k in (F.F_QSIM, F.F_Q0, F.F_Q1, F.F_Q2))
-        BFI = 100 * (torch.sum(Q2r, dim=0) / (torch.sum(Qs, dim=0) + self.nearzero))[:, 0]
+        BFI = Bfi.apply(Qs[:, :, 0], Q2r[:, :, 0], float(self.nearzero))
         pet = x[t0:, :, self.variables.index('pet')]
         out = {
             'streamflow': Qs, 'srflow': Q0r, 'ssflow': Q1r, 'gwflow': Q2r,

@@ -1013,3 +1013,52 @@ extern "C" int hbvx_adj_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void
     if (e != hipSuccess) return hip_fail(e, "hbvx_adj_backward launch");
     return HBVX_OK;
 }
+
+// ---------------------------------------------------------------------------
+// baseflow index (hbv.py:562-567): block = 64 basins x 16 time slices, fixed-order tree
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_bfi(int T, int B, const float *__restrict__ qs,
+                                              const float *__restrict__ q2, float nz,
+                                              float *__restrict__ bfi)
+{
+    __shared__ float r0[16][64], r2[16][64];
+    const int bl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int b = blockIdx.x * 64 + bl;
+    float a0 = 0.0f, a2 = 0.0f, c0 = 0.0f, c2 = 0.0f;
+    if (b < B) {
+        int t = sl;
+        for (; t + 16 < T; t += 32) {
+            a0 += qs[(int64_t)t * B + b];
+            a2 += q2[(int64_t)t * B + b];
+            c0 += qs[(int64_t)(t + 16) * B + b];
+            c2 += q2[(int64_t)(t + 16) * B + b];
+        }
+        if (t < T) {
+            a0 += qs[(int64_t)t * B + b];
+            a2 += q2[(int64_t)t * B + b];
+        }
+    }
+    r0[sl][bl] = a0 + c0;
+    r2[sl][bl] = a2 + c2;
+    __syncthreads();
+    if (sl == 0 && b < B) {
+        float s0 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            s0 += r0[k][bl];
+            s2 += r2[k][bl];
+        }
+        bfi[b] = 100.0f * (s2 / (s0 + nz));
+    }
+}
+
+extern "C" int hbvx_bfi(int32_t T, int32_t B, const float *qs, const float *q2, float nearzero,
+                        float *bfi, void *stream)
+{
+    if (!qs || !q2 || !bfi || T <= 0 || B <= 0) return fail(HBVX_E_NULL, "hbvx_bfi: bad arguments");
+    hipLaunchKernelGGL(k_bfi, dim3((B + 63) / 64), dim3(1024), 0, (hipStream_t)stream, T, B, qs, q2,
+                       nearzero, bfi);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "hbvx_bfi launch");
+    return HBVX_OK;
+}

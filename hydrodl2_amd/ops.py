@@ -359,3 +359,31 @@ class HbvAdjPath(torch.autograd.Function):
         desc = _fill_desc(cfg, x, state_in, None, None, None, ptensors)
         _call(lib, 'hbvx_adj_backward', lib.adj_backward, desc, io, stream)
         return (None, None, gs_in, *gp)
+
+
+class Bfi(torch.autograd.Function):
+    """BFI = 100 * sum_t q2 / (sum_t qs + nearzero)  (hbv.py:562-567), qs/q2 [T,B] views.
+
+    Forward in the library (one deterministic pass); the gradient, which a streamflow loss never
+    asks for, is two broadcasts in torch."""
+
+    @staticmethod
+    def forward(ctx, qs, q2, nearzero: float):
+        lib = get_library()
+        qs_c, q2_c = qs.contiguous(), q2.contiguous()
+        T, B = qs_c.shape
+        out = torch.empty((B,), dtype=torch.float32, device=qs.device)
+        _call(lib, 'hbvx_bfi', lib.bfi, T, B, _ptr(qs_c), _ptr(q2_c), float(nearzero), _ptr(out),
+              _stream_of(lib, qs_c))
+        ctx.save_for_backward(qs_c, q2_c)
+        ctx.nearzero = float(nearzero)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        qs, q2 = ctx.saved_tensors
+        den = qs.sum(0) + ctx.nearzero
+        num = q2.sum(0)
+        g_q2 = (100.0 * g / den).unsqueeze(0).expand_as(q2)
+        g_qs = (-100.0 * g * num / (den * den)).unsqueeze(0).expand_as(qs)
+        return g_qs, g_q2, None

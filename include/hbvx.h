@@ -186,6 +186,11 @@ uint64_t hbvx_backward_workspace_bytes(const hbvx_desc *d);
 /* q [S,T,B] -> uh [B,L] (normalised gamma UH) and q_rout [S,T,B]. */
 int hbvx_route_forward(const hbvx_route_desc *r, const float *q, float *uh, float *q_rout,
                        void *stream);
+/* Baseflow index (hbv.py:562-567): bfi[b] = 100 * sum_t q2[t,b] / (sum_t qs[t,b] + nearzero), with
+ * qs, q2 [T,B] (routed streamflow and routed groundwater flow); fixed-order sums (deterministic). */
+int hbvx_bfi(int32_t T, int32_t B, const float *qs, const float *q2, float nearzero, float *bfi,
+             void *stream);
+
 /* Scratch bytes hbvx_route_backward needs (per-time-chunk partial tap gradients). */
 uint64_t hbvx_route_workspace_bytes(const hbvx_route_desc *r);
 /* grad_q_rout [S,T,B] -> grad_q [S,T,B] (overwritten) and the gradient w.r.t. the

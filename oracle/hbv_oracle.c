@@ -797,3 +797,19 @@ uint64_t hbvx_backward_workspace_bytes(const hbvx_desc *d)
     (void)d;
     return 0; /* the oracle sweeps serially */
 }
+
+/* hbv.py:562-567 */
+int hbvx_bfi(int32_t T, int32_t B, const float *qs, const float *q2, float nearzero, float *bfi,
+             void *stream)
+{
+    (void)stream;
+    for (int b = 0; b < B; b++) {
+        float s0 = 0.0f, s2 = 0.0f;
+        for (int t = 0; t < T; t++) {
+            s0 += qs[(int64_t)t * B + b];
+            s2 += q2[(int64_t)t * B + b];
+        }
+        bfi[b] = 100.0f * (s2 / (s0 + nearzero));
+    }
+    return HBVX_OK;
+}

@@ -322,6 +322,14 @@ extern "C" int hbvx_adj_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void
     return 0;
 }
 
+extern "C" int hbvx_bfi(int32_t T, int32_t B, const float *qs, const float *q2, float nz, float *bfi, void *st)
+{
+    typedef int (*fn_t)(int32_t, int32_t, const float *, const float *, float, float *, void *);
+    fn_t fn = (fn_t)oracle_sym("hbvx_bfi");
+    if (!fn) { snprintf(g_err, sizeof g_err, "set HBVX_ORACLE_LIB for bfi"); return HBVX_E_UNSUPPORTED; }
+    return fn(T, B, qs, q2, nz, bfi, st);
+}
+
 // accuracy probe for hbvx::pow_pos_ (host build of the same source)
 extern "C" void hbvx_test_pow(const float *x, const float *y, float *out, int n)
 {

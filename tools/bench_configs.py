@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Secondary measurements (not the headline): BASELINE configs 3 and 5-per-GPU-share, kernel
+"""Secondary measurements (not the headline): BASELINE configs 3, 4 and 5-per-GPU-share, kernel
 times from per-launch HIP events and achieved algorithmic HBM bandwidth.
 
-    python tools/bench_configs.py [cfg2|cfg2dyn|cfg3|cfg5|dmg] ...
+    python tools/bench_configs.py [cfg2|cfg2dyn|cfg3|cfg4|cfg5|dmg] ...
 """
 import json
 import os
@@ -50,6 +50,11 @@ def run(name, steps=5, warmup=2):
         dyn = ["parBETA", "parK0", "parBETAET"]
         model = hydrodl2_amd.load_model("hbv_2", "Hbv_2")({"nmul": M, "dynamic_params": {"Hbv_2": dyn}}, dev)
         n_dyn, nf = 3, 12
+    elif name == "cfg4":
+        T, B, M = 7300, 671, 16
+        model = hydrodl2_amd.load_model("hbv_adj", "HbvAdj")(
+            {"nmul": M, "dynamic_params": {"HbvAdj": ["parBETAET"]}}, dev)
+        n_dyn, nf = 1, 1
     else:
         raise SystemExit(name)
     x, g = gen(T, B, dev)
@@ -64,14 +69,15 @@ def run(name, steps=5, warmup=2):
     else:
         p = torch.randn((T, B, model.learnable_param_count), generator=g, device=dev).requires_grad_(True)
         params, leaves = p, [p]
-    Tp = T - (model.warm_up if model.warm_up_states else 0)
+    Tp = T - (model.warm_up if getattr(model, "warm_up_states", True) else 0)
     w = torch.randn((Tp, B, 1), generator=g, device=dev)
 
     def step():
         for l in leaves:
             l.grad = None
         out = model(xd, params)
-        (out["streamflow"] * w).sum().backward()
+        key = "flow_sim" if name == "cfg4" else "streamflow"
+        (out[key] * w).sum().backward()
 
     for _ in range(warmup):
         step()
@@ -93,12 +99,13 @@ def run(name, steps=5, warmup=2):
     b_f = ls * (12 / M + 4 * n_dyn + 4 * nf / M + 28)
     b_b = ls * (12 / M + 8 * n_dyn + 28 + 4 * max(routed, 1) / M)
     res = {"config": name, "T": T, "B": B, "M": M, "n_dyn": n_dyn, "ms_per_step": round(dt * 1e3, 3),
-           "lane_steps_per_s": ls / dt, "kernel_ms": {k: round(v, 4) for k, v in kms.items()},
-           "fwd_GBps": round(b_f / (kms["hbvx_forward"] * 1e-3) / 1e9, 1),
-           "bwd_GBps": round(b_b / (kms["hbvx_backward"] * 1e-3) / 1e9, 1)}
+           "lane_steps_per_s": ls / dt, "kernel_ms": {k: round(v, 4) for k, v in kms.items()}}
+    if "hbvx_forward" in kms:
+        res["fwd_GBps"] = round(b_f / (kms["hbvx_forward"] * 1e-3) / 1e9, 1)
+        res["bwd_GBps"] = round(b_b / (kms["hbvx_backward"] * 1e-3) / 1e9, 1)
     print(json.dumps(res))
 
 
 if __name__ == "__main__":
-    for n in (sys.argv[1:] or ["cfg2", "cfg2dyn", "cfg3", "cfg5", "dmg"]):
+    for n in (sys.argv[1:] or ["cfg2", "cfg2dyn", "cfg3", "cfg4", "cfg5", "dmg"]):
         run(n)
