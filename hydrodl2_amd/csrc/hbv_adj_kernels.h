@@ -196,3 +196,140 @@ __global__ void __launch_bounds__(64) k_adj_bwd(const AdjBwdArgs A)
 }
 
 } // namespace hbvx
+
+// ---------------------------------------------------------------------------
+// time-parallel adjoint of the implicit scheme (same structure as hbv_chunked.h):
+//   a_t = lam/dt with (dG/dx)^T lam = a_{t+1} + gQ dQ/dx   -- linear in a.
+// B1 only needs the transpose solves (5 unit vectors + the offset driven by gQ); B3 is the full
+// adj_backstep seeded with the true incoming adjoint; B2 / B4 are shared with hbv_chunked.h.
+// ---------------------------------------------------------------------------
+namespace hbvx {
+
+struct ChunkArgs; // hbv_chunked.h
+
+template <bool BETAET>
+__global__ void __launch_bounds__(64) k_adj_chunk_phi(const hbvx_desc d, const hbvx_bwd_io io, int lgMp,
+                                                      int C, float *phi_ws)
+{
+    constexpr int NP = BETAET ? 13 : 12;
+    const AdjLane L = adj_lane(d, lgMp);
+    const int chunk = blockIdx.y;
+    const int T = d.T, t0 = chunk * C, t1 = min(T, t0 + C);
+    const int64_t N = (int64_t)d.B * d.M;
+    const bool raw = d.raw_sigmoid != 0;
+    const float invM = 1.0f / (float)d.M;
+    float usta[NP];
+    bool use_dyn[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        const hbvx_param_src &s = d.p[i];
+        float v = s.sta[(int64_t)L.b * s.sta_b_stride + L.j];
+        usta[i] = raw ? sigmoid_(v) : v;
+        use_dyn[i] = s.dyn && !(s.drop && s.drop[L.n]);
+    }
+    float Phi[5][5], phi[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        phi[k] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 5; i++) Phi[k][i] = (i == k) ? 1.0f : 0.0f;
+    }
+    const float *xb = d.x + (int64_t)L.b * d.x_b_stride;
+    for (int t = t1 - 1; t >= t0; t--) {
+        float u[NP], p[NPARAM_MAX], x[5];
+        adj_params<NP>(d, L, t, raw, usta, use_dyn, u, p);
+        AdjStep<BETAET> s;
+        const float *xr = xb + (int64_t)t * d.x_t_stride;
+        s.P = xr[d.ch_prcp]; s.Tf = xr[d.ch_tmean]; s.PET = xr[d.ch_pet];
+#pragma unroll
+        for (int k = 0; k < 5; k++) x[k] = io.traj[((int64_t)k * (T + 1) + (t + 1)) * N + L.n];
+        const int64_t gi = (int64_t)t * d.B + L.b;
+        float gQ = io.grad_flux ? io.grad_flux[gi] : 0.0f;
+        if (io.grad_flux4) gQ += io.grad_flux4[gi];
+        gQ *= invM;
+        s.template eval<true>(x, p);
+        float lam[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            s.solve_t(1.0f, Phi[k], lam);
+#pragma unroll
+            for (int i = 0; i < 5; i++) Phi[k][i] = lam[i];
+        }
+        float rhs[5] = {phi[0], phi[1], phi[2], phi[3] + gQ * (p[P_K0] * s.mq0 + p[P_K1]) * s.c3,
+                        phi[4] + gQ * p[P_K2] * s.c4};
+        s.solve_t(1.0f, rhs, lam);
+#pragma unroll
+        for (int i = 0; i < 5; i++) phi[i] = lam[i];
+    }
+    if (L.active) {
+        float *dst = phi_ws + ((int64_t)chunk * 30) * N + L.n;
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+#pragma unroll
+            for (int i = 0; i < 5; i++) dst[(int64_t)(k * 5 + i) * N] = Phi[k][i];
+#pragma unroll
+        for (int i = 0; i < 5; i++) dst[(int64_t)(25 + i) * N] = phi[i];
+    }
+}
+
+template <bool BETAET>
+__global__ void __launch_bounds__(64) k_adj_chunk_sweep(const hbvx_desc d, const hbvx_bwd_io io, int lgMp,
+                                                        int C, const float *abnd, float *gpart)
+{
+    constexpr int NP = BETAET ? 13 : 12;
+    const AdjLane L = adj_lane(d, lgMp);
+    const int chunk = blockIdx.y;
+    const int T = d.T, t0 = chunk * C, t1 = min(T, t0 + C);
+    const int64_t N = (int64_t)d.B * d.M;
+    const bool raw = d.raw_sigmoid != 0;
+    const float invM = 1.0f / (float)d.M;
+    float usta[NP], gsta[NP];
+    bool use_dyn[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        const hbvx_param_src &s = d.p[i];
+        float v = s.sta[(int64_t)L.b * s.sta_b_stride + L.j];
+        usta[i] = raw ? sigmoid_(v) : v;
+        use_dyn[i] = s.dyn && !(s.drop && s.drop[L.n]);
+        gsta[i] = 0.0f;
+    }
+    float a[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) a[k] = abnd[((int64_t)chunk * 5 + k) * N + L.n];
+    const float *xb = d.x + (int64_t)L.b * d.x_b_stride;
+    for (int t = t1 - 1; t >= t0; t--) {
+        float u[NP], p[NPARAM_MAX], x[5], gp[NPARAM_MAX];
+        adj_params<NP>(d, L, t, raw, usta, use_dyn, u, p);
+        AdjStep<BETAET> s;
+        const float *xr = xb + (int64_t)t * d.x_t_stride;
+        s.P = xr[d.ch_prcp]; s.Tf = xr[d.ch_tmean]; s.PET = xr[d.ch_pet];
+#pragma unroll
+        for (int k = 0; k < 5; k++) x[k] = io.traj[((int64_t)k * (T + 1) + (t + 1)) * N + L.n];
+        const int64_t gi = (int64_t)t * d.B + L.b;
+        float gQ = io.grad_flux ? io.grad_flux[gi] : 0.0f;
+        if (io.grad_flux4) gQ += io.grad_flux4[gi];
+        gQ *= invM;
+#pragma unroll
+        for (int i = 0; i < NPARAM_MAX; i++) gp[i] = 0.0f;
+        adj_backstep<BETAET>(s, p, x, 1.0f, gQ, a, gp);
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            const float gu = gp[i] * (d.p[i].hi - d.p[i].lo);
+            if (d.p[i].dyn) {
+                const float gr = raw ? gu * (u[i] * (1.0f - u[i])) : gu;
+                if (io.g[i].dyn && L.active)
+                    io.g[i].dyn[(int64_t)t * io.g[i].dyn_t_stride + (int64_t)L.b * io.g[i].dyn_b_stride + L.j] =
+                        use_dyn[i] ? gr : 0.0f;
+                gsta[i] += use_dyn[i] ? 0.0f : gu;
+            } else {
+                gsta[i] += gu;
+            }
+        }
+    }
+    if (L.active) {
+#pragma unroll
+        for (int i = 0; i < NP; i++) gpart[((int64_t)chunk * NP + i) * N + L.n] = gsta[i];
+    }
+}
+
+} // namespace hbvx

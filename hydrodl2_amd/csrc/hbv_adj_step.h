@@ -169,17 +169,23 @@ HBVX_HD int adj_newton(AdjStep<BETAET> &s, const float *p, const float *xt, floa
         res = fmax_(res, fabsf(g[k]));
     }
     float res0 = 100.0f * res;
+    // `e` always holds f and df/dx at the current iterate (one evaluation per iterate: the RHS costs
+    // two pows); `s` holds the Jacobian the modified Newton step uses, refreshed from `e` only when
+    // the residual ratio exceeds 0.2 (hbv_adj.py:546).  Same numbers as evaluating G and then, for a
+    // refresh, the Jacobian again at the same point.
+    AdjStep<BETAET> e = s;
     int it = 0;
     while (res > gtol && it <= max_iter) {
         it++;
-        if (res > 0.2f * res0) s.template eval<true>(x, p); // Jacobian refresh rule (:546)
+        if (res > 0.2f * res0) {
+            s.F00 = e.F00; s.F01 = e.F01; s.F10 = e.F10; s.F11 = e.F11; s.F20 = e.F20; s.F21 = e.F21;
+            s.F22 = e.F22; s.F30 = e.F30; s.F31 = e.F31; s.F32 = e.F32; s.F33 = e.F33; s.F43 = e.F43;
+            s.F44 = e.F44;
+        }
         s.solve(idt, g, dx);
 #pragma unroll
         for (int k = 0; k < 5; k++) x[k] = x[k] - dx[k];
-        // residual at the new iterate; keep the Jacobian of the last refresh (modified Newton)
-        AdjStep<BETAET> e;
-        e.P = s.P; e.Tf = s.Tf; e.PET = s.PET;
-        e.template eval<false>(x, p);
+        e.template eval<true>(x, p);
         res0 = res;
         res = 0.0f;
 #pragma unroll

@@ -28,7 +28,7 @@
 
 namespace hbvx {
 
-enum : int { MODEL_HBV10 = 0, MODEL_HBV11P = 1, MODEL_HBV20 = 2 };
+enum : int { MODEL_HBV10 = 0, MODEL_HBV11P = 1, MODEL_HBV20 = 2, MODEL_HBVADJ = 3 };
 enum : int {
     P_BETA = 0, P_FC, P_K0, P_K1, P_K2, P_LP, P_PERC, P_UZL, P_TT, P_CFMAX, P_CFR, P_CWH,
     P_BETAET, P_C, P_RT, P_AC, NPARAM_MAX

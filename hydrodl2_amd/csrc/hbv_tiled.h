@@ -24,6 +24,7 @@
 
 #include "../../include/hbvx.h"
 #include "hbv_step.h"
+#include "hbv_adj_step.h"
 
 namespace hbvx {
 
@@ -49,7 +50,7 @@ __device__ __forceinline__ void lds_barrier()
 
 template <int MODEL, bool BETAET>
 struct NParamT {
-    static constexpr int value = MODEL == MODEL_HBV10 ? (BETAET ? 13 : 12)
+    static constexpr int value = (MODEL == MODEL_HBV10 || MODEL == MODEL_HBVADJ) ? (BETAET ? 13 : 12)
                                : MODEL == MODEL_HBV11P ? 14 : 16;
 };
 
@@ -174,7 +175,8 @@ template <int MODEL, bool BETAET, bool DYN>
 __global__ void __launch_bounds__(512) k_fwd_tiled(const FwdTArgs A)
 {
     constexpr int NP = NParamT<MODEL, BETAET>::value;
-    constexpr int NF = (MODEL == MODEL_HBV10) ? 11 : 12;
+    constexpr bool IMPLICIT = (MODEL == MODEL_HBVADJ); // hbv_adj.py: Newton solve per day, flux = Q only
+    constexpr int NF = IMPLICIT ? 1 : ((MODEL == MODEL_HBV10) ? 11 : 12);
     extern __shared__ __align__(16) float lds[];
     const hbvx_desc &d = A.d;
     const hbvx_fwd_out &o = A.o;
@@ -217,7 +219,8 @@ __global__ void __launch_bounds__(512) k_fwd_tiled(const FwdTArgs A)
         for (int i = 0; i < NPARAM_MAX; i++) p[i] = i < NP ? psta[i < NP ? i : 0] : 0.0f;
         float st[5];
 #pragma unroll
-        for (int k = 0; k < 5; k++) st[k] = d.state_in ? d.state_in[k * N + L.n] : 0.001f;
+        for (int k = 0; k < 5; k++)
+            st[k] = d.state_in ? d.state_in[k * N + L.n] : (IMPLICIT ? 0.0f : 0.001f); // hbv_adj.py:254
 
         lds_barrier(); // tile 0 staged
         for (int kt = 0; kt < nT; kt++) {
@@ -235,8 +238,7 @@ __global__ void __launch_bounds__(512) k_fwd_tiled(const FwdTArgs A)
                 nd[i] = ((dmask >> i) & 1) ? pin[dyn_index(dmask, i) * 64 + lane] : 0.0f;
             if (has_mu) nmu = pin[G.ND * 64 + lane];
             for (int tt = 0; tt < nt; tt++) {
-                Step<MODEL, BETAET> s;
-                s.P = nf.x; s.Tf = nf.y; s.PET = nf.z;
+                const float fP = nf.x, fT = nf.y, fE = nf.z;
                 const float wq = nmu;
 #pragma unroll
                 for (int i = 0; i < NP; i++)
@@ -249,29 +251,52 @@ __global__ void __launch_bounds__(512) k_fwd_tiled(const FwdTArgs A)
                         if ((dmask >> i) & 1) nd[i] = pr[dyn_index(dmask, i) * 64];
                     if (has_mu) nmu = pr[G.ND * 64];
                 }
-                s.SP = st[0]; s.MW = st[1]; s.SM = st[2]; s.SUZ = st[3]; s.SLZ = st[4];
-                s.template fwd<false>(p, nz, ac, elev, 0.f, 0.f);
-                if (has_traj) {
-                    float *to = out + G.off_tout + tt * 7 * 64 + lane;
+                if constexpr (IMPLICIT) {
+                    AdjStep<BETAET> s;
+                    s.P = fP; s.Tf = fT; s.PET = fE;
+                    if (has_traj) {
+                        float *to = out + G.off_tout + tt * 7 * 64 + lane;
 #pragma unroll
-                    for (int k = 0; k < 5; k++) to[k * 64] = st[k];
-                    if (has_aux) { to[5 * 64] = s.sw0; to[6 * 64] = s.ef0; }
-                }
-                st[0] = s.SP3; st[1] = s.MW3; st[2] = s.SM4; st[3] = s.SUZ4; st[4] = s.SLZ2;
-                if (has_flux) {
-                    float *fo = out + tt * NF * 64 + lane;
-                    fo[HBVX_F_QSIM * 64] = has_mu ? s.Q * wq : s.Q;
-                    fo[HBVX_F_Q0 * 64] = s.Q0;
-                    fo[HBVX_F_Q1 * 64] = s.Q1;
-                    fo[HBVX_F_Q2 * 64] = s.Q2;
-                    fo[HBVX_F_AET * 64] = s.ET;
-                    fo[HBVX_F_SWE * 64] = s.SP3;
-                    fo[HBVX_F_RECHARGE * 64] = s.rech;
-                    fo[HBVX_F_EXCS * 64] = s.exc;
-                    fo[HBVX_F_EVAPFACTOR * 64] = s.ef;
-                    fo[HBVX_F_TOSOIL * 64] = s.tosoil;
-                    fo[HBVX_F_PERC * 64] = s.PERC;
-                    if (NF > HBVX_F_CAPILLARY) fo[HBVX_F_CAPILLARY * 64] = s.cap;
+                        for (int k = 0; k < 5; k++) to[k * 64] = st[k];
+                    }
+                    float xn[5];
+                    adj_newton<BETAET>(s, p, st, 1.0f, d.adj_gtol, d.adj_max_iter, xn);
+#pragma unroll
+                    for (int k = 0; k < 5; k++) st[k] = xn[k];
+                    if (has_flux) { // hbv_adj.py:309-313,431: Q at the solved storages
+                        const float SUZ = fmaxf(st[3], 0.0f), SLZ = fmaxf(st[4], 0.0f);
+                        const float q0 = p[P_K0] * fmaxf(SUZ - p[P_UZL], 0.0f);
+                        out[tt * NF * 64 + lane] = (q0 + p[P_K1] * SUZ) + p[P_K2] * SLZ;
+                    }
+                } else {
+                    Step<MODEL, BETAET> s;
+                    s.P = fP; s.Tf = fT; s.PET = fE;
+                    s.SP = st[0]; s.MW = st[1]; s.SM = st[2]; s.SUZ = st[3]; s.SLZ = st[4];
+                    s.template fwd<false>(p, nz, ac, elev, 0.f, 0.f);
+                    if (has_traj) {
+                        float *to = out + G.off_tout + tt * 7 * 64 + lane;
+#pragma unroll
+                        for (int k = 0; k < 5; k++) to[k * 64] = st[k];
+                        if (has_aux) { to[5 * 64] = s.sw0; to[6 * 64] = s.ef0; }
+                    }
+                    st[0] = s.SP3; st[1] = s.MW3; st[2] = s.SM4; st[3] = s.SUZ4; st[4] = s.SLZ2;
+                    if (has_flux) {
+                        float *fo = out + tt * NF * 64 + lane;
+                        fo[HBVX_F_QSIM * 64] = has_mu ? s.Q * wq : s.Q;
+                        if constexpr (NF > 1) {
+                            fo[HBVX_F_Q0 * 64] = s.Q0;
+                            fo[HBVX_F_Q1 * 64] = s.Q1;
+                            fo[HBVX_F_Q2 * 64] = s.Q2;
+                            fo[HBVX_F_AET * 64] = s.ET;
+                            fo[HBVX_F_SWE * 64] = s.SP3;
+                            fo[HBVX_F_RECHARGE * 64] = s.rech;
+                            fo[HBVX_F_EXCS * 64] = s.exc;
+                            fo[HBVX_F_EVAPFACTOR * 64] = s.ef;
+                            fo[HBVX_F_TOSOIL * 64] = s.tosoil;
+                            fo[HBVX_F_PERC * 64] = s.PERC;
+                            if (NF > HBVX_F_CAPILLARY) fo[HBVX_F_CAPILLARY * 64] = s.cap;
+                        }
+                    }
                 }
             }
             lds_barrier();
@@ -298,7 +323,7 @@ __global__ void __launch_bounds__(512) k_fwd_tiled(const FwdTArgs A)
         for (int i = 0; i < NP; i++) {
             const hbvx_param_src &s = d.p[i];
             dynp[i] = s.dyn ? s.dyn + (int64_t)L.b * s.dyn_b_stride + L.j : s.sta;
-            use_dyn[i] = s.dyn && !(s.drop && s.drop[L.b]);
+            use_dyn[i] = s.dyn && !(s.drop && s.drop[IMPLICIT ? L.n : (int64_t)L.b]); // hbv_adj.py:182-189
         }
 
         auto fill = [&](int kt) {

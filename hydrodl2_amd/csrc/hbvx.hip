@@ -635,7 +635,7 @@ static bool geom_fwd(const hbvx_desc *d, const hbvx_fwd_out *o, TileGeom &g)
     g.lgMp = lg_members(d->M);
     g.ND = count_dyn(d);
     g.NDm = g.ND + (d->muwts ? 1 : 0);
-    const int NF = (d->model == HBVX_MODEL_HBV10) ? 11 : 12;
+    const int NF = (d->model == HBVX_MODEL_HBV10) ? 11 : (d->model == HBVX_MODEL_HBVADJ ? 1 : 12);
     const int ktmax = env_int("HBVX_KT", 16);
     for (int Kt = 16; Kt >= 1; Kt >>= 1) {
         if (Kt > ktmax) continue;
@@ -767,7 +767,6 @@ static bool chunked_applicable(const hbvx_desc *d)
 {
     const char *v = getenv("HBVX_BWD");
     if (v && !strcmp(v, "tiled")) return false;
-    if (d->model == HBVX_MODEL_HBVADJ) return false;
     return d->T >= 2 * chunk_days();
 }
 
@@ -981,6 +980,28 @@ extern "C" int hbvx_adj_forward(const hbvx_desc *d, const hbvx_fwd_out *out, voi
     if (rc) return rc;
     if (!out || !out->state_out) return fail(HBVX_E_NULL, "state_out is NULL");
     if (out->flux && out->n_flux != 1) return fail(HBVX_E_SHAPE, "hbvx_adj_forward writes n_flux = 1");
+    {
+        FwdTArgs ta;
+        if (use_tiled(d) && geom_fwd(d, out, ta.g)) {
+            ta.d = *d;
+            ta.o = *out;
+            const int bpw_t = 64 >> ta.g.lgMp;
+            dim3 grid_t((d->B + bpw_t - 1) / bpw_t);
+            const size_t lds = (size_t)2 * (ta.g.in_sz + ta.g.out_sz) * 4;
+            const bool dyn = ta.g.NDm > 0, be = d->n_param == 13;
+            int nh = env_int("HBVX_NH", 7);
+            nh = nh < 1 ? 1 : (nh > 7 ? 7 : nh);
+            const int threads = 64 * (1 + nh);
+            hipStream_t st = (hipStream_t)stream;
+            hipError_t e =
+                be ? (dyn ? launch_tiled_one(k_fwd_tiled<MODEL_HBVADJ, true, true>, ta, grid_t, threads, lds, st)
+                          : launch_tiled_one(k_fwd_tiled<MODEL_HBVADJ, true, false>, ta, grid_t, threads, lds, st))
+                   : (dyn ? launch_tiled_one(k_fwd_tiled<MODEL_HBVADJ, false, true>, ta, grid_t, threads, lds, st)
+                          : launch_tiled_one(k_fwd_tiled<MODEL_HBVADJ, false, false>, ta, grid_t, threads, lds, st));
+            if (e != hipSuccess) return hip_fail(e, "hbvx_adj_forward (tiled) launch");
+            return HBVX_OK;
+        }
+    }
     AdjFwdArgs a;
     a.d = *d;
     a.o = *out;
@@ -1001,6 +1022,32 @@ extern "C" int hbvx_adj_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void
     if (!io || !io->traj) return fail(HBVX_E_NULL, "traj is NULL");
     if (io->n_flux != 1) return fail(HBVX_E_SHAPE, "hbvx_adj_backward expects n_flux = 1");
     if (d->T == 0) return HBVX_OK;
+    if (io->workspace && chunked_applicable(d) && io->workspace_bytes >= hbvx_backward_workspace_bytes(d)) {
+        // time-parallel adjoint (hbv_adj_kernels.h + the scan / reduce kernels of hbv_chunked.h)
+        ChunkArgs ca;
+        ca.d = *d;
+        ca.io = *io;
+        ca.lgMp = lg_members(d->M);
+        ca.C = chunk_days();
+        ca.nchunk = (d->T + ca.C - 1) / ca.C;
+        const int64_t N = (int64_t)d->B * d->M;
+        ca.phi = (float *)io->workspace;
+        ca.abnd = ca.phi + (int64_t)ca.nchunk * 30 * N;
+        ca.gpart = ca.abnd + (int64_t)ca.nchunk * 5 * N;
+        hipStream_t st = (hipStream_t)stream;
+        const int bpw_c = 64 >> ca.lgMp;
+        dim3 g2((d->B + bpw_c - 1) / bpw_c, ca.nchunk);
+        if (d->n_param == 13) hipLaunchKernelGGL(k_adj_chunk_phi<true>, g2, dim3(64), 0, st, *d, *io, ca.lgMp, ca.C, ca.phi);
+        else hipLaunchKernelGGL(k_adj_chunk_phi<false>, g2, dim3(64), 0, st, *d, *io, ca.lgMp, ca.C, ca.phi);
+        hipLaunchKernelGGL(k_bwd_chunk_scan, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, st, ca);
+        if (d->n_param == 13) hipLaunchKernelGGL(k_adj_chunk_sweep<true>, g2, dim3(64), 0, st, *d, *io, ca.lgMp, ca.C, ca.abnd, ca.gpart);
+        else hipLaunchKernelGGL(k_adj_chunk_sweep<false>, g2, dim3(64), 0, st, *d, *io, ca.lgMp, ca.C, ca.abnd, ca.gpart);
+        hipLaunchKernelGGL(k_bwd_chunk_reduce, dim3((unsigned)((N + 255) / 256), d->n_param), dim3(256), 0, st,
+                           ca, d->n_param);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "hbvx_adj_backward (chunked) launch");
+        return HBVX_OK;
+    }
     AdjBwdArgs a;
     a.d = *d;
     a.io = *io;

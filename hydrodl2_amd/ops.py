@@ -357,6 +357,10 @@ class HbvAdjPath(torch.autograd.Function):
                 g.dyn = _ptr(gp[ps.dyn_tensor_idx], ps.dyn_off)
                 g.dyn_t_stride, g.dyn_b_stride = ps.dyn_ts, ps.dyn_bs
         desc = _fill_desc(cfg, x, state_in, None, None, None, ptensors)
+        ws_bytes = lib.backward_workspace_bytes(desc)
+        if ws_bytes:
+            ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
+            io.workspace, io.workspace_bytes = _ptr(ws), ws_bytes
         _call(lib, 'hbvx_adj_backward', lib.adj_backward, desc, io, stream)
         return (None, None, gs_in, *gp)
 

@@ -48,6 +48,8 @@ def test_hip_matches_oracle(kw, hip_backend, oracle_path):
     {"HBVX_KT": "2", "HBVX_NH": "1"},
     {"HBVX_KT": "4", "HBVX_NH": "3"},
     {"HBVX_KT": "1", "HBVX_NH": "7"},
+    {"HBVX_CHUNK": "16"},                      # time-parallel adjoint with ragged chunks
+    {"HBVX_BWD": "tiled"},                     # serial tiled adjoint
 ], ids=lambda e: "-".join(f"{k[5:]}{v}" for k, v in e.items()))
 @pytest.mark.parametrize("kw", [ORACLE_CASES[1], ORACLE_CASES[3], ORACLE_CASES[6]],
                          ids=lambda k: f"{k['model']}-M{k['M']}")

@@ -173,3 +173,22 @@ def test_hip_reference_policy_and_size(hip_backend):
     p2 = p.detach()[:, sel].contiguous().requires_grad_(True)
     out2 = m({"x_phy": x[:, sel].contiguous()}, p2)["flow_sim"]
     assert torch.equal(out[:, sel], out2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"M{c['M']}-T{c['T']}")
+def test_hip_time_parallel_adjoint_matches_oracle(case, hip_backend, monkeypatch):
+    """Chunks of 8 days so that these short cases take the time-parallel adjoint (ragged last chunk)."""
+    monkeypatch.setenv("HBVX_CHUNK", "8")
+    got, ggot, want, gwant, _ = _run_case("cuda:0", case, tight=True)
+    _close("flow_sim", got, want, 2e-4, 2e-5)
+    _close("grad", ggot, gwant, 2e-3, 2e-4)
+
+
+@pytest.mark.gpu
+def test_hip_one_wave_kernels_still_match(hip_backend, monkeypatch):
+    """HBVX_KERNEL=simple: the first-cut one-wave forward (kept as a cross-check)."""
+    monkeypatch.setenv("HBVX_KERNEL", "simple")
+    got, ggot, want, gwant, _ = _run_case("cuda:0", CASES[1], tight=True)
+    _close("flow_sim", got, want, 2e-4, 2e-5)
+    _close("grad", ggot, gwant, 2e-3, 2e-4)
