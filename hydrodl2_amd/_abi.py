@@ -9,21 +9,22 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 3
-MAX_PARAM = 16
+ABI_VERSION = 4
+MAX_PARAM = 20
 NSTATE = 5
 MAX_FLUX = 12
 UH_MAXLEN = 15
 
 # enum hbvx_model
-MODEL_HBV10, MODEL_HBV11P, MODEL_HBV20, MODEL_HBVADJ = 0, 1, 2, 3
+MODEL_HBV10, MODEL_HBV11P, MODEL_HBV20, MODEL_HBVADJ, MODEL_HOURLY = 0, 1, 2, 3, 4
 
 # enum hbvx_flux
 (F_QSIM, F_Q0, F_Q1, F_Q2, F_AET, F_SWE, F_RECHARGE, F_EXCS, F_EVAPFACTOR, F_TOSOIL, F_PERC,
  F_CAPILLARY) = range(12)
 
 PARAM_SLOTS = ["parBETA", "parFC", "parK0", "parK1", "parK2", "parLP", "parPERC", "parUZL",
-               "parTT", "parCFMAX", "parCFR", "parCWH", "parBETAET", "parC", "parRT", "parAC"]
+               "parTT", "parCFMAX", "parCFR", "parCWH", "parBETAET", "parC", "parRT", "parAC",
+               "parF0", "parFMIN", "parALPHA"]
 
 _fp = C.c_void_p  # every float*/uint8_t* travels as an address
 

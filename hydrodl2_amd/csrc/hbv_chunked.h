@@ -66,7 +66,7 @@ __device__ __forceinline__ ChunkLane chunk_lane(const hbvx_desc &d, int lgMp)
 template <int MODEL, bool BETAET>
 struct ChunkNP {
     static constexpr int value = MODEL == MODEL_HBV10 ? (BETAET ? 13 : 12)
-                               : MODEL == MODEL_HBV11P ? 14 : 16;
+                               : MODEL == MODEL_HBV11P ? 14 : (MODEL == MODEL_HOURLY ? 19 : 16);
 };
 
 // Raw per-day loads (issued one day ahead), then the recompute that turns them into a Step.
@@ -191,8 +191,8 @@ __global__ void __launch_bounds__(64) k_bwd_chunk_phi(const ChunkArgs A)
     const int64_t N = (int64_t)d.B * d.M;
     const bool raw = d.raw_sigmoid != 0;
     const float nz = d.nearzero, invM = 1.0f / (float)d.M;
-    const float ac = (MODEL == MODEL_HBV20) ? d.ac[L.b] : 0.0f;
-    const float elev = (MODEL == MODEL_HBV20) ? d.elev[L.b] : 0.0f;
+    const float ac = (MODEL == MODEL_HBV20 || MODEL == MODEL_HOURLY) ? d.ac[L.b] : 0.0f;
+    const float elev = (MODEL == MODEL_HBV20 || MODEL == MODEL_HOURLY) ? d.elev[L.b] : 0.0f;
     float usta[NP], psta[NP];
     bool use_dyn[NP];
     chunk_static<NP, DYN>(d, L, raw, usta, psta, use_dyn);
@@ -296,8 +296,8 @@ __global__ void __launch_bounds__(64) k_bwd_chunk_sweep(const ChunkArgs A)
     const int64_t N = (int64_t)d.B * d.M;
     const bool raw = d.raw_sigmoid != 0;
     const float nz = d.nearzero, invM = 1.0f / (float)d.M;
-    const float ac = (MODEL == MODEL_HBV20) ? d.ac[L.b] : 0.0f;
-    const float elev = (MODEL == MODEL_HBV20) ? d.elev[L.b] : 0.0f;
+    const float ac = (MODEL == MODEL_HBV20 || MODEL == MODEL_HOURLY) ? d.ac[L.b] : 0.0f;
+    const float elev = (MODEL == MODEL_HBV20 || MODEL == MODEL_HOURLY) ? d.elev[L.b] : 0.0f;
     float usta[NP], psta[NP], gsta[NP];
     bool use_dyn[NP];
     chunk_static<NP, DYN>(d, L, raw, usta, psta, use_dyn);

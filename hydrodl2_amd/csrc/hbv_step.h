@@ -28,10 +28,10 @@
 
 namespace hbvx {
 
-enum : int { MODEL_HBV10 = 0, MODEL_HBV11P = 1, MODEL_HBV20 = 2, MODEL_HBVADJ = 3 };
+enum : int { MODEL_HBV10 = 0, MODEL_HBV11P = 1, MODEL_HBV20 = 2, MODEL_HBVADJ = 3, MODEL_HOURLY = 4 };
 enum : int {
     P_BETA = 0, P_FC, P_K0, P_K1, P_K2, P_LP, P_PERC, P_UZL, P_TT, P_CFMAX, P_CFR, P_CWH,
-    P_BETAET, P_C, P_RT, P_AC, NPARAM_MAX
+    P_BETAET, P_C, P_RT, P_AC, P_F0, P_FMIN, P_ALPHA, NPARAM_MAX
 };
 
 HBVX_HD float fmax_(float a, float b) { return fmaxf(a, b); } // v_max_f32
@@ -470,3 +470,5 @@ struct Step {
 };
 
 } // namespace hbvx
+
+#include "hbv_step_hourly.h"

@@ -51,7 +51,7 @@ __device__ __forceinline__ void lds_barrier()
 template <int MODEL, bool BETAET>
 struct NParamT {
     static constexpr int value = (MODEL == MODEL_HBV10 || MODEL == MODEL_HBVADJ) ? (BETAET ? 13 : 12)
-                               : MODEL == MODEL_HBV11P ? 14 : 16;
+                               : MODEL == MODEL_HBV11P ? 14 : (MODEL == MODEL_HOURLY ? 19 : 16);
 };
 
 struct LaneT {
@@ -212,8 +212,8 @@ __global__ void __launch_bounds__(512) k_fwd_tiled(const FwdTArgs A)
         // ------------------------------ stepper ------------------------------
         __builtin_amdgcn_s_setprio(3);
         const float nz = d.nearzero;
-        const float ac = (MODEL == MODEL_HBV20) ? d.ac[L.b] : 0.0f;
-        const float elev = (MODEL == MODEL_HBV20) ? d.elev[L.b] : 0.0f;
+        const float ac = (MODEL == MODEL_HBV20 || MODEL == MODEL_HOURLY) ? d.ac[L.b] : 0.0f;
+        const float elev = (MODEL == MODEL_HBV20 || MODEL == MODEL_HOURLY) ? d.elev[L.b] : 0.0f;
         float p[NPARAM_MAX];
 #pragma unroll
         for (int i = 0; i < NPARAM_MAX; i++) p[i] = i < NP ? psta[i < NP ? i : 0] : 0.0f;
@@ -452,8 +452,8 @@ __global__ void __launch_bounds__(512) k_bwd_tiled(const BwdTArgs A)
         // ------------------------------ stepper ------------------------------
         __builtin_amdgcn_s_setprio(3);
         const float nz = d.nearzero;
-        const float ac = (MODEL == MODEL_HBV20) ? d.ac[L.b] : 0.0f;
-        const float elev = (MODEL == MODEL_HBV20) ? d.elev[L.b] : 0.0f;
+        const float ac = (MODEL == MODEL_HBV20 || MODEL == MODEL_HOURLY) ? d.ac[L.b] : 0.0f;
+        const float elev = (MODEL == MODEL_HBV20 || MODEL == MODEL_HOURLY) ? d.elev[L.b] : 0.0f;
         float p[NPARAM_MAX], gsta[NP];
 #pragma unroll
         for (int i = 0; i < NPARAM_MAX; i++) p[i] = i < NP ? psta[i < NP ? i : 0] : 0.0f;

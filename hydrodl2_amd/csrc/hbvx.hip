@@ -62,7 +62,7 @@ extern "C" uint64_t hbvx_sizeof(int which)
 template <int MODEL, bool BETAET>
 struct NParam {
     static constexpr int value = MODEL == MODEL_HBV10 ? (BETAET ? 13 : 12)
-                               : MODEL == MODEL_HBV11P ? 14 : 16;
+                               : MODEL == MODEL_HBV11P ? 14 : (MODEL == MODEL_HOURLY ? 19 : 16);
 };
 
 struct LaneId {
@@ -115,8 +115,8 @@ __global__ void __launch_bounds__(64) k_fwd(const FwdArgs A)
     const int64_t N = (int64_t)d.B * d.M;
     const bool raw = d.raw_sigmoid != 0;
     const float nz = d.nearzero;
-    const float ac = (MODEL == MODEL_HBV20) ? d.ac[L.b] : 0.0f;
-    const float elev = (MODEL == MODEL_HBV20) ? d.elev[L.b] : 0.0f;
+    const float ac = (MODEL == MODEL_HBV20 || MODEL == MODEL_HOURLY) ? d.ac[L.b] : 0.0f;
+    const float elev = (MODEL == MODEL_HBV20 || MODEL == MODEL_HOURLY) ? d.elev[L.b] : 0.0f;
 
     float p[NPARAM_MAX];
     const float *dynp[NP];
@@ -245,8 +245,8 @@ __global__ void __launch_bounds__(64) k_bwd(const BwdArgs A)
     const int64_t N = (int64_t)d.B * d.M;
     const bool raw = d.raw_sigmoid != 0;
     const float nz = d.nearzero;
-    const float ac = (MODEL == MODEL_HBV20) ? d.ac[L.b] : 0.0f;
-    const float elev = (MODEL == MODEL_HBV20) ? d.elev[L.b] : 0.0f;
+    const float ac = (MODEL == MODEL_HBV20 || MODEL == MODEL_HOURLY) ? d.ac[L.b] : 0.0f;
+    const float elev = (MODEL == MODEL_HBV20 || MODEL == MODEL_HOURLY) ? d.elev[L.b] : 0.0f;
     const int nf = io.n_flux;
 
     float p[NPARAM_MAX], usta[NP], gsta[NP];
@@ -572,12 +572,13 @@ static int check_desc(const hbvx_desc *d)
     else if (d->model == HBVX_MODEL_HBV11P) ok = (d->n_param == 14);
     else if (d->model == HBVX_MODEL_HBV20) ok = (d->n_param == 16);
     else if (d->model == HBVX_MODEL_HBVADJ) ok = (d->n_param == 12 || d->n_param == 13);
+    else if (d->model == HBVX_MODEL_HOURLY) ok = (d->n_param == 19);
     else return fail(HBVX_E_UNSUPPORTED, "unknown model");
     if (!ok) return fail(HBVX_E_SHAPE, "n_param does not match model");
     if (!d->x) return fail(HBVX_E_NULL, "forcing pointer is NULL");
     if (d->ch_prcp < 0 || d->ch_tmean < 0 || d->ch_pet < 0)
         return fail(HBVX_E_SHAPE, "negative forcing channel");
-    if (d->model == HBVX_MODEL_HBV20 && (!d->ac || !d->elev))
+    if ((d->model == HBVX_MODEL_HBV20 || d->model == HBVX_MODEL_HOURLY) && (!d->ac || !d->elev))
         return fail(HBVX_E_NULL, "HBV 2.0 needs ac and elev");
     for (int i = 0; i < d->n_param; i++)
         if (!d->p[i].sta) return fail(HBVX_E_NULL, "static parameter pointer is NULL");
@@ -591,10 +592,14 @@ static int lg_members(int M)
     return lg;
 }
 
-template <typename Args, typename K0, typename K1, typename K2, typename K3>
+template <typename Args, typename K0, typename K1, typename K2, typename K3, typename K4>
 static hipError_t launch_variant(const hbvx_desc *d, const Args &a, dim3 grid, hipStream_t st,
-                                 K0 k0, K1 k1, K2 k2, K3 k3)
+                                 K0 k0, K1 k1, K2 k2, K3 k3, K4 k4)
 {
+    if (d->model == HBVX_MODEL_HOURLY) {
+        hipLaunchKernelGGL(k4, grid, dim3(64), 0, st, a);
+        return hipGetLastError();
+    }
     if (d->model == HBVX_MODEL_HBV10 && d->n_param == 12) hipLaunchKernelGGL(k0, grid, dim3(64), 0, st, a);
     else if (d->model == HBVX_MODEL_HBV10) hipLaunchKernelGGL(k1, grid, dim3(64), 0, st, a);
     else if (d->model == HBVX_MODEL_HBV11P) hipLaunchKernelGGL(k2, grid, dim3(64), 0, st, a);
@@ -696,6 +701,7 @@ static hipError_t launch_tiled_one(K kern, const Args &a, dim3 grid, int threads
         if (m == HBVX_MODEL_HBV10 && !be) return launch_tiled_one(K<MODEL_HBV10, false, __VA_ARGS__>, a, grid, threads, lds, st); \
         if (m == HBVX_MODEL_HBV10) return launch_tiled_one(K<MODEL_HBV10, true, __VA_ARGS__>, a, grid, threads, lds, st);         \
         if (m == HBVX_MODEL_HBV11P) return launch_tiled_one(K<MODEL_HBV11P, true, __VA_ARGS__>, a, grid, threads, lds, st);       \
+        if (m == HBVX_MODEL_HOURLY) return launch_tiled_one(K<MODEL_HOURLY, true, __VA_ARGS__>, a, grid, threads, lds, st);       \
         return launch_tiled_one(K<MODEL_HBV20, true, __VA_ARGS__>, a, grid, threads, lds, st);    \
     })()
 
@@ -753,7 +759,7 @@ extern "C" int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *s
     dim3 grid((d->B + bpw - 1) / bpw);
     hipError_t e = launch_variant(d, a, grid, (hipStream_t)stream,
                                   k_fwd<MODEL_HBV10, false>, k_fwd<MODEL_HBV10, true>,
-                                  k_fwd<MODEL_HBV11P, true>, k_fwd<MODEL_HBV20, true>);
+                                  k_fwd<MODEL_HBV11P, true>, k_fwd<MODEL_HBV20, true>, k_fwd<MODEL_HOURLY, true>);
     if (e != hipSuccess) return hip_fail(e, "hbvx_forward launch");
     return HBVX_OK;
 }
@@ -801,6 +807,7 @@ static hipError_t launch_chunked_v(const hbvx_desc *d, const ChunkArgs &a, hipSt
     if (d->model == HBVX_MODEL_HBV10 && d->n_param == 12) return launch_chunked_t<MODEL_HBV10, false, DYN, GFULL>(a, st);
     if (d->model == HBVX_MODEL_HBV10) return launch_chunked_t<MODEL_HBV10, true, DYN, GFULL>(a, st);
     if (d->model == HBVX_MODEL_HBV11P) return launch_chunked_t<MODEL_HBV11P, true, DYN, GFULL>(a, st);
+    if (d->model == HBVX_MODEL_HOURLY) return launch_chunked_t<MODEL_HOURLY, true, DYN, GFULL>(a, st);
     return launch_chunked_t<MODEL_HBV20, true, DYN, GFULL>(a, st);
 }
 
@@ -863,7 +870,7 @@ extern "C" int hbvx_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *st
     dim3 grid((d->B + bpw - 1) / bpw);
     hipError_t e = launch_variant(d, a, grid, (hipStream_t)stream,
                                   k_bwd<MODEL_HBV10, false>, k_bwd<MODEL_HBV10, true>,
-                                  k_bwd<MODEL_HBV11P, true>, k_bwd<MODEL_HBV20, true>);
+                                  k_bwd<MODEL_HBV11P, true>, k_bwd<MODEL_HBV20, true>, k_bwd<MODEL_HOURLY, true>);
     if (e != hipSuccess) return hip_fail(e, "hbvx_backward launch");
     return HBVX_OK;
 }

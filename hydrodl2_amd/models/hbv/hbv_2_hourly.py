@@ -1,0 +1,200 @@
+"""HBV 2.0 hourly on the MI355X-native time-stepper.
+
+Counterpart of `hydrodl2.load_model('hbv_2_hourly')`
+(src/hydrodl2/models/hbv/hbv_2_hourly.py:8-898): HBV 2.0 in rate form with dt = 1/24 day,
+storage guard-rails, Hortonian infiltration excess, 19 physical parameters; `parameters` is the
+tuple (dynamic [T,B,n_dy*nmul], static [B,n_st*nmul(+2)], distributed-routing [n_pairs,3]) in
+[0,1]; needs `ac_all`, `elev_all`, `outlet_topo` [gages,units] and `areas` [units]; returns
+{'Qs': unit runoff [T,B,1], 'streamflow': gage streamflow [T,G,1]}.
+
+What runs where (round 1): the sub-daily recurrence, parameter prep, ensemble mean and their
+adjoint run in the HIP library (`Step<MODEL_HOURLY>`, csrc/hbv_step_hourly.h).  The 72-tap
+lagged-UH gage routing (hbv_2_hourly.py:800-897) and the optional 72-tap unit routing (:693-700)
+are still expressed with torch ops here (conv1d / scatter_add on the GPU) -- the next kernels to
+write; they are O(pairs x T x 72) and not on the recurrence's serial path.
+"""
+from typing import Any, Optional
+
+import torch
+import torch.nn.functional as F
+
+from hydrodl2_amd import _abi
+from hydrodl2_amd.core.hbv_module import HbvModule
+from hydrodl2_amd.ops import HbvPath, ParamSource, StepConfig
+
+
+def _uh_gamma(a: torch.Tensor, b: torch.Tensor, L: int) -> torch.Tensor:
+    """Normalised gamma unit hydrograph [L,P] for shape a [P] and scale b [P]
+    (core/calc/uh_routing.py:5-22)."""
+    aa = torch.relu(a) + 0.1
+    theta = torch.relu(b) + 0.5
+    t = torch.arange(0.5, L * 1.0, device=a.device, dtype=a.dtype).unsqueeze(1)
+    w = 1 / (aa.lgamma().exp() * theta ** aa) * t ** (aa - 1) * torch.exp(-t / theta)
+    return w / w.sum(0)
+
+
+def _frac_shift(w: torch.Tensor, tau: torch.Tensor) -> torch.Tensor:
+    """w(t - tau) by mixing the floor(tau)- and floor(tau)+1-step shifts, zero padded
+    (hbv_2_hourly.py:857-897).  w [L,P], tau [P]."""
+    L = w.shape[0]
+    k = torch.floor(tau).unsqueeze(0)
+    f = tau.unsqueeze(0) - k
+    t = torch.arange(L, device=w.device, dtype=w.dtype).unsqueeze(1)
+    i0, i1 = t - k, t - (k + 1)
+    w0 = torch.gather(w, 0, i0.clamp(0, L - 1).long()) * ((i0 >= 0) & (i0 <= L - 1)).to(w.dtype)
+    w1 = torch.gather(w, 0, i1.clamp(0, L - 1).long()) * ((i1 >= 0) & (i1 <= L - 1)).to(w.dtype)
+    return (1.0 - f) * w0 + f * w1
+
+
+def _causal_fir(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """y[t,p] = sum_k w[k,p] x[t-k,p], zero history (core/calc/uh_routing.py:25-57). x [T,P], w [L,P]."""
+    P, L = x.shape[1], w.shape[0]
+    y = F.conv1d(x.t().unsqueeze(0), torch.flip(w.t().unsqueeze(1), [2]), groups=P, padding=L - 1)
+    return y[0, :, : x.shape[0]].t()
+
+
+class Hbv_2_hourly(HbvModule):
+    """HBV 2.0 hourly: 19 physical parameters x nmul, 3 distributed-routing parameters per pair."""
+
+    _model_id = _abi.MODEL_HOURLY
+    _display_name = 'HBV 2.0 Hourly'
+    _has_capillary = True
+    _default_routing = False  # hbv_2_hourly.py:44
+
+    def __init__(self, config: Optional[dict[str, Any]] = None,
+                 device: Optional[torch.device] = None) -> None:
+        self.dt = 1.0 / 24          # hbv_2_hourly.py:58
+        self.lenF = 72              # :45
+        self.use_distr_routing = True
+        self.infiltration = True
+        self.lag_uh = True
+        self._extra_bounds = {      # :104-114
+            'parBETAET': [0.3, 5], 'parC': [0, 1], 'parRT': [0, 20], 'parAC': [0, 2500],
+            'parF0': [5.0 / self.dt, 120.0 / self.dt], 'parFMIN': [0.0, 1.0], 'parALPHA': [0.5, 5.0],
+        }
+        self.distr_parameter_bounds = {'route_a': [0, 5.0], 'route_b': [0, 12.0],
+                                       'route_tau': [0, 48.0]}  # :120-124
+        self._qs_buffer = []
+        self._max_history = 100
+        super().__init__(config, device)
+        self.routing_parameter_bounds = {'route_a': [0, 5.0], 'route_b': [0, 12.0]}  # :116-119
+        self._state_cache = None
+        self._set_parameters()
+
+    def _read_config(self, config: dict) -> None:
+        super()._read_config(config)
+        self.cache_states = config.get('cache_states', self.cache_states)
+
+    def _set_parameters(self) -> None:
+        """hbv_2_hourly.py:194-211."""
+        self.phy_param_names = self.parameter_bounds.keys()
+        self.routing_param_names = self.routing_parameter_bounds.keys() if self.routing else []
+        self.learnable_param_count1 = len(self.dynamic_params) * self.nmul
+        self.learnable_param_count2 = (
+            len(self.phy_param_names) - len(self.dynamic_params)
+        ) * self.nmul + len(self.routing_param_names)
+        self.learnable_param_count3 = len(getattr(self, 'distr_parameter_bounds', {}))
+        self.learnable_param_count = (self.learnable_param_count1 + self.learnable_param_count2
+                                      + self.learnable_param_count3)
+
+    def get_states(self):
+        # The reference returns `_states_cache` although it stores `_state_cache`
+        # (hbv_2_hourly.py:170 vs :444); the stored series is what a caller wants.
+        return self._state_cache
+
+    def forward(self, x_dict: dict[str, torch.Tensor], parameters):
+        """Reference: hbv_2_hourly.py:376-449 + `_PBM` :451-798."""
+        x = x_dict['x_phy']
+        ac = x_dict['ac_all'].to(torch.float32).contiguous()
+        elev = x_dict['elev_all'].to(torch.float32).contiguous()
+        outlet_topo, areas = x_dict['outlet_topo'], x_dict['areas']
+        self.muwts = x_dict.get('muwts', None)
+        T, ngrid = x.shape[0], x.shape[1]
+        M = self.nmul
+        p_dyn, p_sta, p_distr = parameters[0].contiguous(), parameters[1].contiguous(), parameters[2]
+        n = len(self.parameter_bounds)
+        dy = list(self.dynamic_params)
+        n_dy = len(dy)
+        wd, ws = p_dyn.shape[-1], p_sta.shape[-1]
+        if wd != n_dy * M:
+            raise ValueError(f"dynamic parameters have {wd} columns, need {n_dy * M}")
+
+        srcs = []
+        drops = {name: self._draw_drop_mask(ngrid, x.device) for name in dy}  # :283-288
+        stat_list = [name for name in self.parameter_bounds if name not in dy]
+        for name in self.parameter_bounds:
+            lo, hi = self.parameter_bounds[name]
+            slot = _abi.PARAM_SLOTS.index(name)
+            if name in dy:
+                i = dy.index(name)
+                srcs.append(ParamSource(slot=slot, lo=float(lo), hi=float(hi), tensor_idx=0,
+                                        sta_off=(T - 1) * ngrid * wd + i * M, sta_bs=wd,
+                                        dyn_tensor_idx=0, dyn_off=i * M, dyn_ts=ngrid * wd,
+                                        dyn_bs=wd, drop=drops[name]))
+            else:
+                i = stat_list.index(name)
+                srcs.append(ParamSource(slot=slot, lo=float(lo), hi=float(hi), tensor_idx=1,
+                                        sta_off=i * M, sta_bs=ws))
+
+        if (not self.states) or (not self.cache_states):
+            state_in = None
+        else:
+            state_in = self._stack_states(self.states, ngrid, x.device)
+
+        cfg = StepConfig(model=self._model_id, n_param=n, n_flux=12, T=T, t0=0, B=ngrid, M=M,
+                         raw_sigmoid=False, channels=self._channels(),
+                         nearzero=float(self.nearzero), params=srcs,
+                         want_flux=not self.initialize, want_traj=True)
+        muwts = self._expand_muwts(self.muwts, T, ngrid)
+        flux, _, _, traj = HbvPath.apply(cfg, x, state_in, muwts, ac, elev, p_dyn, p_sta)
+
+        series = traj.detach()[:, 1:, :].reshape(5, T, ngrid, M)
+        self._state_cache = tuple(series[k] for k in range(5))          # :444,725
+        if self.cache_states:
+            self.states = tuple(s[-1].detach() for s in self._state_cache)
+        if self.initialize:
+            return {}
+
+        Qs = flux[_abi.F_QSIM]                                            # [T,B] rate per day
+        if self.routing:                                                  # :684-700 (torch, see module doc)
+            off = (n - n_dy) * M
+            ra = p_sta[:, off] * 5.0
+            rb = p_sta[:, off + 1] * 12.0
+            Qs = _causal_fir(Qs, _uh_gamma(ra, rb, min(T, self.lenF)))
+        Qs = (Qs * self.dt).unsqueeze(-1)                                 # :741
+        out = {'Qs': Qs}
+        if not self.warm_up_states:
+            out['Qs'] = out['Qs'][self.pred_cutoff:, :, :]
+        if self.use_distr_routing:                                        # :766-796
+            if self.cache_states:
+                self._qs_buffer.append(Qs.detach())
+                if len(self._qs_buffer) > self._max_history:
+                    self._qs_buffer.pop(0)
+                hist = torch.cat(self._qs_buffer, dim=0)
+            else:
+                hist = Qs
+            routed = self.distr_routing(hist, p_distr, outlet_topo, areas)
+            out['streamflow'] = routed[-1:] if self.cache_states else routed
+        return out
+
+    def distr_routing(self, Qs, p_distr, outlet_topo, areas):
+        """Gage streamflow from unit runoff: area-weighted, per (gage, unit) pair a gamma unit
+        hydrograph of 72 taps shifted by route_tau, summed per gage and normalised by the upstream
+        area (hbv_2_hourly.py:800-855).  Qs [T,U,1] -> [T,G,1]."""
+        T = Qs.shape[0]
+        b = self.distr_parameter_bounds
+        a = p_distr[:, 0] * (b['route_a'][1] - b['route_a'][0]) + b['route_a'][0]
+        bb = p_distr[:, 1] * (b['route_b'][1] - b['route_b'][0]) + b['route_b'][0]
+        tau = p_distr[:, 2] * (b['route_tau'][1] - b['route_tau'][0]) + b['route_tau'][0]
+        pairs = (outlet_topo == 1).nonzero(as_tuple=False)
+        rows, cols = pairs[:, 0].long(), pairs[:, 1].long()
+        qp = (Qs[:, :, 0] * areas[None, :])[:, cols]                      # [T,P]
+        uh = _uh_gamma(a, bb, min(T, self.lenF))
+        if self.lag_uh:
+            uh = _frac_shift(uh, tau)
+        lagged = _causal_fir(qp, uh)                                      # [T,P]
+        G = int(outlet_topo.shape[0])
+        acc = torch.zeros((T, G), device=lagged.device, dtype=lagged.dtype)
+        acc.index_add_(1, rows, lagged)
+        denom = (outlet_topo * areas[None, :]).sum(dim=1).clamp(min=1e-6)
+        return (acc / denom[None, :]).unsqueeze(-1)

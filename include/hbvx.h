@@ -36,8 +36,8 @@
 extern "C" {
 #endif
 
-#define HBVX_ABI_VERSION 3
-#define HBVX_MAX_PARAM 16
+#define HBVX_ABI_VERSION 4
+#define HBVX_MAX_PARAM 20
 #define HBVX_NSTATE 5   /* SNOWPACK, MELTWATER, SM, SUZ, SLZ  (hbv.py:61-67) */
 #define HBVX_MAX_FLUX 12
 #define HBVX_UH_MAXLEN 15 /* lenF (hbv.py:526, hbv_2.py:52) */
@@ -47,14 +47,18 @@ extern "C" {
 enum hbvx_param_slot {
     HBVX_P_BETA = 0, HBVX_P_FC, HBVX_P_K0, HBVX_P_K1, HBVX_P_K2, HBVX_P_LP,
     HBVX_P_PERC, HBVX_P_UZL, HBVX_P_TT, HBVX_P_CFMAX, HBVX_P_CFR, HBVX_P_CWH,
-    HBVX_P_BETAET, HBVX_P_C, HBVX_P_RT, HBVX_P_AC
+    HBVX_P_BETAET, HBVX_P_C, HBVX_P_RT, HBVX_P_AC,
+    HBVX_P_F0, HBVX_P_FMIN, HBVX_P_ALPHA /* hourly Hortonian infiltration (hbv_2_hourly.py:108-114) */
 };
 
 enum hbvx_model {
     HBVX_MODEL_HBV10 = 0,  /* n_param 12, or 13 when parBETAET is present */
     HBVX_MODEL_HBV11P = 1, /* n_param 14: + parBETAET always, capillary rise */
     HBVX_MODEL_HBV20 = 2,  /* n_param 16: + elevation TT switch, lateral flow */
-    HBVX_MODEL_HBVADJ = 3  /* implicit (backward-Euler) HBV, hbvx_adj_* only; n_param 12 or 13 */
+    HBVX_MODEL_HBVADJ = 3, /* implicit (backward-Euler) HBV, hbvx_adj_* only; n_param 12 or 13 */
+    HBVX_MODEL_HOURLY = 4  /* n_param 19: HBV 2.0 in rate form with dt = 1/24 day, storage guard-rails,
+                              Hortonian infiltration excess (hbv_2_hourly.py:527-675); forcings are
+                              per-step depths, fluxes are rates per day */
 };
 
 /* Ensemble-mean series written by hbvx_forward, flux[k][t][b]

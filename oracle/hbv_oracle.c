@@ -419,6 +419,292 @@ static void step_bwd(int model, int has_betaet, float nz, const float *p, const 
 }
 
 /* ------------------------------------------------------------------ */
+/* Hbv_2_hourly: HBV 2.0 in rate form with dt = 1/24 day (hbv_2_hourly.py:527-675)            */
+
+typedef struct {
+    float SPi, MWi, SMi, SUZi, SLZi;          /* incoming storages (before the guard rails) */
+    float SP, MW, SM, SUZ, SLZ, g0, g1, g2, g3, g4;
+    float P, Tf, PET;                          /* rates: forcing / dt (:485-487) */
+    float TTe, mlo, m_rain, m_snow, RAIN, SP1, dT, mp, mpcdt, melt, MW1, SP2;
+    float cc, dT2, rp, rpcdt, refr, SP3, MW2, ts0, tosoil, MW3;
+    float W, r, s, oms, pw, fmin_, fcap, infil, ie0, IE;
+    float sw0, sw, rech, SM1, e0, exc, SM2, lpfc, q, ef0, ef, pe, pedt, ETm, ET, dd, SM3;
+    float x1, rc, cs, om, capp, capm, cap, smc, SM4, slc, SLZ0;
+    float SUZ1, pdt, PERCm, PERC, SUZ2, u0, u0c, Q0, SUZ3, Q1, SUZ4, SLZ1, SLZ1p, Q2, SLZ2, Q;
+    float a0, a1, m1, m2, ee, sl;
+} hstep_t;
+
+#define HDT ((float)(1.0 / 24.0)) /* self.dt (hbv_2_hourly.py:58) */
+
+static void hstep_fwd(float nz, const float *p, float ac, float elev, hstep_t *s)
+{
+    const float dt = HDT;
+    const float BETA = p[HBVX_P_BETA], FC = p[HBVX_P_FC], K0 = p[HBVX_P_K0], K1 = p[HBVX_P_K1],
+                K2 = p[HBVX_P_K2], LP = p[HBVX_P_LP], PERCp = p[HBVX_P_PERC], UZL = p[HBVX_P_UZL],
+                TT = p[HBVX_P_TT], CFMAX = p[HBVX_P_CFMAX], CFR = p[HBVX_P_CFR], CWH = p[HBVX_P_CWH],
+                BE = p[HBVX_P_BETAET], C = p[HBVX_P_C], RT = p[HBVX_P_RT], AC = p[HBVX_P_AC],
+                F0 = p[HBVX_P_F0], FMIN = p[HBVX_P_FMIN], ALPHA = p[HBVX_P_ALPHA];
+    /* :529-533 guard rails */
+    s->SP = fmaxf(s->SPi, 0.0f);  s->g0 = (s->SPi >= 0.0f) ? 1.0f : 0.0f;
+    s->MW = fmaxf(s->MWi, 0.0f);  s->g1 = (s->MWi >= 0.0f) ? 1.0f : 0.0f;
+    s->SM = fmaxf(s->SMi, nz);    s->g2 = (s->SMi >= nz) ? 1.0f : 0.0f;
+    s->SUZ = fmaxf(s->SUZi, nz);  s->g3 = (s->SUZi >= nz) ? 1.0f : 0.0f;
+    s->SLZ = fmaxf(s->SLZi, nz);  s->g4 = (s->SLZi >= nz) ? 1.0f : 0.0f;
+    /* :544-548 */
+    float mhi = (elev >= 2000.0f) ? 1.0f : 0.0f;
+    s->mlo = (elev < 2000.0f) ? 1.0f : 0.0f;
+    s->TTe = mhi * 4.0f + s->mlo * TT;
+    s->m_rain = (s->Tf >= s->TTe) ? 1.0f : 0.0f;
+    s->m_snow = (s->Tf < s->TTe) ? 1.0f : 0.0f;
+    s->RAIN = s->P * s->m_rain;
+    float SNOW = s->P * s->m_snow;
+    /* :551-572 */
+    s->SP1 = s->SP + SNOW * dt;
+    s->dT = s->Tf - s->TTe;
+    s->mp = CFMAX * s->dT;
+    s->mpcdt = fmaxf(s->mp, 0.0f) * dt;
+    s->melt = fminf(s->mpcdt, s->SP1);
+    s->MW1 = s->MW + s->melt;
+    s->SP2 = s->SP1 - s->melt;
+    s->cc = CFR * CFMAX;
+    s->dT2 = s->TTe - s->Tf;
+    s->rp = s->cc * s->dT2;
+    s->rpcdt = fmaxf(s->rp, 0.0f) * dt;
+    s->refr = fminf(s->rpcdt, s->MW1);
+    s->SP3 = s->SP2 + s->refr;
+    s->MW2 = s->MW1 - s->refr;
+    s->ts0 = (s->MW2 - CWH * s->SP3) / dt;
+    s->tosoil = fmaxf(s->ts0, 0.0f);
+    s->MW3 = s->MW2 - s->tosoil * dt;
+    /* :577-595 Hortonian infiltration excess */
+    s->W = s->RAIN + s->tosoil;
+    s->r = s->SM / FC;
+    s->s = fminf(fmaxf(s->r, 0.0f), (float)(1.0 - 0.01));
+    s->fmin_ = FMIN * F0;
+    s->oms = 1.0f - s->s;
+    s->pw = powf(s->oms, ALPHA);
+    s->fcap = s->fmin_ + (F0 - s->fmin_) * s->pw;
+    s->infil = fminf(s->W, s->fcap);
+    s->ie0 = s->W - s->fcap;
+    s->IE = fmaxf(s->ie0, 0.0f);
+    s->sw0 = powf(s->r, BETA);
+    s->sw = clamp01(s->sw0);
+    s->rech = s->infil * s->sw;
+    s->SM1 = s->SM + (s->infil - s->rech) * dt;
+    /* :603-613 */
+    s->e0 = (s->SM1 - FC) / dt;
+    s->exc = fmaxf(s->e0, 0.0f);
+    s->SM2 = s->SM1 - s->exc * dt;
+    s->lpfc = LP * FC;
+    s->q = s->SM2 / s->lpfc;
+    s->ef0 = powf(s->q, BE);
+    s->ef = clamp01(s->ef0);
+    s->pe = s->PET * s->ef;
+    s->pedt = s->pe * dt;
+    s->ETm = fminf(s->SM2, s->pedt);
+    s->ET = s->ETm / dt;
+    s->dd = s->SM2 - s->ET * dt;
+    s->SM3 = fmaxf(s->dd, nz);
+    /* :616-628 capillary rise */
+    s->x1 = s->SM3 / FC;
+    s->rc = fminf(s->x1, 1.0f);
+    s->cs = C * s->SLZ;
+    s->om = 1.0f - s->rc;
+    s->capp = (s->cs * s->om) * dt;
+    s->capm = fminf(s->SLZ, s->capp);
+    s->cap = s->capm / dt;
+    s->smc = s->SM3 + s->cap * dt;
+    s->SM4 = fmaxf(s->smc, nz);
+    s->slc = s->SLZ - s->cap * dt;
+    s->SLZ0 = fmaxf(s->slc, nz);
+    /* :631-648 groundwater */
+    s->SUZ1 = s->SUZ + (s->rech + s->exc) * dt;
+    s->pdt = PERCp * dt;
+    s->PERCm = fminf(s->SUZ1, s->pdt);
+    s->PERC = s->PERCm / dt;
+    s->SUZ2 = s->SUZ1 - s->PERC * dt;
+    s->u0 = s->SUZ2 - UZL;
+    s->u0c = fmaxf(s->u0, 0.0f);
+    s->Q0 = K0 * s->u0c;
+    s->SUZ3 = s->SUZ2 - s->Q0 * dt;
+    s->Q1 = K1 * s->SUZ3;
+    s->SUZ4 = s->SUZ3 - s->Q1 * dt;
+    s->SLZ1 = s->SLZ0 + s->PERC * dt;
+    s->m1 = (ac < 2500.0f) ? 1.0f : 0.0f;
+    s->m2 = (ac >= 2500.0f) ? 1.0f : 0.0f;
+    s->a0 = (ac - AC) / 1000.0f;
+    s->a1 = fminf(fmaxf(s->a0, -1.0f), 1.0f);
+    float e0 = -(ac - 2500.0f) / 50.0f;
+    float e1 = fminf(fmaxf(e0, -10.0f), 0.0f);
+    s->ee = expf(e1);
+    float LF = (s->a1 * RT) * s->m1 + (s->ee * RT) * s->m2;
+    s->sl = s->SLZ1 + LF * dt;
+    s->SLZ1p = fmaxf(s->sl, 0.0f);
+    s->Q2 = K2 * s->SLZ1p;
+    s->SLZ2 = s->SLZ1p - s->Q2 * dt;
+    /* :652 */
+    s->Q = ((s->Q0 + s->Q1) + s->Q2) + s->IE;
+}
+
+static void hstep_bwd(float nz, const float *p, const hstep_t *s, const fluxgrad_t *g, float *a,
+                      float *gp, float *gx)
+{
+    const float dt = HDT;
+    const float BETA = p[HBVX_P_BETA], FC = p[HBVX_P_FC], K0 = p[HBVX_P_K0], K1 = p[HBVX_P_K1],
+                K2 = p[HBVX_P_K2], LP = p[HBVX_P_LP], CFMAX = p[HBVX_P_CFMAX], CFR = p[HBVX_P_CFR],
+                CWH = p[HBVX_P_CWH], BE = p[HBVX_P_BETAET], C = p[HBVX_P_C], RT = p[HBVX_P_RT],
+                F0 = p[HBVX_P_F0], FMIN = p[HBVX_P_FMIN], ALPHA = p[HBVX_P_ALPHA];
+    float wa, wb;
+    float aSP3 = a[0] + g->gSWE, aMW3 = a[1], aSM4 = a[2], aSUZ4 = a[3], aSLZ2 = a[4];
+    float aQ0 = g->gQ0 + g->gQ, aQ1 = g->gQ1 + g->gQ, aQ2 = g->gQ2 + g->gQ, aIE = g->gQ;
+    /* lower box */
+    aQ2 -= aSLZ2 * dt;
+    float aSLZ1p = aSLZ2 + aQ2 * K2;
+    gp[HBVX_P_K2] += aQ2 * s->SLZ1p;
+    float as = (s->sl >= 0.0f) ? aSLZ1p : 0.0f;
+    float aSLZ1 = as;
+    float aLF = as * dt;
+    float at1 = aLF * s->m1, at2 = aLF * s->m2;
+    gp[HBVX_P_RT] += at1 * s->a1 + at2 * s->ee;
+    float aa1 = at1 * RT;
+    float aa0 = (s->a0 >= -1.0f && s->a0 <= 1.0f) ? aa1 : 0.0f;
+    gp[HBVX_P_AC] += -(aa0 / 1000.0f);
+    float aSLZ0 = aSLZ1;
+    float aPERC = g->gPERC + aSLZ1 * dt;
+    /* upper box */
+    aQ1 -= aSUZ4 * dt;
+    float aSUZ3 = aSUZ4 + aQ1 * K1;
+    gp[HBVX_P_K1] += aQ1 * s->SUZ3;
+    aQ0 -= aSUZ3 * dt;
+    float aSUZ2 = aSUZ3;
+    gp[HBVX_P_K0] += aQ0 * s->u0c;
+    float au0 = (s->u0 >= 0.0f) ? aQ0 * K0 : 0.0f;
+    aSUZ2 += au0;
+    gp[HBVX_P_UZL] -= au0;
+    aPERC -= aSUZ2 * dt;
+    float aSUZ1 = aSUZ2;
+    float aPERCm = aPERC / dt;
+    minw(s->SUZ1, s->pdt, &wa, &wb);
+    aSUZ1 += aPERCm * wa;
+    gp[HBVX_P_PERC] += (aPERCm * wb) * dt;
+    float aSUZ = aSUZ1;
+    float are = aSUZ1 * dt;
+    float arech = g->grech + are;
+    float aexc = g->gexc + are;
+    /* capillary rise */
+    float az = (s->slc >= nz) ? aSLZ0 : 0.0f;
+    float aSLZ = az;
+    float acap = g->gcap - az * dt;
+    float ay = (s->smc >= nz) ? aSM4 : 0.0f;
+    float aSM3 = ay;
+    acap += ay * dt;
+    float acapm = acap / dt;
+    minw(s->SLZ, s->capp, &wa, &wb);
+    aSLZ += acapm * wa;
+    float acsom = (acapm * wb) * dt;
+    float acs = acsom * s->om;
+    float arc = -(acsom * s->cs);
+    gp[HBVX_P_C] += acs * s->SLZ;
+    aSLZ += acs * C;
+    float ax1 = (s->x1 <= 1.0f) ? arc : 0.0f;
+    aSM3 += ax1 / FC;
+    gp[HBVX_P_FC] += -ax1 * ((s->SM3 / FC) / FC);
+    /* evapotranspiration */
+    float add = (s->dd >= nz) ? aSM3 : 0.0f;
+    float aSM2 = add;
+    float aET = g->gET - add * dt;
+    float aETm = aET / dt;
+    minw(s->SM2, s->pedt, &wa, &wb);
+    aSM2 += aETm * wa;
+    float ape = (aETm * wb) * dt;
+    float aef = g->gef + ape * s->PET;
+    gx[2] = (ape * s->ef) / dt;
+    float aef0 = (s->ef0 >= 0.0f && s->ef0 <= 1.0f) ? aef : 0.0f;
+    float aq = aef0 * pow_dx(s->q, BE);
+    gp[HBVX_P_BETAET] += aef0 * pow_dy(s->q, BE, s->ef0);
+    aSM2 += aq / s->lpfc;
+    float alpfc = -aq * ((s->SM2 / s->lpfc) / s->lpfc);
+    gp[HBVX_P_LP] += alpfc * FC;
+    gp[HBVX_P_FC] += alpfc * LP;
+    /* excess */
+    float aSM1 = aSM2;
+    aexc -= aSM2 * dt;
+    float ae0 = (s->e0 >= 0.0f) ? aexc : 0.0f;
+    float ae0d = ae0 / dt;
+    aSM1 += ae0d;
+    gp[HBVX_P_FC] -= ae0d;
+    /* soil: SM1 = SM + (infil - rech)*dt ; rech = infil*sw */
+    float aSM = aSM1;
+    float aird = aSM1 * dt;
+    float ainfil = aird;
+    arech -= aird;
+    ainfil += arech * s->sw;
+    float asw = arech * s->infil;
+    float asw0 = (s->sw0 >= 0.0f && s->sw0 <= 1.0f) ? asw : 0.0f;
+    float ar = asw0 * pow_dx(s->r, BETA);
+    gp[HBVX_P_BETA] += asw0 * pow_dy(s->r, BETA, s->sw0);
+    /* infiltration: infil = min(W, fcap) ; IE = max(W - fcap, 0) */
+    minw(s->W, s->fcap, &wa, &wb);
+    float aW = ainfil * wa;
+    float afcap = ainfil * wb;
+    float aie0 = (s->ie0 >= 0.0f) ? aIE : 0.0f;
+    aW += aie0;
+    afcap -= aie0;
+    /* fcap = fmin + (F0 - fmin)*pw ; fmin = FMIN*F0 ; pw = (1-s)^ALPHA ; s = clamp(r, 0, 0.99) */
+    float afmin = afcap;
+    float adiff = afcap * s->pw;
+    float apw = afcap * (F0 - s->fmin_);
+    gp[HBVX_P_F0] += adiff;
+    afmin -= adiff;
+    gp[HBVX_P_FMIN] += afmin * F0;
+    gp[HBVX_P_F0] += afmin * FMIN;
+    float aoms = apw * pow_dx(s->oms, ALPHA);
+    gp[HBVX_P_ALPHA] += apw * pow_dy(s->oms, ALPHA, s->pw);
+    float as_ = -aoms;
+    ar += (s->r >= 0.0f && s->r <= (float)(1.0 - 0.01)) ? as_ : 0.0f;
+    aSM += ar / FC;
+    gp[HBVX_P_FC] += -ar * ((s->SM / FC) / FC);
+    float aRAIN = aW;
+    float atosoil = g->gtosoil + aW;
+    /* snow */
+    float aMW2 = aMW3;
+    atosoil -= aMW3 * dt;
+    float ats0 = (s->ts0 >= 0.0f) ? atosoil : 0.0f;
+    float ats0d = ats0 / dt;
+    aMW2 += ats0d;
+    gp[HBVX_P_CWH] -= ats0d * s->SP3;
+    aSP3 -= ats0d * CWH;
+    float aSP2 = aSP3;
+    float arefr = aSP3 - aMW2;
+    float aMW1 = aMW2;
+    minw(s->rpcdt, s->MW1, &wa, &wb);
+    float arpc = (arefr * wa) * dt;
+    aMW1 += arefr * wb;
+    float arp = (s->rp >= 0.0f) ? arpc : 0.0f;
+    float acc = arp * s->dT2;
+    gp[HBVX_P_CFR] += acc * CFMAX;
+    gp[HBVX_P_CFMAX] += acc * CFR;
+    float aTTe = arp * s->cc;
+    float aTf = -(arp * s->cc);
+    float aMW = aMW1;
+    float amelt = aMW1 - aSP2;
+    float aSP1 = aSP2;
+    minw(s->mpcdt, s->SP1, &wa, &wb);
+    float ampc = (amelt * wa) * dt;
+    aSP1 += amelt * wb;
+    float amp = (s->mp >= 0.0f) ? ampc : 0.0f;
+    gp[HBVX_P_CFMAX] += amp * s->dT;
+    aTTe -= amp * CFMAX;
+    aTf += amp * CFMAX;
+    float aSP = aSP1;
+    float aSNOW = aSP1 * dt;
+    gx[0] = (aSNOW * s->m_snow + aRAIN * s->m_rain) / dt;
+    gx[1] = aTf;
+    gp[HBVX_P_TT] += aTTe * s->mlo;
+    a[0] = aSP * s->g0; a[1] = aMW * s->g1; a[2] = aSM * s->g2; a[3] = aSUZ * s->g3; a[4] = aSLZ * s->g4;
+}
+
+/* ------------------------------------------------------------------ */
 
 static int check_desc(const hbvx_desc *d)
 {
@@ -429,11 +715,12 @@ static int check_desc(const hbvx_desc *d)
     if (d->model == HBVX_MODEL_HBV10) ok = (d->n_param == 12 || d->n_param == 13);
     else if (d->model == HBVX_MODEL_HBV11P) ok = (d->n_param == 14);
     else if (d->model == HBVX_MODEL_HBV20) ok = (d->n_param == 16);
+    else if (d->model == HBVX_MODEL_HOURLY) ok = (d->n_param == 19);
     else if (d->model == HBVX_MODEL_HBVADJ) return fail(HBVX_E_UNSUPPORTED, "the implicit scheme's oracle is oracle/hbv_adj_oracle.py");
     else return fail(HBVX_E_UNSUPPORTED, "unknown model");
     if (!ok) return fail(HBVX_E_SHAPE, "n_param does not match model");
     if (!d->x) return fail(HBVX_E_NULL, "forcing pointer is NULL");
-    if (d->model == HBVX_MODEL_HBV20 && (!d->ac || !d->elev))
+    if ((d->model == HBVX_MODEL_HBV20 || d->model == HBVX_MODEL_HOURLY) && (!d->ac || !d->elev))
         return fail(HBVX_E_NULL, "HBV 2.0 needs ac and elev");
     for (int i = 0; i < d->n_param; i++)
         if (!d->p[i].sta) return fail(HBVX_E_NULL, "static parameter pointer is NULL");
@@ -488,7 +775,18 @@ int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream)
                 step_t s;
                 s.SP = st[0]; s.MW = st[1]; s.SM = st[2]; s.SUZ = st[3]; s.SLZ = st[4];
                 load_step_inputs(d, t, b, j, p, u, &s);
-                step_fwd(d->model, betaet, d->nearzero, p, ac, elev, &s);
+                if (d->model == HBVX_MODEL_HOURLY) {
+                    hstep_t h;
+                    h.SPi = st[0]; h.MWi = st[1]; h.SMi = st[2]; h.SUZi = st[3]; h.SLZi = st[4];
+                    h.P = s.P / HDT; h.Tf = s.Tf; h.PET = s.PET / HDT; /* hbv_2_hourly.py:485-487 */
+                    hstep_fwd(d->nearzero, p, ac, elev, &h);
+                    s.sw0 = h.sw0; s.ef0 = h.ef0;
+                    s.SP3 = h.SP3; s.MW3 = h.MW3; s.SM4 = h.SM4; s.SUZ4 = h.SUZ4; s.SLZ2 = h.SLZ2;
+                    s.Q = h.Q; s.Q0 = h.Q0; s.Q1 = h.Q1; s.Q2 = h.Q2; s.ET = h.ET; s.rech = h.rech;
+                    s.exc = h.exc; s.ef = h.ef; s.tosoil = h.tosoil; s.PERC = h.PERC; s.cap = h.cap;
+                } else {
+                    step_fwd(d->model, betaet, d->nearzero, p, ac, elev, &s);
+                }
                 if (out->traj)
                     for (int k = 0; k < 5; k++) out->traj[((int64_t)k * (T + 1) + t) * N + n] = st[k];
                 if (out->aux) {
@@ -569,7 +867,15 @@ int hbvx_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *stream)
                 s.SUZ = io->traj[((int64_t)3 * (T + 1) + t) * N + n];
                 s.SLZ = io->traj[((int64_t)4 * (T + 1) + t) * N + n];
                 load_step_inputs(d, t, b, j, p, u, &s);
-                step_fwd(d->model, betaet, d->nearzero, p, ac, elev, &s);
+                hstep_t h;
+                if (d->model == HBVX_MODEL_HOURLY) {
+                    h.SPi = s.SP; h.MWi = s.MW; h.SMi = s.SM; h.SUZi = s.SUZ; h.SLZi = s.SLZ;
+                    h.P = s.P / HDT; h.Tf = s.Tf; h.PET = s.PET / HDT;
+                    hstep_fwd(d->nearzero, p, ac, elev, &h);
+                    s.Q = h.Q;
+                } else {
+                    step_fwd(d->model, betaet, d->nearzero, p, ac, elev, &s);
+                }
                 for (int i = 0; i < HBVX_MAX_PARAM; i++) gp[i] = 0.0f;
                 fluxgrad_t g;
                 const float *gf = io->grad_flux;
@@ -594,7 +900,8 @@ int hbvx_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *stream)
                 if (io->grad_muwts)
                     io->grad_muwts[((int64_t)t * B + b) * M + j] = GF(HBVX_F_QSIM) * s.Q;
 #undef GF
-                step_bwd(d->model, betaet, d->nearzero, p, &s, &g, a, gp, gx);
+                if (d->model == HBVX_MODEL_HOURLY) hstep_bwd(d->nearzero, p, &h, &g, a, gp, gx);
+                else step_bwd(d->model, betaet, d->nearzero, p, &s, &g, a, gp, gx);
                 if (gxacc) {
                     gxacc[t * 3 + 0] += gx[0];
                     gxacc[t * 3 + 1] += gx[1];

@@ -16,8 +16,10 @@ BOUNDS = {
     'parK2': [0.001, 0.2], 'parLP': [0.2, 1], 'parPERC': [0, 10], 'parUZL': [0, 100],
     'parTT': [-2.5, 2.5], 'parCFMAX': [0.5, 10], 'parCFR': [0, 0.1], 'parCWH': [0, 0.2],
     'parBETAET': [0.3, 5], 'parC': [0, 1], 'parRT': [0, 20], 'parAC': [0, 2500],
+    'parF0': [120.0, 2880.0], 'parFMIN': [0.0, 1.0], 'parALPHA': [0.5, 5.0],
 }
-MODEL_ID = {"Hbv": _abi.MODEL_HBV10, "Hbv_1_1p": _abi.MODEL_HBV11P, "Hbv_2": _abi.MODEL_HBV20}
+MODEL_ID = {"Hbv": _abi.MODEL_HBV10, "Hbv_1_1p": _abi.MODEL_HBV11P, "Hbv_2": _abi.MODEL_HBV20,
+            "Hbv_2_hourly": _abi.MODEL_HOURLY}
 
 
 def make_problem(model="Hbv", T=40, B=5, M=4, dyn=(), betaet=False, drop_frac=0.0, seed=1,
@@ -31,10 +33,13 @@ def make_problem(model="Hbv", T=40, B=5, M=4, dyn=(), betaet=False, drop_frac=0.
     prob = dict(model=model, T=T, B=B, M=M, names=names, n=n, ny=ny, dyn=list(dyn),
                 routing=routing)
     prob["x"] = synth.forcing(T, B, seed, cold=cold)
+    if model == "Hbv_2_hourly":  # per-step depths of an hourly record
+        prob["x"] = prob["x"] * np.array([1.0 / 8.0, 1.0, 1.0 / 24.0], np.float32)
+        prob["routing"] = routing = False  # its 72-tap routing is not the library's 15-tap one
     prob["params"] = synth.raw_parameters(T, B, ny, seed, raw_scale)
     prob["gflux"] = synth.loss_weights((12 if model != "Hbv" else 11, T, B), seed, 40)
     prob["grouted"] = synth.loss_weights((4, T, B), seed, 41)
-    if model == "Hbv_2":
+    if model in ("Hbv_2", "Hbv_2_hourly"):
         prob["ac"] = (synth.uniform((B,), seed, 7) * np.float32(5000.0)).astype(np.float32)
         prob["elev"] = (synth.uniform((B,), seed, 8) * np.float32(3000.0)).astype(np.float32)
     if muwts:

@@ -58,13 +58,19 @@ def _run_case(hydrodl2, name: str) -> dict:
     if "muwts" in inp:
         x_dict["muwts"] = torch.from_numpy(inp["muwts"])
     leaves = []
-    if spec["model"] == "Hbv_2":
+    if spec["model"] in ("Hbv_2", "Hbv_2_hourly"):
         pd = torch.from_numpy(inp["p_dyn"]).clone().requires_grad_(True)
         ps = torch.from_numpy(inp["p_sta"]).clone().requires_grad_(True)
         x_dict["ac_all"] = torch.from_numpy(inp["ac_all"])
         x_dict["elev_all"] = torch.from_numpy(inp["elev_all"])
         params = (pd, ps)
         leaves = [("p_dyn", pd), ("p_sta", ps)]
+        if spec["model"] == "Hbv_2_hourly":
+            pr = torch.from_numpy(inp["p_distr"]).clone().requires_grad_(True)
+            x_dict["outlet_topo"] = torch.from_numpy(inp["outlet_topo"])
+            x_dict["areas"] = torch.from_numpy(inp["areas"])
+            params = (pd, ps, pr)
+            leaves.append(("p_distr", pr))
     else:
         p = torch.from_numpy(inp["parameters"]).clone().requires_grad_(True)
         params = p
@@ -104,7 +110,9 @@ def _run_case(hydrodl2, name: str) -> dict:
     for k, v in out.items():
         rec[f"out/{k}"] = v.detach().numpy().copy()
     st = model.get_states()
-    if spec["model"] == "Hbv_2":
+    if spec["model"] == "Hbv_2_hourly":
+        st = model._state_cache  # get_states() reads a differently spelled attribute
+    if spec["model"] in ("Hbv_2", "Hbv_2_hourly"):
         # full state series [5,T,B,M]
         rec["states"] = torch.stack([s.detach() for s in st]).numpy()
     else:

@@ -21,6 +21,9 @@ PHY_NAMES = {
     "Hbv_2": ["parBETA", "parFC", "parK0", "parK1", "parK2", "parLP", "parPERC",
               "parUZL", "parTT", "parCFMAX", "parCFR", "parCWH", "parBETAET", "parC",
               "parRT", "parAC"],
+    "Hbv_2_hourly": ["parBETA", "parFC", "parK0", "parK1", "parK2", "parLP", "parPERC",
+                     "parUZL", "parTT", "parCFMAX", "parCFR", "parCWH", "parBETAET", "parC",
+                     "parRT", "parAC", "parF0", "parFMIN", "parALPHA"],
 }
 
 
@@ -83,6 +86,17 @@ CASES = {
                               T=64, B=8, seed=27, loss="all", torch_seed=77),
     "hbv2_static": dict(model="Hbv_2", config=_cfg("Hbv_2", 2), T=48, B=6, seed=28, loss="all",
                         cold=True),
+    # HBV 2.0 hourly: rate form with dt = 1/24, Hortonian infiltration,
+    # lagged-UH gage routing; units -> gages through `outlet_topo`.
+    "hourly_dyn3": dict(model="Hbv_2_hourly",
+                        config=_cfg("Hbv_2_hourly", 4, ("parBETA", "parK0", "parBETAET")),
+                        T=120, B=7, G=3, seed=29, loss="all"),
+    "hourly_routing_drop": dict(model="Hbv_2_hourly",
+                                config=_cfg("Hbv_2_hourly", 16, ("parBETA", "parF0"), routing=True,
+                                            dy_drop=0.4),
+                                T=100, B=6, G=2, seed=30, loss="all", torch_seed=5),
+    "hourly_static_cold": dict(model="Hbv_2_hourly", config=_cfg("Hbv_2_hourly", 2), T=60, B=5, G=2,
+                               seed=31, loss="all", cold=True),
 }
 
 FLUX_KEYS_BASE = [
@@ -93,6 +107,8 @@ FLUX_KEYS_BASE = [
 
 
 def flux_keys(model: str):
+    if model == "Hbv_2_hourly":
+        return ["Qs", "streamflow"]  # hbv_2_hourly.py:740-741,790-796
     keys = list(FLUX_KEYS_BASE)
     if model in ("Hbv_1_1p", "Hbv_2"):
         keys.append("capillary")
@@ -122,15 +138,23 @@ def build_inputs(name: str) -> dict:
     order = [["prcp", "tmean", "pet"].index(v) for v in variables]
     out["x_phy"] = np.ascontiguousarray(x[:, :, order])
     n = n_phy(spec)
-    routing = cfg.get("routing", model != "Hbv_2")
-    if model == "Hbv_2":
-        dyn = cfg["dynamic_params"].get("Hbv_2", [])
+    routing = cfg.get("routing", model not in ("Hbv_2", "Hbv_2_hourly"))
+    if model in ("Hbv_2", "Hbv_2_hourly"):
+        dyn = cfg["dynamic_params"].get(model, [])
         n_dy = len(dyn)
         out["p_dyn"] = synth.unit_parameters((T, B, n_dy * nmul), seed, 4)
         out["p_sta"] = synth.unit_parameters((B, (n - n_dy) * nmul + (2 if routing else 0)),
                                              seed, 6)
         out["ac_all"] = (synth.uniform((B,), seed, 7) * np.float32(5000.0)).astype(np.float32)
         out["elev_all"] = (synth.uniform((B,), seed, 8) * np.float32(3000.0)).astype(np.float32)
+        if model == "Hbv_2_hourly":
+            G = spec["G"]
+            topo = (synth.uniform((G, B), seed, 13) < np.float32(0.45)).astype(np.float32)
+            topo[np.arange(B) % G, np.arange(B)] = 1.0  # every unit drains to at least one gage
+            out["outlet_topo"] = topo
+            out["areas"] = (synth.uniform((B,), seed, 14) * np.float32(90.0) + np.float32(5.0)).astype(np.float32)
+            out["p_distr"] = synth.unit_parameters((int(topo.sum()), 3), seed, 15)
+            out["x_phy"] = out["x_phy"] * np.array([1.0 / 8.0, 1.0, 1.0 / 24.0], np.float32)[order]
     else:
         ny = n * nmul + 2
         out["parameters"] = synth.raw_parameters(T, B, ny, seed, spec.get("raw_scale", 1.0))

@@ -38,13 +38,19 @@ def run_case(name: str, device: str):
     x_dict = {"x_phy": x}
     if "muwts" in inp:
         x_dict["muwts"] = torch.from_numpy(inp["muwts"]).to(dev)
-    if spec["model"] == "Hbv_2":
+    if spec["model"] in ("Hbv_2", "Hbv_2_hourly"):
         pd = torch.from_numpy(inp["p_dyn"]).to(dev).requires_grad_(True)
         ps = torch.from_numpy(inp["p_sta"]).to(dev).requires_grad_(True)
         x_dict["ac_all"] = torch.from_numpy(inp["ac_all"]).to(dev)
         x_dict["elev_all"] = torch.from_numpy(inp["elev_all"]).to(dev)
         params = (pd, ps)
         leaves = [("p_dyn", pd), ("p_sta", ps)]
+        if spec["model"] == "Hbv_2_hourly":
+            pr = torch.from_numpy(inp["p_distr"]).to(dev).requires_grad_(True)
+            x_dict["outlet_topo"] = torch.from_numpy(inp["outlet_topo"]).to(dev)
+            x_dict["areas"] = torch.from_numpy(inp["areas"]).to(dev)
+            params = (pd, ps, pr)
+            leaves.append(("p_distr", pr))
     else:
         p = torch.from_numpy(inp["parameters"]).to(dev).requires_grad_(True)
         params = p

@@ -179,6 +179,7 @@ static void run_bwd(const hbvx_desc &d, const hbvx_bwd_io &io)
     if (d->model == HBVX_MODEL_HBV10 && d->n_param == 12) fn<MODEL_HBV10, false>(__VA_ARGS__);   \
     else if (d->model == HBVX_MODEL_HBV10) fn<MODEL_HBV10, true>(__VA_ARGS__);                  \
     else if (d->model == HBVX_MODEL_HBV11P) fn<MODEL_HBV11P, true>(__VA_ARGS__);                \
+    else if (d->model == HBVX_MODEL_HOURLY) fn<MODEL_HOURLY, true>(__VA_ARGS__);                \
     else fn<MODEL_HBV20, true>(__VA_ARGS__);
 
 extern "C" int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *o, void *)

@@ -28,6 +28,8 @@ ORACLE_CASES = [
     dict(model="Hbv_1_1p", T=250, B=23, M=16,
          dyn=tuple(gc.PHY_NAMES["Hbv_1_1p"])),
     dict(model="Hbv_2", T=250, B=40, M=8, dyn=("parBETA", "parK0", "parBETAET")),
+    dict(model="Hbv_2_hourly", T=300, B=21, M=16, dyn=("parBETA", "parK0", "parF0")),
+    dict(model="Hbv_2_hourly", T=200, B=9, M=4, dyn=(), cold=True),
 ]
 
 
@@ -38,7 +40,8 @@ def test_hip_matches_oracle(kw, hip_backend, oracle_path):
     got = run_problem(prob, None, device="cuda:0", x_grad=True)
     want = run_problem(prob, oracle_path, device="cpu", x_grad=True)
     for k in ("flux", "routed", "state_out", "traj"):
-        assert_close(k, got[k], want[k], 1e-4, 1e-5)
+        if k in want:
+            assert_close(k, got[k], want[k], 1e-4, 1e-5)
     for k in ("g_params", "g_x") + (("g_muwts",) if "g_muwts" in want else ()):
         assert_close(k, got[k], want[k], 1e-3, 1e-5)
 
@@ -61,7 +64,8 @@ def test_kernel_variants_and_tile_shapes(kw, env, hip_backend, oracle_path, monk
     got = run_problem(prob, None, device="cuda:0", x_grad=True)
     want = run_problem(prob, oracle_path, device="cpu", x_grad=True)
     for k in ("flux", "routed", "state_out", "traj"):
-        assert_close(k, got[k], want[k], 1e-4, 1e-5)
+        if k in want:
+            assert_close(k, got[k], want[k], 1e-4, 1e-5)
     for k in ("g_params", "g_x") + (("g_muwts",) if "g_muwts" in want else ()):
         assert_close(k, got[k], want[k], 1e-3, 1e-5)
 

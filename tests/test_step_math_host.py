@@ -30,6 +30,8 @@ CASES = [
     dict(model="Hbv", M=3, dyn=("parK0", "parTT"), muwts=True, cold=True, raw_scale=2.0),
     dict(model="Hbv_1_1p", M=2, dyn=("parBETA", "parFC", "parC", "parBETAET"), cold=True),
     dict(model="Hbv_2", M=4, dyn=("parBETA", "parK0", "parRT", "parAC")),
+    dict(model="Hbv_2_hourly", M=4, dyn=("parBETA", "parF0", "parALPHA", "parBETAET"), drop_frac=0.3),
+    dict(model="Hbv_2_hourly", M=2, dyn=(), cold=True, raw_scale=2.0),
 ]
 
 
