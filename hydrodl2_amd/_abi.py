@@ -9,8 +9,9 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_PARAM = 20
+GAGE_MAXLEN = 72
 NSTATE = 5
 MAX_FLUX = 12
 UH_MAXLEN = 15
@@ -75,9 +76,20 @@ class RouteDesc(C.Structure):
                 ("b_hi", C.c_float)]
 
 
+class GageDesc(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("T", C.c_int32), ("U", C.c_int32), ("G", C.c_int32),
+                ("NPAIR", C.c_int32), ("L", C.c_int32), ("lag_uh", C.c_int32),
+                ("reserved0", C.c_int32),
+                ("pair_unit", _fp), ("gage_ptr", _fp), ("pair_gage", _fp), ("unit_ptr", _fp),
+                ("unit_pairs", _fp), ("areas", _fp), ("denom", _fp), ("dp", _fp),
+                ("a_lo", C.c_float), ("a_hi", C.c_float), ("b_lo", C.c_float), ("b_hi", C.c_float),
+                ("tau_lo", C.c_float), ("tau_hi", C.c_float)]
+
+
 EXPORTS = ["hbvx_version", "hbvx_last_error", "hbvx_backend", "hbvx_sizeof", "hbvx_forward",
            "hbvx_backward", "hbvx_backward_workspace_bytes", "hbvx_route_forward", "hbvx_route_workspace_bytes",
-           "hbvx_route_backward", "hbvx_adj_forward", "hbvx_adj_backward", "hbvx_bfi"]
+           "hbvx_route_backward", "hbvx_adj_forward", "hbvx_adj_backward", "hbvx_bfi",
+           "hbvx_gage_route_forward", "hbvx_gage_route_backward"]
 
 
 class HbvxError(RuntimeError):
@@ -118,11 +130,15 @@ class Library:
             fn.restype = C.c_int
         d.hbvx_adj_forward.argtypes = [C.POINTER(Desc), C.POINTER(FwdOut), C.c_void_p]
         d.hbvx_adj_backward.argtypes = [C.POINTER(Desc), C.POINTER(BwdIO), C.c_void_p]
+        d.hbvx_gage_route_forward.restype = C.c_int
+        d.hbvx_gage_route_forward.argtypes = [C.POINTER(GageDesc), _fp, _fp, _fp, C.c_void_p]
+        d.hbvx_gage_route_backward.restype = C.c_int
+        d.hbvx_gage_route_backward.argtypes = [C.POINTER(GageDesc), _fp, _fp, _fp, _fp, _fp, C.c_void_p]
         d.hbvx_bfi.restype = C.c_int
         d.hbvx_bfi.argtypes = [C.c_int32, C.c_int32, _fp, _fp, C.c_float, _fp, C.c_void_p]
         if d.hbvx_version() != ABI_VERSION:
             raise HbvxError(f"{path}: ABI version {d.hbvx_version()} != {ABI_VERSION}")
-        for which, st in enumerate([Desc, FwdOut, BwdIO, RouteDesc, ParamSrc, ParamGrad]):
+        for which, st in enumerate([Desc, FwdOut, BwdIO, RouteDesc, ParamSrc, ParamGrad, GageDesc]):
             if d.hbvx_sizeof(which) != C.sizeof(st):
                 raise HbvxError(f"{path}: layout mismatch for {st.__name__}: "
                                 f"{d.hbvx_sizeof(which)} != {C.sizeof(st)}")
@@ -155,6 +171,15 @@ class Library:
     def adj_backward(self, desc: Desc, io: BwdIO, stream: int):
         self._check(self.dll.hbvx_adj_backward(C.byref(desc), C.byref(io), C.c_void_p(stream)),
                     "hbvx_adj_backward")
+
+    def gage_route_forward(self, r: GageDesc, qs: int, uh: int, out: int, stream: int):
+        self._check(self.dll.hbvx_gage_route_forward(C.byref(r), qs, uh, out, C.c_void_p(stream)),
+                    "hbvx_gage_route_forward")
+
+    def gage_route_backward(self, r: GageDesc, qs: int, uh: int, go: int, gqs: int, gdp: int,
+                            stream: int):
+        self._check(self.dll.hbvx_gage_route_backward(C.byref(r), qs, uh, go, gqs, gdp,
+                                                      C.c_void_p(stream)), "hbvx_gage_route_backward")
 
     def bfi(self, T: int, B: int, qs: int, q2: int, nearzero: float, out: int, stream: int):
         self._check(self.dll.hbvx_bfi(T, B, qs, q2, C.c_float(nearzero), out, C.c_void_p(stream)),

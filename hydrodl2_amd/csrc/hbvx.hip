@@ -18,6 +18,7 @@
 #include "hbv_step.h"
 #include "hbv_tiled.h"
 #include "hbv_adj_kernels.h"
+#include "hbv_gage.h"
 #include "hbv_chunked.h"
 #include "hbv_pipe.h"
 
@@ -50,6 +51,7 @@ extern "C" uint64_t hbvx_sizeof(int which)
     case 1: return sizeof(hbvx_fwd_out);
     case 2: return sizeof(hbvx_bwd_io);
     case 3: return sizeof(hbvx_route_desc);
+    case 6: return sizeof(hbvx_gage_desc);
     case 4: return sizeof(hbvx_param_src);
     case 5: return sizeof(hbvx_param_grad);
     default: return 0;
@@ -1114,5 +1116,53 @@ extern "C" int hbvx_bfi(int32_t T, int32_t B, const float *qs, const float *q2, 
                        nearzero, bfi);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "hbvx_bfi launch");
+    return HBVX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// gage routing (hbv_2_hourly.py:800-897)
+// ---------------------------------------------------------------------------
+static int check_gage(const hbvx_gage_desc *r)
+{
+    if (!r) return fail(HBVX_E_NULL, "gage desc is NULL");
+    if (r->abi_version != HBVX_ABI_VERSION) return fail(HBVX_E_ABI, "abi_version mismatch");
+    if (r->T <= 0 || r->U <= 0 || r->G <= 0 || r->NPAIR < 0) return fail(HBVX_E_SHAPE, "bad T/U/G/NPAIR");
+    int L = r->T < HBVX_GAGE_MAXLEN ? r->T : HBVX_GAGE_MAXLEN;
+    if (r->L != L) return fail(HBVX_E_SHAPE, "L must be min(T, 72)");
+    if (r->U > 65535 || r->G > 65535) return fail(HBVX_E_SHAPE, "more than 65535 units or gages per call");
+    if (!r->pair_unit || !r->gage_ptr || !r->pair_gage || !r->unit_ptr || !r->unit_pairs || !r->areas ||
+        !r->denom || !r->dp)
+        return fail(HBVX_E_NULL, "gage routing pointer is NULL");
+    return HBVX_OK;
+}
+
+extern "C" int hbvx_gage_route_forward(const hbvx_gage_desc *r, const float *qs, float *uh, float *out,
+                                       void *stream)
+{
+    int rc = check_gage(r);
+    if (rc) return rc;
+    if (!qs || !uh || !out) return fail(HBVX_E_NULL, "gage routing buffer is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    if (r->NPAIR > 0) hipLaunchKernelGGL(k_gage_uh, dim3((r->NPAIR + 63) / 64), dim3(64), 0, st, *r, uh);
+    hipLaunchKernelGGL(k_gage_fwd, dim3((r->T + GAGE_TILE - 1) / GAGE_TILE, r->G), dim3(GAGE_TILE), 0, st, *r,
+                       qs, uh, out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "hbvx_gage_route_forward launch");
+    return HBVX_OK;
+}
+
+extern "C" int hbvx_gage_route_backward(const hbvx_gage_desc *r, const float *qs, const float *uh,
+                                        const float *grad_out, float *grad_qs, float *grad_dp, void *stream)
+{
+    int rc = check_gage(r);
+    if (rc) return rc;
+    if (!qs || !uh || !grad_out || !grad_qs || !grad_dp) return fail(HBVX_E_NULL, "gage routing buffer is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_gage_bwd_q, dim3((r->T + GAGE_TILE - 1) / GAGE_TILE, r->U), dim3(GAGE_TILE), 0, st, *r,
+                       uh, grad_out, grad_qs);
+    if (r->NPAIR > 0)
+        hipLaunchKernelGGL(k_gage_bwd_p, dim3(r->NPAIR), dim3(GAGE_TILE), 0, st, *r, qs, grad_out, grad_dp);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "hbvx_gage_route_backward launch");
     return HBVX_OK;
 }

@@ -7,50 +7,18 @@ tuple (dynamic [T,B,n_dy*nmul], static [B,n_st*nmul(+2)], distributed-routing [n
 [0,1]; needs `ac_all`, `elev_all`, `outlet_topo` [gages,units] and `areas` [units]; returns
 {'Qs': unit runoff [T,B,1], 'streamflow': gage streamflow [T,G,1]}.
 
-What runs where (round 1): the sub-daily recurrence, parameter prep, ensemble mean and their
-adjoint run in the HIP library (`Step<MODEL_HOURLY>`, csrc/hbv_step_hourly.h).  The 72-tap
-lagged-UH gage routing (hbv_2_hourly.py:800-897) and the optional 72-tap unit routing (:693-700)
-are still expressed with torch ops here (conv1d / scatter_add on the GPU) -- the next kernels to
-write; they are O(pairs x T x 72) and not on the recurrence's serial path.
+Everything numerical runs in the HIP library: the sub-daily recurrence, parameter prep,
+ensemble mean and their adjoint (`Step<MODEL_HOURLY>`, csrc/hbv_step_hourly.h), and the 72-tap
+lagged-UH gage routing (hbv_2_hourly.py:800-897) through `hbvx_gage_route_*`; the optional
+72-tap per-unit routing (:693-700) is the same entry point with the identity topology.
 """
 from typing import Any, Optional
 
 import torch
-import torch.nn.functional as F
 
 from hydrodl2_amd import _abi
 from hydrodl2_amd.core.hbv_module import HbvModule
-from hydrodl2_amd.ops import HbvPath, ParamSource, StepConfig
-
-
-def _uh_gamma(a: torch.Tensor, b: torch.Tensor, L: int) -> torch.Tensor:
-    """Normalised gamma unit hydrograph [L,P] for shape a [P] and scale b [P]
-    (core/calc/uh_routing.py:5-22)."""
-    aa = torch.relu(a) + 0.1
-    theta = torch.relu(b) + 0.5
-    t = torch.arange(0.5, L * 1.0, device=a.device, dtype=a.dtype).unsqueeze(1)
-    w = 1 / (aa.lgamma().exp() * theta ** aa) * t ** (aa - 1) * torch.exp(-t / theta)
-    return w / w.sum(0)
-
-
-def _frac_shift(w: torch.Tensor, tau: torch.Tensor) -> torch.Tensor:
-    """w(t - tau) by mixing the floor(tau)- and floor(tau)+1-step shifts, zero padded
-    (hbv_2_hourly.py:857-897).  w [L,P], tau [P]."""
-    L = w.shape[0]
-    k = torch.floor(tau).unsqueeze(0)
-    f = tau.unsqueeze(0) - k
-    t = torch.arange(L, device=w.device, dtype=w.dtype).unsqueeze(1)
-    i0, i1 = t - k, t - (k + 1)
-    w0 = torch.gather(w, 0, i0.clamp(0, L - 1).long()) * ((i0 >= 0) & (i0 <= L - 1)).to(w.dtype)
-    w1 = torch.gather(w, 0, i1.clamp(0, L - 1).long()) * ((i1 >= 0) & (i1 <= L - 1)).to(w.dtype)
-    return (1.0 - f) * w0 + f * w1
-
-
-def _causal_fir(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
-    """y[t,p] = sum_k w[k,p] x[t-k,p], zero history (core/calc/uh_routing.py:25-57). x [T,P], w [L,P]."""
-    P, L = x.shape[1], w.shape[0]
-    y = F.conv1d(x.t().unsqueeze(0), torch.flip(w.t().unsqueeze(1), [2]), groups=P, padding=L - 1)
-    return y[0, :, : x.shape[0]].t()
+from hydrodl2_amd.ops import GageRoute, GageTopology, HbvPath, ParamSource, StepConfig
 
 
 class Hbv_2_hourly(HbvModule):
@@ -156,11 +124,15 @@ class Hbv_2_hourly(HbvModule):
             return {}
 
         Qs = flux[_abi.F_QSIM]                                            # [T,B] rate per day
-        if self.routing:                                                  # :684-700 (torch, see module doc)
+        if self.routing:                                                  # :684-700
             off = (n - n_dy) * M
-            ra = p_sta[:, off] * 5.0
-            rb = p_sta[:, off + 1] * 12.0
-            Qs = _causal_fir(Qs, _uh_gamma(ra, rb, min(T, self.lenF)))
+            eye = torch.eye(ngrid, device=x.device)
+            rb_ = self.routing_parameter_bounds
+            topo = GageTopology.from_outlet_topo(
+                eye, torch.ones(ngrid, device=x.device), T, False,
+                (rb_['route_a'], rb_['route_b'], (0.0, 0.0)))
+            dp = torch.cat([p_sta[:, off:off + 2], torch.zeros_like(p_sta[:, :1])], dim=1)
+            Qs = GageRoute.apply(topo, Qs, dp)
         Qs = (Qs * self.dt).unsqueeze(-1)                                 # :741
         out = {'Qs': Qs}
         if not self.warm_up_states:
@@ -181,20 +153,8 @@ class Hbv_2_hourly(HbvModule):
         """Gage streamflow from unit runoff: area-weighted, per (gage, unit) pair a gamma unit
         hydrograph of 72 taps shifted by route_tau, summed per gage and normalised by the upstream
         area (hbv_2_hourly.py:800-855).  Qs [T,U,1] -> [T,G,1]."""
-        T = Qs.shape[0]
         b = self.distr_parameter_bounds
-        a = p_distr[:, 0] * (b['route_a'][1] - b['route_a'][0]) + b['route_a'][0]
-        bb = p_distr[:, 1] * (b['route_b'][1] - b['route_b'][0]) + b['route_b'][0]
-        tau = p_distr[:, 2] * (b['route_tau'][1] - b['route_tau'][0]) + b['route_tau'][0]
-        pairs = (outlet_topo == 1).nonzero(as_tuple=False)
-        rows, cols = pairs[:, 0].long(), pairs[:, 1].long()
-        qp = (Qs[:, :, 0] * areas[None, :])[:, cols]                      # [T,P]
-        uh = _uh_gamma(a, bb, min(T, self.lenF))
-        if self.lag_uh:
-            uh = _frac_shift(uh, tau)
-        lagged = _causal_fir(qp, uh)                                      # [T,P]
-        G = int(outlet_topo.shape[0])
-        acc = torch.zeros((T, G), device=lagged.device, dtype=lagged.dtype)
-        acc.index_add_(1, rows, lagged)
-        denom = (outlet_topo * areas[None, :]).sum(dim=1).clamp(min=1e-6)
-        return (acc / denom[None, :]).unsqueeze(-1)
+        topo = GageTopology.from_outlet_topo(
+            outlet_topo, areas, int(Qs.shape[0]), self.lag_uh,
+            (b['route_a'], b['route_b'], b['route_tau']))
+        return GageRoute.apply(topo, Qs[:, :, 0], p_distr).unsqueeze(-1)

@@ -391,3 +391,95 @@ class Bfi(torch.autograd.Function):
         g_q2 = (100.0 * g / den).unsqueeze(0).expand_as(q2)
         g_qs = (-100.0 * g * num / (den * den)).unsqueeze(0).expand_as(qs)
         return g_qs, g_q2, None
+
+
+@dataclass
+class GageTopology:
+    """Index arrays of the (gage, unit) pairs of `outlet_topo == 1` (hbv_2_hourly.py:813-817), in
+    the order `nonzero` yields them (by gage, then unit) plus the unit-side CSR of the backward."""
+
+    T: int = 0
+    U: int = 0
+    G: int = 0
+    n_pair: int = 0
+    lag_uh: bool = True
+    bounds: tuple = ((0.0, 5.0), (0.0, 12.0), (0.0, 48.0))
+    pair_unit: Optional[torch.Tensor] = None
+    pair_gage: Optional[torch.Tensor] = None
+    gage_ptr: Optional[torch.Tensor] = None
+    unit_ptr: Optional[torch.Tensor] = None
+    unit_pairs: Optional[torch.Tensor] = None
+    areas: Optional[torch.Tensor] = None
+    denom: Optional[torch.Tensor] = None
+
+    @staticmethod
+    def from_outlet_topo(outlet_topo: torch.Tensor, areas: torch.Tensor, T: int, lag_uh: bool,
+                         bounds) -> "GageTopology":
+        G, U = int(outlet_topo.shape[0]), int(outlet_topo.shape[1])
+        pairs = (outlet_topo == 1).nonzero(as_tuple=False)
+        rows, cols = pairs[:, 0], pairs[:, 1]
+        dev = outlet_topo.device
+
+        def csr(idx, n):
+            ptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+            ptr[1:] = torch.cumsum(torch.bincount(idx, minlength=n), 0)
+            return ptr.to(torch.int32)
+
+        areas32 = areas.to(torch.float32).contiguous()
+        denom = (outlet_topo.to(torch.float32) * areas32[None, :]).sum(dim=1).clamp(min=1e-6)
+        return GageTopology(
+            T=T, U=U, G=G, n_pair=int(rows.numel()), lag_uh=lag_uh, bounds=tuple(map(tuple, bounds)),
+            pair_unit=cols.to(torch.int32).contiguous(), pair_gage=rows.to(torch.int32).contiguous(),
+            gage_ptr=csr(rows, G), unit_ptr=csr(cols, U),
+            unit_pairs=torch.argsort(cols, stable=True).to(torch.int32).contiguous(),
+            areas=areas32, denom=denom.contiguous())
+
+    def desc(self, dp: torch.Tensor) -> _abi.GageDesc:
+        (alo, ahi), (blo, bhi), (tlo, thi) = self.bounds
+        return _abi.GageDesc(
+            abi_version=_abi.ABI_VERSION, T=self.T, U=self.U, G=self.G, NPAIR=self.n_pair,
+            L=min(self.T, _abi.GAGE_MAXLEN), lag_uh=int(self.lag_uh),
+            pair_unit=self.pair_unit.data_ptr(), gage_ptr=self.gage_ptr.data_ptr(),
+            pair_gage=self.pair_gage.data_ptr(), unit_ptr=self.unit_ptr.data_ptr(),
+            unit_pairs=self.unit_pairs.data_ptr(), areas=self.areas.data_ptr(),
+            denom=self.denom.data_ptr(), dp=dp.data_ptr(),
+            a_lo=alo, a_hi=ahi, b_lo=blo, b_hi=bhi, tau_lo=tlo, tau_hi=thi)
+
+
+class GageRoute(torch.autograd.Function):
+    """Unit runoff [T,U] -> gage streamflow [T,G] through hbvx_gage_route_forward / _backward
+    (hbv_2_hourly.py:800-897)."""
+
+    @staticmethod
+    def forward(ctx, topo: GageTopology, qs, dp):
+        lib = get_library()
+        qs_c, dp_c = qs.contiguous(), dp.contiguous()
+        _check_tensor(lib, qs_c, 'Qs')
+        _check_tensor(lib, dp_c, 'distributed routing parameters')
+        if tuple(qs_c.shape) != (topo.T, topo.U):
+            raise ValueError(f"Qs has shape {tuple(qs_c.shape)}, topology expects {(topo.T, topo.U)}")
+        if tuple(dp_c.shape) != (topo.n_pair, 3):
+            raise ValueError(f"distributed routing parameters have shape {tuple(dp_c.shape)}, "
+                             f"outlet_topo has {topo.n_pair} (gage, unit) pairs x 3")
+        L = min(topo.T, _abi.GAGE_MAXLEN)
+        uh = torch.empty((topo.n_pair, L), dtype=torch.float32, device=qs.device)
+        out = torch.empty((topo.T, topo.G), dtype=torch.float32, device=qs.device)
+        r = topo.desc(dp_c)
+        _call(lib, 'hbvx_gage_route_forward', lib.gage_route_forward, r, _ptr(qs_c), _ptr(uh),
+              _ptr(out), _stream_of(lib, qs_c))
+        ctx.topo = topo
+        ctx.save_for_backward(qs_c, dp_c, uh)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = get_library()
+        qs, dp, uh = ctx.saved_tensors
+        topo = ctx.topo
+        g = g.contiguous()
+        gqs = torch.empty_like(qs)
+        gdp = torch.empty_like(dp)
+        r = topo.desc(dp)
+        _call(lib, 'hbvx_gage_route_backward', lib.gage_route_backward, r, _ptr(qs), _ptr(uh),
+              _ptr(g), _ptr(gqs), _ptr(gdp), _stream_of(lib, qs))
+        return None, gqs, gdp

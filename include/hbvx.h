@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define HBVX_ABI_VERSION 4
+#define HBVX_ABI_VERSION 5
 #define HBVX_MAX_PARAM 20
 #define HBVX_NSTATE 5   /* SNOWPACK, MELTWATER, SM, SUZ, SLZ  (hbv.py:61-67) */
 #define HBVX_MAX_FLUX 12
@@ -180,7 +180,7 @@ int hbvx_version(void);                 /* HBVX_ABI_VERSION */
 const char *hbvx_last_error(void);
 const char *hbvx_backend(void);         /* "hip:gfx950" or "cpu-oracle" */
 uint64_t hbvx_sizeof(int which);        /* 0 desc, 1 fwd_out, 2 bwd_io, 3 route_desc,
-                                           4 param_src, 5 param_grad: layout check */
+                                           4 param_src, 5 param_grad, 6 gage_desc: layout check */
 
 int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream);
 int hbvx_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *stream);
@@ -204,6 +204,40 @@ int hbvx_route_backward(const hbvx_route_desc *r, const float *q, const float *u
                         const float *grad_q_rout, float *grad_q, float *grad_ra,
                         float *grad_rb, void *workspace, uint64_t workspace_bytes,
                         void *stream);
+
+/* Gage routing of unit runoff (hbv_2_hourly.py:800-897 `distr_routing` + `_frac_shift1d`): for every
+ * (gage, unit) pair with outlet_topo == 1 a normalised gamma unit hydrograph of L = min(T, 72)
+ * taps (core/calc/uh_routing.py:5-22), shifted by tau = k + f as (1-f) w[t-k] + f w[t-k-1] with zero
+ * padding when lag_uh; out[t,g] = sum_{pairs of g} sum_k uh[p,k] qs[t-k,unit(p)] areas[unit(p)] / denom[g].
+ * With the identity topology (one pair per unit, areas = denom = 1, lag_uh = 0) this is the
+ * 72-tap per-unit routing of hbv_2_hourly.py:693-700.
+ * Index arrays are built by the caller from outlet_topo: pairs sorted by gage (gage_ptr: CSR over
+ * gages) and, for the backward gather, the pair indices grouped by unit (unit_ptr / unit_pairs). */
+#define HBVX_GAGE_MAXLEN 72
+typedef struct hbvx_gage_desc {
+    int32_t abi_version;
+    int32_t T, U, G;           /* steps, units, gages */
+    int32_t NPAIR;             /* (gage, unit) pairs */
+    int32_t L;                 /* min(T, 72) */
+    int32_t lag_uh;            /* apply the fractional shift by route_tau */
+    int32_t reserved0;
+    const int32_t *pair_unit;  /* [NPAIR] unit of each pair, pairs ordered by gage */
+    const int32_t *gage_ptr;   /* [G+1] pairs of gage g: gage_ptr[g] .. gage_ptr[g+1]-1 */
+    const int32_t *pair_gage;  /* [NPAIR] gage of each pair */
+    const int32_t *unit_ptr;   /* [U+1] CSR over units into unit_pairs */
+    const int32_t *unit_pairs; /* [NPAIR] pair indices grouped by unit */
+    const float *areas;        /* [U] */
+    const float *denom;        /* [G] upstream area of each gage, clamped at 1e-6 (:849) */
+    const float *dp;           /* [NPAIR,3] unit-interval route_a, route_b, route_tau (contiguous) */
+    float a_lo, a_hi, b_lo, b_hi, tau_lo, tau_hi; /* distr_parameter_bounds (:120-124) */
+} hbvx_gage_desc;
+
+/* qs [T,U] -> uh [NPAIR,L] (the lagged unit hydrographs, kept for the backward) and out [T,G]. */
+int hbvx_gage_route_forward(const hbvx_gage_desc *r, const float *qs, float *uh, float *out,
+                            void *stream);
+/* grad_out [T,G] -> grad_qs [T,U] and grad_dp [NPAIR,3] (both overwritten). */
+int hbvx_gage_route_backward(const hbvx_gage_desc *r, const float *qs, const float *uh,
+                             const float *grad_out, float *grad_qs, float *grad_dp, void *stream);
 
 /* Implicit HBV ("HBV adjoint", hbv_adj.py): per day solve G(x) = (x - x_t)/dt - f(x, theta_t, t) = 0
  * (hbv_adj.py:669-687) by modified Newton (hbv_adj.py:507-581) with the analytic 5x5 Jacobian;

@@ -52,6 +52,7 @@ uint64_t hbvx_sizeof(int which)
     case 3: return sizeof(hbvx_route_desc);
     case 4: return sizeof(hbvx_param_src);
     case 5: return sizeof(hbvx_param_grad);
+    case 6: return sizeof(hbvx_gage_desc);
     default: return 0;
     }
 }
@@ -1117,6 +1118,127 @@ int hbvx_bfi(int32_t T, int32_t B, const float *qs, const float *q2, float nearz
             s2 += q2[(int64_t)t * B + b];
         }
         bfi[b] = 100.0f * (s2 / (s0 + nearzero));
+    }
+    return HBVX_OK;
+}
+
+/* ------------------------------------------------------------------ */
+/* gage routing: hbv_2_hourly.py:800-897                                 */
+
+static int check_gage(const hbvx_gage_desc *r)
+{
+    if (!r) return fail(HBVX_E_NULL, "gage desc is NULL");
+    if (r->abi_version != HBVX_ABI_VERSION) return fail(HBVX_E_ABI, "abi_version mismatch");
+    if (r->T <= 0 || r->U <= 0 || r->G <= 0 || r->NPAIR < 0) return fail(HBVX_E_SHAPE, "bad T/U/G/NPAIR");
+    int L = r->T < HBVX_GAGE_MAXLEN ? r->T : HBVX_GAGE_MAXLEN;
+    if (r->L != L) return fail(HBVX_E_SHAPE, "L must be min(T, 72)");
+    if (!r->pair_unit || !r->gage_ptr || !r->pair_gage || !r->unit_ptr || !r->unit_pairs || !r->areas ||
+        !r->denom || !r->dp)
+        return fail(HBVX_E_NULL, "gage routing pointer is NULL");
+    return HBVX_OK;
+}
+
+/* uh_gamma (uh_routing.py:5-22) then _frac_shift1d (hbv_2_hourly.py:857-897) for one pair */
+static void gage_uh_one(const hbvx_gage_desc *r, int p, float *w, float *us, float *kk_out, float *f_out)
+{
+    const int L = r->L;
+    float a = descale(r->dp[p * 3 + 0], r->a_lo, r->a_hi);
+    float b = descale(r->dp[p * 3 + 1], r->b_lo, r->b_hi);
+    float tau = descale(r->dp[p * 3 + 2], r->tau_lo, r->tau_hi);
+    float aa = fmaxf(a, 0.0f) + 0.1f, theta = fmaxf(b, 0.0f) + 0.5f;
+    float denom = expf(lgammaf(aa)) * powf(theta, aa), sum = 0.0f;
+    for (int k = 0; k < L; k++) {
+        float t = (float)k + 0.5f;
+        w[k] = 1.0f / denom * powf(t, aa - 1.0f) * expf(-t / theta);
+        sum += w[k];
+    }
+    for (int k = 0; k < L; k++) w[k] = w[k] / sum;
+    float kk = floorf(tau), f = tau - kk;
+    if (!r->lag_uh) { kk = 0.0f; f = 0.0f; }
+    for (int k = 0; k < L; k++) {
+        float i0 = (float)k - kk, i1 = (float)k - (kk + 1.0f);
+        float w0 = (i0 >= 0.0f && i0 <= (float)(L - 1)) ? w[(int)i0] : 0.0f;
+        float w1 = (i1 >= 0.0f && i1 <= (float)(L - 1)) ? w[(int)i1] : 0.0f;
+        us[k] = r->lag_uh ? (1.0f - f) * w0 + f * w1 : w[k];
+    }
+    *kk_out = kk;
+    *f_out = f;
+}
+
+int hbvx_gage_route_forward(const hbvx_gage_desc *r, const float *qs, float *uh, float *out, void *stream)
+{
+    (void)stream;
+    int rc = check_gage(r);
+    if (rc) return rc;
+    if (!qs || !uh || !out) return fail(HBVX_E_NULL, "gage routing buffer is NULL");
+    const int T = r->T, U = r->U, G = r->G, L = r->L;
+    for (int p = 0; p < r->NPAIR; p++) {
+        float w[HBVX_GAGE_MAXLEN], kk, f;
+        gage_uh_one(r, p, w, uh + (int64_t)p * L, &kk, &f);
+    }
+    for (int g = 0; g < G; g++)
+        for (int t = 0; t < T; t++) {
+            float acc = 0.0f;
+            for (int p = r->gage_ptr[g]; p < r->gage_ptr[g + 1]; p++) {
+                const int u = r->pair_unit[p];
+                float y = 0.0f; /* uh_conv of the area-weighted unit series (:819-837) */
+                for (int k = 0; k < L && k <= t; k++)
+                    y += uh[(int64_t)p * L + k] * (qs[(int64_t)(t - k) * U + u] * r->areas[u]);
+                acc += y; /* scatter_add_ over the pairs of the gage (:841-846) */
+            }
+            out[(int64_t)t * G + g] = acc / r->denom[g]; /* :849-850 */
+        }
+    return HBVX_OK;
+}
+
+int hbvx_gage_route_backward(const hbvx_gage_desc *r, const float *qs, const float *uh,
+                             const float *grad_out, float *grad_qs, float *grad_dp, void *stream)
+{
+    (void)stream;
+    int rc = check_gage(r);
+    if (rc) return rc;
+    if (!qs || !uh || !grad_out || !grad_qs || !grad_dp) return fail(HBVX_E_NULL, "gage routing buffer is NULL");
+    const int T = r->T, U = r->U, G = r->G, L = r->L;
+    for (int64_t i = 0; i < (int64_t)T * U; i++) grad_qs[i] = 0.0f;
+    for (int p = 0; p < r->NPAIR; p++) {
+        const int u = r->pair_unit[p], g = r->pair_gage[p];
+        double guh[HBVX_GAGE_MAXLEN];
+        for (int k = 0; k < L; k++) guh[k] = 0.0;
+        for (int t = 0; t < T; t++) {
+            const float go = grad_out[(int64_t)t * G + g] / r->denom[g];
+            for (int k = 0; k < L && k <= t; k++) {
+                grad_qs[(int64_t)(t - k) * U + u] += go * uh[(int64_t)p * L + k] * r->areas[u];
+                guh[k] += (double)go * (double)(qs[(int64_t)(t - k) * U + u] * r->areas[u]);
+            }
+        }
+        /* shifted UH -> (w, f) -> (aa, theta, tau) */
+        float w[HBVX_GAGE_MAXLEN], us[HBVX_GAGE_MAXLEN], kk, f;
+        gage_uh_one(r, p, w, us, &kk, &f);
+        double gw[HBVX_GAGE_MAXLEN], gf = 0.0;
+        for (int j = 0; j < L; j++) gw[j] = 0.0;
+        if (r->lag_uh) {
+            for (int k = 0; k < L; k++) {
+                int i0 = k - (int)kk, i1 = k - ((int)kk + 1);
+                double w0 = (i0 >= 0 && i0 <= L - 1) ? w[i0] : 0.0, w1 = (i1 >= 0 && i1 <= L - 1) ? w[i1] : 0.0;
+                gf += guh[k] * (w1 - w0);
+                if (i0 >= 0 && i0 <= L - 1) gw[i0] += guh[k] * (1.0 - f);
+                if (i1 >= 0 && i1 <= L - 1) gw[i1] += guh[k] * f;
+            }
+        } else {
+            for (int k = 0; k < L; k++) gw[k] = guh[k];
+        }
+        float a = descale(r->dp[p * 3 + 0], r->a_lo, r->a_hi), b = descale(r->dp[p * 3 + 1], r->b_lo, r->b_hi);
+        double theta = (double)(fmaxf(b, 0.0f) + 0.5f), mlt = 0.0, mt = 0.0;
+        for (int k = 0; k < L; k++) { double tk = k + 0.5; mlt += w[k] * log(tk); mt += w[k] * tk; }
+        double gaa = 0.0, gth = 0.0;
+        for (int k = 0; k < L; k++) {
+            double tk = k + 0.5;
+            gaa += gw[k] * w[k] * (log(tk) - mlt);
+            gth += gw[k] * w[k] * (tk - mt) / (theta * theta);
+        }
+        grad_dp[p * 3 + 0] = (float)(((a > 0.0f) ? gaa : 0.0) * (double)(r->a_hi - r->a_lo));
+        grad_dp[p * 3 + 1] = (float)(((b > 0.0f) ? gth : 0.0) * (double)(r->b_hi - r->b_lo));
+        grad_dp[p * 3 + 2] = (float)((r->lag_uh ? gf : 0.0) * (double)(r->tau_hi - r->tau_lo));
     }
     return HBVX_OK;
 }

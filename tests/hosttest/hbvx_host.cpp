@@ -29,6 +29,7 @@ extern "C" uint64_t hbvx_sizeof(int w)
     case 3: return sizeof(hbvx_route_desc);
     case 4: return sizeof(hbvx_param_src);
     case 5: return sizeof(hbvx_param_grad);
+    case 6: return sizeof(hbvx_gage_desc);
     }
     return 0;
 }
@@ -329,6 +330,22 @@ extern "C" int hbvx_bfi(int32_t T, int32_t B, const float *qs, const float *q2, 
     fn_t fn = (fn_t)oracle_sym("hbvx_bfi");
     if (!fn) { snprintf(g_err, sizeof g_err, "set HBVX_ORACLE_LIB for bfi"); return HBVX_E_UNSUPPORTED; }
     return fn(T, B, qs, q2, nz, bfi, st);
+}
+
+extern "C" int hbvx_gage_route_forward(const hbvx_gage_desc *r, const float *qs, float *uh, float *out, void *st)
+{
+    typedef int (*fn_t)(const hbvx_gage_desc *, const float *, float *, float *, void *);
+    fn_t fn = (fn_t)oracle_sym("hbvx_gage_route_forward");
+    if (!fn) { snprintf(g_err, sizeof g_err, "set HBVX_ORACLE_LIB for gage routing"); return HBVX_E_UNSUPPORTED; }
+    return fn(r, qs, uh, out, st);
+}
+extern "C" int hbvx_gage_route_backward(const hbvx_gage_desc *r, const float *qs, const float *uh,
+                                        const float *go, float *gqs, float *gdp, void *st)
+{
+    typedef int (*fn_t)(const hbvx_gage_desc *, const float *, const float *, const float *, float *, float *, void *);
+    fn_t fn = (fn_t)oracle_sym("hbvx_gage_route_backward");
+    if (!fn) { snprintf(g_err, sizeof g_err, "set HBVX_ORACLE_LIB for gage routing"); return HBVX_E_UNSUPPORTED; }
+    return fn(r, qs, uh, go, gqs, gdp, st);
 }
 
 // accuracy probe for hbvx::pow_pos_ (host build of the same source)

@@ -1,0 +1,123 @@
+"""Gage routing (hbvx_gage_route_*; reference hbv_2_hourly.py:800-897).
+
+CPU tier: the C oracle against a float64 torch restatement of the reference lines (autograd
+gradients) -- on top of the `hourly_*` golden cases, which pin the same entry points to the
+reference itself.  GPU tier: the HIP kernels against the oracle on multi-tile problems.
+Tolerances: outputs rtol 1e-4, gradients rtol 1e-3 (+ 1e-5 of the array's max), fp32 sums.
+"""
+import numpy as np
+import pytest
+import torch
+
+from hydrodl2_amd import _lib
+from hydrodl2_amd.ops import GageRoute, GageTopology
+
+from . import synth
+from .abi_util import assert_close
+
+BOUNDS = ((0.0, 5.0), (0.0, 12.0), (0.0, 48.0))
+
+
+def _problem(T, U, G, seed, dense=0.4):
+    topo = (synth.uniform((G, U), seed, 1) < np.float32(dense)).astype(np.float32)
+    topo[np.arange(U) % G, np.arange(U)] = 1.0
+    if G > 2:
+        topo[G - 1, :] = 0.0  # a gage without units: denominator clamp (:849)
+    return dict(
+        topo=topo,
+        areas=(synth.uniform((U,), seed, 2) * np.float32(80.0) + np.float32(2.0)).astype(np.float32),
+        qs=(synth.uniform((T, U), seed, 3) * np.float32(3.0)).astype(np.float32),
+        dp=synth.unit_parameters((int(topo.sum()), 3), seed, 4),
+        wt=synth.loss_weights((T, G), seed, 5),
+    )
+
+
+def _restatement(pb, lag_uh):
+    """float64 torch restatement of distr_routing / _frac_shift1d."""
+    dt = torch.float64
+    topo = torch.tensor(pb["topo"], dtype=dt)
+    areas = torch.tensor(pb["areas"], dtype=dt)
+    qs = torch.tensor(pb["qs"], dtype=dt, requires_grad=True)
+    dp = torch.tensor(pb["dp"], dtype=dt, requires_grad=True)
+    T = qs.shape[0]
+    L = min(T, 72)
+    a = dp[:, 0] * BOUNDS[0][1]
+    b = dp[:, 1] * BOUNDS[1][1]
+    tau = dp[:, 2] * BOUNDS[2][1]
+    aa, theta = torch.relu(a) + 0.1, torch.relu(b) + 0.5
+    t = torch.arange(0.5, L * 1.0, dtype=dt).unsqueeze(1)
+    w = 1 / (aa.lgamma().exp() * theta ** aa) * t ** (aa - 1) * torch.exp(-t / theta)
+    w = w / w.sum(0)
+    if lag_uh:
+        k = torch.floor(tau).unsqueeze(0)
+        f = tau.unsqueeze(0) - k
+        tt = torch.arange(L, dtype=dt).unsqueeze(1)
+        i0, i1 = tt - k, tt - (k + 1)
+        w0 = torch.gather(w, 0, i0.clamp(0, L - 1).long()) * ((i0 >= 0) & (i0 <= L - 1)).to(dt)
+        w1 = torch.gather(w, 0, i1.clamp(0, L - 1).long()) * ((i1 >= 0) & (i1 <= L - 1)).to(dt)
+        w = (1.0 - f) * w0 + f * w1
+    pairs = (topo == 1).nonzero()
+    rows, cols = pairs[:, 0], pairs[:, 1]
+    qp = (qs * areas[None, :])[:, cols]
+    y = torch.nn.functional.conv1d(qp.t().unsqueeze(0), torch.flip(w.t().unsqueeze(1), [2]),
+                                   groups=qp.shape[1], padding=L - 1)[0, :, :T].t()
+    acc = torch.zeros((T, topo.shape[0]), dtype=dt).index_add(1, rows, y)
+    out = acc / (topo * areas[None, :]).sum(1).clamp(min=1e-6)[None, :]
+    (out * torch.tensor(pb["wt"], dtype=dt)).sum().backward()
+    return out.detach().numpy(), qs.grad.numpy(), dp.grad.numpy()
+
+
+def _run(pb, lag_uh, lib_path, device):
+    _lib._use_library_for_testing(lib_path)
+    try:
+        dev = torch.device(device)
+        topo = GageTopology.from_outlet_topo(torch.tensor(pb["topo"], device=dev),
+                                             torch.tensor(pb["areas"], device=dev),
+                                             pb["qs"].shape[0], lag_uh, BOUNDS)
+        qs = torch.tensor(pb["qs"], device=dev, requires_grad=True)
+        dp = torch.tensor(pb["dp"], device=dev, requires_grad=True)
+        out = GageRoute.apply(topo, qs, dp)
+        (out * torch.tensor(pb["wt"], device=dev)).sum().backward()
+        return out.detach().cpu().numpy(), qs.grad.cpu().numpy(), dp.grad.cpu().numpy()
+    finally:
+        _lib._use_library_for_testing(None)
+
+
+SHAPES = [(130, 9, 3, True), (40, 5, 2, True), (90, 6, 4, False), (300, 12, 5, True)]
+
+
+@pytest.mark.parametrize("T,U,G,lag", SHAPES)
+def test_oracle_matches_float64_restatement(T, U, G, lag, oracle_path):
+    pb = _problem(T, U, G, seed=100 + T)
+    want = _restatement(pb, lag)
+    got = _run(pb, lag, oracle_path, "cpu")
+    assert_close("out", got[0], want[0], 1e-4, 1e-5)
+    assert_close("grad_qs", got[1], want[1], 1e-3, 1e-5)
+    assert_close("grad_dp", got[2], want[2], 1e-3, 1e-5)
+
+
+def test_shape_errors(oracle_path):
+    pb = _problem(50, 4, 2, seed=3)
+    pb["dp"] = pb["dp"][:-1]
+    with pytest.raises(ValueError, match="pairs"):
+        _run(pb, True, oracle_path, "cpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,U,G,lag", SHAPES + [(700, 40, 9, True), (1000, 300, 1, False)])
+def test_hip_matches_oracle(T, U, G, lag, hip_backend, oracle_path):
+    pb = _problem(T, U, G, seed=200 + T)
+    want = _run(pb, lag, oracle_path, "cpu")
+    got = _run(pb, lag, None, "cuda")
+    assert_close("out", got[0], want[0], 1e-4, 1e-5)
+    assert_close("grad_qs", got[1], want[1], 1e-3, 1e-5)
+    assert_close("grad_dp", got[2], want[2], 1e-3, 1e-5)
+
+
+@pytest.mark.gpu
+def test_hip_is_bit_reproducible(hip_backend):
+    pb = _problem(600, 30, 6, seed=9)
+    a = _run(pb, True, None, "cuda")
+    b = _run(pb, True, None, "cuda")
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
