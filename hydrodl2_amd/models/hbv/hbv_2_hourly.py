@@ -70,25 +70,15 @@ class Hbv_2_hourly(HbvModule):
         # (hbv_2_hourly.py:170 vs :444); the stored series is what a caller wants.
         return self._state_cache
 
-    def forward(self, x_dict: dict[str, torch.Tensor], parameters):
-        """Reference: hbv_2_hourly.py:376-449 + `_PBM` :451-798."""
-        x = x_dict['x_phy']
-        ac = x_dict['ac_all'].to(torch.float32).contiguous()
-        elev = x_dict['elev_all'].to(torch.float32).contiguous()
-        outlet_topo, areas = x_dict['outlet_topo'], x_dict['areas']
-        self.muwts = x_dict.get('muwts', None)
-        T, ngrid = x.shape[0], x.shape[1]
+    def _tuple_param_sources(self, T: int, ngrid: int, wd: int, ws: int, device) -> list:
+        """Where each of the 19 physical parameters lives in (dynamic [T,B,wd], static [B,ws])
+        (hbv_2_hourly.py:213-322): dynamic in config order, static in bounds order."""
         M = self.nmul
-        p_dyn, p_sta, p_distr = parameters[0].contiguous(), parameters[1].contiguous(), parameters[2]
-        n = len(self.parameter_bounds)
         dy = list(self.dynamic_params)
-        n_dy = len(dy)
-        wd, ws = p_dyn.shape[-1], p_sta.shape[-1]
-        if wd != n_dy * M:
-            raise ValueError(f"dynamic parameters have {wd} columns, need {n_dy * M}")
-
+        if wd != len(dy) * M:
+            raise ValueError(f"dynamic parameters have {wd} columns, need {len(dy) * M}")
         srcs = []
-        drops = {name: self._draw_drop_mask(ngrid, x.device) for name in dy}  # :283-288
+        drops = {name: self._draw_drop_mask(ngrid, device) for name in dy}  # :283-288
         stat_list = [name for name in self.parameter_bounds if name not in dy]
         for name in self.parameter_bounds:
             lo, hi = self.parameter_bounds[name]
@@ -103,35 +93,53 @@ class Hbv_2_hourly(HbvModule):
                 i = stat_list.index(name)
                 srcs.append(ParamSource(slot=slot, lo=float(lo), hi=float(hi), tensor_idx=1,
                                         sta_off=i * M, sta_bs=ws))
+        return srcs
 
+    def forward(self, x_dict: dict[str, torch.Tensor], parameters):
+        """Reference: hbv_2_hourly.py:376-449."""
+        x = x_dict['x_phy']
+        self.muwts = x_dict.get('muwts', None)
+        T, ngrid = x.shape[0], x.shape[1]
+        p_dyn, p_sta, p_distr = parameters[0].contiguous(), parameters[1].contiguous(), parameters[2]
+        srcs = self._tuple_param_sources(T, ngrid, p_dyn.shape[-1], p_sta.shape[-1], x.device)
         if (not self.states) or (not self.cache_states):
             state_in = None
         else:
             state_in = self._stack_states(self.states, ngrid, x.device)
+        n_sta = len(self.parameter_bounds) - len(self.dynamic_params)
+        p_route = p_sta[:, n_sta * self.nmul: n_sta * self.nmul + 2] if self.routing else None
+        out, series = self._PBM(x, x_dict['ac_all'], x_dict['elev_all'], state_in, srcs, (p_dyn, p_sta),
+                                x_dict['outlet_topo'], x_dict['areas'], p_distr, p_route)
+        self._state_cache = series                                        # :444
+        if self.cache_states:
+            self.states = tuple(s[-1].detach() for s in series)
+        return out
 
-        cfg = StepConfig(model=self._model_id, n_param=n, n_flux=12, T=T, t0=0, B=ngrid, M=M,
-                         raw_sigmoid=False, channels=self._channels(),
+    def _PBM(self, x, ac, elev, state_in, srcs, ptensors, outlet_topo, areas, p_distr, p_route=None):
+        """One pass of the sub-daily recurrence + routing (hbv_2_hourly.py:451-798) with the
+        physical parameters described by `srcs` over `ptensors`.  Returns (flux dict, the five
+        state series [T,B,M], detached)."""
+        T, ngrid, M = x.shape[0], x.shape[1], self.nmul
+        ac = ac.to(torch.float32).contiguous()
+        elev = elev.to(torch.float32).contiguous()
+        cfg = StepConfig(model=self._model_id, n_param=len(self.parameter_bounds), n_flux=12, T=T, t0=0,
+                         B=ngrid, M=M, raw_sigmoid=False, channels=self._channels(),
                          nearzero=float(self.nearzero), params=srcs,
                          want_flux=not self.initialize, want_traj=True)
         muwts = self._expand_muwts(self.muwts, T, ngrid)
-        flux, _, _, traj = HbvPath.apply(cfg, x, state_in, muwts, ac, elev, p_dyn, p_sta)
-
+        flux, _, _, traj = HbvPath.apply(cfg, x, state_in, muwts, ac, elev, *ptensors)
         series = traj.detach()[:, 1:, :].reshape(5, T, ngrid, M)
-        self._state_cache = tuple(series[k] for k in range(5))          # :444,725
-        if self.cache_states:
-            self.states = tuple(s[-1].detach() for s in self._state_cache)
+        series = tuple(series[k] for k in range(5))                       # :725
         if self.initialize:
-            return {}
+            return {}, series
 
         Qs = flux[_abi.F_QSIM]                                            # [T,B] rate per day
         if self.routing:                                                  # :684-700
-            off = (n - n_dy) * M
-            eye = torch.eye(ngrid, device=x.device)
             rb_ = self.routing_parameter_bounds
             topo = GageTopology.from_outlet_topo(
-                eye, torch.ones(ngrid, device=x.device), T, False,
+                torch.eye(ngrid, device=x.device), torch.ones(ngrid, device=x.device), T, False,
                 (rb_['route_a'], rb_['route_b'], (0.0, 0.0)))
-            dp = torch.cat([p_sta[:, off:off + 2], torch.zeros_like(p_sta[:, :1])], dim=1)
+            dp = torch.cat([p_route, torch.zeros_like(p_route[:, :1])], dim=1)
             Qs = GageRoute.apply(topo, Qs, dp)
         Qs = (Qs * self.dt).unsqueeze(-1)                                 # :741
         out = {'Qs': Qs}
@@ -147,7 +155,7 @@ class Hbv_2_hourly(HbvModule):
                 hist = Qs
             routed = self.distr_routing(hist, p_distr, outlet_topo, areas)
             out['streamflow'] = routed[-1:] if self.cache_states else routed
-        return out
+        return out, series
 
     def distr_routing(self, Qs, p_distr, outlet_topo, areas):
         """Gage streamflow from unit runoff: area-weighted, per (gage, unit) pair a gamma unit

@@ -2,7 +2,7 @@
 """Secondary measurements (not the headline): BASELINE configs 3, 4 and 5-per-GPU-share, kernel
 times from per-launch HIP events and achieved algorithmic HBM bandwidth.
 
-    python tools/bench_configs.py [cfg2|cfg2dyn|cfg3|cfg4|cfg5|dmg] ...
+    python tools/bench_configs.py [cfg2|cfg2dyn|cfg3|cfg4|cfg5|dmg|hourly] ...
 """
 import json
 import os
@@ -55,11 +55,32 @@ def run(name, steps=5, warmup=2):
         model = hydrodl2_amd.load_model("hbv_adj", "HbvAdj")(
             {"nmul": M, "dynamic_params": {"HbvAdj": ["parBETAET"]}}, dev)
         n_dyn, nf = 1, 1
+    elif name == "hourly":
+        T, B, M = 2160, 4000, 4    # 90 days of hours, 4000 units draining to 100 gages
+        dyn = ["parBETA", "parK0", "parBETAET"]
+        model = hydrodl2_amd.load_model("hbv_2_hourly", "Hbv_2_hourly")(
+            {"nmul": M, "dynamic_params": {"Hbv_2_hourly": dyn}}, dev)
+        n_dyn, nf = 3, 12
     else:
         raise SystemExit(name)
     x, g = gen(T, B, dev)
     xd = {"x_phy": x}
-    if name == "cfg5":
+    if name == "hourly":
+        G = 100
+        x = x * torch.tensor([1 / 8.0, 1.0, 1 / 24.0], device=dev)
+        xd["x_phy"] = x
+        topo = (torch.rand((G, B), generator=g, device=dev) < 0.02).float()
+        topo[torch.arange(B, device=dev) % G, torch.arange(B, device=dev)] = 1.0
+        pd = torch.rand((T, B, 3 * M), generator=g, device=dev).requires_grad_(True)
+        ps = torch.rand((B, 16 * M), generator=g, device=dev).requires_grad_(True)
+        pr = torch.rand((int(topo.sum()), 3), generator=g, device=dev).requires_grad_(True)
+        params = (pd, ps, pr)
+        xd["ac_all"] = torch.rand(B, generator=g, device=dev) * 5000
+        xd["elev_all"] = torch.rand(B, generator=g, device=dev) * 3000
+        xd["outlet_topo"] = topo
+        xd["areas"] = torch.rand(B, generator=g, device=dev) * 90 + 5
+        leaves = [pd, ps, pr]
+    elif name == "cfg5":
         pd = torch.rand((T, B, 3 * M), generator=g, device=dev).requires_grad_(True)
         ps = torch.rand((B, 13 * M), generator=g, device=dev).requires_grad_(True)
         params = (pd, ps)
@@ -70,7 +91,7 @@ def run(name, steps=5, warmup=2):
         p = torch.randn((T, B, model.learnable_param_count), generator=g, device=dev).requires_grad_(True)
         params, leaves = p, [p]
     Tp = T - (model.warm_up if getattr(model, "warm_up_states", True) else 0)
-    w = torch.randn((Tp, B, 1), generator=g, device=dev)
+    w = torch.randn((Tp, 100 if name == "hourly" else B, 1), generator=g, device=dev)
 
     def step():
         for l in leaves:
