@@ -11,9 +11,19 @@
 //   wave 0  snow         tile it      reads forcings, writes RAIN/tosoil for the soil wave
 //   wave 1  soil         tile it-1    reads RAIN/tosoil + PET, writes recharge/excess for wave 2
 //   wave 2  groundwater  tile it-2
-//   waves 3,4  fillers   stage the forcings of tile it+2 (loads only)
-//   waves 5..11 drainers outputs of tiles it-1/it-2/it-3: ensemble means -> flux series,
-//                        storages -> trajectory, pow results -> aux (stores only)
+//   helpers (loads and stores share the in-order vmcnt counter, so no wave does both):
+//     filler        forcings of tile it+3 -> registers, tile it+2 registers -> LDS (never waits
+//                   for a load it has just issued)
+//     row drainers  storages / pow results of tiles it-1..it-3 -> trajectory / aux rows
+//     reducers      ensemble means of tiles it-1..it-3 -> flux series
+//
+// The stepper waves are bound by vector-ALU issue: the soil wave keeps its SIMD's VALU ~90 % busy
+// (measured with the -DPIPE_PROBE build, tools/pipe_probe.py).  A workgroup's waves go to the four
+// SIMDs cyclically, so waves w and w+4 share a SIMD: helpers on the soil wave's SIMD (5, 9, 13) stay
+// idle, the row drainers sit on the SIMD without a stepper (7, 11, 15, next to the filler 3), the
+// reducers next to the lighter snow / groundwater steppers (4, 8, 12 and 6, 10, 14).  Helper stores
+// use buffer addressing: row base in SGPRs, constant per-lane offset, out-of-range lanes dropped by
+// the hardware -- no 64-bit VALU address arithmetic, no EXEC masking.
 //
 // One raw s_barrier per iteration; every interface is double-buffered (forcings: 4 slots, filled
 // two tiles ahead and read by two stages).  The arithmetic is Step::fwd_snow / fwd_soil / fwd_gw of hbv_step.h, i.e.
@@ -28,6 +38,8 @@
 #include "hbv_tiled.h"
 
 namespace hbvx {
+
+#define PIPE_KT 8   // days per tile (host and device)
 
 struct PipeArgs {
     hbvx_desc d;
@@ -44,55 +56,73 @@ struct PipeLds {
         xin = 0;                    // [4][Kt][64][4]
         ab = xin + 4 * Kt * 256;    // [2][Kt][2][64]
         bc = ab + 2 * Kt * 128;     // [2][Kt][2][64]
-        oa = bc + 2 * Kt * 128;     // [2][Kt][4][64]
-        ob = oa + 2 * Kt * 256;     // [2][Kt][7][64]
-        oc = ob + 2 * Kt * 448;     // [2][Kt][7][64]
+        oa = bc + 2 * Kt * 128;     // [2][Kt][4][64]  SWE, tosoil | SNOWPACK, MELTWATER
+        ob = oa + 2 * Kt * 256;     // [2][Kt][7][64]  AET, recharge, excs, evapfactor | SM, sw0, ef0
+        oc = ob + 2 * Kt * 448;     // [2][Kt][7][64]  Qsim, Q0, Q1, Q2, PERC | SUZ, SLZ
         total = oc + 2 * Kt * 448;
     }
 };
 
-// Drain one stage's output tile (helper waves).  The tile holds NSER series per day: NFS flux
-// series first (global flux index = nibble i of FMAP), then NTS storage series (nibble i of KIND:
-// < 5 -> trajectory row of that storage, 5/6 -> aux 0/1).  Everything that indexes the layout is a
-// compile-time constant (no integer division in the loop).
-template <int NSER, int NFS, unsigned FMAP, int NTS, unsigned KIND>
-__device__ __forceinline__ void pipe_drain(const hbvx_desc &d, const hbvx_fwd_out &o, const LaneT &L,
-                                           const float *buf, int t0, int nt, int w, int NHW, int hid,
-                                           int nhid, int lgMp, int b0, bool has_traj, bool has_aux)
+// Store one value per lane into a row of `row_bytes` bytes starting at the wave-uniform address
+// `row`: buffer addressing keeps the base in SGPRs (scalar address arithmetic only) and drops lanes
+// whose offset is out of range, so inactive lanes need no EXEC masking (voff = 0xFFFFFFFF).
+__device__ __forceinline__ void row_store(float *row, unsigned row_bytes, unsigned voff, float v)
 {
-    const int T = d.T;
-    const int64_t N = (int64_t)d.B * d.M;
-    const int bpw = 64 >> lgMp, M = d.M;
-    const float invM = 1.0f / (float)M;
-    if (has_traj) {
-        for (int tt = w; tt < nt; tt += NHW) {
-            const int t = t0 + tt;
-            const float *src = buf + (tt * NSER + NFS) * 64 + L.lane;
-            float v[NTS];
-#pragma unroll
-            for (int i = 0; i < NTS; i++) v[i] = src[i * 64];
-            if (L.active) {
-#pragma unroll
-                for (int i = 0; i < NTS; i++) {
-                    constexpr unsigned kinds = KIND;
-                    const int kd = (int)((kinds >> (4 * i)) & 0xFu);
-                    if (kd < 5) o.traj[((int64_t)kd * (T + 1) + t) * N + L.n] = v[i];
-                    else if (has_aux) o.aux[((int64_t)(kd - 5) * T + t) * N + L.n] = v[i];
-                }
-            }
-        }
-    }
-    ens_reduce_tile<NSER, NFS>(buf, nt * NFS * bpw, L.lane, w, NHW, M, lgMp,
-                               [&](int tt, int ks, int bl, float acc) {
-                                   const int kk = (int)((FMAP >> (4 * ks)) & 0xFu);
-                                   if (b0 + bl < d.B)
-                                       o.flux[((int64_t)kk * T + (t0 + tt)) * d.B + b0 + bl] = acc * invM;
-                               });
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(row, 0, (int)row_bytes, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, 0, 0);
 }
 
-template <bool BETAET>
+// Drain work of the helper waves.  A stage's output tile holds NSER series per day: NFS flux series
+// first (global flux index = nibble i of FMAP), then NSER - NFS storage series.  Everything that
+// indexes the layout is a compile-time constant.
+//   pipe_reduce_pass: ensemble means of 64 (day, series, basin) items -> flux series
+//   pipe_rows_day:    the storage rows of one day -> trajectory / aux (ROW0..: row index in units
+//                     of N floats relative to `base`, nibble-packed; see the call sites)
+template <int NSER, int NFS, unsigned FMAP>
+__device__ __forceinline__ void pipe_reduce_pass(const hbvx_desc &d, const hbvx_fwd_out &o, const float *buf,
+                                                 int t0, int items, int pass, int lane, int lgMp, int b0)
+{
+    const int T = d.T, B = d.B;
+    const float invM = 1.0f / (float)d.M;
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(o.flux, 0, -1, 0x00020000);
+    ens_reduce_pass<NSER, NFS>(buf, items, pass * 64, lane, d.M, lgMp, [&](int tt, int ks, int bl, float acc) {
+        const int kk = (int)((FMAP >> (4 * ks)) & 0xFu);
+        const unsigned off = b0 + bl < B ? (unsigned)(((kk * T + (t0 + tt)) * B + b0 + bl) * 4) : 0xFFFFFFFFu;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc * invM), r, off, 0, 0);
+    });
+}
+
+#ifdef PIPE_PROBE
+__device__ unsigned long long g_pipe_probe[32];
+#define PIPE_BARRIER()                                                                             \
+    do {                                                                                           \
+        unsigned long long t_a = __builtin_readcyclecounter();                                     \
+        probe_busy += t_a - probe_t;                                                               \
+        lds_barrier();                                                                             \
+        probe_t = __builtin_readcyclecounter();                                                    \
+        probe_wait += probe_t - t_a;                                                               \
+    } while (0)
+#else
+#define PIPE_BARRIER() lds_barrier()
+#endif
+
+// TRAJ: the forward also saves the storage trajectory and the pow results (traj and aux given).
+template <bool BETAET, bool TRAJ>
 __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
 {
+#ifdef PIPE_PROBE
+    unsigned long long probe_busy = 0, probe_wait = 0, probe_t = __builtin_readcyclecounter();
+    struct ProbeFlush {
+        unsigned long long &b, &w;
+        __device__ ~ProbeFlush()
+        {
+            if (blockIdx.x == 5 && (threadIdx.x & 63) == 0) {
+                g_pipe_probe[(threadIdx.x >> 6) * 2] = b;
+                g_pipe_probe[(threadIdx.x >> 6) * 2 + 1] = w;
+            }
+        }
+    } probe_flush{probe_busy, probe_wait};
+#endif
     constexpr int NP = BETAET ? 13 : 12;
     constexpr int NF = 11;
     extern __shared__ __align__(16) float lds[];
@@ -106,7 +136,8 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
     const int nIt = nT + 3;
     const int64_t N = (int64_t)d.B * d.M;
     const bool raw = d.raw_sigmoid != 0;
-    const bool has_traj = o.traj != nullptr, has_aux = o.aux != nullptr;
+    const unsigned row_bytes = (unsigned)(N * 4);
+    const unsigned voff = L.active ? (unsigned)(L.n * 4) : 0xFFFFFFFFu;
     const PipeLds P(Kt);
     const float nz = d.nearzero;
 
@@ -127,7 +158,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
         __builtin_amdgcn_s_setprio(3);
         float SP = d.state_in ? d.state_in[0 * N + L.n] : 0.001f;
         float MW = d.state_in ? d.state_in[1 * N + L.n] : 0.001f;
-        lds_barrier();
+        PIPE_BARRIER();
         for (int it = 0; it < nIt; it++) {
             const int tile = it;
             if (tile < nT) {
@@ -146,16 +177,17 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                     ab[tt * 128] = s.RAIN;
                     ab[tt * 128 + 64] = s.tosoil;
                     float *q = oa + tt * 256;
-                    q[0] = s.SP3; q[64] = s.tosoil; q[128] = SP; q[192] = MW;
+                    q[0] = s.SP3; q[64] = s.tosoil;
+                    if (TRAJ) { q[128] = SP; q[192] = MW; }
                     SP = s.SP3; MW = s.MW3;
                 }
             }
-            lds_barrier();
+            PIPE_BARRIER();
         }
         if (L.active) {
             o.state_out[0 * N + L.n] = SP;
             o.state_out[1 * N + L.n] = MW;
-            if (has_traj) {
+            if (TRAJ) {
                 o.traj[((int64_t)0 * (T + 1) + T) * N + L.n] = SP;
                 o.traj[((int64_t)1 * (T + 1) + T) * N + L.n] = MW;
             }
@@ -164,7 +196,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
         // ------------------------------ soil ------------------------------
         __builtin_amdgcn_s_setprio(3);
         float SM = d.state_in ? d.state_in[2 * N + L.n] : 0.001f;
-        lds_barrier();
+        PIPE_BARRIER();
         for (int it = 0; it < nIt; it++) {
             const int tile = it - 1;
             if (tile >= 0 && tile < nT) {
@@ -188,22 +220,22 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                     bc[tt * 128 + 64] = s.exc;
                     float *q = ob + tt * 448;
                     q[0] = s.ET; q[64] = s.rech; q[128] = s.exc; q[192] = s.ef;
-                    q[256] = SM; q[320] = s.sw0; q[384] = s.ef0;
+                    if (TRAJ) { q[256] = SM; q[320] = s.sw0; q[384] = s.ef0; }
                     SM = s.SM3;
                 }
             }
-            lds_barrier();
+            PIPE_BARRIER();
         }
         if (L.active) {
             o.state_out[2 * N + L.n] = SM;
-            if (has_traj) o.traj[((int64_t)2 * (T + 1) + T) * N + L.n] = SM;
+            if (TRAJ) o.traj[((int64_t)2 * (T + 1) + T) * N + L.n] = SM;
         }
     } else if (wave == 2) {
         // --------------------------- groundwater ---------------------------
         __builtin_amdgcn_s_setprio(3);
         float SUZ = d.state_in ? d.state_in[3 * N + L.n] : 0.001f;
         float SLZ = d.state_in ? d.state_in[4 * N + L.n] : 0.001f;
-        lds_barrier();
+        PIPE_BARRIER();
         for (int it = 0; it < nIt; it++) {
             const int tile = it - 2;
             if (tile >= 0 && tile < nT) {
@@ -222,73 +254,131 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                     s.fwd_gw(p, 0.0f);
                     float *q = oc + tt * 448;
                     q[0] = s.Q; q[64] = s.Q0; q[128] = s.Q1; q[192] = s.Q2; q[256] = s.PERC;
-                    q[320] = SUZ; q[384] = SLZ;
+                    if (TRAJ) { q[320] = SUZ; q[384] = SLZ; }
                     SUZ = s.SUZ4; SLZ = s.SLZ2;
                 }
             }
-            lds_barrier();
+            PIPE_BARRIER();
         }
         if (L.active) {
             o.state_out[3 * N + L.n] = SUZ;
             o.state_out[4 * N + L.n] = SLZ;
-            if (has_traj) {
+            if (TRAJ) {
                 o.traj[((int64_t)3 * (T + 1) + T) * N + L.n] = SUZ;
                 o.traj[((int64_t)4 * (T + 1) + T) * N + L.n] = SLZ;
             }
         }
     } else {
         // ------------------------------ helpers ------------------------------
-        // Two kinds, so that no wave waits for its own stores (loads and stores share the in-order
-        // vmcnt counter): waves 3,4 "fillers" only LOAD (forcings, two tiles ahead); waves 5.. only
-        // STORE (drains).
         const int lgMp = A.lgMp, bpw = 64 >> lgMp;
         const int b0 = blockIdx.x * bpw;
-        constexpr unsigned fmapA = HBVX_F_SWE | (HBVX_F_TOSOIL << 4), kindA = 0u | (1u << 4);
+        constexpr unsigned fmapA = HBVX_F_SWE | (HBVX_F_TOSOIL << 4);
         constexpr unsigned fmapB = HBVX_F_AET | (HBVX_F_RECHARGE << 4) | (HBVX_F_EXCS << 8) |
-                                   (HBVX_F_EVAPFACTOR << 12),
-                           kindB = 2u | (5u << 4) | (6u << 8);
+                                   (HBVX_F_EVAPFACTOR << 12);
         constexpr unsigned fmapC = HBVX_F_QSIM | (HBVX_F_Q0 << 4) | (HBVX_F_Q1 << 8) | (HBVX_F_Q2 << 12) |
-                                   (HBVX_F_PERC << 16),
-                           kindC = 3u | (4u << 4);
-        if (wave < 5) {
-            const int w = wave - 3;            // 0 or 1
+                                   (HBVX_F_PERC << 16);
+        const int nw = blockDim.x >> 6;
+        const int quad = wave & 3;   // waves with the same value share a SIMD
+        if (wave == 3) {
+            // filler: registers hold the tile that goes to LDS next iteration.  Straight-line code
+            // (days past the end of the record are clamped / written but never read): with control
+            // flow between the loads the compiler falls back to vmcnt(0) after every group.
+            constexpr int FD = PIPE_KT;
             const float *xb = d.x + (int64_t)L.b * d.x_b_stride;
-            auto fill = [&](int tile) {
-                float4 *in4 = reinterpret_cast<float4 *>(lds + P.xin + (tile & 3) * Kt * 256);
-                const int t0 = tile * Kt, nt = tile_nt(tile);
-                for (int tt = w; tt < nt; tt += 2) {
-                    const float *xr = xb + (int64_t)(t0 + tt) * d.x_t_stride;
-                    float4 f;
-                    f.x = xr[d.ch_prcp]; f.y = xr[d.ch_tmean]; f.z = xr[d.ch_pet]; f.w = 0.0f;
-                    in4[tt * 64 + lane] = f;
+            float fx[FD], fy[FD], fz[FD];
+            auto issue = [&](int tile) {
+                const int t0 = tile * FD;
+#pragma unroll
+                for (int i = 0; i < FD; i++) {
+                    const int t = min(t0 + i, T - 1);
+                    const float *xr = xb + (int64_t)t * d.x_t_stride;
+                    fx[i] = xr[d.ch_prcp]; fy[i] = xr[d.ch_tmean]; fz[i] = xr[d.ch_pet];
                 }
             };
-            fill(0);
-            if (nT > 1) fill(1);
-            lds_barrier();
+            auto commit = [&](int tile) {
+                float4 *in4 = reinterpret_cast<float4 *>(lds + P.xin + (tile & 3) * FD * 256);
+#pragma unroll
+                for (int i = 0; i < FD; i++) in4[i * 64 + lane] = make_float4(fx[i], fy[i], fz[i], 0.0f);
+            };
+            issue(0);
+            commit(0);
+            if (nT > 1) { issue(1); commit(1); }
+            if (nT > 2) issue(2);
+            PIPE_BARRIER();
             for (int it = 0; it < nIt; it++) {
-                if (it + 2 < nT) fill(it + 2);
-                lds_barrier();
+                // tile it+2 (loaded during the previous iteration) -> LDS slot (it+2)&3, free since
+                // the soil wave finished tile it-2 before the last barrier; then start tile it+3
+                if (it + 2 < nT) commit(it + 2);
+                if (it + 3 < nT) issue(it + 3);
+                PIPE_BARRIER();
+            }
+        } else if (quad == 1 || !(quad == 3 ? TRAJ : true)) {
+            // the soil wave's SIMD stays free; without a trajectory the row drainers have no work
+            PIPE_BARRIER();
+            for (int it = 0; it < nIt; it++) PIPE_BARRIER();
+        } else if (quad == 3) {
+            // row drainers (waves 7, 11, 15): day tt of every stage tile -> 7 rows
+            const int w = (wave - 7) >> 2, NRD = (nw - 7 + 3) >> 2;
+            const int64_t SR = (int64_t)(T + 1) * N;   // storage row blocks in traj
+            PIPE_BARRIER();
+            for (int it = 0; it < nIt; it++) {
+                const int tA = it - 1, tB = it - 2, tC = it - 3;
+                const int ntA = (tA >= 0 && tA < nT) ? tile_nt(tA) : 0;
+                const int ntB = (tB >= 0 && tB < nT) ? tile_nt(tB) : 0;
+                const int ntC = (tC >= 0 && tC < nT) ? tile_nt(tC) : 0;
+                const float *bufA = lds + P.oa + (tA & 1) * Kt * 256 + lane;
+                const float *bufB = lds + P.ob + (tB & 1) * Kt * 448 + lane;
+                const float *bufC = lds + P.oc + (tC & 1) * Kt * 448 + lane;
+                for (int tt = w; tt < Kt; tt += NRD) {
+                    float a0, a1, b0v, b1, b2, c0, c1;
+                    if (tt < ntA) { a0 = bufA[tt * 256 + 128]; a1 = bufA[tt * 256 + 192]; }
+                    if (tt < ntB) { b0v = bufB[tt * 448 + 256]; b1 = bufB[tt * 448 + 320]; b2 = bufB[tt * 448 + 384]; }
+                    if (tt < ntC) { c0 = bufC[tt * 448 + 320]; c1 = bufC[tt * 448 + 384]; }
+                    if (tt < ntA) {
+                        float *r = o.traj + (int64_t)(tA * Kt + tt) * N;
+                        row_store(r, row_bytes, voff, a0);
+                        row_store(r + SR, row_bytes, voff, a1);
+                    }
+                    if (tt < ntB) {
+                        const int64_t t = tB * Kt + tt;
+                        row_store(o.traj + 2 * SR + t * N, row_bytes, voff, b0v);
+                        row_store(o.aux + t * N, row_bytes, voff, b1);
+                        row_store(o.aux + ((int64_t)T + t) * N, row_bytes, voff, b2);
+                    }
+                    if (tt < ntC) {
+                        float *r = o.traj + 3 * SR + (int64_t)(tC * Kt + tt) * N;
+                        row_store(r, row_bytes, voff, c0);
+                        row_store(r + SR, row_bytes, voff, c1);
+                    }
+                }
+                PIPE_BARRIER();
             }
         } else {
-            const int NDR = (blockDim.x >> 6) - 5;
-            const int w = wave - 5;
-            const int hid = w * 64 + lane, nhid = NDR * 64;
-            lds_barrier();
+            // reducers: waves 4, 8, 12 (next to the snow wave) and 6, 10, 14 (next to groundwater)
+            const int w = ((wave - 4) >> 2) * 2 + (quad == 2 ? 1 : 0);
+            const int NDR = ((nw - 4 + 3) >> 2) + ((nw - 6 + 3) >> 2);
+            PIPE_BARRIER();
             for (int it = 0; it < nIt; it++) {
-                int tile = it - 1;
-                if (tile >= 0 && tile < nT)
-                    pipe_drain<4, 2, fmapA, 2, kindA>(d, o, L, lds + P.oa + (tile & 1) * Kt * 256, tile * Kt,
-                                                      tile_nt(tile), w, NDR, hid, nhid, lgMp, b0, has_traj, has_aux);
-                tile = it - 2;
-                if (tile >= 0 && tile < nT)
-                    pipe_drain<7, 4, fmapB, 3, kindB>(d, o, L, lds + P.ob + (tile & 1) * Kt * 448, tile * Kt,
-                                                      tile_nt(tile), w, NDR, hid, nhid, lgMp, b0, has_traj, has_aux);
-                tile = it - 3;
-                if (tile >= 0 && tile < nT)
-                    pipe_drain<7, 5, fmapC, 2, kindC>(d, o, L, lds + P.oc + (tile & 1) * Kt * 448, tile * Kt,
-                                                      tile_nt(tile), w, NDR, hid, nhid, lgMp, b0, has_traj, has_aux);
-                lds_barrier();
+                const int tA = it - 1, tB = it - 2, tC = it - 3;
+                const int ntA = (tA >= 0 && tA < nT) ? tile_nt(tA) : 0;
+                const int ntB = (tB >= 0 && tB < nT) ? tile_nt(tB) : 0;
+                const int ntC = (tC >= 0 && tC < nT) ? tile_nt(tC) : 0;
+                const float *bufA = lds + P.oa + (tA & 1) * Kt * 256;
+                const float *bufB = lds + P.ob + (tB & 1) * Kt * 448;
+                const float *bufC = lds + P.oc + (tC & 1) * Kt * 448;
+                const int iA = ntA * 2 * bpw, iB = ntB * 4 * bpw, iC = ntC * 5 * bpw;
+                const int pA = (iA + 63) >> 6, pB = (iB + 63) >> 6, pC = (iC + 63) >> 6;
+                const int nR = pA + pB + pC;
+                // heaviest passes first (C: 5 series), so the tail of the round-robin is light
+                for (int u = w; u < nR; u += NDR) {
+                    if (u < pC)
+                        pipe_reduce_pass<7, 5, fmapC>(d, o, bufC, tC * Kt, iC, u, lane, lgMp, b0);
+                    else if (u < pC + pB)
+                        pipe_reduce_pass<7, 4, fmapB>(d, o, bufB, tB * Kt, iB, u - pC, lane, lgMp, b0);
+                    else
+                        pipe_reduce_pass<4, 2, fmapA>(d, o, bufA, tA * Kt, iA, u - pC - pB, lane, lgMp, b0);
+                }
+                PIPE_BARRIER();
             }
         }
         (void)NF;

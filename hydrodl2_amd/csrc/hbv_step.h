@@ -107,6 +107,9 @@ HBVX_HD double fma64_(double a, double b, double c)
 
 HBVX_HD float pow_pos_(float x, float y)
 {
+#if defined(HBVX_ABLATE_POW) && defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
+#endif
     const double xd = (double)x;
 #if defined(__HIP_DEVICE_COMPILE__)
     double m = __builtin_amdgcn_frexp_mant(xd);   // [0.5, 1)

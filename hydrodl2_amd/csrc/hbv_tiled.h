@@ -96,62 +96,72 @@ __device__ __forceinline__ float ens_sum_lds(const float *src, int sub, int M, i
     return s;
 }
 
+// Ensemble sum by ONE lane, same fixed tree as ens_sum_lds: quads (x0+x1)+(x2+x3), then pairwise
+// over the quads.  `rot` (0..3) only matters for 4 quads (Mp = 16): the lane reads its quads in
+// the order rot, rot+1, ... so that the 16-lane groups of one ds_read_b128 spread over all banks
+// (rows of a tile are 64 floats apart, i.e. on the same banks).
+__device__ __forceinline__ float ens_sum_lane(const float *src, int M, int lgMp, int rot)
+{
+    if (lgMp < 2) {
+        float s = src[0];
+        if (M > 1) s += src[1];
+        return s;
+    }
+    const bool full = (M == (1 << lgMp));
+    auto quad = [&](int qi) {
+        const float4 v = *reinterpret_cast<const float4 *>(src + 4 * qi);
+        if (full) return (v.x + v.y) + (v.z + v.w);
+        const int m0 = 4 * qi;
+        const float a = ((m0 < M) ? v.x : 0.0f) + ((m0 + 1 < M) ? v.y : 0.0f);
+        const float b = ((m0 + 2 < M) ? v.z : 0.0f) + ((m0 + 3 < M) ? v.w : 0.0f);
+        return a + b;
+    };
+    if (lgMp == 4) {
+        const float t0 = quad(rot & 3), t1 = quad((rot + 1) & 3), t2 = quad((rot + 2) & 3),
+                    t3 = quad((rot + 3) & 3);
+        const bool odd = rot & 1;  // rot odd: (t3,t0,t1,t2) are quads (0,1,2,3) up to the swap of halves
+        return (t0 + (odd ? t3 : t1)) + (t2 + (odd ? t1 : t3));
+    }
+    const int nq = 1 << (lgMp - 2);
+    float q[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) q[i] = (i < nq) ? quad(i) : 0.0f;
+#pragma unroll
+    for (int k = 1; k < 16; k <<= 1)
+        if (k < nq) {
+#pragma unroll
+            for (int i = 0; i < 16; i += 2 * k)
+                if (i < nq) q[i] += q[i + k];
+        }
+    return q[0];
+}
+
 // Reduce `items` (= nt * NFS * bpw) basin-series of an output tile and hand each sum to `emit`.
 // Item e -> (bl = e % bpw, ks = (e / bpw) % NFS, tt = e / (bpw * NFS)); values of item e live at
-// buf[(tt * NSER + ks) * 64 + bl * Mp ...].  `w`/`nw`: this helper wave's index / number of waves.
+// buf[(tt * NSER + ks) * 64 + bl * Mp ...].  One lane per item, 64 items per wave and pass: per
+// item Mp/4 ds_read_b128 and Mp-1 adds, no cross-lane traffic.  `w`/`nw`: this helper wave's
+// index / number of waves.
+template <int NSER, int NFS, typename Emit>
+__device__ __forceinline__ void ens_reduce_pass(const float *buf, int items, int base, int lane, int M,
+                                                int lgMp, Emit emit)
+{
+    const int e = base + lane;
+    const bool valid = e < items;
+    const int ec = valid ? e : items - 1;
+    const int bl = ec & ((64 >> lgMp) - 1);
+    const int r = ec >> (6 - lgMp);
+    const int ks = r % NFS, tt = r / NFS;
+    const float *src = buf + (tt * NSER + ks) * 64 + (bl << lgMp);
+    const float v = ens_sum_lane(src, M, lgMp, r);
+    if (valid) emit(tt, ks, bl, v);
+}
+
 template <int NSER, int NFS, typename Emit>
 __device__ __forceinline__ void ens_reduce_tile(const float *buf, int items, int lane, int w, int nw,
                                                 int M, int lgMp, Emit emit)
 {
-    const int Mp = 1 << lgMp, bpw = 64 >> lgMp;
-    const int lgLPI = lgMp >= 2 ? lgMp - 2 : 0;
-    const int ipp = 64 >> lgLPI;            // items per wave pass
-    const int sub = lane & ((1 << lgLPI) - 1), slot = lane >> lgLPI;
-    // two independent items per lane and pass: the chain ds_read -> add -> 2 shuffles is latency
-    // bound, a second chain in flight nearly halves the time per item
-    for (int base = w * ipp; base < items; base += 2 * nw * ipp) {
-        int e[2], tt[2], ks[2], bl[2];
-        bool valid[2];
-        const float *src[2];
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            e[u] = base + u * nw * ipp + slot;
-            valid[u] = e[u] < items;
-            const int ec = valid[u] ? e[u] : items - 1;
-            bl[u] = ec & (bpw - 1);
-            const int r = ec >> (6 - lgMp);
-            ks[u] = r % NFS;
-            tt[u] = r / NFS;
-            src[u] = buf + (tt[u] * NSER + ks[u]) * 64 + bl[u] * Mp;
-        }
-        float v[2];
-        if (lgMp >= 2) {
-            float4 q[2];
-#pragma unroll
-            for (int u = 0; u < 2; u++) q[u] = *reinterpret_cast<const float4 *>(src[u] + 4 * sub);
-            const int m0 = 4 * sub;
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const float a = ((m0 < M) ? q[u].x : 0.0f) + ((m0 + 1 < M) ? q[u].y : 0.0f);
-                const float b = ((m0 + 2 < M) ? q[u].z : 0.0f) + ((m0 + 3 < M) ? q[u].w : 0.0f);
-                v[u] = a + b;
-            }
-            for (int k = 0; k < lgMp - 2; k++) {
-                const float s0 = __shfl_xor(v[0], 1 << k, 64), s1 = __shfl_xor(v[1], 1 << k, 64);
-                v[0] += s0;
-                v[1] += s1;
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-                v[u] = src[u][0];
-                if (M > 1) v[u] += src[u][1];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 2; u++)
-            if (valid[u] && sub == 0) emit(tt[u], ks[u], bl[u], v[u]);
-    }
+    for (int base = w * 64; base < items; base += nw * 64)
+        ens_reduce_pass<NSER, NFS>(buf, items, base, lane, M, lgMp, emit);
 }
 
 // index of dynamic slot i among the dynamic slots (wave-uniform)

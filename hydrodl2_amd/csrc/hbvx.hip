@@ -718,9 +718,11 @@ extern "C" int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *s
     {
         // HBV 1.0, static parameters, flux requested: three-stage pipelined forward (hbv_pipe.h)
         const char *fv = getenv("HBVX_FWD");
-        const int Kt = 8;
+        const int Kt = PIPE_KT;
         if (use_tiled(d) && !(fv && !strcmp(fv, "tiled")) && d->model == HBVX_MODEL_HBV10 &&
-            count_dyn(d) == 0 && !d->muwts && out->flux && d->T >= 4 * Kt) {
+            count_dyn(d) == 0 && !d->muwts && out->flux && d->T >= 4 * Kt &&
+            (out->traj != nullptr) == (out->aux != nullptr) && (int64_t)d->B * d->M * 4 < (int64_t)1 << 31 &&
+            (int64_t)11 * d->T * d->B * 4 < (int64_t)1 << 31) {
             PipeArgs pa;
             pa.d = *d;
             pa.o = *out;
@@ -729,11 +731,14 @@ extern "C" int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *s
             const int bpw_p = 64 >> pa.lgMp;
             dim3 grid_p((d->B + bpw_p - 1) / bpw_p);
             const size_t lds = (size_t)PipeLds(Kt).total * 4;
-            int pthreads = env_int("HBVX_PIPE_THREADS", 1024); // 3 steppers + 2 fillers + drainers
-            pthreads = pthreads < 384 ? 384 : (pthreads > 1024 ? 1024 : (pthreads / 64) * 64);
-            hipError_t e = (d->n_param == 13)
-                               ? launch_tiled_one(k_fwd_pipe<true>, pa, grid_p, pthreads, lds, (hipStream_t)stream)
-                               : launch_tiled_one(k_fwd_pipe<false>, pa, grid_p, pthreads, lds, (hipStream_t)stream);
+            int pthreads = env_int("HBVX_PIPE_THREADS", 1024); // 3 steppers + filler + drainers (hbv_pipe.h)
+            pthreads = pthreads < 512 ? 512 : (pthreads > 1024 ? 1024 : (pthreads / 64) * 64);
+            const bool be = d->n_param == 13, tr = out->traj != nullptr;
+            hipStream_t st = (hipStream_t)stream;
+            hipError_t e = be ? (tr ? launch_tiled_one(k_fwd_pipe<true, true>, pa, grid_p, pthreads, lds, st)
+                                    : launch_tiled_one(k_fwd_pipe<true, false>, pa, grid_p, pthreads, lds, st))
+                              : (tr ? launch_tiled_one(k_fwd_pipe<false, true>, pa, grid_p, pthreads, lds, st)
+                                    : launch_tiled_one(k_fwd_pipe<false, false>, pa, grid_p, pthreads, lds, st));
             if (e != hipSuccess) return hip_fail(e, "hbvx_forward (pipelined) launch");
             return HBVX_OK;
         }
@@ -1166,3 +1171,11 @@ extern "C" int hbvx_gage_route_backward(const hbvx_gage_desc *r, const float *qs
     if (e != hipSuccess) return hip_fail(e, "hbvx_gage_route_backward launch");
     return HBVX_OK;
 }
+
+#ifdef PIPE_PROBE
+extern "C" int hbvx_debug_pipe_probe(unsigned long long *out32)
+{
+    hipError_t e = hipMemcpyFromSymbol(out32, HIP_SYMBOL(hbvx::g_pipe_probe), 32 * sizeof(unsigned long long));
+    return e == hipSuccess ? 0 : -1;
+}
+#endif

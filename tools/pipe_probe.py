@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Dev probe: per-wave busy / barrier-wait cycles of k_fwd_pipe (library built with -DPIPE_PROBE
+as hydrodl2_amd/csrc/libhbvx_probe.so), BASELINE config 2."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import hydrodl2_amd  # noqa: E402
+from hydrodl2_amd import _lib  # noqa: E402
+from tools.bench_configs import gen  # noqa: E402
+
+_lib._use_library_for_testing(os.path.join(ROOT, "hydrodl2_amd", "csrc", "libhbvx_probe.so"))
+lib = _lib.get_library()
+dev = torch.device("cuda:0")
+T, B, M = 7300, 671, 16
+model = hydrodl2_amd.load_model("hbv", "Hbv")({"nmul": M, "dynamic_params": {"Hbv": []}}, dev)
+x, g = gen(T, B, dev)
+p = torch.randn((T, B, model.learnable_param_count), generator=g, device=dev)
+for grad in (True, False):
+    pp = p.clone().requires_grad_(grad)
+    with torch.set_grad_enabled(grad):
+        for _ in range(3):
+            out = model({"x_phy": x}, pp)
+    torch.cuda.synchronize()
+    buf = (C.c_ulonglong * 32)()
+    assert lib.dll.hbvx_debug_pipe_probe(buf) == 0
+    print("traj" if grad else "no traj")
+    roles = ["snow", "soil", "gw", "fill", "fill"] + ["drain"] * 11
+    for w in range(16):
+        print(f"  wave {w:2d} {roles[w]:6s} busy {buf[2*w]/T:8.1f}  wait {buf[2*w+1]/T:8.1f} counter ticks/step")
