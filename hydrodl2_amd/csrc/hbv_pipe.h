@@ -41,6 +41,17 @@ namespace hbvx {
 
 #define PIPE_KT 8   // days per tile (host and device)
 
+// Run `body(tt, has_next)` for the nt days of a tile; full tiles are unrolled so that every LDS
+// address is base + immediate and the loop-carried registers need no rotation moves.
+#define PIPE_DAYS(nt, body)                                                                        \
+    do {                                                                                           \
+        if ((nt) == PIPE_KT) {                                                                     \
+            _Pragma("unroll") for (int tt_ = 0; tt_ < PIPE_KT; tt_++) body(tt_, tt_ + 1 < PIPE_KT); \
+        } else {                                                                                   \
+            for (int tt_ = 0; tt_ < (nt); tt_++) body(tt_, tt_ + 1 < (nt));                        \
+        }                                                                                          \
+    } while (0)
+
 struct PipeArgs {
     hbvx_desc d;
     hbvx_fwd_out o;
@@ -167,10 +178,10 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                 float *ab = lds + P.ab + (tile & 1) * Kt * 128 + lane;
                 float *oa = lds + P.oa + (tile & 1) * Kt * 256 + lane;
                 float4 fn = in4[lane];
-                for (int tt = 0; tt < nt; tt++) {
+                auto day = [&](int tt, bool more) __attribute__((always_inline)) {
                     Step<MODEL_HBV10, BETAET> s;
                     const float4 f = fn;
-                    if (tt + 1 < nt) fn = in4[(tt + 1) * 64 + lane];
+                    if (more) fn = in4[(tt + 1) * 64 + lane];
                     s.P = f.x; s.Tf = f.y;
                     s.SP = SP; s.MW = MW;
                     s.fwd_snow(p, 0.0f);
@@ -180,7 +191,8 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                     q[0] = s.SP3; q[64] = s.tosoil;
                     if (TRAJ) { q[128] = SP; q[192] = MW; }
                     SP = s.SP3; MW = s.MW3;
-                }
+                };
+                PIPE_DAYS(nt, day);
             }
             PIPE_BARRIER();
         }
@@ -206,10 +218,10 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                 float *bc = lds + P.bc + (tile & 1) * Kt * 128 + lane;
                 float *ob = lds + P.ob + (tile & 1) * Kt * 448 + lane;
                 float npet = in4[lane].z, nrain = ab[0], nts = ab[64];
-                for (int tt = 0; tt < nt; tt++) {
+                auto day = [&](int tt, bool more) __attribute__((always_inline)) {
                     Step<MODEL_HBV10, BETAET> s;
                     s.PET = npet; s.RAIN = nrain; s.tosoil = nts;
-                    if (tt + 1 < nt) {
+                    if (more) {
                         npet = in4[(tt + 1) * 64 + lane].z;
                         nrain = ab[(tt + 1) * 128];
                         nts = ab[(tt + 1) * 128 + 64];
@@ -222,7 +234,8 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                     q[0] = s.ET; q[64] = s.rech; q[128] = s.exc; q[192] = s.ef;
                     if (TRAJ) { q[256] = SM; q[320] = s.sw0; q[384] = s.ef0; }
                     SM = s.SM3;
-                }
+                };
+                PIPE_DAYS(nt, day);
             }
             PIPE_BARRIER();
         }
@@ -243,10 +256,10 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                 const float *bc = lds + P.bc + (tile & 1) * Kt * 128 + lane;
                 float *oc = lds + P.oc + (tile & 1) * Kt * 448 + lane;
                 float nrech = bc[0], nexc = bc[64];
-                for (int tt = 0; tt < nt; tt++) {
+                auto day = [&](int tt, bool more) __attribute__((always_inline)) {
                     Step<MODEL_HBV10, BETAET> s;
                     s.rech = nrech; s.exc = nexc;
-                    if (tt + 1 < nt) {
+                    if (more) {
                         nrech = bc[(tt + 1) * 128];
                         nexc = bc[(tt + 1) * 128 + 64];
                     }
@@ -256,7 +269,8 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                     q[0] = s.Q; q[64] = s.Q0; q[128] = s.Q1; q[192] = s.Q2; q[256] = s.PERC;
                     if (TRAJ) { q[320] = SUZ; q[384] = SLZ; }
                     SUZ = s.SUZ4; SLZ = s.SLZ2;
-                }
+                };
+                PIPE_DAYS(nt, day);
             }
             PIPE_BARRIER();
         }
@@ -317,9 +331,18 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
             PIPE_BARRIER();
             for (int it = 0; it < nIt; it++) PIPE_BARRIER();
         } else if (quad == 3) {
-            // row drainers (waves 7, 11, 15): day tt of every stage tile -> 7 rows
+            // row drainers (waves 7, 11, 15): day tt of every stage tile -> 7 rows.  One buffer
+            // descriptor per storage series and tile (base = row of the tile's first day, range =
+            // the tile's Kt rows: the range check includes the scalar offset), the day inside the
+            // tile goes into the scalar offset operand.
             const int w = (wave - 7) >> 2, NRD = (nw - 7 + 3) >> 2;
             const int64_t SR = (int64_t)(T + 1) * N;   // storage row blocks in traj
+            auto rsrc = [&](float *base) {
+                return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(row_bytes * PIPE_KT), 0x00020000);
+            };
+            auto put = [&](__amdgpu_buffer_rsrc_t r, unsigned soff, float v) {
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+            };
             PIPE_BARRIER();
             for (int it = 0; it < nIt; it++) {
                 const int tA = it - 1, tB = it - 2, tC = it - 3;
@@ -329,27 +352,22 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                 const float *bufA = lds + P.oa + (tA & 1) * Kt * 256 + lane;
                 const float *bufB = lds + P.ob + (tB & 1) * Kt * 448 + lane;
                 const float *bufC = lds + P.oc + (tC & 1) * Kt * 448 + lane;
+                // (invalid tiles: nt = 0, the descriptors are built but never used)
+                const int64_t dA = (int64_t)max(tA, 0) * Kt * N, dB = (int64_t)max(tB, 0) * Kt * N,
+                              dC = (int64_t)max(tC, 0) * Kt * N;
+                const auto rSP = rsrc(o.traj + dA), rMW = rsrc(o.traj + SR + dA);
+                const auto rSM = rsrc(o.traj + 2 * SR + dB), rSW = rsrc(o.aux + dB),
+                           rEF = rsrc(o.aux + (int64_t)T * N + dB);
+                const auto rSUZ = rsrc(o.traj + 3 * SR + dC), rSLZ = rsrc(o.traj + 4 * SR + dC);
                 for (int tt = w; tt < Kt; tt += NRD) {
+                    const unsigned soff = (unsigned)tt * row_bytes;
                     float a0, a1, b0v, b1, b2, c0, c1;
                     if (tt < ntA) { a0 = bufA[tt * 256 + 128]; a1 = bufA[tt * 256 + 192]; }
                     if (tt < ntB) { b0v = bufB[tt * 448 + 256]; b1 = bufB[tt * 448 + 320]; b2 = bufB[tt * 448 + 384]; }
                     if (tt < ntC) { c0 = bufC[tt * 448 + 320]; c1 = bufC[tt * 448 + 384]; }
-                    if (tt < ntA) {
-                        float *r = o.traj + (int64_t)(tA * Kt + tt) * N;
-                        row_store(r, row_bytes, voff, a0);
-                        row_store(r + SR, row_bytes, voff, a1);
-                    }
-                    if (tt < ntB) {
-                        const int64_t t = tB * Kt + tt;
-                        row_store(o.traj + 2 * SR + t * N, row_bytes, voff, b0v);
-                        row_store(o.aux + t * N, row_bytes, voff, b1);
-                        row_store(o.aux + ((int64_t)T + t) * N, row_bytes, voff, b2);
-                    }
-                    if (tt < ntC) {
-                        float *r = o.traj + 3 * SR + (int64_t)(tC * Kt + tt) * N;
-                        row_store(r, row_bytes, voff, c0);
-                        row_store(r + SR, row_bytes, voff, c1);
-                    }
+                    if (tt < ntA) { put(rSP, soff, a0); put(rMW, soff, a1); }
+                    if (tt < ntB) { put(rSM, soff, b0v); put(rSW, soff, b1); put(rEF, soff, b2); }
+                    if (tt < ntC) { put(rSUZ, soff, c0); put(rSLZ, soff, c1); }
                 }
                 PIPE_BARRIER();
             }

@@ -105,11 +105,8 @@ HBVX_HD double fma64_(double a, double b, double c)
 #endif
 }
 
-HBVX_HD float pow_pos_(float x, float y)
+HBVX_HD float pow_f64_(float x, float y)
 {
-#if defined(HBVX_ABLATE_POW) && defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
-#endif
     const double xd = (double)x;
 #if defined(__HIP_DEVICE_COMPILE__)
     double m = __builtin_amdgcn_frexp_mant(xd);   // [0.5, 1)
@@ -148,6 +145,64 @@ HBVX_HD float pow_pos_(float x, float y)
     r = (x == inf) ? (y > 0.0f ? inf : (y == 0.0f ? 1.0f : 0.0f)) : r;
     r = (x < 0.0f || x != x || y != y) ? __builtin_nanf("") : r;
     return r;
+}
+
+// x**y for x >= 0 on the hardware transcendentals, arranged so that their 1-ulp errors stay 1-ulp
+// errors of the result:
+//   x = m 2^k, m in [sqrt(1/2), sqrt(2))  ->  log2 x = k + v_log_f32(m), |log2 m| <= 1/2: the
+//   absolute error of the hardware log2 is <= 2^-25 whatever the magnitude of k;
+//   k + log2 m and its product with y are carried as hi + lo pairs (Fast2Sum / fma residuals);
+//   y log2 x = n + f, |f| <= 1/2  ->  x**y = v_exp_f32(f) 2^n.
+// Error: <= (1 + 0.7 |y| / 4 ...) ~ 2-3 ulp for the exponents of this model (BETA <= 6, BETAET <= 5),
+// measured by hbvx_selftest_pow (tests/test_gpu_parity.py); torch's own GPU pow is in the same class.
+// pow_f64_ below is the 0.5-ulp fp64-polynomial version (-DHBVX_POW_F64 selects it): on the VALU-bound
+// stepper waves it costs ~260 cycles per call against ~130 for this one.
+HBVX_HD float pow_hw_(float x, float y)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    float m = __builtin_amdgcn_frexp_mantf(x);     // [0.5, 1)
+    int k = __builtin_amdgcn_frexp_expf(x);
+#else
+    int k;
+    float m = frexpf(x, &k);
+#endif
+    const bool adj = m < 0.70710678f;
+    m = adj ? m + m : m;
+    k -= adj ? 1 : 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float l0 = __builtin_amdgcn_logf(m);     // v_log_f32: log2
+#else
+    const float l0 = log2f(m);
+#endif
+    const float kf = (float)k;
+    const float lh = kf + l0;                      // Fast2Sum: |kf| >= |l0| or kf == 0
+    const float ll = l0 - (lh - kf);
+    float zh = y * lh;
+    float zl = fmaf(y, lh, -zh);
+    zl = fmaf(y, ll, zl);
+    zh = zh > 130.0f ? 130.0f : (zh < -160.0f ? -160.0f : zh);
+    const float n = rintf(zh);
+    const float f = (zh - n) + zl;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float e = __builtin_amdgcn_exp2f(f);     // v_exp_f32: 2^f
+#else
+    const float e = exp2f(f);
+#endif
+    float r = ldexpf(e, (int)n);
+    const float inf = __builtin_inff();
+    r = (x == 0.0f) ? (y > 0.0f ? 0.0f : (y == 0.0f ? 1.0f : inf)) : r;
+    r = (x == inf) ? (y > 0.0f ? inf : (y == 0.0f ? 1.0f : 0.0f)) : r;
+    r = (x < 0.0f || x != x || y != y) ? __builtin_nanf("") : r;
+    return r;
+}
+
+HBVX_HD float pow_pos_(float x, float y)
+{
+#if defined(HBVX_POW_F64)
+    return pow_f64_(x, y);
+#else
+    return pow_hw_(x, y);
+#endif
 }
 
 // natural log for the adjoint's d(x**y)/dy = x**y ln x: gradients are compared at rtol 1e-3,

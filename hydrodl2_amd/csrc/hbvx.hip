@@ -721,7 +721,7 @@ extern "C" int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *s
         const int Kt = PIPE_KT;
         if (use_tiled(d) && !(fv && !strcmp(fv, "tiled")) && d->model == HBVX_MODEL_HBV10 &&
             count_dyn(d) == 0 && !d->muwts && out->flux && d->T >= 4 * Kt &&
-            (out->traj != nullptr) == (out->aux != nullptr) && (int64_t)d->B * d->M * 4 < (int64_t)1 << 31 &&
+            (out->traj != nullptr) == (out->aux != nullptr) && (int64_t)d->B * d->M * 4 * PIPE_KT < (int64_t)1 << 31 &&
             (int64_t)11 * d->T * d->B * 4 < (int64_t)1 << 31) {
             PipeArgs pa;
             pa.d = *d;

@@ -13,6 +13,7 @@ only; every arithmetic step of the path runs in the HIP library.
 from __future__ import annotations
 
 from dataclasses import dataclass, field
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -85,6 +86,18 @@ def _call(lib, name, fn, *args):
     fn(*args)
     e1.record()
     KERNEL_EVENTS.append((name, e0, e1))
+
+
+_POISON = os.environ.get("HBVX_DEBUG_POISON", "") not in ("", "0")
+
+
+def _out(shape, device) -> torch.Tensor:
+    """Output buffer the library overwrites completely.  HBVX_DEBUG_POISON=1 (set by the GPU
+    test tier) fills it with NaN first, so a kernel that skips an element cannot pass on stale
+    memory the caching allocator handed back."""
+    if _POISON:
+        return torch.full(shape, float("nan"), dtype=torch.float32, device=device)
+    return torch.empty(shape, dtype=torch.float32, device=device)
 
 
 def _ptr(t: Optional[torch.Tensor], off: int = 0) -> Optional[int]:
@@ -184,11 +197,11 @@ class HbvPath(torch.autograd.Function):
         stream = _stream_of(lib, x)
 
         out = _abi.FwdOut()
-        flux = torch.empty((cfg.n_flux, T, B), dtype=torch.float32, device=dev) \
+        flux = _out((cfg.n_flux, T, B), dev) \
             if cfg.want_flux else None
-        state_out = torch.empty((5, B, M), dtype=torch.float32, device=dev)
-        traj = torch.empty((5, T + 1, B * M), dtype=torch.float32, device=dev) if keep else None
-        aux = torch.empty((2, T, B * M), dtype=torch.float32, device=dev) if needs_grad else None
+        state_out = _out((5, B, M), dev)
+        traj = _out((5, T + 1, B * M), dev) if keep else None
+        aux = _out((2, T, B * M), dev) if needs_grad else None
         out.flux, out.state_out = _ptr(flux), _ptr(state_out)
         out.traj, out.aux = _ptr(traj), _ptr(aux)
         out.n_flux = cfg.n_flux
@@ -198,8 +211,8 @@ class HbvPath(torch.autograd.Function):
         routed = uh = None
         if cfg.route is not None and cfg.want_flux:
             r = _route_desc(cfg, ptensors)
-            routed = torch.empty((4, T, B), dtype=torch.float32, device=dev)
-            uh = torch.empty((B, r.L), dtype=torch.float32, device=dev)
+            routed = _out((4, T, B), dev)
+            uh = _out((B, r.L), dev)
             _call(lib, 'hbvx_route_forward', lib.route_forward, r, _ptr(flux), _ptr(uh), _ptr(routed), stream)
 
         ctx.cfg = cfg
@@ -229,7 +242,7 @@ class HbvPath(torch.autograd.Function):
         gq = None
         if g_routed is not None and cfg.route is not None:
             r = _route_desc(cfg, ptensors)
-            gq = torch.empty((4, T, B), dtype=torch.float32, device=dev)
+            gq = _out((4, T, B), dev)
             rs = cfg.route
             gt = gp[rs.tensor_idx]
             ws_bytes = lib.route_workspace_bytes(r)
@@ -293,9 +306,9 @@ class HbvAdjPath(torch.autograd.Function):
         needs_grad = any(ctx.needs_input_grad)
         stream = _stream_of(lib, x)
         out = _abi.FwdOut()
-        flux = torch.empty((1, T, B), dtype=torch.float32, device=dev) if cfg.want_flux else None
-        state_out = torch.empty((5, B, M), dtype=torch.float32, device=dev)
-        traj = torch.empty((5, T + 1, B * M), dtype=torch.float32, device=dev) if needs_grad else None
+        flux = _out((1, T, B), dev) if cfg.want_flux else None
+        state_out = _out((5, B, M), dev)
+        traj = _out((5, T + 1, B * M), dev) if needs_grad else None
         out.flux, out.state_out, out.traj, out.n_flux = _ptr(flux), _ptr(state_out), _ptr(traj), 1
         if state_in is not None:
             state_in = state_in.contiguous()
@@ -304,8 +317,8 @@ class HbvAdjPath(torch.autograd.Function):
         routed = uh = None
         if cfg.route is not None and cfg.want_flux:
             r = _route_desc(cfg, ptensors, S=1)
-            routed = torch.empty((1, T, B), dtype=torch.float32, device=dev)
-            uh = torch.empty((B, r.L), dtype=torch.float32, device=dev)
+            routed = _out((1, T, B), dev)
+            uh = _out((B, r.L), dev)
             _call(lib, 'hbvx_route_forward', lib.route_forward, r, _ptr(flux), _ptr(uh),
                   _ptr(routed), stream)
         ctx.cfg = cfg
@@ -329,7 +342,7 @@ class HbvAdjPath(torch.autograd.Function):
         gq = None
         if g_routed is not None and cfg.route is not None:
             r = _route_desc(cfg, ptensors, S=1)
-            gq = torch.empty((1, T, B), dtype=torch.float32, device=dev)
+            gq = _out((1, T, B), dev)
             rs = cfg.route
             gt = gp[rs.tensor_idx]
             ws_bytes = lib.route_workspace_bytes(r)
@@ -345,7 +358,7 @@ class HbvAdjPath(torch.autograd.Function):
         io.n_flux = 1
         gs_in = None
         if state_in is not None and ctx.needs_input_grad[2]:
-            gs_in = torch.empty((5, B, M), dtype=torch.float32, device=dev)
+            gs_in = _out((5, B, M), dev)
             io.grad_state_in = _ptr(gs_in)
         for ps in cfg.params:
             g = io.g[ps.slot]
@@ -376,7 +389,7 @@ class Bfi(torch.autograd.Function):
         lib = get_library()
         qs_c, q2_c = qs.contiguous(), q2.contiguous()
         T, B = qs_c.shape
-        out = torch.empty((B,), dtype=torch.float32, device=qs.device)
+        out = _out((B,), qs.device)
         _call(lib, 'hbvx_bfi', lib.bfi, T, B, _ptr(qs_c), _ptr(q2_c), float(nearzero), _ptr(out),
               _stream_of(lib, qs_c))
         ctx.save_for_backward(qs_c, q2_c)
@@ -462,8 +475,8 @@ class GageRoute(torch.autograd.Function):
             raise ValueError(f"distributed routing parameters have shape {tuple(dp_c.shape)}, "
                              f"outlet_topo has {topo.n_pair} (gage, unit) pairs x 3")
         L = min(topo.T, _abi.GAGE_MAXLEN)
-        uh = torch.empty((topo.n_pair, L), dtype=torch.float32, device=qs.device)
-        out = torch.empty((topo.T, topo.G), dtype=torch.float32, device=qs.device)
+        uh = _out((topo.n_pair, L), qs.device)
+        out = _out((topo.T, topo.G), qs.device)
         r = topo.desc(dp_c)
         _call(lib, 'hbvx_gage_route_forward', lib.gage_route_forward, r, _ptr(qs_c), _ptr(uh),
               _ptr(out), _stream_of(lib, qs_c))
@@ -477,8 +490,8 @@ class GageRoute(torch.autograd.Function):
         qs, dp, uh = ctx.saved_tensors
         topo = ctx.topo
         g = g.contiguous()
-        gqs = torch.empty_like(qs)
-        gdp = torch.empty_like(dp)
+        gqs = _out(tuple(qs.shape), qs.device)
+        gdp = _out(tuple(dp.shape), dp.device)
         r = topo.desc(dp)
         _call(lib, 'hbvx_gage_route_backward', lib.gage_route_backward, r, _ptr(qs), _ptr(uh),
               _ptr(g), _ptr(gqs), _ptr(gdp), _stream_of(lib, qs))

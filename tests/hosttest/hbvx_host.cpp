@@ -353,3 +353,7 @@ extern "C" void hbvx_test_pow(const float *x, const float *y, float *out, int n)
 {
     for (int i = 0; i < n; i++) out[i] = pow_pos_(x[i], y[i]);
 }
+extern "C" void hbvx_test_pow_f64(const float *x, const float *y, float *out, int n)
+{
+    for (int i = 0; i < n; i++) out[i] = pow_f64_(x[i], y[i]);
+}

@@ -90,10 +90,11 @@ def test_product_refuses_cpu_tensors(hip_backend):
 
 
 def test_pow_on_gpu(hip_backend):
-    """The device pow (fp64 polynomials, v_rcp_f64 path) stays within 1 ulp of exact x**y."""
+    """The device pow (v_log_f32 / v_exp_f32 on the reduced mantissa, hi+lo exponent product) stays
+    within the stated POW_HW_MAX_ULP of exact x**y."""
     import ctypes as C
     import torch
-    from .test_step_math_host import _pow_inputs, pow_error_ulps
+    from .test_step_math_host import POW_HW_MAX_ULP, _pow_inputs, pow_error_ulps
     x, y = _pow_inputs()
     xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
     out = torch.empty_like(xd)
@@ -103,7 +104,9 @@ def test_pow_on_gpu(hip_backend):
             C.c_int(x.size), C.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0
     err = pow_error_ulps(out.cpu().numpy(), x, y)
-    assert err.max() <= 0.75, f"max error {err.max():.3f} ulp"
+    print(f"device pow: max {err.max():.3f} ulp, mean {err.mean():.3f} ulp")
+    assert err.max() <= POW_HW_MAX_ULP, f"max error {err.max():.3f} ulp"
+    assert out[0].item() == 1.0
 
 
 def test_div_on_gpu(hip_backend):
