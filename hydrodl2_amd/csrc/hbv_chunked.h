@@ -218,8 +218,19 @@ __global__ void __launch_bounds__(64) k_bwd_chunk_phi(const ChunkArgs A)
         float gp[NPARAM_MAX], gx[3];
 #pragma unroll
         for (int i = 0; i < NPARAM_MAX; i++) gp[i] = 0.0f;
+        if constexpr (MODEL == MODEL_HBV10) {
+            // feed-forward day: block-triangular J^T, coefficients once, sparse application
+            typedef Step<MODEL, BETAET> S;
+            const typename S::JT c = D.s.jt_coef(D.p, nz);
+            S::template jt_unit<0>(c, Phi[0]);
+            S::template jt_unit<0>(c, Phi[1]);
+            S::template jt_unit<1>(c, Phi[2]);
+            S::template jt_unit<2>(c, Phi[3]);
+            S::template jt_unit<2>(c, Phi[4]);
+        } else {
 #pragma unroll
-        for (int k = 0; k < 5; k++) D.s.bwd(D.p, nz, g0, Phi[k], gp, gx);
+            for (int k = 0; k < 5; k++) D.s.bwd(D.p, nz, g0, Phi[k], gp, gx);
+        }
         D.s.bwd(D.p, nz, D.g, phi, gp, gx);
     }
     if (L.active) {

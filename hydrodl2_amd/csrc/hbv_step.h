@@ -525,6 +525,80 @@ struct Step {
 
         a[0] = aSP; a[1] = aMW; a[2] = aSM; a[3] = aSUZ; a[4] = aSLZ;
     }
+
+    // ---- transposed state Jacobian of one day, HBV 1.0 only --------------------------------
+    // bwd() with zero flux adjoints is the linear map a -> J^T a.  In HBV 1.0 the day is a
+    // feed-forward chain snow -> soil -> groundwater, so J^T is block upper-triangular:
+    //   out[SUZ,SLZ] from a[SUZ,SLZ];  out[SM] from a[SM], a[SUZ,SLZ];  out[SP,MW] from all.
+    // jt_coef() extracts the handful of coefficients once per day (same predicates and tie
+    // weights as bwd()), jt_unit<LEVEL>() applies them to one adjoint vector:
+    //   LEVEL 0: a[2..4] == 0 (stays in the snow block)   LEVEL 1: a[3..4] == 0   LEVEL 2: full.
+    // Used by the time-parallel adjoint to propagate the five unit adjoints of a chunk at ~1/4
+    // of the cost of five bwd() calls.
+    struct JT {
+        float cS, cU, wP;          // groundwater: out[SLZ] = cS a4; U = cU a3 + wP out[SLZ]
+        float kap, me, rho, sw;    // soil
+        float mts, cwh, wr, wm;    // snow
+    };
+
+    HBVX_HDM JT jt_coef(const float *p, float nz) const
+    {
+        static_assert(MODEL == MODEL_HBV10, "jt_coef: HBV 1.0 only");
+        const float BETA = p[P_BETA], FC = p[P_FC], K0 = p[P_K0], K1 = p[P_K1], K2 = p[P_K2];
+        JT c;
+        float wa, wb;
+        c.cS = 1.0f - K2;
+        minw_(SUZ1, p[P_PERC], wa, wb);
+        const float m0k0 = (u0 >= 0.0f) ? K0 : 0.0f;
+        c.cU = ((1.0f - K1) * (1.0f - m0k0)) * (1.0f - wa);
+        c.wP = wa;
+        // soil
+        minw_(SM2, pe, wa, wb);
+        const float mef = (ef0 >= 0.0f && ef0 <= 1.0f) ? 1.0f : 0.0f;
+        float dq = mef;
+        if (BETAET) dq = (q > 0.0f) ? mef * (p[P_BETAET] * div_approx_(ef0, q)) : 0.0f;
+        const float md = (dd >= nz) ? 1.0f : 0.0f;
+        c.kap = md * ((1.0f - wa) - (wb * PET) * div_approx_(dq, lpfc));
+        c.me = (e0 >= 0.0f) ? 1.0f : 0.0f;
+        const float msw = (sw0 >= 0.0f && sw0 <= 1.0f) ? 1.0f : 0.0f;
+        const float dr = (r > 0.0f) ? BETA * div_approx_(sw0, r) : 0.0f;
+        c.rho = div_approx_((rt * msw) * dr, FC);
+        c.sw = sw;
+        // snow
+        c.mts = (ts0 >= 0.0f) ? 1.0f : 0.0f;
+        c.cwh = p[P_CWH];
+        minw_(rpc, MW1, wa, wb);
+        c.wr = wb;
+        minw_(mpc, SP1, wa, wb);
+        c.wm = wb;
+        return c;
+    }
+
+    template <int LEVEL>
+    static HBVX_HDM void jt_unit(const JT &c, float *a)
+    {
+        float ats = 0.0f;
+        if (LEVEL >= 1) {
+            float U = 0.0f;
+            if (LEVEL >= 2) {
+                const float sl = c.cS * a[4];
+                U = c.cU * a[3] + c.wP * sl;
+                a[3] = U;
+                a[4] = sl;
+            }
+            const float s2 = c.kap * a[2];
+            const float s1 = s2 + c.me * (U - s2);
+            const float w = U - s1;
+            a[2] = s1 + c.rho * w;
+            ats = s1 + c.sw * w;
+        }
+        const float t = c.mts * (ats - a[1]);
+        const float mw2 = a[1] + t;
+        const float sp2 = a[0] - t * c.cwh;
+        const float mw1 = mw2 + (sp2 - mw2) * c.wr;
+        a[1] = mw1;
+        a[0] = sp2 + (mw1 - sp2) * c.wm;
+    }
 };
 
 } // namespace hbvx

@@ -348,6 +348,43 @@ extern "C" int hbvx_gage_route_backward(const hbvx_gage_desc *r, const float *qs
     return fn(r, qs, uh, go, gqs, gdp, st);
 }
 
+// Step::jt_unit against Step::bwd with zero flux adjoints (HBV 1.0): for n random days, the worst
+// difference over the five unit adjoints, relative to the largest entry of J^T.
+template <bool BETAET>
+static float jt_check(const float *st, const float *f, const float *p, int n, float nz)
+{
+    float worst = 0.0f;
+    for (int i = 0; i < n; i++) {
+        Step<MODEL_HBV10, BETAET> s;
+        s.SP = st[i * 5]; s.MW = st[i * 5 + 1]; s.SM = st[i * 5 + 2]; s.SUZ = st[i * 5 + 3]; s.SLZ = st[i * 5 + 4];
+        s.P = f[i * 3]; s.Tf = f[i * 3 + 1]; s.PET = f[i * 3 + 2];
+        const float *pp = p + i * NPARAM_MAX;
+        s.template fwd<false>(pp, nz, 0.0f, 0.0f, 0.0f, 0.0f);
+        FluxGrad g0;
+        memset(&g0, 0, sizeof g0);
+        const auto c = s.jt_coef(pp, nz);
+        float scale = 1e-30f, err = 0.0f;
+        for (int k = 0; k < 5; k++) {
+            float a[5] = {0, 0, 0, 0, 0}, b[5] = {0, 0, 0, 0, 0}, gp[NPARAM_MAX] = {0}, gx[3];
+            a[k] = b[k] = 1.0f;
+            s.bwd(pp, nz, g0, a, gp, gx);
+            if (k < 2) Step<MODEL_HBV10, BETAET>::template jt_unit<0>(c, b);
+            else if (k == 2) Step<MODEL_HBV10, BETAET>::template jt_unit<1>(c, b);
+            else Step<MODEL_HBV10, BETAET>::template jt_unit<2>(c, b);
+            for (int j = 0; j < 5; j++) {
+                scale = fmaxf(scale, fabsf(a[j]));
+                err = fmaxf(err, fabsf(a[j] - b[j]));
+            }
+        }
+        worst = fmaxf(worst, err / scale);
+    }
+    return worst;
+}
+extern "C" float hbvx_test_jt(const float *st, const float *f, const float *p, int n, float nz, int betaet)
+{
+    return betaet ? jt_check<true>(st, f, p, n, nz) : jt_check<false>(st, f, p, n, nz);
+}
+
 // accuracy probe for hbvx::pow_pos_ (host build of the same source)
 extern "C" void hbvx_test_pow(const float *x, const float *y, float *out, int n)
 {

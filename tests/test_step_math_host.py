@@ -91,3 +91,31 @@ def test_pow_accuracy(steptest_lib):
         assert out[0] == 1.0
         want = np.power(np.float64(np.float32(1e-38)), np.float64(np.float32(0.3)))
         assert abs(float(out[3]) - want) <= bound * np.spacing(np.float32(want))
+
+
+def test_sparse_transposed_jacobian_matches_bwd(steptest_lib):
+    """Step::jt_coef / jt_unit (block-triangular J^T of HBV 1.0, used by the time-parallel adjoint's
+    chunk maps) reproduces Step::bwd with zero flux adjoints on random days, including tie cases
+    (empty snow pack, SM at FC, SUZ below PERC)."""
+    import ctypes as C
+    import numpy as np
+    from . import synth
+    from .abi_util import BOUNDS
+    from .golden_cases import PHY_NAMES
+    lib = C.CDLL(steptest_lib)
+    lib.hbvx_test_jt.restype = C.c_float
+    n = 20000
+    u = lambda k: synth.uniform((n,), 55, k).astype(np.float64)
+    st = np.stack([np.where(u(1) < 0.3, 0.0, 80 * u(2)), np.where(u(3) < 0.3, 0.0, 10 * u(4)),
+                   1e-5 + 900 * u(5) ** 2, 60 * u(6), 200 * u(7)], 1).astype(np.float32)
+    f = np.stack([np.where(u(8) < 0.6, 0.0, 40 * u(9)), 30 * u(10) - 12, 6 * u(11)], 1).astype(np.float32)
+    names = PHY_NAMES["Hbv"] + ["parBETAET"]
+    p = np.zeros((n, 19), np.float32)   # NPARAM_MAX slots
+    for i, nm in enumerate(names):
+        lo, hi = BOUNDS[nm]
+        p[:, i] = (lo + (hi - lo) * u(20 + i)).astype(np.float32)
+    st[: n // 10, 2] = p[: n // 10, 1]          # SM == FC exactly
+    for be in (0, 1):
+        worst = lib.hbvx_test_jt(st.ctypes.data_as(C.c_void_p), f.ctypes.data_as(C.c_void_p),
+                                 p.ctypes.data_as(C.c_void_p), C.c_int(n), C.c_float(1e-5), C.c_int(be))
+        assert worst < 2e-6, f"betaet={be}: worst relative difference {worst:.3g}"
