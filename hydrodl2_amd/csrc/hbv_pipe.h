@@ -39,7 +39,8 @@
 
 namespace hbvx {
 
-#define PIPE_KT 8   // days per tile (host and device)
+#define PIPE_KT 8       // days per tile (host and device)
+#define PIPE_MAXDYN 3   // dynamic parameters the pipelined kernel stages (LDS: 5 slots x Kt x 3 rows)
 
 // Run `body(tt, has_next)` for the nt days of a tile; full tiles are unrolled so that every LDS
 // address is base + immediate and the loop-carried registers need no rotation moves.
@@ -61,8 +62,8 @@ struct PipeArgs {
 
 // LDS layout in floats for Kt days per tile
 struct PipeLds {
-    int xin, ab, bc, oa, ob, oc, total;
-    __host__ __device__ explicit PipeLds(int Kt)
+    int xin, ab, bc, oa, ob, oc, pin, total;
+    __host__ __device__ explicit PipeLds(int Kt, bool dyn = false)
     {
         xin = 0;                    // [4][Kt][64][4]
         ab = xin + 4 * Kt * 256;    // [2][Kt][2][64]
@@ -70,7 +71,8 @@ struct PipeLds {
         oa = bc + 2 * Kt * 128;     // [2][Kt][4][64]  SWE, tosoil | SNOWPACK, MELTWATER
         ob = oa + 2 * Kt * 256;     // [2][Kt][7][64]  AET, recharge, excs, evapfactor | SM, sw0, ef0
         oc = ob + 2 * Kt * 448;     // [2][Kt][7][64]  Qsim, Q0, Q1, Q2, PERC | SUZ, SLZ
-        total = oc + 2 * Kt * 448;
+        pin = oc + 2 * Kt * 448;    // [5][Kt][PIPE_MAXDYN][64]  de-scaled dynamic parameters (DYN only)
+        total = pin + (dyn ? 5 * Kt * PIPE_MAXDYN * 64 : 0);
     }
 };
 
@@ -117,8 +119,19 @@ __device__ unsigned long long g_pipe_probe[32];
 #define PIPE_BARRIER() lds_barrier()
 #endif
 
+// Dynamic parameters in the stepper waves: DY_DECL names the per-parameter flag / LDS row / prefetch
+// register, DY_LOAD reads the value of a day from the staged tile (one day ahead of its use, like
+// the forcings), DY_USE moves it into the parameter array.
+// Branch-free: a static parameter reads row 0 of the tile (always valid) and keeps its value through
+// a select, so the stepper loop has no scalar branches.
+#define DY_DECL(X) const bool dy_##X = DYN && ((dmask >> X) & 1u); const int ix_##X = dy_##X ? dyn_index(dmask, X) * 64 : 0; float pn_##X = 0.0f
+#define DY_LOAD(X, ptr) do { pn_##X = (ptr)[ix_##X]; } while (0)
+#define DY_USE(X) do { p[X] = dy_##X ? pn_##X : p[X]; } while (0)
+
 // TRAJ: the forward also saves the storage trajectory and the pow results (traj and aux given).
-template <bool BETAET, bool TRAJ>
+// DYN: 1..PIPE_MAXDYN parameters vary per day: the filler de-scales them (sigmoid, range, dy_drop
+// blend) into LDS tiles five deep (snow reads tile it, groundwater tile it-2, the filler writes it+2).
+template <bool BETAET, bool TRAJ, bool DYN>
 __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
 {
 #ifdef PIPE_PROBE
@@ -149,8 +162,15 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
     const bool raw = d.raw_sigmoid != 0;
     const unsigned row_bytes = (unsigned)(N * 4);
     const unsigned voff = L.active ? (unsigned)(L.n * 4) : 0xFFFFFFFFu;
-    const PipeLds P(Kt);
+    const PipeLds P(Kt, DYN);
     const float nz = d.nearzero;
+    unsigned dmask = 0;
+    if (DYN) {
+#pragma unroll
+        for (int i = 0; i < NP; i++) dmask |= d.p[i].dyn ? (1u << i) : 0u;
+    }
+    constexpr int PD = PIPE_MAXDYN;
+    auto pin_of = [&](int tile) { return lds + P.pin + (tile % 5) * Kt * PD * 64 + lane; };
 
     float p[NPARAM_MAX];
 #pragma unroll
@@ -178,10 +198,20 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                 float *ab = lds + P.ab + (tile & 1) * Kt * 128 + lane;
                 float *oa = lds + P.oa + (tile & 1) * Kt * 256 + lane;
                 float4 fn = in4[lane];
+                const float *pin = pin_of(tile);
+                DY_DECL(P_TT); DY_DECL(P_CFMAX); DY_DECL(P_CFR); DY_DECL(P_CWH);
+                if (DYN) { DY_LOAD(P_TT, pin); DY_LOAD(P_CFMAX, pin); DY_LOAD(P_CFR, pin); DY_LOAD(P_CWH, pin); }
                 auto day = [&](int tt, bool more) __attribute__((always_inline)) {
                     Step<MODEL_HBV10, BETAET> s;
                     const float4 f = fn;
-                    if (more) fn = in4[(tt + 1) * 64 + lane];
+                    if (DYN) { DY_USE(P_TT); DY_USE(P_CFMAX); DY_USE(P_CFR); DY_USE(P_CWH); }
+                    if (more) {
+                        fn = in4[(tt + 1) * 64 + lane];
+                        if (DYN) {
+                            const float *pt = pin + (tt + 1) * PD * 64;
+                            DY_LOAD(P_TT, pt); DY_LOAD(P_CFMAX, pt); DY_LOAD(P_CFR, pt); DY_LOAD(P_CWH, pt);
+                        }
+                    }
                     s.P = f.x; s.Tf = f.y;
                     s.SP = SP; s.MW = MW;
                     s.fwd_snow(p, 0.0f);
@@ -218,13 +248,21 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                 float *bc = lds + P.bc + (tile & 1) * Kt * 128 + lane;
                 float *ob = lds + P.ob + (tile & 1) * Kt * 448 + lane;
                 float npet = in4[lane].z, nrain = ab[0], nts = ab[64];
+                const float *pin = pin_of(tile);
+                DY_DECL(P_BETA); DY_DECL(P_FC); DY_DECL(P_LP); DY_DECL(P_BETAET);
+                if (DYN) { DY_LOAD(P_BETA, pin); DY_LOAD(P_FC, pin); DY_LOAD(P_LP, pin); DY_LOAD(P_BETAET, pin); }
                 auto day = [&](int tt, bool more) __attribute__((always_inline)) {
                     Step<MODEL_HBV10, BETAET> s;
                     s.PET = npet; s.RAIN = nrain; s.tosoil = nts;
+                    if (DYN) { DY_USE(P_BETA); DY_USE(P_FC); DY_USE(P_LP); DY_USE(P_BETAET); }
                     if (more) {
                         npet = in4[(tt + 1) * 64 + lane].z;
                         nrain = ab[(tt + 1) * 128];
                         nts = ab[(tt + 1) * 128 + 64];
+                        if (DYN) {
+                            const float *pt = pin + (tt + 1) * PD * 64;
+                            DY_LOAD(P_BETA, pt); DY_LOAD(P_FC, pt); DY_LOAD(P_LP, pt); DY_LOAD(P_BETAET, pt);
+                        }
                     }
                     s.SM = SM;
                     s.template fwd_soil<false>(p, nz, 0.0f, 0.0f);
@@ -256,12 +294,20 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                 const float *bc = lds + P.bc + (tile & 1) * Kt * 128 + lane;
                 float *oc = lds + P.oc + (tile & 1) * Kt * 448 + lane;
                 float nrech = bc[0], nexc = bc[64];
+                const float *pin = pin_of(tile);
+                DY_DECL(P_K0); DY_DECL(P_K1); DY_DECL(P_K2); DY_DECL(P_PERC); DY_DECL(P_UZL);
+                if (DYN) { DY_LOAD(P_K0, pin); DY_LOAD(P_K1, pin); DY_LOAD(P_K2, pin); DY_LOAD(P_PERC, pin); DY_LOAD(P_UZL, pin); }
                 auto day = [&](int tt, bool more) __attribute__((always_inline)) {
                     Step<MODEL_HBV10, BETAET> s;
                     s.rech = nrech; s.exc = nexc;
+                    if (DYN) { DY_USE(P_K0); DY_USE(P_K1); DY_USE(P_K2); DY_USE(P_PERC); DY_USE(P_UZL); }
                     if (more) {
                         nrech = bc[(tt + 1) * 128];
                         nexc = bc[(tt + 1) * 128 + 64];
+                        if (DYN) {
+                            const float *pt = pin + (tt + 1) * PD * 64;
+                            DY_LOAD(P_K0, pt); DY_LOAD(P_K1, pt); DY_LOAD(P_K2, pt); DY_LOAD(P_PERC, pt); DY_LOAD(P_UZL, pt);
+                        }
                     }
                     s.SUZ = SUZ; s.SLZ0 = SLZ;
                     s.fwd_gw(p, 0.0f);
@@ -293,26 +339,83 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                                    (HBVX_F_PERC << 16);
         const int nw = blockDim.x >> 6;
         const int quad = wave & 3;   // waves with the same value share a SIMD
-        if (wave == 3) {
-            // filler: registers hold the tile that goes to LDS next iteration.  Straight-line code
-            // (days past the end of the record are clamped / written but never read): with control
-            // flow between the loads the compiler falls back to vmcnt(0) after every group.
+        // fillers: wave 3 stages the forcings (and dynamic-parameter row 0); with dynamic parameters
+        // waves 4 and 6 stage rows 1 and 2 -- the de-scaling (sigmoid) of a row is ~140 VALU cycles
+        // per day, too much for one wave beside the forcings.
+        const bool is_fill = wave == 3 || (DYN && (wave == 4 || wave == 6));
+        const int rbase = DYN ? 8 : 4;   // first reducer wave
+        if (is_fill) {
+            // Registers hold the tile that goes to LDS next iteration.  Straight-line code (days past
+            // the end of the record read 0 / are written but never consumed): with control flow
+            // between the loads the compiler falls back to vmcnt(0) after every group.
+            // Loads use buffer addressing: one descriptor per tensor and tile (base = first day of
+            // the tile, range = the days that exist), the day offset is a scalar operand and the
+            // per-lane offset a constant, so issuing a tile costs no vector address arithmetic.
             constexpr int FD = PIPE_KT;
-            const float *xb = d.x + (int64_t)L.b * d.x_b_stride;
-            float fx[FD], fy[FD], fz[FD];
+            const int fidx = wave == 3 ? 0 : (wave == 4 ? 1 : 2);
+            const bool forc = fidx == 0;
+            const int nd = __builtin_popcount(dmask);
+            const bool dyrow = DYN && fidx < nd;     // this wave stages dynamic row `fidx`
+            float fx[FD], fy[FD], fz[FD], dv[FD];
+            auto rsrc_of = [&](const float *base, int64_t row_floats, int rows) {
+                return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0,
+                                                         (int)(row_floats * 4 * rows), 0x00020000);
+            };
+            auto bload = [&](__amdgpu_buffer_rsrc_t r, unsigned vo, unsigned so) {
+                return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, vo, so, 0));
+            };
+            const unsigned xvo = (unsigned)(L.b * d.x_b_stride * 4);
+            const unsigned xcp = d.ch_prcp * 4, xct = d.ch_tmean * 4, xce = d.ch_pet * 4;
+            // dynamic row k = k-th set bit of dmask
+            const float *dsrc = d.x;
+            unsigned dvo = 0;
+            int64_t dts = 0;
+            float dlo = 0.0f, dhi = 0.0f, dsta = 0.0f;
+            bool duse = false;
+            if (dyrow) {
+                int slot = 0;
+                for (int i = 0, c = 0; i < NP; i++)
+                    if ((dmask >> i) & 1u) { if (c == fidx) slot = i; c++; }
+                const hbvx_param_src &ps = d.p[slot];
+                dsrc = ps.dyn;
+                dvo = (unsigned)((L.b * ps.dyn_b_stride + L.j) * 4);
+                dts = ps.dyn_t_stride;
+                dlo = ps.lo; dhi = ps.hi;
+                float v = ps.sta[(int64_t)L.b * ps.sta_b_stride + L.j];
+                v = raw ? sigmoid_(v) : v;
+                dsta = descale_(v, ps.lo, ps.hi);
+                duse = ps.drop ? (ps.drop[L.b] == 0) : true;
+            }
             auto issue = [&](int tile) {
-                const int t0 = tile * FD;
+                const int t0 = tile * FD, rows = min(FD, T - t0);
+                if (forc) {
+                    const auto rx = rsrc_of(d.x + (int64_t)t0 * d.x_t_stride, d.x_t_stride, rows);
 #pragma unroll
-                for (int i = 0; i < FD; i++) {
-                    const int t = min(t0 + i, T - 1);
-                    const float *xr = xb + (int64_t)t * d.x_t_stride;
-                    fx[i] = xr[d.ch_prcp]; fy[i] = xr[d.ch_tmean]; fz[i] = xr[d.ch_pet];
+                    for (int i = 0; i < FD; i++) {
+                        const unsigned so = (unsigned)(i * (int)d.x_t_stride * 4);
+                        fx[i] = bload(rx, xvo, so + xcp); fy[i] = bload(rx, xvo, so + xct); fz[i] = bload(rx, xvo, so + xce);
+                    }
+                }
+                if (dyrow) {
+                    const auto rd = rsrc_of(dsrc + (int64_t)t0 * dts, dts, rows);
+#pragma unroll
+                    for (int i = 0; i < FD; i++) dv[i] = bload(rd, dvo, (unsigned)(i * (int)dts * 4));
                 }
             };
             auto commit = [&](int tile) {
-                float4 *in4 = reinterpret_cast<float4 *>(lds + P.xin + (tile & 3) * FD * 256);
+                if (forc) {
+                    float4 *in4 = reinterpret_cast<float4 *>(lds + P.xin + (tile & 3) * FD * 256);
 #pragma unroll
-                for (int i = 0; i < FD; i++) in4[i * 64 + lane] = make_float4(fx[i], fy[i], fz[i], 0.0f);
+                    for (int i = 0; i < FD; i++) in4[i * 64 + lane] = make_float4(fx[i], fy[i], fz[i], 0.0f);
+                }
+                if (dyrow) {
+                    float *pin = lds + P.pin + (tile % 5) * FD * PD * 64 + fidx * 64 + lane;
+#pragma unroll
+                    for (int i = 0; i < FD; i++) {
+                        const float u = raw ? sigmoid_(dv[i]) : dv[i];
+                        pin[i * PD * 64] = duse ? descale_(u, dlo, dhi) : dsta;
+                    }
+                }
             };
             issue(0);
             commit(0);
@@ -372,9 +475,10 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                 PIPE_BARRIER();
             }
         } else {
-            // reducers: waves 4, 8, 12 (next to the snow wave) and 6, 10, 14 (next to groundwater)
-            const int w = ((wave - 4) >> 2) * 2 + (quad == 2 ? 1 : 0);
-            const int NDR = ((nw - 4 + 3) >> 2) + ((nw - 6 + 3) >> 2);
+            // reducers: waves 4, 8, 12 (next to the snow wave) and 6, 10, 14 (next to groundwater);
+            // with dynamic parameters 4 and 6 are fillers and the reducers start at wave 8
+            const int w = ((wave - rbase) >> 2) * 2 + (quad == 2 ? 1 : 0);
+            const int NDR = ((nw - rbase + 3) >> 2) + ((nw - rbase - 2 + 3) >> 2);
             PIPE_BARRIER();
             for (int it = 0; it < nIt; it++) {
                 const int tA = it - 1, tB = it - 2, tC = it - 3;

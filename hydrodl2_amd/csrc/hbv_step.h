@@ -157,7 +157,7 @@ HBVX_HD float pow_f64_(float x, float y)
 // measured by hbvx_selftest_pow (tests/test_gpu_parity.py); torch's own GPU pow is in the same class.
 // pow_f64_ below is the 0.5-ulp fp64-polynomial version (-DHBVX_POW_F64 selects it): on the VALU-bound
 // stepper waves it costs ~260 cycles per call against ~130 for this one.
-HBVX_HD float pow_hw_(float x, float y)
+HBVX_HD float pow_core_(float x, float y)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     float m = __builtin_amdgcn_frexp_mantf(x);     // [0.5, 1)
@@ -188,11 +188,21 @@ HBVX_HD float pow_hw_(float x, float y)
 #else
     const float e = exp2f(f);
 #endif
-    float r = ldexpf(e, (int)n);
+    return ldexpf(e, (int)n);
+}
+
+HBVX_HD float pow_hw_(float x, float y)
+{
+    float r = pow_core_(x, y);
+    // special bases as flat selects of ready values (nested conditionals become EXEC-masked
+    // branches when y is not loop-invariant)
     const float inf = __builtin_inff();
-    r = (x == 0.0f) ? (y > 0.0f ? 0.0f : (y == 0.0f ? 1.0f : inf)) : r;
-    r = (x == inf) ? (y > 0.0f ? inf : (y == 0.0f ? 1.0f : 0.0f)) : r;
-    r = (x < 0.0f || x != x || y != y) ? __builtin_nanf("") : r;
+    const float at0 = (y > 0.0f) ? 0.0f : inf, atinf = (y > 0.0f) ? inf : 0.0f;
+    const float r0 = (y == 0.0f) ? 1.0f : at0, ri = (y == 0.0f) ? 1.0f : atinf;
+    r = (x == 0.0f) ? r0 : r;
+    r = (x == inf) ? ri : r;
+    const bool bad = (x < 0.0f) | (x != x) | (y != y);
+    r = bad ? __builtin_nanf("") : r;
     return r;
 }
 
@@ -202,6 +212,20 @@ HBVX_HD float pow_pos_(float x, float y)
     return pow_f64_(x, y);
 #else
     return pow_hw_(x, y);
+#endif
+}
+
+// The power inside the time step: bases are finite and >= 0 by construction (storage ratios; the
+// storages are clamped at nearzero), exponents finite and > 0 (parameter ranges).  The base is
+// clamped at the smallest normal number instead of special-casing 0 -- 0**y becomes
+// (1.2e-38)**y <= 4e-12 for y >= 0.3, far below the flux tolerance -- which removes the
+// special-value selects from the VALU-bound stepper loop.
+HBVX_HD float pow_step_(float x, float y)
+{
+#if defined(HBVX_POW_F64)
+    return pow_f64_(x, y);
+#else
+    return pow_core_(fmax_(x, 1.17549435e-38f), y);
 #endif
 }
 
@@ -293,7 +317,7 @@ struct Step {
     {
         const float BETA = p[P_BETA], FC = p[P_FC], LP = p[P_LP];
         r = div_(SM, FC);
-        sw0 = USE_AUX ? aux_sw0 : pow_pos_(r, BETA);
+        sw0 = USE_AUX ? aux_sw0 : pow_step_(r, BETA);
         sw = fmin_(fmax_(sw0, 0.0f), 1.0f);
         rt = RAIN + tosoil;
         rech = rt * sw;
@@ -303,7 +327,7 @@ struct Step {
         SM2 = SM1 - exc;
         lpfc = LP * FC;
         q = div_(SM2, lpfc);
-        if (BETAET) ef0 = USE_AUX ? aux_ef0 : pow_pos_(q, p[P_BETAET]);
+        if (BETAET) ef0 = USE_AUX ? aux_ef0 : pow_step_(q, p[P_BETAET]);
         else ef0 = q;
         ef = fmin_(fmax_(ef0, 0.0f), 1.0f);
         pe = PET * ef;

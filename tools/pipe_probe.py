@@ -17,7 +17,9 @@ _lib._use_library_for_testing(os.path.join(ROOT, "hydrodl2_amd", "csrc", "libhbv
 lib = _lib.get_library()
 dev = torch.device("cuda:0")
 T, B, M = 7300, 671, 16
-model = hydrodl2_amd.load_model("hbv", "Hbv")({"nmul": M, "dynamic_params": {"Hbv": []}}, dev)
+DYN = os.environ.get("PROBE_DYN", "").split(",") if os.environ.get("PROBE_DYN") else []
+model = hydrodl2_amd.load_model("hbv", "Hbv")({"nmul": M, "dynamic_params": {"Hbv": DYN}}, dev)
+print("dynamic:", DYN)
 x, g = gen(T, B, dev)
 p = torch.randn((T, B, model.learnable_param_count), generator=g, device=dev)
 for grad in (True, False):
