@@ -40,7 +40,32 @@ struct ChunkArgs {
     float *phi;   // [nchunk][30][N]  Phi (5 propagated unit adjoints x 5) then phi (5)
     float *abnd;  // [nchunk][5][N]   adjoint entering each chunk from the future
     float *gpart; // [nchunk][NP][N]  per-chunk static-parameter gradient (unit space)
+    int nd;       // DYN == 1: number of dynamic parameters (<= CHUNK_FEW) and their slots
+    int dslot[3];
 };
+
+// DYN template values: 0 all static; 1 "few": at most CHUNK_FEW dynamic parameters, no muwts -- only
+// those rows are loaded / de-scaled / stored, addressed through the wave-uniform slot list (the
+// generic mode walks all NP slots every day and needs 230+ VGPRs); 2 generic.
+#define CHUNK_FEW 3
+
+// p[slot] = v / return p[slot] for a wave-uniform runtime slot without dynamic register indexing
+template <int NP>
+__device__ __forceinline__ void slot_set(float *p, int slot, float v)
+{
+#pragma unroll
+    for (int i = 0; i < NP; i++)
+        if (slot == i) p[i] = v;
+}
+template <int NP>
+__device__ __forceinline__ float slot_get(const float *p, int slot)
+{
+    float v = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NP; i++)
+        if (slot == i) v = p[i];
+    return v;
+}
 
 struct ChunkLane {
     int jm, b, j;
@@ -89,9 +114,10 @@ struct ChunkDay {
     float gq;       // raw dL/dQsim (before the member weight), for the muwts gradient
 };
 
-template <int NP, bool DYN, bool GFULL>
+template <int NP, int DYN, bool GFULL>
 __device__ __forceinline__ void chunk_issue(const hbvx_desc &d, const hbvx_bwd_io &io,
-                                            const ChunkLane &L, int t, int nf, ChunkRaw<NP> &R)
+                                            const ChunkLane &L, int t, int nf, ChunkRaw<NP> &R,
+                                            int nd, const int *dslot)
 {
     const int T = d.T;
     const int64_t N = (int64_t)d.B * d.M;
@@ -115,7 +141,15 @@ __device__ __forceinline__ void chunk_issue(const hbvx_desc &d, const hbvx_bwd_i
         R.gf[k] = v;
     }
     R.mu = 0.0f;
-    if (DYN) {
+    if (DYN == 1) {
+#pragma unroll
+        for (int k = 0; k < CHUNK_FEW; k++)
+            if (k < nd) {
+                const hbvx_param_src &ps = d.p[dslot[k]];
+                R.dv[k] = ps.dyn[(int64_t)t * ps.dyn_t_stride + (int64_t)L.b * ps.dyn_b_stride + L.j];
+            }
+    }
+    if (DYN == 2) {
 #pragma unroll
         for (int i = 0; i < NP; i++)
             R.dv[i] = d.p[i].dyn ? d.p[i].dyn[(int64_t)t * d.p[i].dyn_t_stride +
@@ -125,19 +159,35 @@ __device__ __forceinline__ void chunk_issue(const hbvx_desc &d, const hbvx_bwd_i
     }
 }
 
-template <int MODEL, bool BETAET, int NP, bool DYN, bool GFULL>
+template <int MODEL, bool BETAET, int NP, int DYN, bool GFULL>
 __device__ __forceinline__ void chunk_finish(const hbvx_desc &d, const ChunkRaw<NP> &R, bool raw, float nz,
                                              float ac, float elev, const float *usta, const float *psta,
                                              const bool *use_dyn, int nf, float invM,
-                                             ChunkDay<MODEL, BETAET, NP> &D)
+                                             ChunkDay<MODEL, BETAET, NP> &D, int nd, const int *dslot)
 {
     D.s.P = R.f[0]; D.s.Tf = R.f[1]; D.s.PET = R.f[2];
     D.s.SP = R.st[0]; D.s.MW = R.st[1]; D.s.SM = R.st[2]; D.s.SUZ = R.st[3]; D.s.SLZ = R.st[4];
+    if (DYN == 1) {
+        // use_dyn[k] / D.ud[k] are indexed by the position k in the slot list
+#pragma unroll
+        for (int i = 0; i < NP; i++) D.p[i] = psta[i];
+#pragma unroll
+        for (int k = 0; k < CHUNK_FEW; k++)
+            if (k < nd) {
+                const hbvx_param_src &ps = d.p[dslot[k]];
+                const float v = raw ? sigmoid_(R.dv[k]) : R.dv[k];
+                D.ud[k] = v;
+                const float pv = descale_(v, ps.lo, ps.hi);
+                const float cur = slot_get<NP>(D.p, dslot[k]);
+                slot_set<NP>(D.p, dslot[k], use_dyn[k] ? pv : cur);
+            }
+    }
 #pragma unroll
     for (int i = 0; i < NP; i++) {
+        if (DYN == 1) break;
         D.ud[i] = usta[i];
         D.p[i] = psta[i];
-        if (DYN && d.p[i].dyn) {
+        if (DYN == 2 && d.p[i].dyn) {
             const float v = raw ? sigmoid_(R.dv[i]) : R.dv[i];
             if (use_dyn[i]) {
                 D.ud[i] = v;
@@ -149,7 +199,7 @@ __device__ __forceinline__ void chunk_finish(const hbvx_desc &d, const ChunkRaw<
     for (int i = NP; i < NPARAM_MAX; i++) D.p[i] = 0.0f;
     D.s.template fwd<true>(D.p, nz, ac, elev, R.sw0, R.ef0);
     D.gq = R.gf[HBVX_F_QSIM];
-    const float wq = (DYN && d.muwts) ? R.mu : invM;
+    const float wq = (DYN == 2 && d.muwts) ? R.mu : invM;
     D.g.gQ = D.gq * wq;
     D.g.gQ0 = R.gf[HBVX_F_Q0] * invM;
     D.g.gQ1 = R.gf[HBVX_F_Q1] * invM;
@@ -164,9 +214,10 @@ __device__ __forceinline__ void chunk_finish(const hbvx_desc &d, const ChunkRaw<
     D.g.gcap = (GFULL && nf > HBVX_F_CAPILLARY) ? R.gf[HBVX_F_CAPILLARY] * invM : 0.0f;
 }
 
-template <int NP, bool DYN>
+template <int NP, int DYN>
 __device__ __forceinline__ void chunk_static(const hbvx_desc &d, const ChunkLane &L, bool raw,
-                                             float *usta, float *psta, bool *use_dyn)
+                                             float *usta, float *psta, bool *use_dyn, int nd,
+                                             const int *dslot)
 {
 #pragma unroll
     for (int i = 0; i < NP; i++) {
@@ -174,12 +225,22 @@ __device__ __forceinline__ void chunk_static(const hbvx_desc &d, const ChunkLane
         float v = s.sta[(int64_t)L.b * s.sta_b_stride + L.j];
         usta[i] = raw ? sigmoid_(v) : v;
         psta[i] = descale_(usta[i], s.lo, s.hi);
-        use_dyn[i] = DYN && s.dyn && !(s.drop && s.drop[L.b]);
+        use_dyn[i] = DYN == 2 && s.dyn && !(s.drop && s.drop[L.b]);
+    }
+    if (DYN == 1) {
+#pragma unroll
+        for (int k = 0; k < CHUNK_FEW; k++) {
+            use_dyn[k] = false;
+            if (k < nd) {
+                const hbvx_param_src &s = d.p[dslot[k]];
+                use_dyn[k] = !(s.drop && s.drop[L.b]);
+            }
+        }
     }
 }
 
 // ---- B1 -------------------------------------------------------------------------------------
-template <int MODEL, bool BETAET, bool DYN, bool GFULL>
+template <int MODEL, bool BETAET, int DYN, bool GFULL>
 __global__ void __launch_bounds__(64) k_bwd_chunk_phi(const ChunkArgs A)
 {
     constexpr int NP = ChunkNP<MODEL, BETAET>::value;
@@ -195,7 +256,7 @@ __global__ void __launch_bounds__(64) k_bwd_chunk_phi(const ChunkArgs A)
     const float elev = (MODEL == MODEL_HBV20 || MODEL == MODEL_HOURLY) ? d.elev[L.b] : 0.0f;
     float usta[NP], psta[NP];
     bool use_dyn[NP];
-    chunk_static<NP, DYN>(d, L, raw, usta, psta, use_dyn);
+    chunk_static<NP, DYN>(d, L, raw, usta, psta, use_dyn, A.nd, A.dslot);
 
     float Phi[5][5], phi[5];
 #pragma unroll
@@ -208,13 +269,13 @@ __global__ void __launch_bounds__(64) k_bwd_chunk_phi(const ChunkArgs A)
     g0.gQ = g0.gQ0 = g0.gQ1 = g0.gQ2 = g0.gET = g0.gSWE = g0.grech = g0.gexc = g0.gef = g0.gtosoil =
         g0.gPERC = g0.gcap = 0.0f;
     ChunkRaw<NP> Rn;
-    chunk_issue<NP, DYN, GFULL>(d, io, L, t1 - 1, io.n_flux, Rn);
+    chunk_issue<NP, DYN, GFULL>(d, io, L, t1 - 1, io.n_flux, Rn, A.nd, A.dslot);
     for (int t = t1 - 1; t >= t0; t--) {
         const ChunkRaw<NP> Rc = Rn;
-        if (t > t0) chunk_issue<NP, DYN, GFULL>(d, io, L, t - 1, io.n_flux, Rn); // next day's loads in flight
+        if (t > t0) chunk_issue<NP, DYN, GFULL>(d, io, L, t - 1, io.n_flux, Rn, A.nd, A.dslot); // next day's loads in flight
         ChunkDay<MODEL, BETAET, NP> D;
         chunk_finish<MODEL, BETAET, NP, DYN, GFULL>(d, Rc, raw, nz, ac, elev, usta, psta, use_dyn,
-                                                    io.n_flux, invM, D);
+                                                    io.n_flux, invM, D, A.nd, A.dslot);
         float gp[NPARAM_MAX], gx[3];
 #pragma unroll
         for (int i = 0; i < NPARAM_MAX; i++) gp[i] = 0.0f;
@@ -295,7 +356,7 @@ __device__ __forceinline__ float chunk_ens_sum(float v, int lgMp)
     return v;
 }
 
-template <int MODEL, bool BETAET, bool DYN, bool GFULL>
+template <int MODEL, bool BETAET, int DYN, bool GFULL>
 __global__ void __launch_bounds__(64) k_bwd_chunk_sweep(const ChunkArgs A)
 {
     constexpr int NP = ChunkNP<MODEL, BETAET>::value;
@@ -311,30 +372,47 @@ __global__ void __launch_bounds__(64) k_bwd_chunk_sweep(const ChunkArgs A)
     const float elev = (MODEL == MODEL_HBV20 || MODEL == MODEL_HOURLY) ? d.elev[L.b] : 0.0f;
     float usta[NP], psta[NP], gsta[NP];
     bool use_dyn[NP];
-    chunk_static<NP, DYN>(d, L, raw, usta, psta, use_dyn);
+    chunk_static<NP, DYN>(d, L, raw, usta, psta, use_dyn, A.nd, A.dslot);
 #pragma unroll
     for (int i = 0; i < NP; i++) gsta[i] = 0.0f;
+    float gused[CHUNK_FEW] = {0.0f, 0.0f, 0.0f};
     float a[5];
 #pragma unroll
     for (int k = 0; k < 5; k++) a[k] = A.abnd[((int64_t)chunk * 5 + k) * N + L.n];
 
     ChunkRaw<NP> Rn;
-    chunk_issue<NP, DYN, GFULL>(d, io, L, t1 - 1, io.n_flux, Rn);
+    chunk_issue<NP, DYN, GFULL>(d, io, L, t1 - 1, io.n_flux, Rn, A.nd, A.dslot);
     for (int t = t1 - 1; t >= t0; t--) {
         const ChunkRaw<NP> Rc = Rn;
-        if (t > t0) chunk_issue<NP, DYN, GFULL>(d, io, L, t - 1, io.n_flux, Rn);
+        if (t > t0) chunk_issue<NP, DYN, GFULL>(d, io, L, t - 1, io.n_flux, Rn, A.nd, A.dslot);
         ChunkDay<MODEL, BETAET, NP> D;
         chunk_finish<MODEL, BETAET, NP, DYN, GFULL>(d, Rc, raw, nz, ac, elev, usta, psta, use_dyn,
-                                                    io.n_flux, invM, D);
-        if (DYN && io.grad_muwts && L.active) io.grad_muwts[((int64_t)t * d.B + L.b) * d.M + L.j] = D.gq * D.s.Q;
+                                                    io.n_flux, invM, D, A.nd, A.dslot);
+        if (DYN == 2 && io.grad_muwts && L.active) io.grad_muwts[((int64_t)t * d.B + L.b) * d.M + L.j] = D.gq * D.s.Q;
         float gp[NPARAM_MAX], gx[3];
 #pragma unroll
         for (int i = 0; i < NPARAM_MAX; i++) gp[i] = 0.0f;
         D.s.bwd(D.p, nz, D.g, a, gp, gx);
+        if (DYN == 1) {
+#pragma unroll
+            for (int i = 0; i < NP; i++) gsta[i] += gp[i] * (d.p[i].hi - d.p[i].lo);
+#pragma unroll
+            for (int k = 0; k < CHUNK_FEW; k++)
+                if (k < A.nd) {
+                    const int sl = A.dslot[k];
+                    const float gu = slot_get<NP>(gp, sl) * (d.p[sl].hi - d.p[sl].lo);
+                    const float gr = raw ? gu * (D.ud[k] * (1.0f - D.ud[k])) : gu;
+                    if (io.g[sl].dyn && L.active)
+                        io.g[sl].dyn[(int64_t)t * io.g[sl].dyn_t_stride + (int64_t)L.b * io.g[sl].dyn_b_stride + L.j] =
+                            use_dyn[k] ? gr : 0.0f;
+                    gused[k] += use_dyn[k] ? gu : 0.0f;   // goes to the dynamic rows, not to the static one
+                }
+        }
 #pragma unroll
         for (int i = 0; i < NP; i++) {
+            if (DYN == 1) break;
             const float gu = gp[i] * (d.p[i].hi - d.p[i].lo);
-            if (DYN && d.p[i].dyn) {
+            if (DYN == 2 && d.p[i].dyn) {
                 const float gr = raw ? gu * (D.ud[i] * (1.0f - D.ud[i])) : gu;
                 if (io.g[i].dyn && L.active)
                     io.g[i].dyn[(int64_t)t * io.g[i].dyn_t_stride + (int64_t)L.b * io.g[i].dyn_b_stride + L.j] =
@@ -353,6 +431,12 @@ __global__ void __launch_bounds__(64) k_bwd_chunk_sweep(const ChunkArgs A)
                 gr[d.ch_prcp] = g0; gr[d.ch_tmean] = g1; gr[d.ch_pet] = g2;
             }
         }
+    }
+    if (DYN == 1) {
+        // the same daily terms were added to gsta and gused in the same order: exact cancellation
+#pragma unroll
+        for (int k = 0; k < CHUNK_FEW; k++)
+            if (k < A.nd) slot_set<NP>(gsta, A.dslot[k], slot_get<NP>(gsta, A.dslot[k]) - gused[k]);
     }
     if (L.active) {
 #pragma unroll

@@ -808,7 +808,7 @@ extern "C" uint64_t hbvx_backward_workspace_bytes(const hbvx_desc *d)
     return nchunk * (uint64_t)d->B * (uint64_t)d->M * (uint64_t)(35 + np_of(d)) * sizeof(float);
 }
 
-template <int MODEL, bool BETAET, bool DYN, bool GFULL>
+template <int MODEL, bool BETAET, int DYN, bool GFULL>
 static hipError_t launch_chunked_t(const ChunkArgs &a, hipStream_t st)
 {
     const hbvx_desc &d = a.d;
@@ -823,7 +823,7 @@ static hipError_t launch_chunked_t(const ChunkArgs &a, hipStream_t st)
     return hipGetLastError();
 }
 
-template <bool DYN, bool GFULL>
+template <int DYN, bool GFULL>
 static hipError_t launch_chunked_v(const hbvx_desc *d, const ChunkArgs &a, hipStream_t st)
 {
     if (d->model == HBVX_MODEL_HBV10 && d->n_param == 12) return launch_chunked_t<MODEL_HBV10, false, DYN, GFULL>(a, st);
@@ -845,9 +845,17 @@ static hipError_t launch_chunked(const hbvx_desc *d, const hbvx_bwd_io *io, hipS
     a.phi = (float *)io->workspace;
     a.abnd = a.phi + (int64_t)a.nchunk * 30 * N;
     a.gpart = a.abnd + (int64_t)a.nchunk * 5 * N;
-    const bool dyn = count_dyn(d) > 0 || d->muwts, gfull = io->grad_flux != nullptr;
-    if (dyn) return gfull ? launch_chunked_v<true, true>(d, a, st) : launch_chunked_v<true, false>(d, a, st);
-    return gfull ? launch_chunked_v<false, true>(d, a, st) : launch_chunked_v<false, false>(d, a, st);
+    const bool gfull = io->grad_flux != nullptr;
+    a.nd = 0;
+    a.dslot[0] = a.dslot[1] = a.dslot[2] = 0;
+    const int ndyn = count_dyn(d);
+    if (ndyn > 0 && ndyn <= CHUNK_FEW && !d->muwts) {   // few dynamic parameters: slot-list kernels
+        for (int i = 0; i < d->n_param; i++)
+            if (d->p[i].dyn) a.dslot[a.nd++] = i;
+        return gfull ? launch_chunked_v<1, true>(d, a, st) : launch_chunked_v<1, false>(d, a, st);
+    }
+    if (ndyn > 0 || d->muwts) return gfull ? launch_chunked_v<2, true>(d, a, st) : launch_chunked_v<2, false>(d, a, st);
+    return gfull ? launch_chunked_v<0, true>(d, a, st) : launch_chunked_v<0, false>(d, a, st);
 }
 
 extern "C" int hbvx_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *stream)
