@@ -194,21 +194,28 @@ def main():
     n_flux = 11
     bytes_fwd = lane_steps * (12.0 / M + 4.0 * n_flux / M + 28.0)
     bytes_bwd = lane_steps * (2.0 * (12.0 / M + 28.0 + 4.0 * 4 / M) + 2.0 * 4.0 * (35 + 12) / 64.0)
-    dom = max((k for k in kavg if k in ("hbvx_forward", "hbvx_backward")), key=lambda k: kavg[k])
-    dom_bytes = bytes_bwd if dom == "hbvx_backward" else bytes_fwd
-    achieved = dom_bytes / (kavg[dom] * 1e-3) / 1e9
-    traffic = None
+    # Dominant kernel: k_fwd_pipe, the one kernel behind hbvx_forward (rocprofv3 --stats,
+    # profiles/r01_kernel_stats.csv: the largest single kernel; hbvx_backward is four kernels, the two
+    # big ones ~0.65 ms each).  The adjoint call is reported beside it in `calls`.
     tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    pmc = {}
     if os.path.exists(tj):
         try:
-            traffic = json.load(open(tj)).get(dom, {}).get("hbm_bytes_raw")
+            pmc = json.load(open(tj))
         except Exception:
-            traffic = None
-    hip_kernels = {"hbvx_forward": "k_fwd_pipe (hbv_pipe.h)",
-                   "hbvx_backward": "k_bwd_chunk_phi + _scan + _sweep + _reduce (hbv_chunked.h)"}
-    roofline = {"bound": "hbm", "kernel": dom, "hip_kernels": hip_kernels.get(dom), "achieved": round(achieved, 2),
-                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
-                "traffic": traffic, "avg_ms": round(kavg[dom], 4),
+            pmc = {}
+    calls = {}
+    for call, nbytes in (("hbvx_forward", bytes_fwd), ("hbvx_backward", bytes_bwd)):
+        if call in kavg:
+            calls[call] = {"avg_ms": round(kavg[call], 4), "algorithmic_bytes": nbytes,
+                           "achieved_GBps": round(nbytes / (kavg[call] * 1e-3) / 1e9, 2),
+                           "traffic": pmc.get(call, {}).get("hbm_bytes_raw")}
+    dom = "hbvx_forward"
+    achieved = bytes_fwd / (kavg[dom] * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": "k_fwd_pipe (hbv_pipe.h), the kernel of hbvx_forward",
+                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": calls[dom]["traffic"],
+                "avg_ms": round(kavg[dom], 4), "calls": calls,
                 "kernel_ms": {k: round(v, 4) for k, v in kavg.items()}}
 
     if rank == 0:

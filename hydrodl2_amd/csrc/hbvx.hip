@@ -643,7 +643,11 @@ static bool geom_fwd(const hbvx_desc *d, const hbvx_fwd_out *o, TileGeom &g)
     g.ND = count_dyn(d);
     g.NDm = g.ND + (d->muwts ? 1 : 0);
     const int NF = (d->model == HBVX_MODEL_HBV10) ? 11 : (d->model == HBVX_MODEL_HBVADJ ? 1 : 12);
-    const int ktmax = env_int("HBVX_KT", 16);
+    // Few workgroups (cfg2: 168 on 256 CUs): deep tiles, one workgroup owns its CU.  Many
+    // workgroups (cfg5: 3125): shallow tiles so that several steppers share a CU (LDS decides how
+    // many) -- measured at cfg5: Kt 16/8 -> 7.4 ms, Kt 4 -> 5.8 ms.
+    const int wgs = (d->B + (64 >> g.lgMp) - 1) / (64 >> g.lgMp);
+    const int ktmax = env_int("HBVX_KT", wgs >= 1024 ? 4 : 16);
     for (int Kt = 16; Kt >= 1; Kt >>= 1) {
         if (Kt > ktmax) continue;
         g.Kt = Kt;
@@ -695,7 +699,7 @@ static hipError_t launch_tiled_one(K kern, const Args &a, dim3 grid, int threads
 
 #define LAUNCH_TILED_V(K, d, a, grid, lds, st, ...)                                                \
     ([&]() -> hipError_t {                                                                        \
-        int nh = env_int("HBVX_NH", 7);                                                           \
+        int nh = env_int("HBVX_NH", (grid).x >= 1024 ? 3 : 7);                                    \
         nh = nh < 1 ? 1 : (nh > 7 ? 7 : nh);                                                      \
         const int threads = 64 * (1 + nh);                                                        \
         const int m = (d)->model;                                                                 \

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Turn the raw rocprofv3 output of tools/profile_round.sh into the committed summaries:
+
+    python tools/profile_collect.py <tag>
+
+    profiles/<tag>_kernel_stats.csv      per-kernel time (rocprofv3 --kernel-trace --stats)
+    profiles/<tag>_pmc_fetch_size.csv    per-kernel FETCH_SIZE (KiB) of the hbvx kernels, averaged
+    profiles/<tag>_pmc_write_size.csv    per-kernel WRITE_SIZE (KiB)
+    profiles/<tag>_bench.json            the bench line of the profiled run
+    profiles/pmc_traffic.json            HBM bytes per ABI call (read by bench.py for roofline.traffic)
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CALLS = {
+    "hbvx_forward": ["k_fwd_pipe", "k_fwd_tiled"],
+    "hbvx_backward": ["k_bwd_chunk_phi", "k_bwd_chunk_scan", "k_bwd_chunk_sweep", "k_bwd_chunk_reduce",
+                      "k_bwd_tiled"],
+    "hbvx_route_forward": ["k_route_fwd", "k_uh_gamma"],
+    "hbvx_route_backward": ["k_route_bwd"],
+    "hbvx_bfi": ["k_bfi"],
+}
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "").strip()
+
+
+def counter_table(path):
+    """kernel -> (dispatches, mean counter value) from a rocprofv3 counter_collection csv."""
+    acc = defaultdict(list)
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            acc[short(row["Kernel_Name"])].append(float(row["Counter_Value"]))
+    return {k: (len(v), sum(v) / len(v)) for k, v in acc.items()}
+
+
+def main(tag):
+    raw = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+    out = os.path.join(ROOT, "profiles")
+    stats = glob.glob(os.path.join(raw, "kt", "**", "*kernel_stats.csv"), recursive=True)
+    shutil.copy(stats[0], os.path.join(out, f"{tag}_kernel_stats.csv"))
+    with open(os.path.join(ROOT, "gpurun_out", f"prof_{tag}.bench.json")) as f:
+        line = [l for l in f if l.startswith("{")][-1]
+    with open(os.path.join(out, f"{tag}_bench.json"), "w") as f:
+        f.write(line)
+    tables = {}
+    for kind in ("fetch", "write"):
+        src = glob.glob(os.path.join(raw, kind, "**", "*counter_collection.csv"), recursive=True)[0]
+        tab = {k: v for k, v in counter_table(src).items() if "hbvx" in k or k.startswith("k_")}
+        tables[kind] = tab
+        with open(os.path.join(out, f"{tag}_pmc_{kind}_size.csv"), "w") as f:
+            f.write("kernel,dispatches,mean_%s_SIZE_KiB\n" % kind.upper())
+            for k, (n, v) in sorted(tab.items()):
+                f.write(f"\"{k}\",{n},{v:.3f}\n")
+    traffic = {}
+    for call, pats in CALLS.items():
+        ks = sorted({k for kind in tables.values() for k in kind if any(p in k for p in pats)})
+        if not ks:
+            continue
+        fb = sum(tables["fetch"].get(k, (0, 0.0))[1] for k in ks) * 1024
+        wb = sum(tables["write"].get(k, (0, 0.0))[1] for k in ks) * 1024
+        traffic[call] = {
+            "kernels": ks, "fetch_bytes_raw": fb, "write_bytes": wb, "hbm_bytes_raw": fb + wb,
+            "note": "per ABI call (sum over its kernels), rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "
+                    "separate passes, KiB x1024; FETCH_SIZE is NOT doubled: the guide's x2 is calibrated "
+                    "for 16 B/lane streams, these kernels load 4 B/lane"}
+    with open(os.path.join(out, "pmc_traffic.json"), "w") as f:
+        json.dump(traffic, f, indent=1)
+    print(json.dumps({k: (round(v["fetch_bytes_raw"] / 1e9, 3), round(v["write_bytes"] / 1e9, 3))
+                      for k, v in traffic.items()}))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "r01")
