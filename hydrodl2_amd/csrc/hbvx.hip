@@ -419,7 +419,10 @@ __device__ __forceinline__ void load_uh(const float *__restrict__ uh, int b, int
     for (int k = 0; k < HBVX_UH_MAXLEN; k++) w[k] = (k < L) ? uh[(int64_t)b * L + k] : 0.0f;
 }
 
-// uh_conv (uh_routing.py:25-57): y[s,t,b] = sum_k UH[b,k] * q[s,t-k,b], zero history
+// uh_conv (uh_routing.py:25-57): y[s,t,b] = sum_k UH[b,k] * q[s,t-k,b], zero history.
+// grid.z = series; the chunk is consumed in groups of ROUTE_GROUP days whose loads are all issued
+// before the first is used (a thread would otherwise have one load in flight at a time).
+#define ROUTE_GROUP 8
 __global__ void __launch_bounds__(256) k_route_fwd(int T, int B, int S, int L,
                                                    const float *__restrict__ q,
                                                    const float *__restrict__ uh,
@@ -430,20 +433,25 @@ __global__ void __launch_bounds__(256) k_route_fwd(int T, int B, int S, int L,
     const int t0 = chunk * ROUTE_CHUNK;
     if (b >= B || t0 >= T) return;
     const int t1 = min(T, t0 + ROUTE_CHUNK);
+    const int s = blockIdx.z;
     float w[HBVX_UH_MAXLEN];
     load_uh(uh, b, L, w);
-    for (int s = 0; s < S; s++) {
-        const float *qs = q + (int64_t)s * T * B + b;
-        float *ys = y + (int64_t)s * T * B + b;
-        float win[HBVX_UH_MAXLEN];
+    const float *qs = q + (int64_t)s * T * B + b;
+    float *ys = y + (int64_t)s * T * B + b;
+    float win[HBVX_UH_MAXLEN];
 #pragma unroll
-        for (int k = 1; k < HBVX_UH_MAXLEN; k++) win[k] = (t0 - k >= 0) ? qs[(int64_t)(t0 - k) * B] : 0.0f;
-        for (int t = t0; t < t1; t++) {
-            win[0] = qs[(int64_t)t * B];
+    for (int k = 1; k < HBVX_UH_MAXLEN; k++) win[k] = (t0 - k >= 0) ? qs[(int64_t)(t0 - k) * B] : 0.0f;
+    for (int tg = t0; tg < t1; tg += ROUTE_GROUP) {
+        float v[ROUTE_GROUP];
+#pragma unroll
+        for (int j = 0; j < ROUTE_GROUP; j++) v[j] = (tg + j < t1) ? qs[(int64_t)(tg + j) * B] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < ROUTE_GROUP; j++) {
+            win[0] = v[j];
             float acc = 0.0f;
 #pragma unroll
             for (int k = 0; k < HBVX_UH_MAXLEN; k++) acc += w[k] * win[k];
-            ys[(int64_t)t * B] = acc;
+            if (tg + j < t1) ys[(int64_t)(tg + j) * B] = acc;
 #pragma unroll
             for (int k = HBVX_UH_MAXLEN - 1; k > 0; k--) win[k] = win[k - 1];
         }
@@ -469,29 +477,40 @@ __global__ void __launch_bounds__(256) k_route_bwd(int T, int B, int S, int L,
 #pragma unroll
     for (int k = 0; k < HBVX_UH_MAXLEN; k++) gw[k] = 0.0f;
     for (int s = 0; s < S; s++) {
-        const float *qs = q + (int64_t)s * T * B + b;
-        const float *gs = gy + (int64_t)s * T * B + b;
-        float *gqs = gq + (int64_t)s * T * B + b;
-        float qwin[HBVX_UH_MAXLEN], gwin[HBVX_UH_MAXLEN]; // q[t-k], gy[t+k]
+    const float *qs = q + (int64_t)s * T * B + b;
+    const float *gs = gy + (int64_t)s * T * B + b;
+    float *gqs = gq + (int64_t)s * T * B + b;
+    float qwin[HBVX_UH_MAXLEN], gwin[HBVX_UH_MAXLEN]; // q[t-k], gy[t+k]
 #pragma unroll
-        for (int k = 1; k < HBVX_UH_MAXLEN; k++) qwin[k] = (t0 - k >= 0) ? qs[(int64_t)(t0 - k) * B] : 0.0f;
+    for (int k = 1; k < HBVX_UH_MAXLEN; k++) qwin[k] = (t0 - k >= 0) ? qs[(int64_t)(t0 - k) * B] : 0.0f;
 #pragma unroll
-        for (int k = 0; k < HBVX_UH_MAXLEN - 1; k++) gwin[k + 1] = (t0 + k < T) ? gs[(int64_t)(t0 + k) * B] : 0.0f;
-        for (int t = t0; t < t1; t++) {
+    for (int k = 0; k < HBVX_UH_MAXLEN - 1; k++) gwin[k + 1] = (t0 + k < T) ? gs[(int64_t)(t0 + k) * B] : 0.0f;
+    for (int tg = t0; tg < t1; tg += ROUTE_GROUP) {
+        float vq[ROUTE_GROUP], vg[ROUTE_GROUP];
+#pragma unroll
+        for (int j = 0; j < ROUTE_GROUP; j++) {
+            const int t = tg + j;
+            vq[j] = (t < t1) ? qs[(int64_t)t * B] : 0.0f;
+            vg[j] = (t + HBVX_UH_MAXLEN - 1 < T) ? gs[(int64_t)(t + HBVX_UH_MAXLEN - 1) * B] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < ROUTE_GROUP; j++) {
+            const bool on = tg + j < t1;
 #pragma unroll
             for (int k = 0; k < HBVX_UH_MAXLEN - 1; k++) gwin[k] = gwin[k + 1];
-            gwin[HBVX_UH_MAXLEN - 1] = (t + HBVX_UH_MAXLEN - 1 < T) ? gs[(int64_t)(t + HBVX_UH_MAXLEN - 1) * B] : 0.0f;
-            qwin[0] = qs[(int64_t)t * B];
+            gwin[HBVX_UH_MAXLEN - 1] = vg[j];
+            qwin[0] = vq[j];
             float acc = 0.0f;
 #pragma unroll
             for (int k = 0; k < HBVX_UH_MAXLEN; k++) {
                 acc += w[k] * gwin[k];
-                gw[k] += gwin[0] * qwin[k];
+                gw[k] += on ? gwin[0] * qwin[k] : 0.0f;
             }
-            gqs[(int64_t)t * B] = acc;
+            if (on) gqs[(int64_t)(tg + j) * B] = acc;
 #pragma unroll
             for (int k = HBVX_UH_MAXLEN - 1; k > 0; k--) qwin[k] = qwin[k - 1];
         }
+    }
     }
     if (ws) {
 #pragma unroll
@@ -929,7 +948,7 @@ extern "C" int hbvx_route_forward(const hbvx_route_desc *r, const float *q, floa
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_uh_gamma, dim3((r->B + 63) / 64), dim3(64), 0, st, *r, uh);
     const int nchunk = (r->T + ROUTE_CHUNK - 1) / ROUTE_CHUNK;
-    hipLaunchKernelGGL(k_route_fwd, dim3((r->B + 63) / 64, (nchunk + 3) / 4), dim3(256), 0, st, r->T,
+    hipLaunchKernelGGL(k_route_fwd, dim3((r->B + 63) / 64, (nchunk + 3) / 4, r->S), dim3(256), 0, st, r->T,
                        r->B, r->S, r->L, q, uh, q_rout);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "hbvx_route_forward launch");
@@ -1103,23 +1122,24 @@ extern "C" int hbvx_adj_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void
 }
 
 // ---------------------------------------------------------------------------
-// baseflow index (hbv.py:562-567): block = 64 basins x 16 time slices, fixed-order tree
+// baseflow index (hbv.py:562-567): block = 16 basins x 64 time slices (64-byte row segments; four
+// times the blocks of a 64-basin tile: B / 16 instead of B / 64 CUs busy), fixed-order sums
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) k_bfi(int T, int B, const float *__restrict__ qs,
                                               const float *__restrict__ q2, float nz,
                                               float *__restrict__ bfi)
 {
-    __shared__ float r0[16][64], r2[16][64];
-    const int bl = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int b = blockIdx.x * 64 + bl;
+    __shared__ float r0[64][16], r2[64][16];
+    const int bl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int b = blockIdx.x * 16 + bl;
     float a0 = 0.0f, a2 = 0.0f, c0 = 0.0f, c2 = 0.0f;
     if (b < B) {
         int t = sl;
-        for (; t + 16 < T; t += 32) {
+        for (; t + 64 < T; t += 128) {
             a0 += qs[(int64_t)t * B + b];
             a2 += q2[(int64_t)t * B + b];
-            c0 += qs[(int64_t)(t + 16) * B + b];
-            c2 += q2[(int64_t)(t + 16) * B + b];
+            c0 += qs[(int64_t)(t + 64) * B + b];
+            c2 += q2[(int64_t)(t + 64) * B + b];
         }
         if (t < T) {
             a0 += qs[(int64_t)t * B + b];
@@ -1132,7 +1152,7 @@ __global__ void __launch_bounds__(1024) k_bfi(int T, int B, const float *__restr
     if (sl == 0 && b < B) {
         float s0 = 0.0f, s2 = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
+        for (int k = 0; k < 64; k++) {
             s0 += r0[k][bl];
             s2 += r2[k][bl];
         }
@@ -1144,7 +1164,7 @@ extern "C" int hbvx_bfi(int32_t T, int32_t B, const float *qs, const float *q2, 
                         float *bfi, void *stream)
 {
     if (!qs || !q2 || !bfi || T <= 0 || B <= 0) return fail(HBVX_E_NULL, "hbvx_bfi: bad arguments");
-    hipLaunchKernelGGL(k_bfi, dim3((B + 63) / 64), dim3(1024), 0, (hipStream_t)stream, T, B, qs, q2,
+    hipLaunchKernelGGL(k_bfi, dim3((B + 15) / 16), dim3(1024), 0, (hipStream_t)stream, T, B, qs, q2,
                        nearzero, bfi);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "hbvx_bfi launch");
