@@ -157,6 +157,9 @@ HBVX_HD float pow_f64_(float x, float y)
 // measured by hbvx_selftest_pow (tests/test_gpu_parity.py); torch's own GPU pow is in the same class.
 // pow_f64_ below is the 0.5-ulp fp64-polynomial version (-DHBVX_POW_F64 selects it): on the VALU-bound
 // stepper waves it costs ~260 cycles per call against ~130 for this one.
+// CLAMP: bound y log2 x before splitting it (needed when the product can overflow to +-inf:
+// arbitrary y; inside the time step |y log2 x| < 800 and v_ldexp_f32 saturates by itself).
+template <bool CLAMP>
 HBVX_HD float pow_core_(float x, float y)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -180,7 +183,7 @@ HBVX_HD float pow_core_(float x, float y)
     float zh = y * lh;
     float zl = fmaf(y, lh, -zh);
     zl = fmaf(y, ll, zl);
-    zh = zh > 130.0f ? 130.0f : (zh < -160.0f ? -160.0f : zh);
+    if (CLAMP) zh = zh > 130.0f ? 130.0f : (zh < -160.0f ? -160.0f : zh);
     const float n = rintf(zh);
     const float f = (zh - n) + zl;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -193,7 +196,7 @@ HBVX_HD float pow_core_(float x, float y)
 
 HBVX_HD float pow_hw_(float x, float y)
 {
-    float r = pow_core_(x, y);
+    float r = pow_core_<true>(x, y);
     // special bases as flat selects of ready values (nested conditionals become EXEC-masked
     // branches when y is not loop-invariant)
     const float inf = __builtin_inff();
@@ -225,7 +228,7 @@ HBVX_HD float pow_step_(float x, float y)
 #if defined(HBVX_POW_F64)
     return pow_f64_(x, y);
 #else
-    return pow_core_(fmax_(x, 1.17549435e-38f), y);
+    return pow_core_<false>(fmax_(x, 1.17549435e-38f), y);
 #endif
 }
 
