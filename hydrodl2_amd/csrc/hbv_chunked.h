@@ -288,6 +288,15 @@ __global__ void __launch_bounds__(64) k_bwd_chunk_phi(const ChunkArgs A)
             S::template jt_unit<1>(c, Phi[2]);
             S::template jt_unit<2>(c, Phi[3]);
             S::template jt_unit<2>(c, Phi[4]);
+        } else if constexpr (MODEL == MODEL_HBV11P || MODEL == MODEL_HBV20) {
+            // capillary rise couples soil and groundwater, but the snow block still stands alone:
+            // the SNOWPACK / MELTWATER unit adjoints never leave it
+            typedef Step<MODEL, BETAET> S;
+            const typename S::JT c = D.s.jt_coef_snow(D.p);
+            S::template jt_unit<0>(c, Phi[0]);
+            S::template jt_unit<0>(c, Phi[1]);
+#pragma unroll
+            for (int k = 2; k < 5; k++) D.s.bwd(D.p, nz, g0, Phi[k], gp, gx);
         } else {
 #pragma unroll
             for (int k = 0; k < 5; k++) D.s.bwd(D.p, nz, g0, Phi[k], gp, gx);

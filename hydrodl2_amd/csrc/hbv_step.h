@@ -568,6 +568,21 @@ struct Step {
         float mts, cwh, wr, wm;    // snow
     };
 
+    // snow block only (all daily variants share the snow stage): enough for jt_unit<0>
+    HBVX_HDM JT jt_coef_snow(const float *p) const
+    {
+        JT c;
+        float wa, wb;
+        c.cS = c.cU = c.wP = c.kap = c.me = c.rho = c.sw = 0.0f;
+        c.mts = (ts0 >= 0.0f) ? 1.0f : 0.0f;
+        c.cwh = p[P_CWH];
+        minw_(rpc, MW1, wa, wb);
+        c.wr = wb;
+        minw_(mpc, SP1, wa, wb);
+        c.wm = wb;
+        return c;
+    }
+
     HBVX_HDM JT jt_coef(const float *p, float nz) const
     {
         static_assert(MODEL == MODEL_HBV10, "jt_coef: HBV 1.0 only");

@@ -380,6 +380,29 @@ static float jt_check(const float *st, const float *f, const float *p, int n, fl
     }
     return worst;
 }
+// snow rows of the capillary models: jt_coef_snow + jt_unit<0> against bwd (HBV 2.0 instantiation)
+extern "C" float hbvx_test_jt_snow(const float *st, const float *f, const float *p, int n, float nz)
+{
+    float worst = 0.0f;
+    for (int i = 0; i < n; i++) {
+        Step<MODEL_HBV20, true> s;
+        s.SP = st[i * 5]; s.MW = st[i * 5 + 1]; s.SM = st[i * 5 + 2]; s.SUZ = st[i * 5 + 3]; s.SLZ = st[i * 5 + 4];
+        s.P = f[i * 3]; s.Tf = f[i * 3 + 1]; s.PET = f[i * 3 + 2];
+        const float *pp = p + i * NPARAM_MAX;
+        s.template fwd<false>(pp, nz, 1500.0f, (i & 1) ? 2500.0f : 500.0f, 0.0f, 0.0f);
+        FluxGrad g0;
+        memset(&g0, 0, sizeof g0);
+        const auto c = s.jt_coef_snow(pp);
+        for (int k = 0; k < 2; k++) {
+            float a[5] = {0, 0, 0, 0, 0}, b[5] = {0, 0, 0, 0, 0}, gp[NPARAM_MAX] = {0}, gx[3];
+            a[k] = b[k] = 1.0f;
+            s.bwd(pp, nz, g0, a, gp, gx);
+            Step<MODEL_HBV20, true>::template jt_unit<0>(c, b);
+            for (int j = 0; j < 5; j++) worst = fmaxf(worst, fabsf(a[j] - b[j]));
+        }
+    }
+    return worst;
+}
 extern "C" float hbvx_test_jt(const float *st, const float *f, const float *p, int n, float nz, int betaet)
 {
     return betaet ? jt_check<true>(st, f, p, n, nz) : jt_check<false>(st, f, p, n, nz);

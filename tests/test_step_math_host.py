@@ -119,3 +119,12 @@ def test_sparse_transposed_jacobian_matches_bwd(steptest_lib):
         worst = lib.hbvx_test_jt(st.ctypes.data_as(C.c_void_p), f.ctypes.data_as(C.c_void_p),
                                  p.ctypes.data_as(C.c_void_p), C.c_int(n), C.c_float(1e-5), C.c_int(be))
         assert worst < 2e-6, f"betaet={be}: worst relative difference {worst:.3g}"
+    # capillary models: the snow rows alone (HBV 2.0 instantiation, both sides of the 2000 m switch)
+    lib.hbvx_test_jt_snow.restype = C.c_float
+    p2 = np.zeros((n, 19), np.float32)
+    for i, nm in enumerate(PHY_NAMES["Hbv_2"]):
+        lo, hi = BOUNDS[nm]
+        p2[:, i] = (lo + (hi - lo) * u(60 + i)).astype(np.float32)
+    worst = lib.hbvx_test_jt_snow(st.ctypes.data_as(C.c_void_p), f.ctypes.data_as(C.c_void_p),
+                                  p2.ctypes.data_as(C.c_void_p), C.c_int(n), C.c_float(1e-5))
+    assert worst < 2e-6, f"snow rows: worst difference {worst:.3g}"
