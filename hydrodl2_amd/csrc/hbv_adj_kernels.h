@@ -60,7 +60,7 @@ __device__ __forceinline__ void adj_params(const hbvx_desc &d, const AdjLane &L,
         float uv = usta[i];
         if (s.dyn) {
             float v = s.dyn[(int64_t)t * s.dyn_t_stride + (int64_t)L.b * s.dyn_b_stride + L.j];
-            v = raw ? sigmoid_(v) : v;
+            v = raw ? sigmoid_dyn_(v) : v;
             uv = use_dyn[i] ? v : uv;
         }
         u[i] = uv;

@@ -175,7 +175,7 @@ __device__ __forceinline__ void chunk_finish(const hbvx_desc &d, const ChunkRaw<
         for (int k = 0; k < CHUNK_FEW; k++)
             if (k < nd) {
                 const hbvx_param_src &ps = d.p[dslot[k]];
-                const float v = raw ? sigmoid_(R.dv[k]) : R.dv[k];
+                const float v = raw ? sigmoid_dyn_(R.dv[k]) : R.dv[k];
                 D.ud[k] = v;
                 const float pv = descale_(v, ps.lo, ps.hi);
                 const float cur = slot_get<NP>(D.p, dslot[k]);
@@ -188,7 +188,7 @@ __device__ __forceinline__ void chunk_finish(const hbvx_desc &d, const ChunkRaw<
         D.ud[i] = usta[i];
         D.p[i] = psta[i];
         if (DYN == 2 && d.p[i].dyn) {
-            const float v = raw ? sigmoid_(R.dv[i]) : R.dv[i];
+            const float v = raw ? sigmoid_dyn_(R.dv[i]) : R.dv[i];
             if (use_dyn[i]) {
                 D.ud[i] = v;
                 D.p[i] = descale_(v, d.p[i].lo, d.p[i].hi);

@@ -412,7 +412,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                     float *pin = lds + P.pin + (tile % 5) * FD * PD * 64 + fidx * 64 + lane;
 #pragma unroll
                     for (int i = 0; i < FD; i++) {
-                        const float u = raw ? sigmoid_(dv[i]) : dv[i];
+                        const float u = raw ? sigmoid_dyn_(dv[i]) : dv[i];
                         pin[i * PD * 64] = duse ? descale_(u, dlo, dhi) : dsta;
                     }
                 }

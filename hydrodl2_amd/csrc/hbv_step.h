@@ -68,6 +68,21 @@ HBVX_HD float div_approx_(float a, float b)
 
 // torch.sigmoid: 1/(1+exp(-x))  (hbv.py:201)
 HBVX_HD float sigmoid_(float v) { return 1.0f / (1.0f + expf(-v)); }
+// The same for the per-day values of DYNAMIC parameters: v_exp_f32 + v_rcp_f32, 4 instructions
+// instead of ~25 (expf + IEEE division).  Every dynamic parameter costs one sigmoid per lane-day
+// in the forward and two in the time-parallel adjoint; with 14 of them (config 3) the accurate
+// version was more work than the rest of the adjoint step.  Error: a few ulp of the unit value,
+// < 1e-6 relative on the de-scaled parameter; saturates to exactly 0 / 1.  Static values (read
+// once per launch) keep sigmoid_, so thresholds on static parameters (TT, FC, PERC, UZL ...) see
+// the library-accurate value.
+HBVX_HD float sigmoid_dyn_(float v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504f));
+#else
+    return 1.0f / (1.0f + expf(-v));
+#endif
+}
 // core/calc/utils.py:24: multiply, then add (no FMA)
 HBVX_HD float descale_(float u, float lo, float hi) { return u * (hi - lo) + lo; }
 

@@ -356,7 +356,7 @@ __global__ void __launch_bounds__(512) k_fwd_tiled(const FwdTArgs A)
 #pragma unroll
                 for (int i = 0; i < NP; i++)
                     if ((dmask >> i) & 1) {
-                        float v = raw ? sigmoid_(rv[i]) : rv[i];
+                        float v = raw ? sigmoid_dyn_(rv[i]) : rv[i];
                         float pv = descale_(v, d.p[i].lo, d.p[i].hi);
                         pr[dyn_index(dmask, i) * 64] = use_dyn[i] ? pv : psta[i];
                     }
@@ -594,7 +594,7 @@ __global__ void __launch_bounds__(512) k_bwd_tiled(const BwdTArgs A)
 #pragma unroll
                 for (int i = 0; i < NP; i++)
                     if ((dmask >> i) & 1) {
-                        float v = raw ? sigmoid_(rv[i]) : rv[i];
+                        float v = raw ? sigmoid_dyn_(rv[i]) : rv[i];
                         float pv = descale_(v, d.p[i].lo, d.p[i].hi);
                         pr[dyn_index(dmask, i) * 64] = use_dyn[i] ? pv : psta[i];
                     }
@@ -633,7 +633,7 @@ __global__ void __launch_bounds__(512) k_bwd_tiled(const BwdTArgs A)
                         if (((dmask >> i) & 1) && gdyn[i]) {
                             float gu = go[dyn_index(dmask, i) * 64];
                             if (raw) {
-                                float u = sigmoid_(rv[i]);
+                                float u = sigmoid_dyn_(rv[i]);
                                 gu = gu * (u * (1.0f - u));
                             }
                             if (L.active)

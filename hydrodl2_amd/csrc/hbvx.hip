@@ -174,7 +174,7 @@ __global__ void __launch_bounds__(64) k_fwd(const FwdArgs A)
 #pragma unroll
         for (int i = 0; i < NP; i++)
             if ((dmask >> i) & 1) {
-                float v = raw ? sigmoid_(cur[i]) : cur[i];
+                float v = raw ? sigmoid_dyn_(cur[i]) : cur[i];
                 float pv = descale_(v, d.p[i].lo, d.p[i].hi);
                 if (use_dyn[i]) p[i] = pv;
             }
@@ -295,7 +295,7 @@ __global__ void __launch_bounds__(64) k_bwd(const BwdArgs A)
             ud[i] = usta[i];
             if ((dmask >> i) & 1) {
                 float v = dynp[i][(int64_t)t * d.p[i].dyn_t_stride];
-                v = raw ? sigmoid_(v) : v;
+                v = raw ? sigmoid_dyn_(v) : v;
                 if (use_dyn[i]) {
                     ud[i] = v;
                     p[i] = descale_(v, d.p[i].lo, d.p[i].hi);
