@@ -1,0 +1,199 @@
+// hbv_stream.h -- forward for LARGE grids (thousands of wavefronts of state, e.g. 12 500+ basins x 16).
+//
+// With 3 000+ independent wavefronts the time loop is throughput-bound, not latency-bound: the
+// right shape is the plain one -- one wavefront per 64 lanes, no LDS, no helper waves, as many
+// wavefronts per SIMD as the registers allow -- provided the wave never stalls on its own memory
+// traffic.  On CDNA loads and stores retire through one in-order counter (vmcnt), so a wave that
+// consumes a load issued one day ago also waits for every store issued before that load.  The ring
+// below keeps the inputs of STREAM_D days in registers: by the time a day's loads are consumed the
+// stores that precede them are STREAM_D days old.  All memory operations use buffer addressing
+// (descriptor + scalar day offset + constant per-lane offset, out-of-range lanes dropped), so the
+// loop has no vector address arithmetic, no EXEC masking and no branches around memory operations.
+// Ensemble means: DPP butterflies inside the wave with the same add tree as the tiled kernels
+// (quad, quad pair, row halves ...), so results are bit-identical to them.
+//
+// Supports all explicit variants with static parameters or up to three dynamic ones (slot list,
+// as in the time-parallel adjoint); muwts and larger dynamic sets stay on the tiled kernel.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/hbvx.h"
+#include "hbv_step.h"
+#include "hbv_tiled.h"
+#include "hbv_chunked.h"
+
+namespace hbvx {
+
+#define STREAM_D 4
+
+struct StreamArgs {
+    hbvx_desc d;
+    hbvx_fwd_out o;
+    int lgMp;
+    int nd;
+    int dslot[3];
+};
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+// sum over the Mp lanes of a basin; every lane of the basin gets the sum
+__device__ __forceinline__ float ens_sum_dpp(float v, int lgMp)
+{
+    if (lgMp >= 1) v += dpp_<0xB1>(v);   // quad_perm [1,0,3,2]
+    if (lgMp >= 2) v += dpp_<0x4E>(v);   // quad_perm [2,3,0,1]
+    if (lgMp >= 3) v += dpp_<0x141>(v);  // row_half_mirror: the other quad of the 8
+    if (lgMp >= 4) v += dpp_<0x140>(v);  // row_mirror: the other half of the 16
+    if (lgMp >= 5) v += __shfl_xor(v, 16, 64);
+    if (lgMp >= 6) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+template <int MODEL, bool BETAET, bool TRAJ, bool FEW>
+__global__ void __launch_bounds__(64) k_fwd_stream(const StreamArgs A)
+{
+    constexpr int NP = NParamT<MODEL, BETAET>::value;
+    constexpr int NF = MODEL == MODEL_HBV10 ? 11 : 12;
+    constexpr int D = STREAM_D;
+    const hbvx_desc &d = A.d;
+    const hbvx_fwd_out &o = A.o;
+    const int lgMp = A.lgMp;
+    const LaneT L = lane_t(d, lgMp);
+    const int T = d.T, B = d.B;
+    const int64_t N = (int64_t)B * d.M;
+    const bool raw = d.raw_sigmoid != 0;
+    const float nz = d.nearzero, invM = 1.0f / (float)d.M;
+    const float ac = (MODEL == MODEL_HBV20 || MODEL == MODEL_HOURLY) ? d.ac[L.b] : 0.0f;
+    const float elev = (MODEL == MODEL_HBV20 || MODEL == MODEL_HOURLY) ? d.elev[L.b] : 0.0f;
+    const bool leader = L.active && L.jm == 0;
+
+    float p[NPARAM_MAX];
+#pragma unroll
+    for (int i = 0; i < NPARAM_MAX; i++) p[i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        const hbvx_param_src &s = d.p[i];
+        float v = s.sta[(int64_t)L.b * s.sta_b_stride + L.j];
+        v = raw ? sigmoid_(v) : v;
+        p[i] = descale_(v, s.lo, s.hi);
+    }
+
+    auto rsrc = [&](const void *base) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, -1, 0x00020000);
+    };
+    auto bload = [&](__amdgpu_buffer_rsrc_t r, unsigned vo, unsigned so) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, vo, so, 0));
+    };
+    auto bstore = [&](__amdgpu_buffer_rsrc_t r, unsigned vo, unsigned so, float v) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, vo, so, 0);
+    };
+    const unsigned OOB = 0xFFFFFFFFu;
+
+    // inputs
+    const auto rx = rsrc(d.x);
+    const unsigned xvo = (unsigned)(L.b * d.x_b_stride * 4);
+    const unsigned xts = (unsigned)(d.x_t_stride * 4);
+    const unsigned xcp = d.ch_prcp * 4, xct = d.ch_tmean * 4, xce = d.ch_pet * 4;
+    __amdgpu_buffer_rsrc_t rd[3];
+    unsigned dvo[3], dts[3];
+    float dlo[3], dhi[3], dsta[3];
+    bool duse[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        rd[k] = rx; dvo[k] = 0; dts[k] = 0; dlo[k] = dhi[k] = dsta[k] = 0.0f; duse[k] = false;
+        if (FEW && k < A.nd) {
+            const hbvx_param_src &ps = d.p[A.dslot[k]];
+            rd[k] = rsrc(ps.dyn);
+            dvo[k] = (unsigned)((L.b * ps.dyn_b_stride + L.j) * 4);
+            dts[k] = (unsigned)(ps.dyn_t_stride * 4);
+            dlo[k] = ps.lo; dhi[k] = ps.hi;
+            dsta[k] = p[A.dslot[k]];
+            duse[k] = !(ps.drop && ps.drop[L.b]);
+        }
+    }
+    // outputs
+    const auto rtraj = rsrc(o.traj), raux = rsrc(o.aux), rflux = rsrc(o.flux);
+    unsigned tvo[5], avo[2];
+#pragma unroll
+    for (int k = 0; k < 5; k++) tvo[k] = (TRAJ && L.active) ? (unsigned)((k * (int64_t)(T + 1) * N + L.n) * 4) : OOB;
+#pragma unroll
+    for (int k = 0; k < 2; k++) avo[k] = (TRAJ && L.active) ? (unsigned)((k * (int64_t)T * N + L.n) * 4) : OOB;
+    const unsigned row4 = (unsigned)(N * 4);
+    const unsigned fvo = leader ? (unsigned)(L.b * 4) : OOB;
+    const unsigned fT = (unsigned)((int64_t)T * B * 4), fB = (unsigned)(B * 4);
+
+    float st[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) st[k] = d.state_in ? d.state_in[k * N + L.n] : 0.001f;
+
+    float fx[D], fy[D], fz[D], dv[D][3];
+    auto issue = [&](int t, int j) {
+        const unsigned tc = (unsigned)min(t, T - 1);
+        const unsigned so = tc * xts;
+        fx[j] = bload(rx, xvo, so + xcp); fy[j] = bload(rx, xvo, so + xct); fz[j] = bload(rx, xvo, so + xce);
+        if (FEW) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) dv[j][k] = bload(rd[k], dvo[k], tc * dts[k]);
+        }
+    };
+    auto day = [&](int t, int j) {
+        Step<MODEL, BETAET> s;
+        s.P = fx[j]; s.Tf = fy[j]; s.PET = fz[j];
+        if (FEW) {
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                if (k < A.nd) {
+                    const float u = raw ? sigmoid_dyn_(dv[j][k]) : dv[j][k];
+                    // wave-uniform index: stays in VGPRs (s_set_gpr_idx / v_movrel; checked: no scratch)
+                    p[A.dslot[k]] = duse[k] ? descale_(u, dlo[k], dhi[k]) : dsta[k];
+                }
+        }
+        s.SP = st[0]; s.MW = st[1]; s.SM = st[2]; s.SUZ = st[3]; s.SLZ = st[4];
+        s.template fwd<false>(p, nz, ac, elev, 0.0f, 0.0f);
+        const unsigned so = (unsigned)t * row4;
+        if (TRAJ) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) bstore(rtraj, tvo[k], so, st[k]);
+            bstore(raux, avo[0], so, s.sw0);
+            bstore(raux, avo[1], so, s.ef0);
+        }
+        st[0] = s.SP3; st[1] = s.MW3; st[2] = s.SM4; st[3] = s.SUZ4; st[4] = s.SLZ2;
+        const float act = L.active ? 1.0f : 0.0f;
+        float f[HBVX_MAX_FLUX];
+        f[HBVX_F_QSIM] = s.Q; f[HBVX_F_Q0] = s.Q0; f[HBVX_F_Q1] = s.Q1; f[HBVX_F_Q2] = s.Q2;
+        f[HBVX_F_AET] = s.ET; f[HBVX_F_SWE] = s.SP3; f[HBVX_F_RECHARGE] = s.rech; f[HBVX_F_EXCS] = s.exc;
+        f[HBVX_F_EVAPFACTOR] = s.ef; f[HBVX_F_TOSOIL] = s.tosoil; f[HBVX_F_PERC] = s.PERC;
+        f[HBVX_F_CAPILLARY] = s.cap;
+        unsigned fso = (unsigned)t * fB;
+#pragma unroll
+        for (int k = 0; k < NF; k++) {
+            const float v = ens_sum_dpp(f[k] * act, lgMp) * invM;
+            bstore(rflux, fvo, fso, v);
+            fso += fT;
+        }
+    };
+
+#pragma unroll
+    for (int j = 0; j < D; j++) issue(j, j);
+    for (int t0 = 0; t0 < T; t0 += D) {
+#pragma unroll
+        for (int j = 0; j < D; j++) {
+            const int t = t0 + j;
+            if (t < T) day(t, j);
+            issue(t + D, j);
+        }
+    }
+    if (L.active) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            o.state_out[k * N + L.n] = st[k];
+            if (TRAJ) o.traj[((int64_t)k * (T + 1) + T) * N + L.n] = st[k];
+        }
+    }
+}
+
+} // namespace hbvx

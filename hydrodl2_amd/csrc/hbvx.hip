@@ -21,6 +21,7 @@
 #include "hbv_gage.h"
 #include "hbv_chunked.h"
 #include "hbv_pipe.h"
+#include "hbv_stream.h"
 
 using namespace hbvx;
 
@@ -750,7 +751,9 @@ extern "C" int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *s
             if (d->p[i].dyn)
                 off32 = off32 && ((int64_t)d->B * d->p[i].dyn_b_stride + (int64_t)PIPE_KT * d->p[i].dyn_t_stride) * 4 <
                                      (int64_t)1 << 31;
-        if (use_tiled(d) && !(fv && !strcmp(fv, "tiled")) && d->model == HBVX_MODEL_HBV10 && off32 &&
+        const bool large = ((int64_t)d->B + (64 >> lg_members(d->M)) - 1) / (64 >> lg_members(d->M)) >= 1024 &&
+                           env_int("HBVX_STREAM", 1) != 0;   // large grids: hbv_stream.h below
+        if (use_tiled(d) && !(fv && !strcmp(fv, "tiled")) && d->model == HBVX_MODEL_HBV10 && off32 && !large &&
             nd <= PIPE_MAXDYN && !d->muwts && out->flux && d->T >= 4 * Kt &&
             (out->traj != nullptr) == (out->aux != nullptr) && (int64_t)d->B * d->M * 4 * PIPE_KT < (int64_t)1 << 31 &&
             (int64_t)11 * d->T * d->B * 4 < (int64_t)1 << 31) {
@@ -778,6 +781,51 @@ extern "C" int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *s
             }
 #undef PIPE_GO
             if (e != hipSuccess) return hip_fail(e, "hbvx_forward (pipelined) launch");
+            return HBVX_OK;
+        }
+    }
+    {
+        // large grids: streaming one-wave kernel (hbv_stream.h)
+        const int lg = lg_members(d->M);
+        const int bpw_s = 64 >> lg;
+        const int64_t wgs = ((int64_t)d->B + bpw_s - 1) / bpw_s;
+        const int64_t N = (int64_t)d->B * d->M, lim = (int64_t)1 << 32;
+        const int nd = count_dyn(d);
+        const int nf = (d->model == HBVX_MODEL_HBV10) ? 11 : 12;
+        bool ok = use_tiled(d) && env_int("HBVX_STREAM", 1) != 0 && wgs >= 1024 && nd <= 3 && !d->muwts &&
+                  out->flux && (out->traj != nullptr) == (out->aux != nullptr) && d->T > 0 &&
+                  5 * (int64_t)(d->T + 1) * N * 4 < lim && (int64_t)nf * d->T * d->B * 4 < lim &&
+                  ((int64_t)d->T * d->x_t_stride + (int64_t)d->B * d->x_b_stride) * 4 < lim;
+        for (int i = 0; i < d->n_param && ok; i++)
+            if (d->p[i].dyn)
+                ok = ((int64_t)d->T * d->p[i].dyn_t_stride + (int64_t)d->B * d->p[i].dyn_b_stride) * 4 < lim;
+        if (ok) {
+            StreamArgs sa;
+            sa.d = *d;
+            sa.o = *out;
+            sa.lgMp = lg;
+            sa.nd = 0;
+            sa.dslot[0] = sa.dslot[1] = sa.dslot[2] = 0;
+            for (int i = 0; i < d->n_param; i++)
+                if (d->p[i].dyn) sa.dslot[sa.nd++] = i;
+            const bool tr = out->traj != nullptr, few = nd > 0;
+            dim3 grid_s((unsigned)wgs);
+            hipStream_t st = (hipStream_t)stream;
+#define STREAM_GO(MODEL, BE)                                                                          \
+    do {                                                                                              \
+        if (tr) { if (few) hipLaunchKernelGGL((k_fwd_stream<MODEL, BE, true, true>), grid_s, dim3(64), 0, st, sa);   \
+                  else hipLaunchKernelGGL((k_fwd_stream<MODEL, BE, true, false>), grid_s, dim3(64), 0, st, sa); }   \
+        else { if (few) hipLaunchKernelGGL((k_fwd_stream<MODEL, BE, false, true>), grid_s, dim3(64), 0, st, sa);    \
+               else hipLaunchKernelGGL((k_fwd_stream<MODEL, BE, false, false>), grid_s, dim3(64), 0, st, sa); }     \
+    } while (0)
+            if (d->model == HBVX_MODEL_HBV10 && d->n_param == 12) STREAM_GO(MODEL_HBV10, false);
+            else if (d->model == HBVX_MODEL_HBV10) STREAM_GO(MODEL_HBV10, true);
+            else if (d->model == HBVX_MODEL_HBV11P) STREAM_GO(MODEL_HBV11P, true);
+            else if (d->model == HBVX_MODEL_HOURLY) STREAM_GO(MODEL_HOURLY, true);
+            else STREAM_GO(MODEL_HBV20, true);
+#undef STREAM_GO
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return hip_fail(e, "hbvx_forward (stream) launch");
             return HBVX_OK;
         }
     }

@@ -148,3 +148,22 @@ def test_pipelined_forward_equals_tiled_forward(M, B, T, dyn, betaet, drop, hip_
     for k in ("flux", "routed", "state_out", "traj", "g_params"):
         assert np.array_equal(a[k], b[k]), k
     assert np.array_equal(a2["flux"], b["flux"])
+
+
+@pytest.mark.parametrize("model,dyn,M,B", [
+    ("Hbv", (), 16, 4100), ("Hbv", ("parBETA", "parBETAET"), 16, 4100),
+    ("Hbv_1_1p", ("parK0", "parTT", "parFC"), 5, 8200), ("Hbv_2", ("parBETA",), 16, 4100),
+    ("Hbv_2_hourly", ("parBETA", "parK0", "parBETAET"), 4, 16400)])
+def test_stream_forward_equals_tiled_forward(model, dyn, M, B, hip_backend, monkeypatch):
+    """Large grids (>= 1024 wavefronts of state) run the streaming one-wave forward (hbv_stream.h);
+    it is bit-identical to the tiled / pipelined kernels (same step arithmetic, same ensemble add
+    tree), with and without the saved trajectory, including the gradients computed from it."""
+    T = 37
+    prob = make_problem(model=model, T=T, B=B, M=M, dyn=dyn, drop_frac=0.3 if dyn else 0.0, seed=33)
+    a = run_problem(prob, None, device="cuda:0", backward=True)
+    a2 = run_problem(prob, None, device="cuda:0", backward=False)
+    monkeypatch.setenv("HBVX_STREAM", "0")
+    b = run_problem(prob, None, device="cuda:0", backward=True)
+    for k in ("flux", "state_out", "traj", "g_params"):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(a2["flux"], b["flux"])
