@@ -196,4 +196,208 @@ __global__ void __launch_bounds__(64) k_fwd_stream(const StreamArgs A)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Adjoint for large grids: the plain serial sweep (ONE pass over the trajectory, where the
+// time-parallel scheme needs two), one wavefront per 64 lanes, same register ring / buffer
+// addressing.  With thousands of wavefronts there is no need to parallelise over time.
+// Per-lane static-parameter gradients accumulate in registers over the whole record and go straight
+// into the gradient row (each lane owns its element: deterministic, no partials, no workspace).
+// ---------------------------------------------------------------------------------------------
+#define STREAM_DB 2
+
+struct StreamBwdArgs {
+    hbvx_desc d;
+    hbvx_bwd_io io;
+    int lgMp;
+    int nd;
+    int dslot[3];
+};
+
+template <int MODEL, bool BETAET, bool FEW, bool GFULL>
+__global__ void __launch_bounds__(64) k_bwd_stream(const StreamBwdArgs A)
+{
+    constexpr int NP = NParamT<MODEL, BETAET>::value;
+    constexpr int NF = MODEL == MODEL_HBV10 ? 11 : 12;
+    constexpr int NG = GFULL ? NF : 4;      // flux series that carry gradient
+    constexpr int D = STREAM_DB;
+    const hbvx_desc &d = A.d;
+    const hbvx_bwd_io &io = A.io;
+    const int lgMp = A.lgMp;
+    const LaneT L = lane_t(d, lgMp);
+    const int T = d.T, B = d.B;
+    const int64_t N = (int64_t)B * d.M;
+    const bool raw = d.raw_sigmoid != 0;
+    const float nz = d.nearzero, invM = 1.0f / (float)d.M;
+    const float ac = (MODEL == MODEL_HBV20 || MODEL == MODEL_HOURLY) ? d.ac[L.b] : 0.0f;
+    const float elev = (MODEL == MODEL_HBV20 || MODEL == MODEL_HOURLY) ? d.elev[L.b] : 0.0f;
+    const bool leader = L.active && L.jm == 0;
+    const unsigned OOB = 0xFFFFFFFFu;
+
+    float p[NPARAM_MAX], usta[NP], gsta[NP];
+#pragma unroll
+    for (int i = 0; i < NPARAM_MAX; i++) p[i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        const hbvx_param_src &s = d.p[i];
+        const float v = s.sta[(int64_t)L.b * s.sta_b_stride + L.j];
+        usta[i] = raw ? sigmoid_(v) : v;
+        p[i] = descale_(usta[i], s.lo, s.hi);
+        gsta[i] = 0.0f;
+    }
+
+    auto rsrc = [&](const void *base) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, -1, 0x00020000);
+    };
+    auto bload = [&](__amdgpu_buffer_rsrc_t r, unsigned vo, unsigned so) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, vo, so, 0));
+    };
+    auto bstore = [&](__amdgpu_buffer_rsrc_t r, unsigned vo, unsigned so, float v) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, vo, so, 0);
+    };
+
+    const auto rx = rsrc(d.x), rtraj = rsrc(io.traj), raux = rsrc(io.aux);
+    const auto rgf = rsrc(io.grad_flux ? io.grad_flux : io.grad_flux4);
+    const auto rg4 = rsrc(io.grad_flux4 ? io.grad_flux4 : io.grad_flux);
+    const bool has_gf = io.grad_flux != nullptr, has_g4 = io.grad_flux4 != nullptr;
+    const unsigned xvo = (unsigned)(L.b * d.x_b_stride * 4), xts = (unsigned)(d.x_t_stride * 4);
+    const unsigned xcp = d.ch_prcp * 4, xct = d.ch_tmean * 4, xce = d.ch_pet * 4;
+    unsigned tvo[5], avo[2];
+#pragma unroll
+    for (int k = 0; k < 5; k++) tvo[k] = (unsigned)((k * (int64_t)(T + 1) * N + L.n) * 4);
+#pragma unroll
+    for (int k = 0; k < 2; k++) avo[k] = (unsigned)((k * (int64_t)T * N + L.n) * 4);
+    const unsigned row4 = (unsigned)(N * 4);
+    const unsigned gvo = (unsigned)(L.b * 4);
+    const unsigned fT = (unsigned)((int64_t)T * B * 4), fB = (unsigned)(B * 4);
+
+    __amdgpu_buffer_rsrc_t rd[3], rgd[3];
+    unsigned dvo[3], dts[3], gdvo[3], gdts[3];
+    float dlo[3], dhi[3], dsta[3], gused[3];
+    bool duse[3], dgrad[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        rd[k] = rgd[k] = rx; dvo[k] = dts[k] = gdts[k] = 0; gdvo[k] = OOB;
+        dlo[k] = dhi[k] = dsta[k] = gused[k] = 0.0f; duse[k] = dgrad[k] = false;
+        if (FEW && k < A.nd) {
+            const int sl = A.dslot[k];
+            const hbvx_param_src &ps = d.p[sl];
+            rd[k] = rsrc(ps.dyn);
+            dvo[k] = (unsigned)((L.b * ps.dyn_b_stride + L.j) * 4);
+            dts[k] = (unsigned)(ps.dyn_t_stride * 4);
+            dlo[k] = ps.lo; dhi[k] = ps.hi;
+            dsta[k] = p[sl];
+            duse[k] = !(ps.drop && ps.drop[L.b]);
+            dgrad[k] = io.g[sl].dyn != nullptr;
+            if (dgrad[k]) {
+                rgd[k] = rsrc(io.g[sl].dyn);
+                gdvo[k] = L.active ? (unsigned)((L.b * io.g[sl].dyn_b_stride + L.j) * 4) : OOB;
+                gdts[k] = (unsigned)(io.g[sl].dyn_t_stride * 4);
+            }
+        }
+    }
+    const auto rgx = rsrc(io.grad_x ? io.grad_x : const_cast<float *>(d.x));
+    const bool has_gx = io.grad_x != nullptr;
+    const unsigned gxvo = leader ? xvo : OOB;
+
+    float a[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) a[k] = io.grad_state_out ? io.grad_state_out[k * N + L.n] : 0.0f;
+
+    float fx[D][3], st[D][5], ax[D][2], gf[D][NG], dv[D][3];
+    auto issue = [&](int t, int j) {
+        const unsigned tc = (unsigned)max(t, 0);
+        const unsigned so = tc * xts, sr = tc * row4, sg = tc * fB;
+        fx[j][0] = bload(rx, xvo, so + xcp); fx[j][1] = bload(rx, xvo, so + xct); fx[j][2] = bload(rx, xvo, so + xce);
+#pragma unroll
+        for (int k = 0; k < 5; k++) st[j][k] = bload(rtraj, tvo[k], sr);
+        ax[j][0] = bload(raux, avo[0], sr); ax[j][1] = bload(raux, avo[1], sr);
+#pragma unroll
+        for (int k = 0; k < NG; k++) {
+            float v = 0.0f;
+            if (GFULL) { if (has_gf) v = bload(rgf, gvo, sg + (unsigned)k * fT); }
+            if (k < 4) { if (has_g4) v += bload(rg4, gvo, sg + (unsigned)k * fT); }
+            gf[j][k] = v;
+        }
+        if (FEW) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) dv[j][k] = bload(rd[k], dvo[k], tc * dts[k]);
+        }
+    };
+    auto day = [&](int t, int j) {
+        Step<MODEL, BETAET> s;
+        s.P = fx[j][0]; s.Tf = fx[j][1]; s.PET = fx[j][2];
+        s.SP = st[j][0]; s.MW = st[j][1]; s.SM = st[j][2]; s.SUZ = st[j][3]; s.SLZ = st[j][4];
+        float ud[3] = {0.0f, 0.0f, 0.0f};
+        if (FEW) {
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                if (k < A.nd) {
+                    ud[k] = raw ? sigmoid_dyn_(dv[j][k]) : dv[j][k];
+                    p[A.dslot[k]] = duse[k] ? descale_(ud[k], dlo[k], dhi[k]) : dsta[k];
+                }
+        }
+        s.template fwd<true>(p, nz, ac, elev, ax[j][0], ax[j][1]);
+        FluxGrad g;
+        auto GF = [&](int k) -> float { return k < NG ? gf[j][k] * invM : 0.0f; };
+        g.gQ = GF(HBVX_F_QSIM); g.gQ0 = GF(HBVX_F_Q0); g.gQ1 = GF(HBVX_F_Q1); g.gQ2 = GF(HBVX_F_Q2);
+        g.gET = GF(HBVX_F_AET); g.gSWE = GF(HBVX_F_SWE); g.grech = GF(HBVX_F_RECHARGE);
+        g.gexc = GF(HBVX_F_EXCS); g.gef = GF(HBVX_F_EVAPFACTOR); g.gtosoil = GF(HBVX_F_TOSOIL);
+        g.gPERC = GF(HBVX_F_PERC); g.gcap = (NF > HBVX_F_CAPILLARY) ? GF(HBVX_F_CAPILLARY) : 0.0f;
+        float gp[NPARAM_MAX], gx[3];
+#pragma unroll
+        for (int i = 0; i < NPARAM_MAX; i++) gp[i] = 0.0f;
+        s.bwd(p, nz, g, a, gp, gx);
+#pragma unroll
+        for (int i = 0; i < NP; i++) gsta[i] += gp[i] * (d.p[i].hi - d.p[i].lo);
+        if (FEW) {
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                if (k < A.nd) {
+                    const int sl = A.dslot[k];
+                    const float gu = gp[sl] * (d.p[sl].hi - d.p[sl].lo);
+                    const float gr = raw ? gu * (ud[k] * (1.0f - ud[k])) : gu;
+                    if (dgrad[k]) bstore(rgd[k], gdvo[k], (unsigned)t * gdts[k], duse[k] ? gr : 0.0f);
+                    gused[k] += duse[k] ? gu : 0.0f;
+                }
+        }
+        if (has_gx) {
+            const float act = L.active ? 1.0f : 0.0f;
+            const float g0 = ens_sum_dpp(gx[0] * act, lgMp), g1 = ens_sum_dpp(gx[1] * act, lgMp),
+                        g2 = ens_sum_dpp(gx[2] * act, lgMp);
+            const unsigned so = (unsigned)t * xts;
+            bstore(rgx, gxvo, so + xcp, g0); bstore(rgx, gxvo, so + xct, g1); bstore(rgx, gxvo, so + xce, g2);
+        }
+    };
+
+#pragma unroll
+    for (int j = 0; j < D; j++) issue(T - 1 - j, j);
+    for (int t0 = T - 1; t0 >= 0; t0 -= D) {
+#pragma unroll
+        for (int j = 0; j < D; j++) {
+            const int t = t0 - j;
+            if (t >= 0) day(t, j);
+            issue(t - D, j);
+        }
+    }
+    if (FEW) {
+        // the same daily terms went into gsta and gused in the same order: exact cancellation
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            if (k < A.nd) gsta[A.dslot[k]] = gsta[A.dslot[k]] - gused[k];
+    }
+    if (L.active) {
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            if (!io.g[i].sta) continue;
+            const float gr = raw ? gsta[i] * (usta[i] * (1.0f - usta[i])) : gsta[i];
+            float *dst = io.g[i].sta + (int64_t)L.b * io.g[i].sta_b_stride + L.j;
+            *dst += gr;
+        }
+        if (io.grad_state_in) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) io.grad_state_in[k * N + L.n] = a[k];
+        }
+    }
+}
+
 } // namespace hbvx

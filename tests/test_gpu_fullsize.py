@@ -153,5 +153,8 @@ def test_hbv2_many_basins(hip_backend):
     out2 = m2(xd2, (pd2, ps2))
     (out2["streamflow"] * w[:, sel]).sum().backward()
     assert torch.equal(out["streamflow"][:, sel], out2["streamflow"])
-    assert torch.equal(pd.grad[:, sel], pd2.grad) and torch.equal(ps.grad[sel], ps2.grad)
     assert torch.equal(st[2][:, sel], m2.get_states()[2])
+    # gradients: the full run takes the single-pass streaming adjoint, the 6-basin run the
+    # time-parallel one; they agree to rounding (composed chunk maps vs the serial sweep)
+    torch.testing.assert_close(pd.grad[:, sel], pd2.grad, rtol=1e-4, atol=1e-6 * float(pd2.grad.abs().max()))
+    torch.testing.assert_close(ps.grad[sel], ps2.grad, rtol=1e-4, atol=1e-6 * float(ps2.grad.abs().max()))
