@@ -153,7 +153,8 @@ def test_pipelined_forward_equals_tiled_forward(M, B, T, dyn, betaet, drop, hip_
 @pytest.mark.parametrize("model,dyn,M,B", [
     ("Hbv", (), 16, 4100), ("Hbv", ("parBETA", "parBETAET"), 16, 4100),
     ("Hbv_1_1p", ("parK0", "parTT", "parFC"), 5, 8200), ("Hbv_2", ("parBETA",), 16, 4100),
-    ("Hbv_2_hourly", ("parBETA", "parK0", "parBETAET"), 4, 16400)])
+    ("Hbv_2_hourly", ("parBETA", "parK0", "parBETAET"), 4, 16400),
+    ("Hbv", (), 1, 66000), ("Hbv_2", (), 2, 33000), ("Hbv", ("parK1",), 64, 1030)])
 def test_stream_forward_equals_tiled_forward(model, dyn, M, B, hip_backend, monkeypatch):
     """Large grids (>= 1024 wavefronts of state) run the streaming one-wave forward (hbv_stream.h);
     it is bit-identical to the tiled / pipelined kernels (same step arithmetic, same ensemble add
