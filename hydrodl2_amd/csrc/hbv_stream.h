@@ -41,16 +41,36 @@ __device__ __forceinline__ float dpp_(float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
 
-// sum over the Mp lanes of a basin; every lane of the basin gets the sum
-__device__ __forceinline__ float ens_sum_dpp(float v, int lgMp)
+// sums over the Mp lanes of a basin for NV values at once (every lane of the basin gets the sums);
+// the wave-uniform tests on lgMp are outside the loops over the values: 6 scalar branches per call
+// instead of 6 per value
+template <int NV>
+__device__ __forceinline__ void ens_sum_dpp(float *v, int lgMp)
 {
-    if (lgMp >= 1) v += dpp_<0xB1>(v);   // quad_perm [1,0,3,2]
-    if (lgMp >= 2) v += dpp_<0x4E>(v);   // quad_perm [2,3,0,1]
-    if (lgMp >= 3) v += dpp_<0x141>(v);  // row_half_mirror: the other quad of the 8
-    if (lgMp >= 4) v += dpp_<0x140>(v);  // row_mirror: the other half of the 16
-    if (lgMp >= 5) v += __shfl_xor(v, 16, 64);
-    if (lgMp >= 6) v += __shfl_xor(v, 32, 64);
-    return v;
+    if (lgMp >= 1) {
+#pragma unroll
+        for (int k = 0; k < NV; k++) v[k] += dpp_<0xB1>(v[k]);   // quad_perm [1,0,3,2]
+    }
+    if (lgMp >= 2) {
+#pragma unroll
+        for (int k = 0; k < NV; k++) v[k] += dpp_<0x4E>(v[k]);   // quad_perm [2,3,0,1]
+    }
+    if (lgMp >= 3) {
+#pragma unroll
+        for (int k = 0; k < NV; k++) v[k] += dpp_<0x141>(v[k]);  // row_half_mirror: the other quad of the 8
+    }
+    if (lgMp >= 4) {
+#pragma unroll
+        for (int k = 0; k < NV; k++) v[k] += dpp_<0x140>(v[k]);  // row_mirror: the other half of the 16
+    }
+    if (lgMp >= 5) {
+#pragma unroll
+        for (int k = 0; k < NV; k++) v[k] += __shfl_xor(v[k], 16, 64);
+    }
+    if (lgMp >= 6) {
+#pragma unroll
+        for (int k = 0; k < NV; k++) v[k] += __shfl_xor(v[k], 32, 64);
+    }
 }
 
 template <int MODEL, bool BETAET, bool TRAJ, bool FEW>
@@ -168,25 +188,33 @@ __global__ void __launch_bounds__(64) k_fwd_stream(const StreamArgs A)
         f[HBVX_F_AET] = s.ET; f[HBVX_F_SWE] = s.SP3; f[HBVX_F_RECHARGE] = s.rech; f[HBVX_F_EXCS] = s.exc;
         f[HBVX_F_EVAPFACTOR] = s.ef; f[HBVX_F_TOSOIL] = s.tosoil; f[HBVX_F_PERC] = s.PERC;
         f[HBVX_F_CAPILLARY] = s.cap;
+#pragma unroll
+        for (int k = 0; k < NF; k++) f[k] *= act;
+        ens_sum_dpp<NF>(f, lgMp);
         unsigned fso = (unsigned)t * fB;
 #pragma unroll
         for (int k = 0; k < NF; k++) {
-            const float v = ens_sum_dpp(f[k] * act, lgMp) * invM;
-            bstore(rflux, fvo, fso, v);
+            bstore(rflux, fvo, fso, f[k] * invM);
             fso += fT;
         }
     };
 
 #pragma unroll
     for (int j = 0; j < D; j++) issue(j, j);
-    for (int t0 = 0; t0 < T; t0 += D) {
+    // Full groups are straight-line code: with a branch around a day the compiler's wait-counter
+    // bookkeeping turns conservative (vmcnt(0) at the top of every day = wait for yesterday's
+    // stores), which defeats the ring.
+    int t0 = 0;
+    for (; t0 + D <= T; t0 += D) {
 #pragma unroll
         for (int j = 0; j < D; j++) {
-            const int t = t0 + j;
-            if (t < T) day(t, j);
-            issue(t + D, j);
+            day(t0 + j, j);
+            issue(t0 + j + D, j);
         }
     }
+#pragma unroll
+    for (int j = 0; j < D; j++)
+        if (t0 + j < T) day(t0 + j, j);
     if (L.active) {
 #pragma unroll
         for (int k = 0; k < 5; k++) {
@@ -362,15 +390,18 @@ __global__ void __launch_bounds__(64) k_bwd_stream(const StreamBwdArgs A)
         }
         if (has_gx) {
             const float act = L.active ? 1.0f : 0.0f;
-            const float g0 = ens_sum_dpp(gx[0] * act, lgMp), g1 = ens_sum_dpp(gx[1] * act, lgMp),
-                        g2 = ens_sum_dpp(gx[2] * act, lgMp);
+            float gs[3] = {gx[0] * act, gx[1] * act, gx[2] * act};
+            ens_sum_dpp<3>(gs, lgMp);
             const unsigned so = (unsigned)t * xts;
-            bstore(rgx, gxvo, so + xcp, g0); bstore(rgx, gxvo, so + xct, g1); bstore(rgx, gxvo, so + xce, g2);
+            bstore(rgx, gxvo, so + xcp, gs[0]); bstore(rgx, gxvo, so + xct, gs[1]); bstore(rgx, gxvo, so + xce, gs[2]);
         }
     };
 
 #pragma unroll
     for (int j = 0; j < D; j++) issue(T - 1 - j, j);
+    // (measured: unlike the forward, the adjoint is faster with the day under a branch -- it has
+    // few stores, and the conservative waits cost less than the longer live ranges of the
+    // straight-line schedule: 3.4 vs 3.9 ms at config 5)
     for (int t0 = T - 1; t0 >= 0; t0 -= D) {
 #pragma unroll
         for (int j = 0; j < D; j++) {

@@ -55,6 +55,18 @@ def run(name, steps=5, warmup=2):
         model = hydrodl2_amd.load_model("hbv_adj", "HbvAdj")(
             {"nmul": M, "dynamic_params": {"HbvAdj": ["parBETAET"]}}, dev)
         n_dyn, nf = 1, 1
+    elif name.startswith("grid:"):
+        # grid:<hbv|hbv_2>:<B>:<T>  -- 16 members, 3 dynamic parameters for hbv_2, 2 for hbv
+        _, fam, Bs, Ts = name.split(":")
+        T, B, M = int(Ts), int(Bs), 16
+        if fam == "hbv":
+            dyn = ["parBETA", "parBETAET"]
+            model = hydrodl2_amd.load_model("hbv", "Hbv")({"nmul": M, "dynamic_params": {"Hbv": dyn}}, dev)
+            n_dyn, nf = 2, 11
+        else:
+            dyn = ["parBETA", "parK0", "parBETAET"]
+            model = hydrodl2_amd.load_model("hbv_2", "Hbv_2")({"nmul": M, "dynamic_params": {"Hbv_2": dyn}}, dev)
+            n_dyn, nf = 3, 12
     elif name == "hourly":
         T, B, M = 2160, 4000, 4    # 90 days of hours, 4000 units draining to 100 gages
         dyn = ["parBETA", "parK0", "parBETAET"]
@@ -80,7 +92,7 @@ def run(name, steps=5, warmup=2):
         xd["outlet_topo"] = topo
         xd["areas"] = torch.rand(B, generator=g, device=dev) * 90 + 5
         leaves = [pd, ps, pr]
-    elif name == "cfg5":
+    elif name == "cfg5" or name.startswith("grid:hbv_2"):
         pd = torch.rand((T, B, 3 * M), generator=g, device=dev).requires_grad_(True)
         ps = torch.rand((B, 13 * M), generator=g, device=dev).requires_grad_(True)
         params = (pd, ps)
