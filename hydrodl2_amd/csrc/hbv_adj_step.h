@@ -206,7 +206,7 @@ HBVX_HD void adj_backstep(AdjStep<BETAET> &s, const float *p, const float *x, fl
                           float *a, float *gp)
 {
     const float BETA = p[P_BETA], FC = p[P_FC], K0 = p[P_K0], K1 = p[P_K1], K2 = p[P_K2],
-                LP = p[P_LP], CFMAX = p[P_CFMAX], CFR = p[P_CFR], CWH = p[P_CWH];
+                LP = p[P_LP], CFMAX = p[P_CFMAX], CFR = p[P_CFR];
     s.template eval<true>(x, p);
     // direct dependence of Q on the solved state
     float rhs[5] = {a[0], a[1], a[2], a[3] + gQ * (K0 * s.mq0 + K1) * s.c3, a[4] + gQ * K2 * s.c4};

@@ -76,21 +76,10 @@ struct PipeLds {
     }
 };
 
-// Store one value per lane into a row of `row_bytes` bytes starting at the wave-uniform address
-// `row`: buffer addressing keeps the base in SGPRs (scalar address arithmetic only) and drops lanes
-// whose offset is out of range, so inactive lanes need no EXEC masking (voff = 0xFFFFFFFF).
-__device__ __forceinline__ void row_store(float *row, unsigned row_bytes, unsigned voff, float v)
-{
-    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(row, 0, (int)row_bytes, 0x00020000);
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, 0, 0);
-}
-
 // Drain work of the helper waves.  A stage's output tile holds NSER series per day: NFS flux series
 // first (global flux index = nibble i of FMAP), then NSER - NFS storage series.  Everything that
 // indexes the layout is a compile-time constant.
 //   pipe_reduce_pass: ensemble means of 64 (day, series, basin) items -> flux series
-//   pipe_rows_day:    the storage rows of one day -> trajectory / aux (ROW0..: row index in units
-//                     of N floats relative to `base`, nibble-packed; see the call sites)
 template <int NSER, int NFS, unsigned FMAP>
 __device__ __forceinline__ void pipe_reduce_pass(const hbvx_desc &d, const hbvx_fwd_out &o, const float *buf,
                                                  int t0, int items, int pass, int lane, int lgMp, int b0)
@@ -148,7 +137,6 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
     } probe_flush{probe_busy, probe_wait};
 #endif
     constexpr int NP = BETAET ? 13 : 12;
-    constexpr int NF = 11;
     extern __shared__ __align__(16) float lds[];
     const hbvx_desc &d = A.d;
     const hbvx_fwd_out &o = A.o;
@@ -503,7 +491,6 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                 PIPE_BARRIER();
             }
         }
-        (void)NF;
     }
 }
 

@@ -321,8 +321,7 @@ __global__ void __launch_bounds__(512) k_fwd_tiled(const FwdTArgs A)
     } else {
         // ------------------------------ helpers ------------------------------
         const int w = wave - 1;
-        const int hid = w * 64 + lane, nhid = NH * 64;
-        const int lgMp = G.lgMp, Mp = 1 << lgMp, bpw = 64 >> lgMp;
+        const int lgMp = G.lgMp, bpw = 64 >> lgMp;
         const int b0 = blockIdx.x * bpw;
         const float invM = 1.0f / (float)d.M;
         const float *xb = d.x + (int64_t)L.b * d.x_b_stride;
@@ -437,7 +436,7 @@ __global__ void __launch_bounds__(512) k_bwd_tiled(const BwdTArgs A)
     constexpr int NG = GFULL ? NF : 4; // staged gradient series per day
     const bool has_mu = DYN && d.muwts != nullptr;
     const bool has_gx = io.grad_x != nullptr, has_gmu = DYN && io.grad_muwts != nullptr;
-    const int lgMp = G.lgMp, Mp = 1 << lgMp, bpw = 64 >> lgMp;
+    const int lgMp = G.lgMp, bpw = 64 >> lgMp;
     const float invM = 1.0f / (float)d.M;
 
     unsigned dmask = 0;
