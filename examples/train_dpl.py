@@ -1,0 +1,148 @@
+#!/usr/bin/env python3
+"""End-to-end differentiable-parameter-learning step around the HBV plug-in (SURVEY.md §8f rank 4:
+the caller side, outside the reference repository -- delta-MG style).
+
+    python examples/train_dpl.py [--basins 100] [--rho 365] [--warm-up 365] [--nmul 16] [--steps 20]
+    python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 examples/train_dpl.py ...
+
+A small LSTM maps normalised forcings + static attributes to the raw parameter tensor [T,B,ny];
+`hydrodl2_amd.load_model('hbv')` turns it into streamflow; the loss is 1 - NSE per basin.  With
+several processes every rank owns a contiguous block of basins (no collective inside the physics);
+the LSTM gradients and the loss normalisers travel in ONE bucketed all-reduce per step
+(`hydrodl2_amd.sharding.all_reduce_sum_`).  Data are synthetic: "observations" are produced by the
+same physics with a hidden parameter field, so the loss has a meaningful minimum.
+Prints one JSON line with ms/step and the share spent in the HBV calls.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import hydrodl2_amd  # noqa: E402
+from hydrodl2_amd import ops, sharding  # noqa: E402
+
+
+class ParamNet(torch.nn.Module):
+    """LSTM parameterisation network: [T,B,n_in] -> raw parameters [T,B,ny]."""
+
+    def __init__(self, n_in: int, hidden: int, ny: int):
+        super().__init__()
+        self.inp = torch.nn.Linear(n_in, hidden)
+        self.lstm = torch.nn.LSTM(hidden, hidden)
+        self.out = torch.nn.Linear(hidden, ny)
+
+    def forward(self, z):
+        h, _ = self.lstm(torch.relu(self.inp(z)))
+        return self.out(h)
+
+
+def nse_loss(sim, obs):
+    """mean over basins of 1 - NSE; sim/obs [T,B].  Returns (sum over local basins, count)."""
+    num = ((sim - obs) ** 2).sum(0)
+    den = ((obs - obs.mean(0, keepdim=True)) ** 2).sum(0) + 1e-6
+    return (num / den).sum(), sim.shape[1]
+
+
+def synth(T, B, n_attr, dev, seed):
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    day = torch.arange(T, device=dev, dtype=torch.float32)[:, None]
+    season = torch.sin(2 * torch.pi * day / 365.0)
+    P = torch.clamp((torch.rand((T, B), generator=g, device=dev) - 0.7) * 60.0, min=0.0)
+    Tm = 10 * season + 5 * torch.randn((T, B), generator=g, device=dev) \
+        + torch.rand((1, B), generator=g, device=dev) * 25 - 10
+    PET = torch.clamp(3 + 2.5 * season, min=0).expand(T, B)
+    x = torch.stack([P, Tm, PET], -1).contiguous()
+    attrs = torch.randn((B, n_attr), generator=g, device=dev)
+    return x, attrs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--basins", type=int, default=100)
+    ap.add_argument("--rho", type=int, default=365)
+    ap.add_argument("--warm-up", type=int, default=365)
+    ap.add_argument("--nmul", type=int, default=16)
+    ap.add_argument("--hidden", type=int, default=256)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--device", default="cuda")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    on_gpu = args.device.startswith("cuda")
+    if on_gpu:
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dev = torch.device(args.device if not on_gpu else f"cuda:{torch.cuda.current_device()}")
+    if world > 1:
+        dist.init_process_group("nccl" if on_gpu else "gloo")
+
+    T, B, M = args.warm_up + args.rho, args.basins, args.nmul
+    dyn = ["parBETA", "parBETAET"]
+    cfg = {"nmul": M, "warm_up": args.warm_up, "dynamic_params": {"Hbv": dyn}}
+    Hbv = hydrodl2_amd.load_model("hbv", "Hbv")
+    phy = Hbv(cfg, dev)
+    ny = phy.learnable_param_count
+    n_attr = 8
+
+    # global synthetic data set, identical on every rank; each rank keeps its block of basins
+    x_all, attrs_all = synth(T, B, n_attr, dev, seed=0)
+    torch.manual_seed(1)
+    truth = ParamNet(3 + n_attr, 32, ny).to(dev)
+    b0, b1 = sharding.basin_range(B, world, rank)
+    x, attrs = x_all[:, b0:b1].contiguous(), attrs_all[b0:b1]
+    mean, std = x_all.mean((0, 1)), x_all.std((0, 1)) + 1e-6
+    z = torch.cat([(x - mean) / std, attrs[None].expand(T, -1, -1)], -1)
+    with torch.no_grad():
+        obs = Hbv(cfg, dev)({"x_phy": x}, truth(z))["streamflow"][:, :, 0]
+
+    torch.manual_seed(2)                       # same initial network on every rank
+    net = ParamNet(3 + n_attr, args.hidden, ny).to(dev)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    params = [p for p in net.parameters()]
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        raw = net(z)
+        sim = phy({"x_phy": x}, raw)["streamflow"][:, :, 0]
+        loss_sum, count = nse_loss(sim, obs)
+        loss_sum.backward()
+        # one bucketed all-reduce: [loss sum, basin count, every network gradient]
+        stats = torch.tensor([float(loss_sum.detach()), float(count)], device=dev)
+        sharding.all_reduce_sum_([stats] + [p.grad for p in params])
+        for p in params:
+            p.grad /= stats[1]
+        opt.step()
+        return float(stats[0] / stats[1])
+
+    losses = [step() for _ in range(3)]        # warm-up
+    ops.KERNEL_EVENTS = [] if on_gpu else None
+    if on_gpu:
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses.append(step())
+    if on_gpu:
+        torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    hbv_ms = None
+    if on_gpu:
+        ev, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
+        hbv_ms = sum(e0.elapsed_time(e1) for _, e0, e1 in ev) / args.steps
+    if rank == 0:
+        print(json.dumps({"basins": B, "nmul": M, "days": T, "world": world, "ms_per_step": round(dt * 1e3, 3),
+                          "hbv_calls_ms": None if hbv_ms is None else round(hbv_ms, 3),
+                          "loss_first": round(losses[0], 4), "loss_last": round(losses[-1], 4)}))
+    if world > 1:
+        dist.destroy_process_group()
+    return losses
+
+
+if __name__ == "__main__":
+    main()
