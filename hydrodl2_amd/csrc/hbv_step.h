@@ -88,14 +88,16 @@ HBVX_HD float descale_(float u, float lo, float hi) { return u * (hi - lo) + lo;
 
 // ---------------------------------------------------------------------------
 // x**y for x > 0 (reference: `(SM / parFC) ** parBETA`, hbv.py:462; evapfactor ** parBETAET,
-// hbv.py:476).  The time loop is latency-bound on one wave per 64 lanes, and ocml's
-// correctly-rounded powf is ~200 dependent fp32 instructions (double-float log/exp).
-// This version does the same job in fp64 polynomials (~40 instructions): log2 via
-// atanh series after frexp, exp2 via Taylor after rint; relative error < 2e-9 before the
-// final rounding, i.e. within 1 ulp (fp32) of the exact result like libm/ATen's powf
-// (tests/test_step_math_host.py::test_pow_accuracy, tests/test_gpu_parity.py::test_pow_on_gpu).
-// Special bases are patched branch-free after the polynomial: 0**y, inf**y as powf; NaN or a
-// negative base give NaN (the reference can only reach x < 0 with nearzero < 0).
+// hbv.py:476).  Three versions, fastest last:
+//   pow_f64_   fp64 polynomials (~40 instructions): log2 via atanh series after frexp, exp2 via
+//              Taylor after rint; 0.5 ulp.  The first fast version (ocml's correctly-rounded powf
+//              is ~200 dependent fp32 instructions); kept for -DHBVX_POW_F64 and as the accuracy
+//              yardstick in the tests.
+//   pow_hw_    hardware log2 / exp2 on the reduced mantissa with hi+lo exponent arithmetic, all
+//              special bases handled like powf; <= 2.1 ulp measured.  The general pow_pos_.
+//   pow_step_  pow_hw_'s core for the time step: base clamped at FLT_MIN, no special-value
+//              selects, no exponent clamp (see there).
+// (tests/test_step_math_host.py::test_pow_accuracy, tests/test_gpu_parity.py::test_pow_on_gpu)
 HBVX_HD double rcp64_(double v)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
