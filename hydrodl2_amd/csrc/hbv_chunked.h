@@ -288,6 +288,12 @@ __global__ void __launch_bounds__(64) k_bwd_chunk_phi(const ChunkArgs A)
             S::template jt_unit<1>(c, Phi[2]);
             S::template jt_unit<2>(c, Phi[3]);
             S::template jt_unit<2>(c, Phi[4]);
+            if constexpr (!GFULL) {
+                // loss on the runoff series only: the offset vector takes the same sparse map plus
+                // the three source terms instead of a full adjoint step
+                S::jt_affine(c, phi, D.g.gQ0 + D.g.gQ, D.g.gQ1 + D.g.gQ, D.g.gQ2 + D.g.gQ);
+                continue;
+            }
         } else if constexpr (MODEL == MODEL_HBV11P || MODEL == MODEL_HBV20) {
             // capillary rise couples soil and groundwater, but the snow block still stands alone:
             // the SNOWPACK / MELTWATER unit adjoints never leave it

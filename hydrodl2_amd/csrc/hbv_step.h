@@ -583,6 +583,7 @@ struct Step {
         float cS, cU, wP;          // groundwater: out[SLZ] = cS a4; U = cU a3 + wP out[SLZ]
         float kap, me, rho, sw;    // soil
         float mts, cwh, wr, wm;    // snow
+        float K1, K2, k1c, k0c, k0m, wac;   // groundwater factors of cU, for jt_affine
     };
 
     // snow block only (all daily variants share the snow stage): enough for jt_unit<0>
@@ -591,6 +592,7 @@ struct Step {
         JT c;
         float wa, wb;
         c.cS = c.cU = c.wP = c.kap = c.me = c.rho = c.sw = 0.0f;
+        c.K1 = c.K2 = c.k1c = c.k0c = c.k0m = c.wac = 0.0f;
         c.mts = (ts0 >= 0.0f) ? 1.0f : 0.0f;
         c.cwh = p[P_CWH];
         minw_(rpc, MW1, wa, wb);
@@ -611,6 +613,7 @@ struct Step {
         const float m0k0 = (u0 >= 0.0f) ? K0 : 0.0f;
         c.cU = ((1.0f - K1) * (1.0f - m0k0)) * (1.0f - wa);
         c.wP = wa;
+        c.K1 = K1; c.K2 = K2; c.k1c = 1.0f - K1; c.k0c = 1.0f - m0k0; c.k0m = m0k0; c.wac = 1.0f - wa;
         // soil
         minw_(SM2, pe, wa, wb);
         const float mef = (ef0 >= 0.0f && ef0 <= 1.0f) ? 1.0f : 0.0f;
@@ -631,6 +634,30 @@ struct Step {
         minw_(mpc, SP1, wa, wb);
         c.wm = wb;
         return c;
+    }
+
+    // a <- J^T a + c(g) when only the runoff series carry gradient (loss on streamflow):
+    // s0 = gQ0 + gQ, s1 = gQ1 + gQ, s2 = gQ2 + gQ enter through the groundwater block, the rest
+    // is jt_unit<2>.  Replaces a full bwd() for the offset vector of the chunk maps.
+    static HBVX_HDM void jt_affine(const JT &c, float *a, float s0, float s1, float s2)
+    {
+        const float sl = c.cS * a[4] + c.K2 * s2;
+        const float z3 = c.k1c * a[3] + c.K1 * s1;
+        const float z2 = z3 * c.k0c + c.k0m * s0;
+        const float U = z2 * c.wac + c.wP * sl;
+        a[3] = U;
+        a[4] = sl;
+        const float s2_ = c.kap * a[2];
+        const float s1_ = s2_ + c.me * (U - s2_);
+        const float w = U - s1_;
+        a[2] = s1_ + c.rho * w;
+        const float ats = s1_ + c.sw * w;
+        const float t = c.mts * (ats - a[1]);
+        const float mw2 = a[1] + t;
+        const float sp2 = a[0] - t * c.cwh;
+        const float mw1 = mw2 + (sp2 - mw2) * c.wr;
+        a[1] = mw1;
+        a[0] = sp2 + (mw1 - sp2) * c.wm;
     }
 
     template <int LEVEL>

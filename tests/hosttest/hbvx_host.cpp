@@ -376,6 +376,20 @@ static float jt_check(const float *st, const float *f, const float *p, int n, fl
                 err = fmaxf(err, fabsf(a[j] - b[j]));
             }
         }
+        // affine form: random incoming adjoint + gradients on the runoff series only
+        {
+            float a[5], b[5], gp[NPARAM_MAX] = {0}, gx[3];
+            for (int j = 0; j < 5; j++) a[j] = b[j] = 0.3f * (float)(((i * 7 + j * 13) % 11) - 5);
+            FluxGrad g = g0;
+            g.gQ = 0.01f * (float)((i % 7) - 3); g.gQ0 = 0.02f * (float)((i % 5) - 2);
+            g.gQ1 = -0.015f * (float)((i % 3) - 1); g.gQ2 = 0.005f * (float)((i % 9) - 4);
+            s.bwd(pp, nz, g, a, gp, gx);
+            Step<MODEL_HBV10, BETAET>::jt_affine(c, b, g.gQ0 + g.gQ, g.gQ1 + g.gQ, g.gQ2 + g.gQ);
+            for (int j = 0; j < 5; j++) {
+                scale = fmaxf(scale, fabsf(a[j]));
+                err = fmaxf(err, fabsf(a[j] - b[j]));
+            }
+        }
         worst = fmaxf(worst, err / scale);
     }
     return worst;
