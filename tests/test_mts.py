@@ -76,3 +76,51 @@ def test_states_and_mode(oracle_backend):
 @pytest.mark.parametrize("name", list(gm.CASES))
 def test_mts_matches_reference_gpu(name, hip_backend):
     _check(name, "cuda")
+
+
+def _hourly_inputs(T, B, G, seed, dev):
+    import numpy as np
+    from . import synth
+    x = synth.forcing(T, B, seed) * np.array([1.0 / 8.0, 1.0, 1.0 / 24.0], np.float32)
+    topo = (synth.uniform((G, B), seed, 13) < np.float32(0.5)).astype(np.float32)
+    topo[np.arange(B) % G, np.arange(B)] = 1.0
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    xd = {"x_phy": t(x), "ac_all": t((synth.uniform((B,), seed, 7) * np.float32(5000)).astype(np.float32)),
+          "elev_all": t((synth.uniform((B,), seed, 8) * np.float32(3000)).astype(np.float32)),
+          "outlet_topo": t(topo), "areas": t((synth.uniform((B,), seed, 14) * np.float32(90) + 5).astype(np.float32))}
+    pd = t(np.zeros((T, B, 0), np.float32))
+    ps = t(synth.unit_parameters((B, 19 * gm.M), seed, 6))
+    pr = t(synth.unit_parameters((int(topo.sum()), 3), seed, 15))
+    return xd, (pd, ps, pr)
+
+
+def _hourly_streaming(dev):
+    """cache_states (hbv_2_hourly.py:424-447,766-796): calls on consecutive windows carry the storages
+    and the runoff history.  With static parameters the unit runoff equals the one-call run bit for
+    bit, and the gage value returned for the last hour equals the one-call value (the history
+    buffer holds the whole record here, so the routing sees the same series)."""
+    T, B, G = 30, 5, 2
+    cls = hydrodl2_amd.load_model("hbv_2_hourly", "Hbv_2_hourly")
+    cfg = {"nmul": gm.M, "dynamic_params": {"Hbv_2_hourly": []}}
+    xd, (pd, ps, pr) = _hourly_inputs(T, B, G, 77, torch.device(dev))
+    with torch.no_grad():
+        one = cls(dict(cfg), torch.device(dev))(xd, (pd, ps, pr))
+        m = cls(dict(cfg, cache_states=True), torch.device(dev))
+        qs, last = [], None
+        for t0 in range(0, T, 10):
+            sl = slice(t0, t0 + 10)
+            out = m(dict(xd, x_phy=xd["x_phy"][sl]), (pd[sl].contiguous(), ps, pr))
+            qs.append(out["Qs"])
+            last = out["streamflow"]
+    assert torch.equal(torch.cat(qs, 0), one["Qs"])
+    assert last.shape == (1, G, 1)
+    assert torch.equal(last[0], one["streamflow"][-1])
+
+
+def test_hourly_cache_states_streaming_oracle(oracle_backend):
+    _hourly_streaming("cpu")
+
+
+@pytest.mark.gpu
+def test_hourly_cache_states_streaming_gpu(hip_backend):
+    _hourly_streaming("cuda")
