@@ -243,23 +243,30 @@ __global__ void __launch_bounds__(512) k_fwd_tiled(const FwdTArgs A)
             float4 nf = in4[lane];
             float nd[NP];
             float nmu = 1.0f;
+            // Branch-free parameter pick-up: a static slot reads row 0 of the day (always inside the
+            // tile) and keeps its value through a select on the wave-uniform mask; the prefetch of
+            // day tt+1 runs unconditionally (past the last day it reads rows nobody consumes, still
+            // inside this workgroup's LDS).  With 14 dynamic parameters the scalar branches these
+            // replace were ~30 per day on the stepper wave.
 #pragma unroll
             for (int i = 0; i < NP; i++)
-                nd[i] = ((dmask >> i) & 1) ? pin[dyn_index(dmask, i) * 64 + lane] : 0.0f;
+                nd[i] = DYN ? pin[(((dmask >> i) & 1) ? dyn_index(dmask, i) * 64 : 0) + lane] : 0.0f;
             if (has_mu) nmu = pin[G.ND * 64 + lane];
             for (int tt = 0; tt < nt; tt++) {
                 const float fP = nf.x, fT = nf.y, fE = nf.z;
                 const float wq = nmu;
+                if (DYN) {
 #pragma unroll
-                for (int i = 0; i < NP; i++)
-                    if ((dmask >> i) & 1) p[i] = nd[i];
-                if (tt + 1 < nt) { // LDS -> register prefetch of the next day
+                    for (int i = 0; i < NP; i++) p[i] = ((dmask >> i) & 1) ? nd[i] : p[i];
+                }
+                { // LDS -> register prefetch of the next day
                     nf = in4[(tt + 1) * 64 + lane];
-                    const float *pr = pin + (tt + 1) * G.NDm * 64 + lane;
+                    if (DYN) {
+                        const float *pr = pin + (tt + 1) * G.NDm * 64 + lane;
 #pragma unroll
-                    for (int i = 0; i < NP; i++)
-                        if ((dmask >> i) & 1) nd[i] = pr[dyn_index(dmask, i) * 64];
-                    if (has_mu) nmu = pr[G.ND * 64];
+                        for (int i = 0; i < NP; i++) nd[i] = pr[((dmask >> i) & 1) ? dyn_index(dmask, i) * 64 : 0];
+                        if (has_mu) nmu = pr[G.ND * 64];
+                    }
                 }
                 if constexpr (IMPLICIT) {
                     AdjStep<BETAET> s;
