@@ -150,11 +150,15 @@ __device__ __forceinline__ void chunk_issue(const hbvx_desc &d, const hbvx_bwd_i
             }
     }
     if (DYN == 2) {
+        // branch-free: a static slot re-reads its static value (never used: use_dyn is false)
 #pragma unroll
-        for (int i = 0; i < NP; i++)
-            R.dv[i] = d.p[i].dyn ? d.p[i].dyn[(int64_t)t * d.p[i].dyn_t_stride +
-                                              (int64_t)L.b * d.p[i].dyn_b_stride + L.j]
-                                 : 0.0f;
+        for (int i = 0; i < NP; i++) {
+            const hbvx_param_src &ps = d.p[i];
+            const bool dy = ps.dyn != nullptr;
+            const float *base = dy ? ps.dyn : ps.sta;
+            const int64_t ts = dy ? ps.dyn_t_stride : 0, bs = dy ? ps.dyn_b_stride : ps.sta_b_stride;
+            R.dv[i] = base[(int64_t)t * ts + (int64_t)L.b * bs + L.j];
+        }
         if (d.muwts) R.mu = d.muwts[(int64_t)t * d.mu_t_stride + (int64_t)L.b * d.mu_b_stride + L.j];
     }
 }
@@ -187,12 +191,10 @@ __device__ __forceinline__ void chunk_finish(const hbvx_desc &d, const ChunkRaw<
         if (DYN == 1) break;
         D.ud[i] = usta[i];
         D.p[i] = psta[i];
-        if (DYN == 2 && d.p[i].dyn) {
+        if (DYN == 2) {   // selects on the per-lane flag (false for static slots), no branches
             const float v = raw ? sigmoid_dyn_(R.dv[i]) : R.dv[i];
-            if (use_dyn[i]) {
-                D.ud[i] = v;
-                D.p[i] = descale_(v, d.p[i].lo, d.p[i].hi);
-            }
+            D.ud[i] = use_dyn[i] ? v : usta[i];
+            D.p[i] = use_dyn[i] ? descale_(v, d.p[i].lo, d.p[i].hi) : psta[i];
         }
     }
 #pragma unroll
@@ -427,7 +429,8 @@ __global__ void __launch_bounds__(64) k_bwd_chunk_sweep(const ChunkArgs A)
         for (int i = 0; i < NP; i++) {
             if (DYN == 1) break;
             const float gu = gp[i] * (d.p[i].hi - d.p[i].lo);
-            if (DYN == 2 && d.p[i].dyn) {
+            if (DYN == 2) {
+                // io.g[i].dyn is only set for dynamic slots; use_dyn is false for static ones
                 const float gr = raw ? gu * (D.ud[i] * (1.0f - D.ud[i])) : gu;
                 if (io.g[i].dyn && L.active)
                     io.g[i].dyn[(int64_t)t * io.g[i].dyn_t_stride + (int64_t)L.b * io.g[i].dyn_b_stride + L.j] =
