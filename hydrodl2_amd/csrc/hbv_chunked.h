@@ -242,9 +242,23 @@ __device__ __forceinline__ void chunk_static(const hbvx_desc &d, const ChunkLane
 }
 
 // ---- B1 -------------------------------------------------------------------------------------
-template <int MODEL, bool BETAET, int DYN, bool GFULL>
+// SC: compile-time slot list of the "few" mode for the configurations users actually run
+// (0 = runtime list; 1 = {parBETA, parBETAET}, the delta-MG default; 2 = {parBETA, parK0, parBETAET}):
+// with constant slots the slot_get / slot_set chains fold into plain register accesses.
+template <int SC>
+struct SlotCombo {
+    static constexpr int nd = SC == 1 ? 2 : (SC == 2 ? 3 : 0);
+    static constexpr int s0 = P_BETA, s1 = SC == 1 ? P_BETAET : P_K0, s2 = P_BETAET;
+};
+#define CHUNK_SLOTS(A)                                                                             \
+    const int nd_ = SC ? SlotCombo<SC>::nd : (A).nd;                                               \
+    const int ds_[3] = {SC ? SlotCombo<SC>::s0 : (A).dslot[0], SC ? SlotCombo<SC>::s1 : (A).dslot[1], \
+                        SC ? SlotCombo<SC>::s2 : (A).dslot[2]}
+
+template <int MODEL, bool BETAET, int DYN, bool GFULL, int SC = 0>
 __global__ void __launch_bounds__(64) k_bwd_chunk_phi(const ChunkArgs A)
 {
+    CHUNK_SLOTS(A);
     constexpr int NP = ChunkNP<MODEL, BETAET>::value;
     const hbvx_desc &d = A.d;
     const hbvx_bwd_io &io = A.io;
@@ -258,7 +272,7 @@ __global__ void __launch_bounds__(64) k_bwd_chunk_phi(const ChunkArgs A)
     const float elev = (MODEL == MODEL_HBV20 || MODEL == MODEL_HOURLY) ? d.elev[L.b] : 0.0f;
     float usta[NP], psta[NP];
     bool use_dyn[NP];
-    chunk_static<NP, DYN>(d, L, raw, usta, psta, use_dyn, A.nd, A.dslot);
+    chunk_static<NP, DYN>(d, L, raw, usta, psta, use_dyn, nd_, ds_);
 
     float Phi[5][5], phi[5];
 #pragma unroll
@@ -271,13 +285,13 @@ __global__ void __launch_bounds__(64) k_bwd_chunk_phi(const ChunkArgs A)
     g0.gQ = g0.gQ0 = g0.gQ1 = g0.gQ2 = g0.gET = g0.gSWE = g0.grech = g0.gexc = g0.gef = g0.gtosoil =
         g0.gPERC = g0.gcap = 0.0f;
     ChunkRaw<NP> Rn;
-    chunk_issue<NP, DYN, GFULL>(d, io, L, t1 - 1, io.n_flux, Rn, A.nd, A.dslot);
+    chunk_issue<NP, DYN, GFULL>(d, io, L, t1 - 1, io.n_flux, Rn, nd_, ds_);
     for (int t = t1 - 1; t >= t0; t--) {
         const ChunkRaw<NP> Rc = Rn;
-        if (t > t0) chunk_issue<NP, DYN, GFULL>(d, io, L, t - 1, io.n_flux, Rn, A.nd, A.dslot); // next day's loads in flight
+        if (t > t0) chunk_issue<NP, DYN, GFULL>(d, io, L, t - 1, io.n_flux, Rn, nd_, ds_); // next day's loads in flight
         ChunkDay<MODEL, BETAET, NP> D;
         chunk_finish<MODEL, BETAET, NP, DYN, GFULL>(d, Rc, raw, nz, ac, elev, usta, psta, use_dyn,
-                                                    io.n_flux, invM, D, A.nd, A.dslot);
+                                                    io.n_flux, invM, D, nd_, ds_);
         float gp[NPARAM_MAX], gx[3];
 #pragma unroll
         for (int i = 0; i < NPARAM_MAX; i++) gp[i] = 0.0f;
@@ -373,9 +387,10 @@ __device__ __forceinline__ float chunk_ens_sum(float v, int lgMp)
     return v;
 }
 
-template <int MODEL, bool BETAET, int DYN, bool GFULL>
+template <int MODEL, bool BETAET, int DYN, bool GFULL, int SC = 0>
 __global__ void __launch_bounds__(64) k_bwd_chunk_sweep(const ChunkArgs A)
 {
+    CHUNK_SLOTS(A);
     constexpr int NP = ChunkNP<MODEL, BETAET>::value;
     const hbvx_desc &d = A.d;
     const hbvx_bwd_io &io = A.io;
@@ -389,7 +404,7 @@ __global__ void __launch_bounds__(64) k_bwd_chunk_sweep(const ChunkArgs A)
     const float elev = (MODEL == MODEL_HBV20 || MODEL == MODEL_HOURLY) ? d.elev[L.b] : 0.0f;
     float usta[NP], psta[NP], gsta[NP];
     bool use_dyn[NP];
-    chunk_static<NP, DYN>(d, L, raw, usta, psta, use_dyn, A.nd, A.dslot);
+    chunk_static<NP, DYN>(d, L, raw, usta, psta, use_dyn, nd_, ds_);
 #pragma unroll
     for (int i = 0; i < NP; i++) gsta[i] = 0.0f;
     float gused[CHUNK_FEW] = {0.0f, 0.0f, 0.0f};
@@ -398,13 +413,13 @@ __global__ void __launch_bounds__(64) k_bwd_chunk_sweep(const ChunkArgs A)
     for (int k = 0; k < 5; k++) a[k] = A.abnd[((int64_t)chunk * 5 + k) * N + L.n];
 
     ChunkRaw<NP> Rn;
-    chunk_issue<NP, DYN, GFULL>(d, io, L, t1 - 1, io.n_flux, Rn, A.nd, A.dslot);
+    chunk_issue<NP, DYN, GFULL>(d, io, L, t1 - 1, io.n_flux, Rn, nd_, ds_);
     for (int t = t1 - 1; t >= t0; t--) {
         const ChunkRaw<NP> Rc = Rn;
-        if (t > t0) chunk_issue<NP, DYN, GFULL>(d, io, L, t - 1, io.n_flux, Rn, A.nd, A.dslot);
+        if (t > t0) chunk_issue<NP, DYN, GFULL>(d, io, L, t - 1, io.n_flux, Rn, nd_, ds_);
         ChunkDay<MODEL, BETAET, NP> D;
         chunk_finish<MODEL, BETAET, NP, DYN, GFULL>(d, Rc, raw, nz, ac, elev, usta, psta, use_dyn,
-                                                    io.n_flux, invM, D, A.nd, A.dslot);
+                                                    io.n_flux, invM, D, nd_, ds_);
         if (DYN == 2 && io.grad_muwts && L.active) io.grad_muwts[((int64_t)t * d.B + L.b) * d.M + L.j] = D.gq * D.s.Q;
         float gp[NPARAM_MAX], gx[3];
 #pragma unroll
@@ -415,8 +430,8 @@ __global__ void __launch_bounds__(64) k_bwd_chunk_sweep(const ChunkArgs A)
             for (int i = 0; i < NP; i++) gsta[i] += gp[i] * (d.p[i].hi - d.p[i].lo);
 #pragma unroll
             for (int k = 0; k < CHUNK_FEW; k++)
-                if (k < A.nd) {
-                    const int sl = A.dslot[k];
+                if (k < nd_) {
+                    const int sl = ds_[k];
                     const float gu = slot_get<NP>(gp, sl) * (d.p[sl].hi - d.p[sl].lo);
                     const float gr = raw ? gu * (D.ud[k] * (1.0f - D.ud[k])) : gu;
                     if (io.g[sl].dyn && L.active)
@@ -454,7 +469,7 @@ __global__ void __launch_bounds__(64) k_bwd_chunk_sweep(const ChunkArgs A)
         // the same daily terms were added to gsta and gused in the same order: exact cancellation
 #pragma unroll
         for (int k = 0; k < CHUNK_FEW; k++)
-            if (k < A.nd) slot_set<NP>(gsta, A.dslot[k], slot_get<NP>(gsta, A.dslot[k]) - gused[k]);
+            if (k < nd_) slot_set<NP>(gsta, ds_[k], slot_get<NP>(gsta, ds_[k]) - gused[k]);
     }
     if (L.active) {
 #pragma unroll

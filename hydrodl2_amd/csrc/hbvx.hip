@@ -886,6 +886,31 @@ static hipError_t launch_chunked_t(const ChunkArgs &a, hipStream_t st)
     const int bpw = 64 >> a.lgMp;
     const int64_t N = (int64_t)d.B * d.M;
     dim3 g2((d.B + bpw - 1) / bpw, a.nchunk);
+    // the two slot lists users actually run get compile-time slots (hbv_chunked.h::SlotCombo)
+    int sc = 0;
+    if (DYN == 1 && MODEL == MODEL_HBV10 && BETAET && a.nd == 2 && a.dslot[0] == P_BETA && a.dslot[1] == P_BETAET) sc = 1;
+    if (DYN == 1 && MODEL == MODEL_HBV20 && a.nd == 3 && a.dslot[0] == P_BETA && a.dslot[1] == P_K0 &&
+        a.dslot[2] == P_BETAET)
+        sc = 2;
+    if constexpr (DYN == 1 && MODEL == MODEL_HBV10 && BETAET) {
+        if (sc == 1) {
+            hipLaunchKernelGGL((k_bwd_chunk_phi<MODEL, BETAET, DYN, GFULL, 1>), g2, dim3(64), 0, st, a);
+            hipLaunchKernelGGL(k_bwd_chunk_scan, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, st, a);
+            hipLaunchKernelGGL((k_bwd_chunk_sweep<MODEL, BETAET, DYN, GFULL, 1>), g2, dim3(64), 0, st, a);
+        }
+    }
+    if constexpr (DYN == 1 && MODEL == MODEL_HBV20) {
+        if (sc == 2) {
+            hipLaunchKernelGGL((k_bwd_chunk_phi<MODEL, BETAET, DYN, GFULL, 2>), g2, dim3(64), 0, st, a);
+            hipLaunchKernelGGL(k_bwd_chunk_scan, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, st, a);
+            hipLaunchKernelGGL((k_bwd_chunk_sweep<MODEL, BETAET, DYN, GFULL, 2>), g2, dim3(64), 0, st, a);
+        }
+    }
+    if (sc != 0) {
+        hipLaunchKernelGGL(k_bwd_chunk_reduce, dim3((unsigned)((N + 255) / 256), d.n_param), dim3(256), 0, st,
+                           a, d.n_param);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL((k_bwd_chunk_phi<MODEL, BETAET, DYN, GFULL>), g2, dim3(64), 0, st, a);
     hipLaunchKernelGGL(k_bwd_chunk_scan, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, st, a);
     hipLaunchKernelGGL((k_bwd_chunk_sweep<MODEL, BETAET, DYN, GFULL>), g2, dim3(64), 0, st, a);
