@@ -667,7 +667,7 @@ static bool geom_fwd(const hbvx_desc *d, const hbvx_fwd_out *o, TileGeom &g)
     // workgroups (cfg5: 3125): shallow tiles so that several steppers share a CU (LDS decides how
     // many) -- measured at cfg5: Kt 16/8 -> 7.4 ms, Kt 4 -> 5.8 ms.
     const int wgs = (d->B + (64 >> g.lgMp) - 1) / (64 >> g.lgMp);
-    const int ktmax = env_int("HBVX_KT", wgs >= env_int("HBVX_STREAM_MIN", 1024) ? 4 : 16);
+    const int ktmax = env_int("HBVX_KT", wgs >= 1024 ? 4 : 16);
     for (int Kt = 16; Kt >= 1; Kt >>= 1) {
         if (Kt > ktmax) continue;
         g.Kt = Kt;
@@ -751,8 +751,9 @@ extern "C" int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *s
             if (d->p[i].dyn)
                 off32 = off32 && ((int64_t)d->B * d->p[i].dyn_b_stride + (int64_t)PIPE_KT * d->p[i].dyn_t_stride) * 4 <
                                      (int64_t)1 << 31;
-        const bool large = ((int64_t)d->B + (64 >> lg_members(d->M)) - 1) / (64 >> lg_members(d->M)) >= env_int("HBVX_STREAM_MIN", 1024) &&
-                           env_int("HBVX_STREAM", 1) != 0;   // large grids: hbv_stream.h below
+        const bool large = ((int64_t)d->B + (64 >> lg_members(d->M)) - 1) / (64 >> lg_members(d->M)) >= 1024 &&
+                           env_int("HBVX_STREAM", 1) != 0;   // the pipelined kernel (one workgroup per CU) holds up to
+                                                             // ~1000 wavefronts; beyond that hbv_stream.h below
         if (use_tiled(d) && !(fv && !strcmp(fv, "tiled")) && d->model == HBVX_MODEL_HBV10 && off32 && !large &&
             nd <= PIPE_MAXDYN && !d->muwts && out->flux && d->T >= 4 * Kt &&
             (out->traj != nullptr) == (out->aux != nullptr) && (int64_t)d->B * d->M * 4 * PIPE_KT < (int64_t)1 << 31 &&
@@ -792,7 +793,7 @@ extern "C" int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *s
         const int64_t N = (int64_t)d->B * d->M, lim = (int64_t)1 << 32;
         const int nd = count_dyn(d);
         const int nf = (d->model == HBVX_MODEL_HBV10) ? 11 : 12;
-        bool ok = use_tiled(d) && env_int("HBVX_STREAM", 1) != 0 && wgs >= env_int("HBVX_STREAM_MIN", 1024) && nd <= 3 && !d->muwts &&
+        bool ok = use_tiled(d) && env_int("HBVX_STREAM", 1) != 0 && wgs >= env_int("HBVX_STREAM_MIN", 512) && nd <= 3 && !d->muwts &&
                   out->flux && (out->traj != nullptr) == (out->aux != nullptr) && d->T > 0 &&
                   5 * (int64_t)(d->T + 1) * N * 4 < lim && (int64_t)nf * d->T * d->B * 4 < lim &&
                   ((int64_t)d->T * d->x_t_stride + (int64_t)d->B * d->x_b_stride) * 4 < lim;
@@ -964,14 +965,15 @@ extern "C" int hbvx_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *st
     if (io->n_flux != want_nf) return fail(HBVX_E_SHAPE, "n_flux does not match model");
     if (d->T == 0) return HBVX_OK;
     {
-        // large grids: single-pass streaming adjoint (hbv_stream.h), no workspace
+        // large grids: single-pass streaming adjoint (hbv_stream.h), no workspace.  Measured cross-over
+        // against the time-parallel kernels: ~1500 wavefronts (forward stream vs tiled: ~400)
         const int lg = lg_members(d->M);
         const int bpw_s = 64 >> lg;
         const int64_t wgs = ((int64_t)d->B + bpw_s - 1) / bpw_s;
         const int64_t N = (int64_t)d->B * d->M, lim = (int64_t)1 << 32;
         const int nd = count_dyn(d);
         const int nf = (d->model == HBVX_MODEL_HBV10) ? 11 : 12;
-        bool ok = use_tiled(d) && env_int("HBVX_STREAM", 1) != 0 && wgs >= env_int("HBVX_STREAM_MIN", 1024) && nd <= 3 && !d->muwts &&
+        bool ok = use_tiled(d) && env_int("HBVX_STREAM", 1) != 0 && wgs >= env_int("HBVX_STREAM_MIN_BWD", 2048) && nd <= 3 && !d->muwts &&
                   (io->grad_flux || io->grad_flux4) && 5 * (int64_t)(d->T + 1) * N * 4 < lim &&
                   (int64_t)nf * d->T * d->B * 4 < lim &&
                   ((int64_t)d->T * d->x_t_stride + (int64_t)d->B * d->x_b_stride) * 4 < lim;

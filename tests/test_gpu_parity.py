@@ -151,14 +151,15 @@ def test_pipelined_forward_equals_tiled_forward(M, B, T, dyn, betaet, drop, hip_
 
 
 @pytest.mark.parametrize("model,dyn,M,B", [
-    ("Hbv", (), 16, 4100), ("Hbv", ("parBETA", "parBETAET"), 16, 4100),
-    ("Hbv_1_1p", ("parK0", "parTT", "parFC"), 5, 8200), ("Hbv_2", ("parBETA",), 16, 4100),
-    ("Hbv_2_hourly", ("parBETA", "parK0", "parBETAET"), 4, 16400),
-    ("Hbv", (), 1, 66000), ("Hbv_2", (), 2, 33000), ("Hbv", ("parK1",), 64, 1030)])
+    ("Hbv", (), 16, 8200), ("Hbv", ("parBETA", "parBETAET"), 16, 8200),
+    ("Hbv_1_1p", ("parK0", "parTT", "parFC"), 5, 16400), ("Hbv_2", ("parBETA",), 16, 8200),
+    ("Hbv_2_hourly", ("parBETA", "parK0", "parBETAET"), 4, 32800),
+    ("Hbv", (), 1, 131200), ("Hbv_2", (), 2, 65600), ("Hbv", ("parK1",), 64, 2050)])
 def test_stream_forward_equals_tiled_forward(model, dyn, M, B, hip_backend, monkeypatch):
-    """Large grids (>= 1024 wavefronts of state) run the streaming one-wave forward (hbv_stream.h);
-    it is bit-identical to the tiled / pipelined kernels (same step arithmetic, same ensemble add
-    tree), with and without the saved trajectory, including the gradients computed from it."""
+    """Large grids (>= 2048 wavefronts of state here, so that both directions take it) run the
+    streaming one-wave kernels (hbv_stream.h).  The forward is bit-identical to the tiled /
+    pipelined kernels (same step arithmetic, same ensemble add tree), with and without the saved
+    trajectory; the single-pass adjoint is bit-identical to the serial tiled adjoint (T < 128)."""
     T = 37
     prob = make_problem(model=model, T=T, B=B, M=M, dyn=dyn, drop_frac=0.3 if dyn else 0.0, seed=33)
     a = run_problem(prob, None, device="cuda:0", backward=True)
