@@ -890,7 +890,7 @@ static hipError_t launch_chunked_t(const ChunkArgs &a, hipStream_t st)
     // the two slot lists users actually run get compile-time slots (hbv_chunked.h::SlotCombo)
     int sc = 0;
     if (DYN == 1 && MODEL == MODEL_HBV10 && BETAET && a.nd == 2 && a.dslot[0] == P_BETA && a.dslot[1] == P_BETAET) sc = 1;
-    if (DYN == 1 && MODEL == MODEL_HBV20 && a.nd == 3 && a.dslot[0] == P_BETA && a.dslot[1] == P_K0 &&
+    if (DYN == 1 && (MODEL == MODEL_HBV20 || MODEL == MODEL_HOURLY) && a.nd == 3 && a.dslot[0] == P_BETA && a.dslot[1] == P_K0 &&
         a.dslot[2] == P_BETAET)
         sc = 2;
     if constexpr (DYN == 1 && MODEL == MODEL_HBV10 && BETAET) {
@@ -900,7 +900,7 @@ static hipError_t launch_chunked_t(const ChunkArgs &a, hipStream_t st)
             hipLaunchKernelGGL((k_bwd_chunk_sweep<MODEL, BETAET, DYN, GFULL, 1>), g2, dim3(64), 0, st, a);
         }
     }
-    if constexpr (DYN == 1 && MODEL == MODEL_HBV20) {
+    if constexpr (DYN == 1 && (MODEL == MODEL_HBV20 || MODEL == MODEL_HOURLY)) {
         if (sc == 2) {
             hipLaunchKernelGGL((k_bwd_chunk_phi<MODEL, BETAET, DYN, GFULL, 2>), g2, dim3(64), 0, st, a);
             hipLaunchKernelGGL(k_bwd_chunk_scan, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, st, a);
