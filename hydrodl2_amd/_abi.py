@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_PARAM = 20
 GAGE_MAXLEN = 72
 NSTATE = 5
@@ -89,7 +89,8 @@ class GageDesc(C.Structure):
 EXPORTS = ["hbvx_version", "hbvx_last_error", "hbvx_backend", "hbvx_sizeof", "hbvx_forward",
            "hbvx_backward", "hbvx_backward_workspace_bytes", "hbvx_route_forward", "hbvx_route_workspace_bytes",
            "hbvx_route_backward", "hbvx_adj_forward", "hbvx_adj_backward", "hbvx_bfi",
-           "hbvx_gage_route_forward", "hbvx_gage_route_backward"]
+           "hbvx_gage_route_forward", "hbvx_gage_route_backward",
+           "hbvx_gage_route_workspace_bytes"]
 
 
 class HbvxError(RuntimeError):
@@ -131,9 +132,12 @@ class Library:
         d.hbvx_adj_forward.argtypes = [C.POINTER(Desc), C.POINTER(FwdOut), C.c_void_p]
         d.hbvx_adj_backward.argtypes = [C.POINTER(Desc), C.POINTER(BwdIO), C.c_void_p]
         d.hbvx_gage_route_forward.restype = C.c_int
-        d.hbvx_gage_route_forward.argtypes = [C.POINTER(GageDesc), _fp, _fp, _fp, C.c_void_p]
+        d.hbvx_gage_route_workspace_bytes.restype = C.c_uint64
+        d.hbvx_gage_route_workspace_bytes.argtypes = [C.POINTER(GageDesc)]
+        d.hbvx_gage_route_forward.argtypes = [C.POINTER(GageDesc), _fp, _fp, _fp, C.c_void_p, C.c_uint64, C.c_void_p]
         d.hbvx_gage_route_backward.restype = C.c_int
-        d.hbvx_gage_route_backward.argtypes = [C.POINTER(GageDesc), _fp, _fp, _fp, _fp, _fp, C.c_void_p]
+        d.hbvx_gage_route_backward.argtypes = [C.POINTER(GageDesc), _fp, _fp, _fp, _fp, _fp, C.c_void_p, C.c_uint64,
+                                               C.c_void_p]
         d.hbvx_bfi.restype = C.c_int
         d.hbvx_bfi.argtypes = [C.c_int32, C.c_int32, _fp, _fp, C.c_float, _fp, C.c_void_p]
         if d.hbvx_version() != ABI_VERSION:
@@ -172,14 +176,18 @@ class Library:
         self._check(self.dll.hbvx_adj_backward(C.byref(desc), C.byref(io), C.c_void_p(stream)),
                     "hbvx_adj_backward")
 
-    def gage_route_forward(self, r: GageDesc, qs: int, uh: int, out: int, stream: int):
-        self._check(self.dll.hbvx_gage_route_forward(C.byref(r), qs, uh, out, C.c_void_p(stream)),
-                    "hbvx_gage_route_forward")
+    def gage_route_workspace_bytes(self, r: GageDesc) -> int:
+        return int(self.dll.hbvx_gage_route_workspace_bytes(C.byref(r)))
 
-    def gage_route_backward(self, r: GageDesc, qs: int, uh: int, go: int, gqs: int, gdp: int,
-                            stream: int):
-        self._check(self.dll.hbvx_gage_route_backward(C.byref(r), qs, uh, go, gqs, gdp,
-                                                      C.c_void_p(stream)), "hbvx_gage_route_backward")
+    def gage_route_forward(self, r: GageDesc, qs: int, uh: int, out: int, ws, ws_bytes: int, stream: int):
+        self._check(self.dll.hbvx_gage_route_forward(C.byref(r), qs, uh, out, ws, C.c_uint64(ws_bytes),
+                                                     C.c_void_p(stream)), "hbvx_gage_route_forward")
+
+    def gage_route_backward(self, r: GageDesc, qs: int, uh: int, go: int, gqs: int, gdp: int, ws,
+                            ws_bytes: int, stream: int):
+        self._check(self.dll.hbvx_gage_route_backward(C.byref(r), qs, uh, go, gqs, gdp, ws,
+                                                      C.c_uint64(ws_bytes), C.c_void_p(stream)),
+                    "hbvx_gage_route_backward")
 
     def bfi(self, T: int, B: int, qs: int, q2: int, nearzero: float, out: int, stream: int):
         self._check(self.dll.hbvx_bfi(T, B, qs, q2, C.c_float(nearzero), out, C.c_void_p(stream)),

@@ -1311,32 +1311,57 @@ static int check_gage(const hbvx_gage_desc *r)
     return HBVX_OK;
 }
 
+extern "C" uint64_t hbvx_gage_route_workspace_bytes(const hbvx_gage_desc *r)
+{
+    if (!r || r->T <= 0 || r->U <= 0 || r->G <= 0) return 0;
+    // transposed runoff [U,T], transposed gradient [G,T], transposed input gradient [U,T]
+    return ((uint64_t)2 * r->U + r->G) * (uint64_t)r->T * sizeof(float);
+}
+
+static void launch_transpose(int R, int C, const float *in, float *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_transpose, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, st, R, C, in, out);
+}
+
 extern "C" int hbvx_gage_route_forward(const hbvx_gage_desc *r, const float *qs, float *uh, float *out,
-                                       void *stream)
+                                       void *workspace, uint64_t workspace_bytes, void *stream)
 {
     int rc = check_gage(r);
     if (rc) return rc;
     if (!qs || !uh || !out) return fail(HBVX_E_NULL, "gage routing buffer is NULL");
+    if (!workspace || workspace_bytes < hbvx_gage_route_workspace_bytes(r))
+        return fail(HBVX_E_NULL, "gage routing workspace missing or too small");
     hipStream_t st = (hipStream_t)stream;
+    float *qsT = (float *)workspace;
+    launch_transpose(r->T, r->U, qs, qsT, st);
     if (r->NPAIR > 0) hipLaunchKernelGGL(k_gage_uh, dim3((r->NPAIR + 63) / 64), dim3(64), 0, st, *r, uh);
     hipLaunchKernelGGL(k_gage_fwd, dim3((r->T + GAGE_TILE - 1) / GAGE_TILE, r->G), dim3(GAGE_TILE), 0, st, *r,
-                       qs, uh, out);
+                       qsT, uh, out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "hbvx_gage_route_forward launch");
     return HBVX_OK;
 }
 
 extern "C" int hbvx_gage_route_backward(const hbvx_gage_desc *r, const float *qs, const float *uh,
-                                        const float *grad_out, float *grad_qs, float *grad_dp, void *stream)
+                                        const float *grad_out, float *grad_qs, float *grad_dp,
+                                        void *workspace, uint64_t workspace_bytes, void *stream)
 {
     int rc = check_gage(r);
     if (rc) return rc;
     if (!qs || !uh || !grad_out || !grad_qs || !grad_dp) return fail(HBVX_E_NULL, "gage routing buffer is NULL");
+    if (!workspace || workspace_bytes < hbvx_gage_route_workspace_bytes(r))
+        return fail(HBVX_E_NULL, "gage routing workspace missing or too small");
     hipStream_t st = (hipStream_t)stream;
+    float *qsT = (float *)workspace;
+    float *goT = qsT + (int64_t)r->U * r->T;
+    float *gqsT = goT + (int64_t)r->G * r->T;
+    launch_transpose(r->T, r->U, qs, qsT, st);
+    launch_transpose(r->T, r->G, grad_out, goT, st);
     hipLaunchKernelGGL(k_gage_bwd_q, dim3((r->T + GAGE_TILE - 1) / GAGE_TILE, r->U), dim3(GAGE_TILE), 0, st, *r,
-                       uh, grad_out, grad_qs);
+                       uh, goT, gqsT);
+    launch_transpose(r->U, r->T, gqsT, grad_qs, st);
     if (r->NPAIR > 0)
-        hipLaunchKernelGGL(k_gage_bwd_p, dim3(r->NPAIR), dim3(GAGE_TILE), 0, st, *r, qs, grad_out, grad_dp);
+        hipLaunchKernelGGL(k_gage_bwd_p, dim3(r->NPAIR), dim3(GAGE_TILE), 0, st, *r, qsT, goT, grad_dp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "hbvx_gage_route_backward launch");
     return HBVX_OK;

@@ -478,8 +478,10 @@ class GageRoute(torch.autograd.Function):
         uh = _out((topo.n_pair, L), qs.device)
         out = _out((topo.T, topo.G), qs.device)
         r = topo.desc(dp_c)
+        ws_bytes = lib.gage_route_workspace_bytes(r)
+        ws = torch.empty((max(ws_bytes, 4) + 3) // 4, dtype=torch.float32, device=qs.device)
         _call(lib, 'hbvx_gage_route_forward', lib.gage_route_forward, r, _ptr(qs_c), _ptr(uh),
-              _ptr(out), _stream_of(lib, qs_c))
+              _ptr(out), _ptr(ws), ws_bytes, _stream_of(lib, qs_c))
         ctx.topo = topo
         ctx.save_for_backward(qs_c, dp_c, uh)
         return out
@@ -493,6 +495,8 @@ class GageRoute(torch.autograd.Function):
         gqs = _out(tuple(qs.shape), qs.device)
         gdp = _out(tuple(dp.shape), dp.device)
         r = topo.desc(dp)
+        ws_bytes = lib.gage_route_workspace_bytes(r)
+        ws = torch.empty((max(ws_bytes, 4) + 3) // 4, dtype=torch.float32, device=qs.device)
         _call(lib, 'hbvx_gage_route_backward', lib.gage_route_backward, r, _ptr(qs), _ptr(uh),
-              _ptr(g), _ptr(gqs), _ptr(gdp), _stream_of(lib, qs))
+              _ptr(g), _ptr(gqs), _ptr(gdp), _ptr(ws), ws_bytes, _stream_of(lib, qs))
         return None, gqs, gdp

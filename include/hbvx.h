@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define HBVX_ABI_VERSION 5
+#define HBVX_ABI_VERSION 6
 #define HBVX_MAX_PARAM 20
 #define HBVX_NSTATE 5   /* SNOWPACK, MELTWATER, SM, SUZ, SLZ  (hbv.py:61-67) */
 #define HBVX_MAX_FLUX 12
@@ -232,12 +232,17 @@ typedef struct hbvx_gage_desc {
     float a_lo, a_hi, b_lo, b_hi, tau_lo, tau_hi; /* distr_parameter_bounds (:120-124) */
 } hbvx_gage_desc;
 
+/* Scratch for the two calls below (bytes; caller-owned, contents undefined afterwards): the
+ * time-major runoff / gradient are transposed once per call so that a unit's (gage's) series is
+ * contiguous when the kernels stage it. */
+uint64_t hbvx_gage_route_workspace_bytes(const hbvx_gage_desc *r);
 /* qs [T,U] -> uh [NPAIR,L] (the lagged unit hydrographs, kept for the backward) and out [T,G]. */
 int hbvx_gage_route_forward(const hbvx_gage_desc *r, const float *qs, float *uh, float *out,
-                            void *stream);
+                            void *workspace, uint64_t workspace_bytes, void *stream);
 /* grad_out [T,G] -> grad_qs [T,U] and grad_dp [NPAIR,3] (both overwritten). */
 int hbvx_gage_route_backward(const hbvx_gage_desc *r, const float *qs, const float *uh,
-                             const float *grad_out, float *grad_qs, float *grad_dp, void *stream);
+                             const float *grad_out, float *grad_qs, float *grad_dp,
+                             void *workspace, uint64_t workspace_bytes, void *stream);
 
 /* Implicit HBV ("HBV adjoint", hbv_adj.py): per day solve G(x) = (x - x_t)/dt - f(x, theta_t, t) = 0
  * (hbv_adj.py:669-687) by modified Newton (hbv_adj.py:507-581) with the analytic 5x5 Jacobian;

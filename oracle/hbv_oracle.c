@@ -1165,9 +1165,16 @@ static void gage_uh_one(const hbvx_gage_desc *r, int p, float *w, float *us, flo
     *f_out = f;
 }
 
-int hbvx_gage_route_forward(const hbvx_gage_desc *r, const float *qs, float *uh, float *out, void *stream)
+uint64_t hbvx_gage_route_workspace_bytes(const hbvx_gage_desc *r)
 {
-    (void)stream;
+    (void)r;
+    return 0;
+}
+
+int hbvx_gage_route_forward(const hbvx_gage_desc *r, const float *qs, float *uh, float *out,
+                            void *workspace, uint64_t workspace_bytes, void *stream)
+{
+    (void)stream; (void)workspace; (void)workspace_bytes;
     int rc = check_gage(r);
     if (rc) return rc;
     if (!qs || !uh || !out) return fail(HBVX_E_NULL, "gage routing buffer is NULL");
@@ -1192,9 +1199,10 @@ int hbvx_gage_route_forward(const hbvx_gage_desc *r, const float *qs, float *uh,
 }
 
 int hbvx_gage_route_backward(const hbvx_gage_desc *r, const float *qs, const float *uh,
-                             const float *grad_out, float *grad_qs, float *grad_dp, void *stream)
+                             const float *grad_out, float *grad_qs, float *grad_dp,
+                             void *workspace, uint64_t workspace_bytes, void *stream)
 {
-    (void)stream;
+    (void)stream; (void)workspace; (void)workspace_bytes;
     int rc = check_gage(r);
     if (rc) return rc;
     if (!qs || !uh || !grad_out || !grad_qs || !grad_dp) return fail(HBVX_E_NULL, "gage routing buffer is NULL");

@@ -332,20 +332,23 @@ extern "C" int hbvx_bfi(int32_t T, int32_t B, const float *qs, const float *q2, 
     return fn(T, B, qs, q2, nz, bfi, st);
 }
 
-extern "C" int hbvx_gage_route_forward(const hbvx_gage_desc *r, const float *qs, float *uh, float *out, void *st)
+extern "C" uint64_t hbvx_gage_route_workspace_bytes(const hbvx_gage_desc *) { return 0; }
+extern "C" int hbvx_gage_route_forward(const hbvx_gage_desc *r, const float *qs, float *uh, float *out, void *ws,
+                                       uint64_t wsb, void *st)
 {
-    typedef int (*fn_t)(const hbvx_gage_desc *, const float *, float *, float *, void *);
+    typedef int (*fn_t)(const hbvx_gage_desc *, const float *, float *, float *, void *, uint64_t, void *);
     fn_t fn = (fn_t)oracle_sym("hbvx_gage_route_forward");
     if (!fn) { snprintf(g_err, sizeof g_err, "set HBVX_ORACLE_LIB for gage routing"); return HBVX_E_UNSUPPORTED; }
-    return fn(r, qs, uh, out, st);
+    return fn(r, qs, uh, out, ws, wsb, st);
 }
 extern "C" int hbvx_gage_route_backward(const hbvx_gage_desc *r, const float *qs, const float *uh,
-                                        const float *go, float *gqs, float *gdp, void *st)
+                                        const float *go, float *gqs, float *gdp, void *ws, uint64_t wsb, void *st)
 {
-    typedef int (*fn_t)(const hbvx_gage_desc *, const float *, const float *, const float *, float *, float *, void *);
+    typedef int (*fn_t)(const hbvx_gage_desc *, const float *, const float *, const float *, float *, float *, void *,
+                        uint64_t, void *);
     fn_t fn = (fn_t)oracle_sym("hbvx_gage_route_backward");
     if (!fn) { snprintf(g_err, sizeof g_err, "set HBVX_ORACLE_LIB for gage routing"); return HBVX_E_UNSUPPORTED; }
-    return fn(r, qs, uh, go, gqs, gdp, st);
+    return fn(r, qs, uh, go, gqs, gdp, ws, wsb, st);
 }
 
 // Step::jt_unit against Step::bwd with zero flux adjoints (HBV 1.0): for n random days, the worst
