@@ -31,9 +31,9 @@ def gen(T, B, dev, seed=0):
 
 def run(name, steps=5, warmup=2):
     dev = torch.device("cuda:0")
-    if name in ("cfg2", "cfg2dyn", "dmg"):
+    if name in ("cfg2", "cfg2dyn", "cfg2dynK", "dmg"):
         T, B, M = (730, 100, 16) if name == "dmg" else (7300, 671, 16)
-        dyn = [] if name == "cfg2" else ["parBETA", "parBETAET"]
+        dyn = [] if name == "cfg2" else (["parK0", "parK1"] if name == "cfg2dynK" else ["parBETA", "parBETAET"])
         cfgd = {"nmul": M, "dynamic_params": {"Hbv": dyn}}
         if name == "dmg":
             cfgd["warm_up"] = 365
