@@ -30,6 +30,12 @@ ORACLE_CASES = [
     dict(model="Hbv_2", T=250, B=40, M=8, dyn=("parBETA", "parK0", "parBETAET")),
     dict(model="Hbv_2_hourly", T=300, B=21, M=16, dyn=("parBETA", "parK0", "parF0")),
     dict(model="Hbv_2_hourly", T=200, B=9, M=4, dyn=(), cold=True),
+    # smallest shapes: one basin, one member (a single active lane), T just past the pipelined
+    # kernel's threshold and below it, T shorter than a tile
+    dict(model="Hbv", T=33, B=1, M=1, dyn=()),
+    dict(model="Hbv", T=31, B=1, M=2, dyn=("parBETA",)),
+    dict(model="Hbv_2", T=3, B=2, M=3, dyn=("parK0",)),
+    dict(model="Hbv", T=129, B=3, M=16, dyn=("parBETA", "parBETAET", "parK0")),
 ]
 
 
