@@ -25,6 +25,10 @@
 // use buffer addressing: row base in SGPRs, constant per-lane offset, out-of-range lanes dropped by
 // the hardware -- no 64-bit VALU address arithmetic, no EXEC masking.
 //
+// HBV 1.1p / 2.0: capillary rise feeds the lower zone back into the soil (SLZ -> SM), so soil and
+// groundwater form ONE recurrence; the pipeline then has two stages (snow | soil + capillary +
+// groundwater on wave 1, wave 2 idle) and the groundwater tile is drained one iteration earlier.
+//
 // One raw s_barrier per iteration; every interface is double-buffered (forcings: 4 slots, filled
 // two tiles ahead and read by two stages).  The arithmetic is Step::fwd_snow / fwd_soil / fwd_gw of hbv_step.h, i.e.
 // operation for operation what the tiled kernel computes; ensemble sums use the same member order,
@@ -63,14 +67,15 @@ struct PipeArgs {
 // LDS layout in floats for Kt days per tile
 struct PipeLds {
     int xin, ab, bc, oa, ob, oc, pin, total;
-    __host__ __device__ explicit PipeLds(int Kt, bool dyn = false)
+    __host__ __device__ explicit PipeLds(int Kt, bool dyn = false, bool cap = false)
     {
+        const int obr = cap ? 8 : 7;   // + capillary flux
         xin = 0;                    // [4][Kt][64][4]
         ab = xin + 4 * Kt * 256;    // [2][Kt][2][64]
         bc = ab + 2 * Kt * 128;     // [2][Kt][2][64]
         oa = bc + 2 * Kt * 128;     // [2][Kt][4][64]  SWE, tosoil | SNOWPACK, MELTWATER
-        ob = oa + 2 * Kt * 256;     // [2][Kt][7][64]  AET, recharge, excs, evapfactor | SM, sw0, ef0
-        oc = ob + 2 * Kt * 448;     // [2][Kt][7][64]  Qsim, Q0, Q1, Q2, PERC | SUZ, SLZ
+        ob = oa + 2 * Kt * 256;     // [2][Kt][7|8][64]  AET, recharge, excs, evapfactor (, capillary) | SM, sw0, ef0
+        oc = ob + 2 * Kt * obr * 64; // [2][Kt][7][64]  Qsim, Q0, Q1, Q2, PERC | SUZ, SLZ
         pin = oc + 2 * Kt * 448;    // [5][Kt][PIPE_MAXDYN][64]  de-scaled dynamic parameters (DYN only)
         total = pin + (dyn ? 5 * Kt * PIPE_MAXDYN * 64 : 0);
     }
@@ -120,9 +125,11 @@ __device__ unsigned long long g_pipe_probe[32];
 // TRAJ: the forward also saves the storage trajectory and the pow results (traj and aux given).
 // DYN: 1..PIPE_MAXDYN parameters vary per day: the filler de-scales them (sigmoid, range, dy_drop
 // blend) into LDS tiles five deep (snow reads tile it, groundwater tile it-2, the filler writes it+2).
-template <bool BETAET, bool TRAJ, bool DYN>
+template <int MODEL, bool BETAET, bool TRAJ, bool DYN>
 __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
 {
+    constexpr bool CAP = MODEL != MODEL_HBV10;   // two-stage pipeline (see the header comment)
+    constexpr int OBR = CAP ? 8 : 7, NFB = CAP ? 5 : 4;
 #ifdef PIPE_PROBE
     unsigned long long probe_busy = 0, probe_wait = 0, probe_t = __builtin_readcyclecounter();
     struct ProbeFlush {
@@ -136,7 +143,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
         }
     } probe_flush{probe_busy, probe_wait};
 #endif
-    constexpr int NP = BETAET ? 13 : 12;
+    constexpr int NP = NParamT<MODEL, BETAET>::value;
     extern __shared__ __align__(16) float lds[];
     const hbvx_desc &d = A.d;
     const hbvx_fwd_out &o = A.o;
@@ -150,8 +157,10 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
     const bool raw = d.raw_sigmoid != 0;
     const unsigned row_bytes = (unsigned)(N * 4);
     const unsigned voff = L.active ? (unsigned)(L.n * 4) : 0xFFFFFFFFu;
-    const PipeLds P(Kt, DYN);
+    const PipeLds P(Kt, DYN, CAP);
     const float nz = d.nearzero;
+    const float ac = MODEL == MODEL_HBV20 ? d.ac[L.b] : 0.0f;
+    const float elev = MODEL == MODEL_HBV20 ? d.elev[L.b] : 0.0f;
     unsigned dmask = 0;
     if (DYN) {
 #pragma unroll
@@ -190,7 +199,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                 DY_DECL(P_TT); DY_DECL(P_CFMAX); DY_DECL(P_CFR); DY_DECL(P_CWH);
                 if (DYN) { DY_LOAD(P_TT, pin); DY_LOAD(P_CFMAX, pin); DY_LOAD(P_CFR, pin); DY_LOAD(P_CWH, pin); }
                 auto day = [&](int tt, bool more) __attribute__((always_inline)) {
-                    Step<MODEL_HBV10, BETAET> s;
+                    Step<MODEL, BETAET> s;
                     const float4 f = fn;
                     if (DYN) { DY_USE(P_TT); DY_USE(P_CFMAX); DY_USE(P_CFR); DY_USE(P_CWH); }
                     if (more) {
@@ -202,7 +211,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                     }
                     s.P = f.x; s.Tf = f.y;
                     s.SP = SP; s.MW = MW;
-                    s.fwd_snow(p, 0.0f);
+                    s.fwd_snow(p, elev);
                     ab[tt * 128] = s.RAIN;
                     ab[tt * 128 + 64] = s.tosoil;
                     float *q = oa + tt * 256;
@@ -223,6 +232,76 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
             }
         }
     } else if (wave == 1) {
+      if constexpr (CAP) {
+        // -------------- soil + capillary rise + groundwater (one recurrence) --------------
+        __builtin_amdgcn_s_setprio(3);
+        float SM = d.state_in ? d.state_in[2 * N + L.n] : 0.001f;
+        float SUZ = d.state_in ? d.state_in[3 * N + L.n] : 0.001f;
+        float SLZ = d.state_in ? d.state_in[4 * N + L.n] : 0.001f;
+        PIPE_BARRIER();
+        for (int it = 0; it < nIt; it++) {
+            const int tile = it - 1;
+            if (tile >= 0 && tile < nT) {
+                const int nt = tile_nt(tile);
+                const float4 *in4 = reinterpret_cast<const float4 *>(lds + P.xin + (tile & 3) * Kt * 256);
+                const float *ab = lds + P.ab + (tile & 1) * Kt * 128 + lane;
+                float *ob = lds + P.ob + (tile & 1) * Kt * OBR * 64 + lane;
+                float *oc = lds + P.oc + (tile & 1) * Kt * 448 + lane;
+                float npet = in4[lane].z, nrain = ab[0], nts = ab[64];
+                const float *pin = pin_of(tile);
+                DY_DECL(P_BETA); DY_DECL(P_FC); DY_DECL(P_LP); DY_DECL(P_BETAET); DY_DECL(P_C);
+                DY_DECL(P_K0); DY_DECL(P_K1); DY_DECL(P_K2); DY_DECL(P_PERC); DY_DECL(P_UZL);
+                DY_DECL(P_RT); DY_DECL(P_AC);
+#define DY_ALL(OP, ptr)                                                                            \
+    do {                                                                                           \
+        OP(P_BETA, ptr); OP(P_FC, ptr); OP(P_LP, ptr); OP(P_BETAET, ptr); OP(P_C, ptr); OP(P_K0, ptr); \
+        OP(P_K1, ptr); OP(P_K2, ptr); OP(P_PERC, ptr); OP(P_UZL, ptr);                             \
+        if (MODEL == MODEL_HBV20) { OP(P_RT, ptr); OP(P_AC, ptr); }                                \
+    } while (0)
+#define DY_USE2(X, unused) DY_USE(X)
+                if (DYN) DY_ALL(DY_LOAD, pin);
+                auto day = [&](int tt, bool more) __attribute__((always_inline)) {
+                    Step<MODEL, BETAET> s;
+                    s.PET = npet; s.RAIN = nrain; s.tosoil = nts;
+                    if (DYN) DY_ALL(DY_USE2, 0);
+                    if (more) {
+                        npet = in4[(tt + 1) * 64 + lane].z;
+                        nrain = ab[(tt + 1) * 128];
+                        nts = ab[(tt + 1) * 128 + 64];
+                        if (DYN) {
+                            const float *pt = pin + (tt + 1) * PD * 64;
+                            DY_ALL(DY_LOAD, pt);
+                        }
+                    }
+                    s.SM = SM; s.SUZ = SUZ; s.SLZ = SLZ;
+                    s.template fwd_soil<false>(p, nz, 0.0f, 0.0f);
+                    s.fwd_cap(p, nz);
+                    s.fwd_gw(p, ac);
+                    float *q = ob + tt * OBR * 64;
+                    q[0] = s.ET; q[64] = s.rech; q[128] = s.exc; q[192] = s.ef; q[256] = s.cap;
+                    if (TRAJ) { q[320] = SM; q[384] = s.sw0; q[448] = s.ef0; }
+                    float *r = oc + tt * 448;
+                    r[0] = s.Q; r[64] = s.Q0; r[128] = s.Q1; r[192] = s.Q2; r[256] = s.PERC;
+                    if (TRAJ) { r[320] = SUZ; r[384] = SLZ; }
+                    SM = s.SM4; SUZ = s.SUZ4; SLZ = s.SLZ2;
+                };
+                PIPE_DAYS(nt, day);
+#undef DY_ALL
+#undef DY_USE2
+            }
+            PIPE_BARRIER();
+        }
+        if (L.active) {
+            o.state_out[2 * N + L.n] = SM;
+            o.state_out[3 * N + L.n] = SUZ;
+            o.state_out[4 * N + L.n] = SLZ;
+            if (TRAJ) {
+                o.traj[((int64_t)2 * (T + 1) + T) * N + L.n] = SM;
+                o.traj[((int64_t)3 * (T + 1) + T) * N + L.n] = SUZ;
+                o.traj[((int64_t)4 * (T + 1) + T) * N + L.n] = SLZ;
+            }
+        }
+      } else {
         // ------------------------------ soil ------------------------------
         __builtin_amdgcn_s_setprio(3);
         float SM = d.state_in ? d.state_in[2 * N + L.n] : 0.001f;
@@ -234,13 +313,13 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                 const float4 *in4 = reinterpret_cast<const float4 *>(lds + P.xin + (tile & 3) * Kt * 256);
                 const float *ab = lds + P.ab + (tile & 1) * Kt * 128 + lane;
                 float *bc = lds + P.bc + (tile & 1) * Kt * 128 + lane;
-                float *ob = lds + P.ob + (tile & 1) * Kt * 448 + lane;
+                float *ob = lds + P.ob + (tile & 1) * Kt * OBR * 64 + lane;
                 float npet = in4[lane].z, nrain = ab[0], nts = ab[64];
                 const float *pin = pin_of(tile);
                 DY_DECL(P_BETA); DY_DECL(P_FC); DY_DECL(P_LP); DY_DECL(P_BETAET);
                 if (DYN) { DY_LOAD(P_BETA, pin); DY_LOAD(P_FC, pin); DY_LOAD(P_LP, pin); DY_LOAD(P_BETAET, pin); }
                 auto day = [&](int tt, bool more) __attribute__((always_inline)) {
-                    Step<MODEL_HBV10, BETAET> s;
+                    Step<MODEL, BETAET> s;
                     s.PET = npet; s.RAIN = nrain; s.tosoil = nts;
                     if (DYN) { DY_USE(P_BETA); DY_USE(P_FC); DY_USE(P_LP); DY_USE(P_BETAET); }
                     if (more) {
@@ -256,7 +335,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                     s.template fwd_soil<false>(p, nz, 0.0f, 0.0f);
                     bc[tt * 128] = s.rech;
                     bc[tt * 128 + 64] = s.exc;
-                    float *q = ob + tt * 448;
+                    float *q = ob + tt * OBR * 64;
                     q[0] = s.ET; q[64] = s.rech; q[128] = s.exc; q[192] = s.ef;
                     if (TRAJ) { q[256] = SM; q[320] = s.sw0; q[384] = s.ef0; }
                     SM = s.SM3;
@@ -269,7 +348,12 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
             o.state_out[2 * N + L.n] = SM;
             if (TRAJ) o.traj[((int64_t)2 * (T + 1) + T) * N + L.n] = SM;
         }
+      }
     } else if (wave == 2) {
+      if constexpr (CAP) {
+        PIPE_BARRIER();
+        for (int it = 0; it < nIt; it++) PIPE_BARRIER();
+      } else {
         // --------------------------- groundwater ---------------------------
         __builtin_amdgcn_s_setprio(3);
         float SUZ = d.state_in ? d.state_in[3 * N + L.n] : 0.001f;
@@ -286,7 +370,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                 DY_DECL(P_K0); DY_DECL(P_K1); DY_DECL(P_K2); DY_DECL(P_PERC); DY_DECL(P_UZL);
                 if (DYN) { DY_LOAD(P_K0, pin); DY_LOAD(P_K1, pin); DY_LOAD(P_K2, pin); DY_LOAD(P_PERC, pin); DY_LOAD(P_UZL, pin); }
                 auto day = [&](int tt, bool more) __attribute__((always_inline)) {
-                    Step<MODEL_HBV10, BETAET> s;
+                    Step<MODEL, BETAET> s;
                     s.rech = nrech; s.exc = nexc;
                     if (DYN) { DY_USE(P_K0); DY_USE(P_K1); DY_USE(P_K2); DY_USE(P_PERC); DY_USE(P_UZL); }
                     if (more) {
@@ -316,13 +400,14 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                 o.traj[((int64_t)4 * (T + 1) + T) * N + L.n] = SLZ;
             }
         }
+      }
     } else {
         // ------------------------------ helpers ------------------------------
         const int lgMp = A.lgMp, bpw = 64 >> lgMp;
         const int b0 = blockIdx.x * bpw;
         constexpr unsigned fmapA = HBVX_F_SWE | (HBVX_F_TOSOIL << 4);
         constexpr unsigned fmapB = HBVX_F_AET | (HBVX_F_RECHARGE << 4) | (HBVX_F_EXCS << 8) |
-                                   (HBVX_F_EVAPFACTOR << 12);
+                                   (HBVX_F_EVAPFACTOR << 12) | (CAP ? (unsigned)HBVX_F_CAPILLARY << 16 : 0u);
         constexpr unsigned fmapC = HBVX_F_QSIM | (HBVX_F_Q0 << 4) | (HBVX_F_Q1 << 8) | (HBVX_F_Q2 << 12) |
                                    (HBVX_F_PERC << 16);
         const int nw = blockDim.x >> 6;
@@ -436,12 +521,12 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
             };
             PIPE_BARRIER();
             for (int it = 0; it < nIt; it++) {
-                const int tA = it - 1, tB = it - 2, tC = it - 3;
+                const int tA = it - 1, tB = it - 2, tC = CAP ? it - 2 : it - 3;
                 const int ntA = (tA >= 0 && tA < nT) ? tile_nt(tA) : 0;
                 const int ntB = (tB >= 0 && tB < nT) ? tile_nt(tB) : 0;
                 const int ntC = (tC >= 0 && tC < nT) ? tile_nt(tC) : 0;
                 const float *bufA = lds + P.oa + (tA & 1) * Kt * 256 + lane;
-                const float *bufB = lds + P.ob + (tB & 1) * Kt * 448 + lane;
+                const float *bufB = lds + P.ob + (tB & 1) * Kt * OBR * 64 + lane;
                 const float *bufC = lds + P.oc + (tC & 1) * Kt * 448 + lane;
                 // (invalid tiles: nt = 0, the descriptors are built but never used)
                 const int64_t dA = (int64_t)max(tA, 0) * Kt * N, dB = (int64_t)max(tB, 0) * Kt * N,
@@ -454,7 +539,10 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                     const unsigned soff = (unsigned)tt * row_bytes;
                     float a0, a1, b0v, b1, b2, c0, c1;
                     if (tt < ntA) { a0 = bufA[tt * 256 + 128]; a1 = bufA[tt * 256 + 192]; }
-                    if (tt < ntB) { b0v = bufB[tt * 448 + 256]; b1 = bufB[tt * 448 + 320]; b2 = bufB[tt * 448 + 384]; }
+                    if (tt < ntB) {
+                        const float *rb = bufB + (tt * OBR + NFB) * 64;
+                        b0v = rb[0]; b1 = rb[64]; b2 = rb[128];
+                    }
                     if (tt < ntC) { c0 = bufC[tt * 448 + 320]; c1 = bufC[tt * 448 + 384]; }
                     if (tt < ntA) { put(rSP, soff, a0); put(rMW, soff, a1); }
                     if (tt < ntB) { put(rSM, soff, b0v); put(rSW, soff, b1); put(rEF, soff, b2); }
@@ -469,14 +557,14 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
             const int NDR = ((nw - rbase + 3) >> 2) + ((nw - rbase - 2 + 3) >> 2);
             PIPE_BARRIER();
             for (int it = 0; it < nIt; it++) {
-                const int tA = it - 1, tB = it - 2, tC = it - 3;
+                const int tA = it - 1, tB = it - 2, tC = CAP ? it - 2 : it - 3;
                 const int ntA = (tA >= 0 && tA < nT) ? tile_nt(tA) : 0;
                 const int ntB = (tB >= 0 && tB < nT) ? tile_nt(tB) : 0;
                 const int ntC = (tC >= 0 && tC < nT) ? tile_nt(tC) : 0;
                 const float *bufA = lds + P.oa + (tA & 1) * Kt * 256;
-                const float *bufB = lds + P.ob + (tB & 1) * Kt * 448;
+                const float *bufB = lds + P.ob + (tB & 1) * Kt * OBR * 64;
                 const float *bufC = lds + P.oc + (tC & 1) * Kt * 448;
-                const int iA = ntA * 2 * bpw, iB = ntB * 4 * bpw, iC = ntC * 5 * bpw;
+                const int iA = ntA * 2 * bpw, iB = ntB * NFB * bpw, iC = ntC * 5 * bpw;
                 const int pA = (iA + 63) >> 6, pB = (iB + 63) >> 6, pC = (iC + 63) >> 6;
                 const int nR = pA + pB + pC;
                 // heaviest passes first (C: 5 series), so the tail of the round-robin is light
@@ -484,7 +572,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                     if (u < pC)
                         pipe_reduce_pass<7, 5, fmapC>(d, o, bufC, tC * Kt, iC, u, lane, lgMp, b0);
                     else if (u < pC + pB)
-                        pipe_reduce_pass<7, 4, fmapB>(d, o, bufB, tB * Kt, iB, u - pC, lane, lgMp, b0);
+                        pipe_reduce_pass<OBR, NFB, fmapB>(d, o, bufB, tB * Kt, iB, u - pC, lane, lgMp, b0);
                     else
                         pipe_reduce_pass<4, 2, fmapA>(d, o, bufA, tA * Kt, iA, u - pC - pB, lane, lgMp, b0);
                 }

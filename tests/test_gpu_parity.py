@@ -138,14 +138,17 @@ def test_div_on_gpu(hip_backend):
     assert mism == 0, f"{mism} of {n} quotients differ from IEEE division"
 
 
-@pytest.mark.parametrize("dyn,betaet,drop", [((), False, 0.0), (("parBETA", "parBETAET"), True, 0.0),
-                                             (("parK0", "parTT", "parFC"), False, 0.4)])
+@pytest.mark.parametrize("model,dyn,betaet,drop", [
+    ("Hbv", (), False, 0.0), ("Hbv", ("parBETA", "parBETAET"), True, 0.0),
+    ("Hbv", ("parK0", "parTT", "parFC"), False, 0.4),
+    ("Hbv_1_1p", (), False, 0.0), ("Hbv_1_1p", ("parC", "parK2", "parBETAET"), False, 0.3),
+    ("Hbv_2", ("parBETA", "parK0", "parBETAET"), False, 0.0), ("Hbv_2", ("parRT", "parAC"), False, 0.5)])
 @pytest.mark.parametrize("M,B,T", [(16, 37, 411), (1, 130, 97), (5, 19, 64)])
-def test_pipelined_forward_equals_tiled_forward(M, B, T, dyn, betaet, drop, hip_backend, monkeypatch):
-    """HBV 1.0, up to three dynamic parameters: the three-stage pipelined kernel and the tiled kernel
-    are bit-identical (same stage arithmetic, same ensemble-sum order), with and without the saved
-    trajectory."""
-    prob = make_problem(model="Hbv", T=T, B=B, M=M, dyn=dyn, betaet=betaet, drop_frac=drop, seed=21,
+def test_pipelined_forward_equals_tiled_forward(M, B, T, model, dyn, betaet, drop, hip_backend, monkeypatch):
+    """Up to three dynamic parameters: the pipelined kernel (three stages for HBV 1.0, two for the
+    capillary models) and the tiled kernel are bit-identical (same stage arithmetic, same
+    ensemble-sum order), with and without the saved trajectory."""
+    prob = make_problem(model=model, T=T, B=B, M=M, dyn=dyn, betaet=betaet, drop_frac=drop, seed=21,
                         cold=True)
     a = run_problem(prob, None, device="cuda:0", backward=True)
     a2 = run_problem(prob, None, device="cuda:0", backward=False)
