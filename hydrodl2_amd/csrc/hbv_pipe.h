@@ -159,8 +159,8 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
     const unsigned voff = L.active ? (unsigned)(L.n * 4) : 0xFFFFFFFFu;
     const PipeLds P(Kt, DYN, CAP);
     const float nz = d.nearzero;
-    const float ac = MODEL == MODEL_HBV20 ? d.ac[L.b] : 0.0f;
-    const float elev = MODEL == MODEL_HBV20 ? d.elev[L.b] : 0.0f;
+    const float ac = (MODEL == MODEL_HBV20 || MODEL == MODEL_HOURLY) ? d.ac[L.b] : 0.0f;
+    const float elev = (MODEL == MODEL_HBV20 || MODEL == MODEL_HOURLY) ? d.elev[L.b] : 0.0f;
     unsigned dmask = 0;
     if (DYN) {
 #pragma unroll
@@ -251,12 +251,13 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                 const float *pin = pin_of(tile);
                 DY_DECL(P_BETA); DY_DECL(P_FC); DY_DECL(P_LP); DY_DECL(P_BETAET); DY_DECL(P_C);
                 DY_DECL(P_K0); DY_DECL(P_K1); DY_DECL(P_K2); DY_DECL(P_PERC); DY_DECL(P_UZL);
-                DY_DECL(P_RT); DY_DECL(P_AC);
+                DY_DECL(P_RT); DY_DECL(P_AC); DY_DECL(P_F0); DY_DECL(P_FMIN); DY_DECL(P_ALPHA);
 #define DY_ALL(OP, ptr)                                                                            \
     do {                                                                                           \
         OP(P_BETA, ptr); OP(P_FC, ptr); OP(P_LP, ptr); OP(P_BETAET, ptr); OP(P_C, ptr); OP(P_K0, ptr); \
         OP(P_K1, ptr); OP(P_K2, ptr); OP(P_PERC, ptr); OP(P_UZL, ptr);                             \
-        if (MODEL == MODEL_HBV20) { OP(P_RT, ptr); OP(P_AC, ptr); }                                \
+        if (MODEL == MODEL_HBV20 || MODEL == MODEL_HOURLY) { OP(P_RT, ptr); OP(P_AC, ptr); }       \
+        if (MODEL == MODEL_HOURLY) { OP(P_F0, ptr); OP(P_FMIN, ptr); OP(P_ALPHA, ptr); }           \
     } while (0)
 #define DY_USE2(X, unused) DY_USE(X)
                 if (DYN) DY_ALL(DY_LOAD, pin);
@@ -274,9 +275,13 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                         }
                     }
                     s.SM = SM; s.SUZ = SUZ; s.SLZ = SLZ;
-                    s.template fwd_soil<false>(p, nz, 0.0f, 0.0f);
-                    s.fwd_cap(p, nz);
-                    s.fwd_gw(p, ac);
+                    if constexpr (MODEL == MODEL_HOURLY) {
+                        s.template fwd_rest<false>(p, nz, ac, 0.0f, 0.0f);
+                    } else {
+                        s.template fwd_soil<false>(p, nz, 0.0f, 0.0f);
+                        s.fwd_cap(p, nz);
+                        s.fwd_gw(p, ac);
+                    }
                     float *q = ob + tt * OBR * 64;
                     q[0] = s.ET; q[64] = s.rech; q[128] = s.exc; q[192] = s.ef; q[256] = s.cap;
                     if (TRAJ) { q[320] = SM; q[384] = s.sw0; q[448] = s.ef0; }

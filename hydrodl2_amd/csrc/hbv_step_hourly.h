@@ -30,22 +30,18 @@ struct Step<MODEL_HOURLY, BETAET_UNUSED> {
 
     static HBVX_HDM float dt_() { return (float)(1.0 / 24.0); } // self.dt (:58)
 
-    template <bool USE_AUX>
-    HBVX_HDM void fwd(const float *p, float nz, float ac, float elev, float aux_sw0, float aux_ef0)
+    // The step in two parts, split where the pipelined forward splits it (hbv_pipe.h): the snow
+    // routine (needs SP, MW, P, Tf; produces RAIN, tosoil) and everything else (needs SM, SUZ, SLZ,
+    // PET, RAIN, tosoil).  fwd() is the two in order -- the same operations in the same order as the
+    // single routine it replaces.
+    HBVX_HDM void fwd_snow(const float *p, float elev)
     {
         const float dt = dt_();
-        const float BETA = p[P_BETA], FC = p[P_FC], K0 = p[P_K0], K1 = p[P_K1], K2 = p[P_K2],
-                    LP = p[P_LP], PERCp = p[P_PERC], UZL = p[P_UZL], TT = p[P_TT], CFMAX = p[P_CFMAX],
-                    CFR = p[P_CFR], CWH = p[P_CWH], BE = p[P_BETAET], C = p[P_C], RT = p[P_RT],
-                    AC = p[P_AC], F0 = p[P_F0], FMIN = p[P_FMIN], ALPHA = p[P_ALPHA];
+        const float TT = p[P_TT], CFMAX = p[P_CFMAX], CFR = p[P_CFR], CWH = p[P_CWH];
         Pr = div_(P, dt);      // :485
-        PETr = div_(PET, dt);  // :487
         // :529-533
         SPc = fmax_(SP, 0.0f);  g0 = (SP >= 0.0f) ? 1.0f : 0.0f;
         MWc = fmax_(MW, 0.0f);  g1 = (MW >= 0.0f) ? 1.0f : 0.0f;
-        SMc = fmax_(SM, nz);    g2 = (SM >= nz) ? 1.0f : 0.0f;
-        SUZc = fmax_(SUZ, nz);  g3 = (SUZ >= nz) ? 1.0f : 0.0f;
-        SLZc = fmax_(SLZ, nz);  g4 = (SLZ >= nz) ? 1.0f : 0.0f;
         // :544-548
         const float mhi = (elev >= 2000.0f) ? 1.0f : 0.0f;
         mlo = (elev < 2000.0f) ? 1.0f : 0.0f;
@@ -72,6 +68,19 @@ struct Step<MODEL_HOURLY, BETAET_UNUSED> {
         ts0 = div_(MW2 - CWH * SP3, dt);
         tosoil = fmax_(ts0, 0.0f);
         MW3 = MW2 - tosoil * dt;
+    }
+
+    template <bool USE_AUX>
+    HBVX_HDM void fwd_rest(const float *p, float nz, float ac, float aux_sw0, float aux_ef0)
+    {
+        const float dt = dt_();
+        const float BETA = p[P_BETA], FC = p[P_FC], K0 = p[P_K0], K1 = p[P_K1], K2 = p[P_K2],
+                    LP = p[P_LP], PERCp = p[P_PERC], UZL = p[P_UZL], BE = p[P_BETAET], C = p[P_C],
+                    RT = p[P_RT], AC = p[P_AC], F0 = p[P_F0], FMIN = p[P_FMIN], ALPHA = p[P_ALPHA];
+        PETr = div_(PET, dt);  // :487
+        SMc = fmax_(SM, nz);    g2 = (SM >= nz) ? 1.0f : 0.0f;   // :529-533
+        SUZc = fmax_(SUZ, nz);  g3 = (SUZ >= nz) ? 1.0f : 0.0f;
+        SLZc = fmax_(SLZ, nz);  g4 = (SLZ >= nz) ? 1.0f : 0.0f;
         // :577-595
         W = RAIN + tosoil;
         r = div_(SMc, FC);
@@ -139,6 +148,13 @@ struct Step<MODEL_HOURLY, BETAET_UNUSED> {
         Q2 = K2 * SLZ1p;
         SLZ2 = SLZ1p - Q2 * dt;
         Q = ((Q0 + Q1) + Q2) + IE; // :652
+    }
+
+    template <bool USE_AUX>
+    HBVX_HDM void fwd(const float *p, float nz, float ac, float elev, float aux_sw0, float aux_ef0)
+    {
+        fwd_snow(p, elev);
+        fwd_rest<USE_AUX>(p, nz, ac, aux_sw0, aux_ef0);
     }
 
     HBVX_HDM void bwd(const float *p, float nz, const FluxGrad &g, float *a, float *gp, float *gx) const

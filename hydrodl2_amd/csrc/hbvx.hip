@@ -757,7 +757,8 @@ extern "C" int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *s
         // HBV 1.0: the pipelined kernel (one workgroup per CU) holds up to ~1000 wavefronts; the
         // two-stage variant gives way to the streaming kernel at its cross-over (512)
         const bool large = wgs_p >= (cap ? env_int("HBVX_STREAM_MIN", 512) : 1024) && env_int("HBVX_STREAM", 1) != 0;
-        const bool pmodel = d->model == HBVX_MODEL_HBV10 || d->model == HBVX_MODEL_HBV11P || d->model == HBVX_MODEL_HBV20;
+        const bool pmodel = d->model == HBVX_MODEL_HBV10 || d->model == HBVX_MODEL_HBV11P ||
+                            d->model == HBVX_MODEL_HBV20 || d->model == HBVX_MODEL_HOURLY;
         if (use_tiled(d) && !(fv && !strcmp(fv, "tiled")) && pmodel && off32 && !large &&
             nd <= PIPE_MAXDYN && !d->muwts && out->flux && d->T >= 4 * Kt &&
             (out->traj != nullptr) == (out->aux != nullptr) && (int64_t)d->B * d->M * 4 * PIPE_KT < (int64_t)1 << 31 &&
@@ -784,6 +785,7 @@ extern "C" int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *s
     } while (0)
             if (d->model == HBVX_MODEL_HBV11P) PIPE_GO4(MODEL_HBV11P, true);
             else if (d->model == HBVX_MODEL_HBV20) PIPE_GO4(MODEL_HBV20, true);
+            else if (d->model == HBVX_MODEL_HOURLY) PIPE_GO4(MODEL_HOURLY, true);
             else if (be) PIPE_GO4(MODEL_HBV10, true);
             else PIPE_GO4(MODEL_HBV10, false);
 #undef PIPE_GO4

@@ -142,7 +142,8 @@ def test_div_on_gpu(hip_backend):
     ("Hbv", (), False, 0.0), ("Hbv", ("parBETA", "parBETAET"), True, 0.0),
     ("Hbv", ("parK0", "parTT", "parFC"), False, 0.4),
     ("Hbv_1_1p", (), False, 0.0), ("Hbv_1_1p", ("parC", "parK2", "parBETAET"), False, 0.3),
-    ("Hbv_2", ("parBETA", "parK0", "parBETAET"), False, 0.0), ("Hbv_2", ("parRT", "parAC"), False, 0.5)])
+    ("Hbv_2", ("parBETA", "parK0", "parBETAET"), False, 0.0), ("Hbv_2", ("parRT", "parAC"), False, 0.5),
+    ("Hbv_2_hourly", (), False, 0.0), ("Hbv_2_hourly", ("parBETA", "parF0", "parALPHA"), False, 0.3)])
 @pytest.mark.parametrize("M,B,T", [(16, 37, 411), (1, 130, 97), (5, 19, 64)])
 def test_pipelined_forward_equals_tiled_forward(M, B, T, model, dyn, betaet, drop, hip_backend, monkeypatch):
     """Up to three dynamic parameters: the pipelined kernel (three stages for HBV 1.0, two for the
@@ -155,7 +156,8 @@ def test_pipelined_forward_equals_tiled_forward(M, B, T, model, dyn, betaet, dro
     monkeypatch.setenv("HBVX_FWD", "tiled")
     b = run_problem(prob, None, device="cuda:0", backward=True)
     for k in ("flux", "routed", "state_out", "traj", "g_params"):
-        assert np.array_equal(a[k], b[k]), k
+        if k in b:      # the hourly model has no 15-tap routing
+            assert np.array_equal(a[k], b[k]), k
     assert np.array_equal(a2["flux"], b["flux"])
 
 
