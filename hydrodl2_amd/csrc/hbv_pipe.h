@@ -43,15 +43,18 @@
 
 namespace hbvx {
 
-#define PIPE_KT 8       // days per tile (host and device)
-#define PIPE_MAXDYN 3   // dynamic parameters the pipelined kernel stages (LDS: 5 slots x Kt x 3 rows)
+#define PIPE_KT 8       // days per tile with at most PIPE_FEWDYN dynamic parameters (host and device)
+#define PIPE_KT_MANY 4  // ... with more: the staged parameter rows need the LDS
+#define PIPE_FEWDYN 3   // rows staged one per filler wave
+#define PIPE_MAXDYN 18  // rows staged at most (three filler waves, PIPE_ROWS_MANY rows each)
+#define PIPE_ROWS_MANY 6
 
 // Run `body(tt, has_next)` for the nt days of a tile; full tiles are unrolled so that every LDS
 // address is base + immediate and the loop-carried registers need no rotation moves.
 #define PIPE_DAYS(nt, body)                                                                        \
     do {                                                                                           \
-        if ((nt) == PIPE_KT) {                                                                     \
-            _Pragma("unroll") for (int tt_ = 0; tt_ < PIPE_KT; tt_++) body(tt_, tt_ + 1 < PIPE_KT); \
+        if ((nt) == KT) {                                                                          \
+            _Pragma("unroll") for (int tt_ = 0; tt_ < KT; tt_++) body(tt_, tt_ + 1 < KT);          \
         } else {                                                                                   \
             for (int tt_ = 0; tt_ < (nt); tt_++) body(tt_, tt_ + 1 < (nt));                        \
         }                                                                                          \
@@ -67,7 +70,7 @@ struct PipeArgs {
 // LDS layout in floats for Kt days per tile
 struct PipeLds {
     int xin, ab, bc, oa, ob, oc, pin, total;
-    __host__ __device__ explicit PipeLds(int Kt, bool dyn = false, bool cap = false)
+    __host__ __device__ explicit PipeLds(int Kt, int pd = 0, bool cap = false)
     {
         const int obr = cap ? 8 : 7;   // + capillary flux
         xin = 0;                    // [4][Kt][64][4]
@@ -76,8 +79,8 @@ struct PipeLds {
         oa = bc + 2 * Kt * 128;     // [2][Kt][4][64]  SWE, tosoil | SNOWPACK, MELTWATER
         ob = oa + 2 * Kt * 256;     // [2][Kt][7|8][64]  AET, recharge, excs, evapfactor (, capillary) | SM, sw0, ef0
         oc = ob + 2 * Kt * obr * 64; // [2][Kt][7][64]  Qsim, Q0, Q1, Q2, PERC | SUZ, SLZ
-        pin = oc + 2 * Kt * 448;    // [5][Kt][PIPE_MAXDYN][64]  de-scaled dynamic parameters (DYN only)
-        total = pin + (dyn ? 5 * Kt * PIPE_MAXDYN * 64 : 0);
+        pin = oc + 2 * Kt * 448;    // [5][Kt][pd][64]  de-scaled dynamic parameters (pd rows per day)
+        total = pin + 5 * Kt * pd * 64;
     }
 };
 
@@ -123,12 +126,14 @@ __device__ unsigned long long g_pipe_probe[32];
 #define DY_USE(X) do { p[X] = dy_##X ? pn_##X : p[X]; } while (0)
 
 // TRAJ: the forward also saves the storage trajectory and the pow results (traj and aux given).
-// DYN: 1..PIPE_MAXDYN parameters vary per day: the filler de-scales them (sigmoid, range, dy_drop
-// blend) into LDS tiles five deep (snow reads tile it, groundwater tile it-2, the filler writes it+2).
-template <int MODEL, bool BETAET, bool TRAJ, bool DYN>
+// DYN: parameters vary per day: filler waves de-scale them (sigmoid, range, dy_drop blend) into LDS
+// tiles five deep (snow reads tile it, groundwater tile it-2, the fillers write it+2).
+// MANY: more than PIPE_FEWDYN of them: 4-day tiles, each filler wave stages up to PIPE_ROWS_MANY rows.
+template <int MODEL, bool BETAET, bool TRAJ, bool DYN, bool MANY = false>
 __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
 {
     constexpr bool CAP = MODEL != MODEL_HBV10;   // two-stage pipeline (see the header comment)
+    constexpr int KT = MANY ? PIPE_KT_MANY : PIPE_KT;
     constexpr int OBR = CAP ? 8 : 7, NFB = CAP ? 5 : 4;
 #ifdef PIPE_PROBE
     unsigned long long probe_busy = 0, probe_wait = 0, probe_t = __builtin_readcyclecounter();
@@ -157,16 +162,16 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
     const bool raw = d.raw_sigmoid != 0;
     const unsigned row_bytes = (unsigned)(N * 4);
     const unsigned voff = L.active ? (unsigned)(L.n * 4) : 0xFFFFFFFFu;
-    const PipeLds P(Kt, DYN, CAP);
-    const float nz = d.nearzero;
-    const float ac = (MODEL == MODEL_HBV20 || MODEL == MODEL_HOURLY) ? d.ac[L.b] : 0.0f;
-    const float elev = (MODEL == MODEL_HBV20 || MODEL == MODEL_HOURLY) ? d.elev[L.b] : 0.0f;
     unsigned dmask = 0;
     if (DYN) {
 #pragma unroll
         for (int i = 0; i < NP; i++) dmask |= d.p[i].dyn ? (1u << i) : 0u;
     }
-    constexpr int PD = PIPE_MAXDYN;
+    const int PD = DYN ? (MANY ? __builtin_popcount(dmask) : PIPE_FEWDYN) : 0;   // staged rows per day
+    const PipeLds P(Kt, PD, CAP);
+    const float nz = d.nearzero;
+    const float ac = (MODEL == MODEL_HBV20 || MODEL == MODEL_HOURLY) ? d.ac[L.b] : 0.0f;
+    const float elev = (MODEL == MODEL_HBV20 || MODEL == MODEL_HOURLY) ? d.elev[L.b] : 0.0f;
     auto pin_of = [&](int tile) { return lds + P.pin + (tile % 5) * Kt * PD * 64 + lane; };
 
     float p[NPARAM_MAX];
@@ -429,12 +434,12 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
             // Loads use buffer addressing: one descriptor per tensor and tile (base = first day of
             // the tile, range = the days that exist), the day offset is a scalar operand and the
             // per-lane offset a constant, so issuing a tile costs no vector address arithmetic.
-            constexpr int FD = PIPE_KT;
+            constexpr int FD = KT;
+            constexpr int NRW = MANY ? PIPE_ROWS_MANY : 1;   // dynamic rows per filler wave
             const int fidx = wave == 3 ? 0 : (wave == 4 ? 1 : 2);
             const bool forc = fidx == 0;
             const int nd = __builtin_popcount(dmask);
-            const bool dyrow = DYN && fidx < nd;     // this wave stages dynamic row `fidx`
-            float fx[FD], fy[FD], fz[FD], dv[FD];
+            float fx[FD], fy[FD], fz[FD], dv[NRW][FD];
             auto rsrc_of = [&](const float *base, int64_t row_floats, int rows) {
                 return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0,
                                                          (int)(row_floats * 4 * rows), 0x00020000);
@@ -444,25 +449,31 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
             };
             const unsigned xvo = (unsigned)(L.b * d.x_b_stride * 4);
             const unsigned xcp = d.ch_prcp * 4, xct = d.ch_tmean * 4, xce = d.ch_pet * 4;
-            // dynamic row k = k-th set bit of dmask
-            const float *dsrc = d.x;
-            unsigned dvo = 0;
-            int64_t dts = 0;
-            float dlo = 0.0f, dhi = 0.0f, dsta = 0.0f;
-            bool duse = false;
-            if (dyrow) {
-                int slot = 0;
-                for (int i = 0, c = 0; i < NP; i++)
-                    if ((dmask >> i) & 1u) { if (c == fidx) slot = i; c++; }
-                const hbvx_param_src &ps = d.p[slot];
-                dsrc = ps.dyn;
-                dvo = (unsigned)((L.b * ps.dyn_b_stride + L.j) * 4);
-                dts = ps.dyn_t_stride;
-                dlo = ps.lo; dhi = ps.hi;
-                float v = ps.sta[(int64_t)L.b * ps.sta_b_stride + L.j];
-                v = raw ? sigmoid_(v) : v;
-                dsta = descale_(v, ps.lo, ps.hi);
-                duse = ps.drop ? (ps.drop[L.b] == 0) : true;
+            // this wave stages the dynamic rows fidx, fidx + 3, ... (row k = k-th set bit of dmask)
+            const float *dsrc[NRW];
+            unsigned dvo[NRW];
+            int64_t dts[NRW];
+            float dlo[NRW], dhi[NRW], dsta[NRW];
+            bool duse[NRW], dyrow[NRW];
+#pragma unroll
+            for (int r = 0; r < NRW; r++) {
+                const int k = fidx + 3 * r;
+                dyrow[r] = DYN && k < nd;
+                dsrc[r] = d.x; dvo[r] = 0; dts[r] = 0; dlo[r] = dhi[r] = dsta[r] = 0.0f; duse[r] = false;
+                if (dyrow[r]) {
+                    int slot = 0;
+                    for (int i = 0, c = 0; i < NP; i++)
+                        if ((dmask >> i) & 1u) { if (c == k) slot = i; c++; }
+                    const hbvx_param_src &ps = d.p[slot];
+                    dsrc[r] = ps.dyn;
+                    dvo[r] = (unsigned)((L.b * ps.dyn_b_stride + L.j) * 4);
+                    dts[r] = ps.dyn_t_stride;
+                    dlo[r] = ps.lo; dhi[r] = ps.hi;
+                    float v = ps.sta[(int64_t)L.b * ps.sta_b_stride + L.j];
+                    v = raw ? sigmoid_(v) : v;
+                    dsta[r] = descale_(v, ps.lo, ps.hi);
+                    duse[r] = ps.drop ? (ps.drop[L.b] == 0) : true;
+                }
             }
             auto issue = [&](int tile) {
                 const int t0 = tile * FD, rows = min(FD, T - t0);
@@ -474,11 +485,13 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                         fx[i] = bload(rx, xvo, so + xcp); fy[i] = bload(rx, xvo, so + xct); fz[i] = bload(rx, xvo, so + xce);
                     }
                 }
-                if (dyrow) {
-                    const auto rd = rsrc_of(dsrc + (int64_t)t0 * dts, dts, rows);
 #pragma unroll
-                    for (int i = 0; i < FD; i++) dv[i] = bload(rd, dvo, (unsigned)(i * (int)dts * 4));
-                }
+                for (int r = 0; r < NRW; r++)
+                    if (dyrow[r]) {
+                        const auto rd = rsrc_of(dsrc[r] + (int64_t)t0 * dts[r], dts[r], rows);
+#pragma unroll
+                        for (int i = 0; i < FD; i++) dv[r][i] = bload(rd, dvo[r], (unsigned)(i * (int)dts[r] * 4));
+                    }
             };
             auto commit = [&](int tile) {
                 if (forc) {
@@ -486,14 +499,16 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
 #pragma unroll
                     for (int i = 0; i < FD; i++) in4[i * 64 + lane] = make_float4(fx[i], fy[i], fz[i], 0.0f);
                 }
-                if (dyrow) {
-                    float *pin = lds + P.pin + (tile % 5) * FD * PD * 64 + fidx * 64 + lane;
 #pragma unroll
-                    for (int i = 0; i < FD; i++) {
-                        const float u = raw ? sigmoid_dyn_(dv[i]) : dv[i];
-                        pin[i * PD * 64] = duse ? descale_(u, dlo, dhi) : dsta;
+                for (int r = 0; r < NRW; r++)
+                    if (dyrow[r]) {
+                        float *pin = lds + P.pin + (tile % 5) * FD * PD * 64 + (fidx + 3 * r) * 64 + lane;
+#pragma unroll
+                        for (int i = 0; i < FD; i++) {
+                            const float u = raw ? sigmoid_dyn_(dv[r][i]) : dv[r][i];
+                            pin[i * PD * 64] = duse[r] ? descale_(u, dlo[r], dhi[r]) : dsta[r];
+                        }
                     }
-                }
             };
             issue(0);
             commit(0);
@@ -519,7 +534,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
             const int w = (wave - 7) >> 2, NRD = (nw - 7 + 3) >> 2;
             const int64_t SR = (int64_t)(T + 1) * N;   // storage row blocks in traj
             auto rsrc = [&](float *base) {
-                return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(row_bytes * PIPE_KT), 0x00020000);
+                return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(row_bytes * KT), 0x00020000);
             };
             auto put = [&](__amdgpu_buffer_rsrc_t r, unsigned soff, float v) {
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);

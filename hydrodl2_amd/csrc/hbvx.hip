@@ -743,25 +743,29 @@ extern "C" int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *s
         // HBV 1.0 / 1.1p / 2.0, at most PIPE_MAXDYN dynamic parameters, flux requested: pipelined
         // forward (hbv_pipe.h; three stages for HBV 1.0, two for the capillary models)
         const char *fv = getenv("HBVX_FWD");
-        const int Kt = PIPE_KT;
         const int nd = count_dyn(d);
+        const bool many = nd > PIPE_FEWDYN;          // 4-day tiles, several staged rows per filler wave
+        const int Kt = many ? PIPE_KT_MANY : PIPE_KT;
         const bool cap = d->model != HBVX_MODEL_HBV10;
         const int nfl = cap ? 12 : 11;
         // per-lane and per-tile byte offsets are 32-bit in the pipelined kernel
-        bool off32 = ((int64_t)d->B * d->x_b_stride + (int64_t)PIPE_KT * d->x_t_stride) * 4 < (int64_t)1 << 31;
+        bool off32 = ((int64_t)d->B * d->x_b_stride + (int64_t)Kt * d->x_t_stride) * 4 < (int64_t)1 << 31;
         for (int i = 0; i < d->n_param; i++)
             if (d->p[i].dyn)
-                off32 = off32 && ((int64_t)d->B * d->p[i].dyn_b_stride + (int64_t)PIPE_KT * d->p[i].dyn_t_stride) * 4 <
+                off32 = off32 && ((int64_t)d->B * d->p[i].dyn_b_stride + (int64_t)Kt * d->p[i].dyn_t_stride) * 4 <
                                      (int64_t)1 << 31;
         const int64_t wgs_p = ((int64_t)d->B + (64 >> lg_members(d->M)) - 1) / (64 >> lg_members(d->M));
         // HBV 1.0: the pipelined kernel (one workgroup per CU) holds up to ~1000 wavefronts; the
-        // two-stage variant gives way to the streaming kernel at its cross-over (512)
-        const bool large = wgs_p >= (cap ? env_int("HBVX_STREAM_MIN", 512) : 1024) && env_int("HBVX_STREAM", 1) != 0;
+        // two-stage variant gives way to the streaming kernel at its cross-over (512); with more
+        // than three dynamic parameters there is no streaming kernel to give way to
+        const bool large = nd <= 3 && wgs_p >= (cap ? env_int("HBVX_STREAM_MIN", 512) : 1024) &&
+                           env_int("HBVX_STREAM", 1) != 0;
         const bool pmodel = d->model == HBVX_MODEL_HBV10 || d->model == HBVX_MODEL_HBV11P ||
                             d->model == HBVX_MODEL_HBV20 || d->model == HBVX_MODEL_HOURLY;
+        const size_t lds = (size_t)PipeLds(Kt, nd > 0 ? (many ? nd : PIPE_FEWDYN) : 0, cap).total * 4;
         if (use_tiled(d) && !(fv && !strcmp(fv, "tiled")) && pmodel && off32 && !large &&
-            nd <= PIPE_MAXDYN && !d->muwts && out->flux && d->T >= 4 * Kt &&
-            (out->traj != nullptr) == (out->aux != nullptr) && (int64_t)d->B * d->M * 4 * PIPE_KT < (int64_t)1 << 31 &&
+            nd <= PIPE_MAXDYN && (int)lds <= LDS_BUDGET && wgs_p < 4096 && !d->muwts && out->flux && d->T >= 4 * Kt &&
+            (out->traj != nullptr) == (out->aux != nullptr) && (int64_t)d->B * d->M * 4 * Kt < (int64_t)1 << 31 &&
             (int64_t)nfl * d->T * d->B * 4 < (int64_t)1 << 31) {
             PipeArgs pa;
             pa.d = *d;
@@ -770,18 +774,24 @@ extern "C" int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *s
             pa.Kt = Kt;
             const int bpw_p = 64 >> pa.lgMp;
             dim3 grid_p((d->B + bpw_p - 1) / bpw_p);
-            const size_t lds = (size_t)PipeLds(Kt, nd > 0, cap).total * 4;
             int pthreads = env_int("HBVX_PIPE_THREADS", 1024); // 3 steppers + filler + drainers (hbv_pipe.h)
             pthreads = pthreads < 512 ? 512 : (pthreads > 1024 ? 1024 : (pthreads / 64) * 64);
             if (nd > 0) pthreads = 1024;   // the dynamic-parameter roles assume all 16 waves
             const bool be = d->n_param == 13, tr = out->traj != nullptr, dy = nd > 0;
             hipStream_t st = (hipStream_t)stream;
             hipError_t e;
-#define PIPE_GO(MODEL, BE, TR, DY) e = launch_tiled_one(k_fwd_pipe<MODEL, BE, TR, DY>, pa, grid_p, pthreads, lds, st)
+#define PIPE_GO(MODEL, BE, TR, DY, MANY) e = launch_tiled_one(k_fwd_pipe<MODEL, BE, TR, DY, MANY>, pa, grid_p, pthreads, lds, st)
 #define PIPE_GO4(MODEL, BE)                                                                        \
     do {                                                                                           \
-        if (tr) { if (dy) PIPE_GO(MODEL, BE, true, true); else PIPE_GO(MODEL, BE, true, false); }  \
-        else { if (dy) PIPE_GO(MODEL, BE, false, true); else PIPE_GO(MODEL, BE, false, false); }   \
+        if (tr) {                                                                                  \
+            if (many) PIPE_GO(MODEL, BE, true, true, true);                                        \
+            else if (dy) PIPE_GO(MODEL, BE, true, true, false);                                    \
+            else PIPE_GO(MODEL, BE, true, false, false);                                           \
+        } else {                                                                                   \
+            if (many) PIPE_GO(MODEL, BE, false, true, true);                                       \
+            else if (dy) PIPE_GO(MODEL, BE, false, true, false);                                   \
+            else PIPE_GO(MODEL, BE, false, false, false);                                          \
+        }                                                                                          \
     } while (0)
             if (d->model == HBVX_MODEL_HBV11P) PIPE_GO4(MODEL_HBV11P, true);
             else if (d->model == HBVX_MODEL_HBV20) PIPE_GO4(MODEL_HBV20, true);

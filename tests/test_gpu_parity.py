@@ -143,7 +143,12 @@ def test_div_on_gpu(hip_backend):
     ("Hbv", ("parK0", "parTT", "parFC"), False, 0.4),
     ("Hbv_1_1p", (), False, 0.0), ("Hbv_1_1p", ("parC", "parK2", "parBETAET"), False, 0.3),
     ("Hbv_2", ("parBETA", "parK0", "parBETAET"), False, 0.0), ("Hbv_2", ("parRT", "parAC"), False, 0.5),
-    ("Hbv_2_hourly", (), False, 0.0), ("Hbv_2_hourly", ("parBETA", "parF0", "parALPHA"), False, 0.3)])
+    ("Hbv_2_hourly", (), False, 0.0), ("Hbv_2_hourly", ("parBETA", "parF0", "parALPHA"), False, 0.3),
+    # more than three dynamic parameters: 4-day tiles, several staged rows per filler wave
+    ("Hbv", tuple(gc.PHY_NAMES["Hbv"]) + ("parBETAET",), True, 0.3),
+    ("Hbv_1_1p", tuple(gc.PHY_NAMES["Hbv_1_1p"]), False, 0.0),
+    ("Hbv_2", ("parBETA", "parFC", "parK0", "parC", "parRT"), False, 0.2),
+    ("Hbv_2_hourly", ("parBETA", "parK0", "parBETAET", "parF0", "parFMIN", "parALPHA", "parTT"), False, 0.0)])
 @pytest.mark.parametrize("M,B,T", [(16, 37, 411), (1, 130, 97), (5, 19, 64)])
 def test_pipelined_forward_equals_tiled_forward(M, B, T, model, dyn, betaet, drop, hip_backend, monkeypatch):
     """Up to three dynamic parameters: the pipelined kernel (three stages for HBV 1.0, two for the
