@@ -129,11 +129,13 @@ class HbvModule(torch.nn.Module):
     def _n_flux(self) -> int:
         return 12 if self._has_capillary else 11
 
-    def _draw_drop_mask(self, ngrid: int, device) -> torch.Tensor:
+    def _draw_drop_mask(self, ngrid: int, device) -> Optional[torch.Tensor]:
         """One Bernoulli(dy_drop) draw per basin from the CPU global RNG, exactly as the
         reference consumes it (hbv.py:240,245) -- also when dy_drop == 0."""
         pmat = torch.ones([1, ngrid, 1]) * self.dy_drop
-        drmask = torch.bernoulli(pmat)
+        drmask = torch.bernoulli(pmat)      # drawn even for dy_drop == 0: same RNG consumption
+        if self.dy_drop <= 0:
+            return None                     # nothing dropped: the kernels take their mask-free paths
         return drmask.reshape(ngrid).to(torch.uint8).to(device)
 
     def _stack_states(self, states, ngrid: int, device):

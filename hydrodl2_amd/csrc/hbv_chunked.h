@@ -46,7 +46,9 @@ struct ChunkArgs {
 
 // DYN template values: 0 all static; 1 "few": at most CHUNK_FEW dynamic parameters, no muwts -- only
 // those rows are loaded / de-scaled / stored, addressed through the wave-uniform slot list (the
-// generic mode walks all NP slots every day and needs 230+ VGPRs); 2 generic.
+// generic mode walks all NP slots every day and needs 230+ VGPRs); 2 generic; 3 "all": every
+// parameter dynamic, no dy_drop mask, no muwts (config 3) -- no static values, selects or static
+// gradient accumulators at all, and the B4 reduction is skipped (the static gradient is zero).
 #define CHUNK_FEW 3
 
 // p[slot] = v / return p[slot] for a wave-uniform runtime slot without dynamic register indexing
@@ -149,6 +151,13 @@ __device__ __forceinline__ void chunk_issue(const hbvx_desc &d, const hbvx_bwd_i
                 R.dv[k] = ps.dyn[(int64_t)t * ps.dyn_t_stride + (int64_t)L.b * ps.dyn_b_stride + L.j];
             }
     }
+    if (DYN == 3) {
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            const hbvx_param_src &ps = d.p[i];
+            R.dv[i] = ps.dyn[(int64_t)t * ps.dyn_t_stride + (int64_t)L.b * ps.dyn_b_stride + L.j];
+        }
+    }
     if (DYN == 2) {
         // branch-free: a static slot re-reads its static value (never used: use_dyn is false)
 #pragma unroll
@@ -186,9 +195,16 @@ __device__ __forceinline__ void chunk_finish(const hbvx_desc &d, const ChunkRaw<
                 slot_set<NP>(D.p, dslot[k], use_dyn[k] ? pv : cur);
             }
     }
+    if (DYN == 3) {
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            D.ud[i] = raw ? sigmoid_dyn_(R.dv[i]) : R.dv[i];
+            D.p[i] = descale_(D.ud[i], d.p[i].lo, d.p[i].hi);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < NP; i++) {
-        if (DYN == 1) break;
+        if (DYN == 1 || DYN == 3) break;
         D.ud[i] = usta[i];
         D.p[i] = psta[i];
         if (DYN == 2) {   // selects on the per-lane flag (false for static slots), no branches
@@ -223,6 +239,11 @@ __device__ __forceinline__ void chunk_static(const hbvx_desc &d, const ChunkLane
 {
 #pragma unroll
     for (int i = 0; i < NP; i++) {
+        if (DYN == 3) {   // never read
+            usta[i] = psta[i] = 0.0f;
+            use_dyn[i] = true;
+            continue;
+        }
         const hbvx_param_src &s = d.p[i];
         float v = s.sta[(int64_t)L.b * s.sta_b_stride + L.j];
         usta[i] = raw ? sigmoid_(v) : v;
@@ -440,9 +461,18 @@ __global__ void __launch_bounds__(64) k_bwd_chunk_sweep(const ChunkArgs A)
                     gused[k] += use_dyn[k] ? gu : 0.0f;   // goes to the dynamic rows, not to the static one
                 }
         }
+        if (DYN == 3) {
+#pragma unroll
+            for (int i = 0; i < NP; i++) {
+                const float gu = gp[i] * (d.p[i].hi - d.p[i].lo);
+                const float gr = raw ? gu * (D.ud[i] * (1.0f - D.ud[i])) : gu;
+                if (io.g[i].dyn && L.active)
+                    io.g[i].dyn[(int64_t)t * io.g[i].dyn_t_stride + (int64_t)L.b * io.g[i].dyn_b_stride + L.j] = gr;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NP; i++) {
-            if (DYN == 1) break;
+            if (DYN == 1 || DYN == 3) break;
             const float gu = gp[i] * (d.p[i].hi - d.p[i].lo);
             if (DYN == 2) {
                 // io.g[i].dyn is only set for dynamic slots; use_dyn is false for static ones
@@ -471,7 +501,7 @@ __global__ void __launch_bounds__(64) k_bwd_chunk_sweep(const ChunkArgs A)
         for (int k = 0; k < CHUNK_FEW; k++)
             if (k < nd_) slot_set<NP>(gsta, ds_[k], slot_get<NP>(gsta, ds_[k]) - gused[k]);
     }
-    if (L.active) {
+    if (DYN != 3 && L.active) {
 #pragma unroll
         for (int i = 0; i < NP; i++) A.gpart[((int64_t)chunk * NP + i) * N + L.n] = gsta[i];
     }

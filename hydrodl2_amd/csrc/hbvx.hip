@@ -934,6 +934,7 @@ static hipError_t launch_chunked_t(const ChunkArgs &a, hipStream_t st)
     hipLaunchKernelGGL((k_bwd_chunk_phi<MODEL, BETAET, DYN, GFULL>), g2, dim3(64), 0, st, a);
     hipLaunchKernelGGL(k_bwd_chunk_scan, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, st, a);
     hipLaunchKernelGGL((k_bwd_chunk_sweep<MODEL, BETAET, DYN, GFULL>), g2, dim3(64), 0, st, a);
+    if (DYN == 3) return hipGetLastError();   // every parameter dynamic: the static gradient is zero
     hipLaunchKernelGGL(k_bwd_chunk_reduce, dim3((unsigned)((N + 255) / 256), d.n_param), dim3(256), 0, st,
                        a, d.n_param);
     return hipGetLastError();
@@ -970,6 +971,9 @@ static hipError_t launch_chunked(const hbvx_desc *d, const hbvx_bwd_io *io, hipS
             if (d->p[i].dyn) a.dslot[a.nd++] = i;
         return gfull ? launch_chunked_v<1, true>(d, a, st) : launch_chunked_v<1, false>(d, a, st);
     }
+    bool alldyn = ndyn == d->n_param && !d->muwts;
+    for (int i = 0; i < d->n_param && alldyn; i++) alldyn = d->p[i].drop == nullptr;
+    if (alldyn) return gfull ? launch_chunked_v<3, true>(d, a, st) : launch_chunked_v<3, false>(d, a, st);
     if (ndyn > 0 || d->muwts) return gfull ? launch_chunked_v<2, true>(d, a, st) : launch_chunked_v<2, false>(d, a, st);
     return gfull ? launch_chunked_v<0, true>(d, a, st) : launch_chunked_v<0, false>(d, a, st);
 }
