@@ -10,10 +10,12 @@
 // 71-step halo) in LDS and run the 72-tap window out of LDS.  grad_qs is produced transposed and
 // transposed back.  No atomics anywhere: sums over pairs and over time run in a fixed order,
 // results are bit-reproducible.
-// (Measured at 4000 units / 100 gages / 12 000 pairs / 2160 steps: transposition 0.44 -> 0.38 ms
-// forward, 0.78 -> 0.72 ms backward.  A register-tiled FIR -- 4 outputs per thread, 1024-step
-// tiles, 1 LDS read per 4 FMAs -- was slower both before and after: what remains is the serial
-// loop over a gage's pairs with two barriers per pair, not LDS bandwidth.)
+// The FIR itself is pair-parallel (k_gage_lag_*: one block per pair and 1024-step tile, register-
+// tiled), the sums over a gage's / unit's pairs are separate fixed-order kernels.  History at 4000
+// units / 100 gages / 12 000 pairs / 2160 steps, forward / backward: per-gage loop with strided
+// staging 0.44 / 0.78 ms; transposed staging 0.38 / 0.72 ms; a register-tiled FIR inside the
+// per-gage loop was SLOWER (the serial loop over a gage's ~120 pairs with two barriers per pair was
+// the bound, not LDS bandwidth); pair-parallel: see DESIGN.md.
 #pragma once
 #include "hbv_step.h"
 
@@ -66,88 +68,138 @@ __device__ __forceinline__ float gamma_tap(const GagePair &g, float denom, int k
     return 1.0f / denom * powf(t, g.aa - 1.0f) * expf(-t / g.theta);
 }
 
-// uh_gamma (uh_routing.py:5-22) + _frac_shift1d (hbv_2_hourly.py:857-897): one thread per pair.
-// The unshifted taps go to uh[p,:] first; the shift runs in place from the last tap down (tap k
-// only reads taps <= k).
-__global__ void __launch_bounds__(64) k_gage_uh(const hbvx_gage_desc r, float *__restrict__ uh)
+// uh_gamma (uh_routing.py:5-22) + _frac_shift1d (hbv_2_hourly.py:857-897): one block per pair, one
+// thread per tap (pow / exp in parallel), the normalising sum accumulated by one thread in tap order
+// (the order the reference's sum and the oracle use), then the fractional shift out of LDS.
+__global__ void __launch_bounds__(128) k_gage_uh(const hbvx_gage_desc r, float *__restrict__ uh)
 {
-    int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= r.NPAIR) return;
+    __shared__ float w[GAGE_L];
+    __shared__ float ssum;
+    const int p = blockIdx.x, k = threadIdx.x;
     const int L = r.L;
     GagePair g = gage_pair(r, p);
-    float denom = expf(lgammaf(g.aa)) * powf(g.theta, g.aa);
-    float *w = uh + (int64_t)p * L;
-    float sum = 0.0f;
-    for (int k = 0; k < L; k++) {
-        float v = gamma_tap(g, denom, k);
-        w[k] = v;
-        sum += v;
+    const float denom = expf(lgammaf(g.aa)) * powf(g.theta, g.aa);
+    if (k < L) w[k] = gamma_tap(g, denom, k);
+    __syncthreads();
+    if (k == 0) {
+        float sum = 0.0f;
+        for (int j = 0; j < L; j++) sum += w[j];
+        ssum = sum;
     }
+    __syncthreads();
+    if (k >= L) return;
+    const float sum = ssum;
+    float *dst = uh + (int64_t)p * L;
     if (!r.lag_uh) {
-        for (int k = 0; k < L; k++) w[k] = w[k] / sum;
+        dst[k] = w[k] / sum;
         return;
     }
     const int kk = (int)g.kk;
-    for (int k = L - 1; k >= 0; k--) {
-        int i0 = k - kk, i1 = k - kk - 1;
-        float w0 = (i0 >= 0 && i0 <= L - 1) ? w[i0] / sum : 0.0f;
-        float w1 = (i1 >= 0 && i1 <= L - 1) ? w[i1] / sum : 0.0f;
-        w[k] = (1.0f - g.f) * w0 + g.f * w1;
-    }
+    const int i0 = k - kk, i1 = k - kk - 1;
+    const float w0 = (i0 >= 0 && i0 <= L - 1) ? w[i0] / sum : 0.0f;
+    const float w1 = (i1 >= 0 && i1 <= L - 1) ? w[i1] / sum : 0.0f;
+    dst[k] = (1.0f - g.f) * w0 + g.f * w1;
 }
 
-// out[t,g] = (sum_{p in gage g} sum_k uh[p,k] * qs[t-k,unit(p)] * areas[unit(p)]) / denom[g]
-// block = (time tile, gage); the unit column segment [t0-(L-1), t0+TILE) is staged in LDS.
-__global__ void __launch_bounds__(GAGE_TILE) k_gage_fwd(const hbvx_gage_desc r, const float *__restrict__ qsT,
-                                                         const float *__restrict__ uh, float *__restrict__ out)
+// Pair-parallel FIR: one block per (1024-step time tile, pair) -- no serial loop over the pairs of
+// a gage / unit, 4 outputs per thread (the four windows overlap: per tap ONE new column value, the
+// other three slide through registers; tap weights by scalar loads; the column is padded one word
+// per 32 so that the stride-4 accesses fall on distinct banks).  Writes the pair's series to
+// lag[p][t]; the fixed-order sums over a gage's / unit's pairs are separate, trivially parallel
+// kernels.  Same operations in the same order as a per-gage loop: bit-identical results.
+#define GAGE_TILE4 (4 * GAGE_TILE)
+#define GAGE_COLN (GAGE_TILE4 + GAGE_L + (GAGE_TILE4 + GAGE_L) / 32 + 1)
+__device__ __forceinline__ int gage_phys(int i) { return i + (i >> 5); }
+
+// lag[p][t] = sum_k uh[p,k] * qs[t-k,unit(p)] * areas[unit(p)]      (forward, causal)
+__global__ void __launch_bounds__(GAGE_TILE) k_gage_lag_fwd(const hbvx_gage_desc r, const float *__restrict__ qsT,
+                                                             const float *__restrict__ uh, float *__restrict__ lag)
 {
-    __shared__ float col[GAGE_TILE + GAGE_L];
-    __shared__ float wl[GAGE_L];
-    const int g = blockIdx.y, t0 = blockIdx.x * GAGE_TILE, tid = threadIdx.x, t = t0 + tid;
-    const int T = r.T, U = r.U, L = r.L, H = L - 1;
+    __shared__ float col[GAGE_COLN];
+    const int p = blockIdx.x, t0 = blockIdx.y * GAGE_TILE4, tid = threadIdx.x;   // pairs on x: no 65535 limit
+    const int T = r.T, L = r.L, H = L - 1;
+    const int u = clampi_(r.pair_unit[p], 0, r.U - 1);
+    const float ar = r.areas[u];
+    const float *w = uh + (int64_t)p * L;
+    for (int i = tid; i < GAGE_TILE4 + H; i += GAGE_TILE) {
+        const int ts = t0 - H + i;
+        col[gage_phys(i)] = (ts >= 0 && ts < T) ? qsT[(int64_t)u * T + ts] * ar : 0.0f; // zero history
+    }
+    __syncthreads();
+    const int i0 = tid * 4 + H;   // column index of (output 0, tap 0)
+    float r0 = col[gage_phys(i0)], r1 = col[gage_phys(i0 + 1)], r2 = col[gage_phys(i0 + 2)],
+          r3 = col[gage_phys(i0 + 3)];
+    float y0 = 0.0f, y1 = 0.0f, y2 = 0.0f, y3 = 0.0f;
+    for (int k = 0; k < L; k++) {
+        const float wk = w[k];
+        y0 += wk * r0; y1 += wk * r1; y2 += wk * r2; y3 += wk * r3;
+        r3 = r2; r2 = r1; r1 = r0;
+        r0 = col[gage_phys(max(i0 - k - 1, 0))];
+    }
+    float *dst = lag + (int64_t)p * T + t0 + tid * 4;
+    const int t = t0 + tid * 4;
+    if (t < T) dst[0] = y0;
+    if (t + 1 < T) dst[1] = y1;
+    if (t + 2 < T) dst[2] = y2;
+    if (t + 3 < T) dst[3] = y3;
+}
+
+// out[t,g] = (sum over the pairs of gage g, in CSR order, of lag[p][t]) / denom[g]
+__global__ void __launch_bounds__(256) k_gage_sum_fwd(const hbvx_gage_desc r, const float *__restrict__ lag,
+                                                       float *__restrict__ out)
+{
+    const int g = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= r.T) return;
     float acc = 0.0f;
-    for (int p = r.gage_ptr[g]; p < r.gage_ptr[g + 1]; p++) {
-        const int u = clampi_(r.pair_unit[p], 0, U - 1);
-        const float ar = r.areas[u];
-        __syncthreads();
-        for (int i = tid; i < GAGE_TILE + H; i += GAGE_TILE) {
-            int ts = t0 - H + i;
-            col[i] = (ts >= 0 && ts < T) ? qsT[(int64_t)u * T + ts] * ar : 0.0f;
-        }
-        if (tid < L) wl[tid] = uh[(int64_t)p * L + tid];
-        __syncthreads();
-        float y = 0.0f;
-        for (int k = 0; k < L; k++) y += wl[k] * col[tid + H - k]; // zero history: col is 0 for ts < 0
-        acc += y;
-    }
-    if (t < T) out[(int64_t)t * r.G + g] = acc / r.denom[g];
+    for (int p = r.gage_ptr[g]; p < r.gage_ptr[g + 1]; p++) acc += lag[(int64_t)p * r.T + t];
+    out[(int64_t)t * r.G + g] = acc / r.denom[g];
 }
 
-// grad_qs[t,u] = areas[u] * sum_{p in unit u} sum_k uh[p,k] * grad_out[t+k, gage(p)] / denom[gage(p)]
-__global__ void __launch_bounds__(GAGE_TILE) k_gage_bwd_q(const hbvx_gage_desc r, const float *__restrict__ uh,
-                                                           const float *__restrict__ goT, float *__restrict__ gqsT)
+// lag[p][t] = sum_k uh[p,k] * grad_out[t+k, gage(p)] / denom[gage(p)]      (backward, anti-causal)
+__global__ void __launch_bounds__(GAGE_TILE) k_gage_lag_bwd(const hbvx_gage_desc r, const float *__restrict__ uh,
+                                                             const float *__restrict__ goT, float *__restrict__ lag)
 {
-    __shared__ float col[GAGE_TILE + GAGE_L];
-    __shared__ float wl[GAGE_L];
-    const int u = blockIdx.y, t0 = blockIdx.x * GAGE_TILE, tid = threadIdx.x, t = t0 + tid;
-    const int T = r.T, G = r.G, L = r.L, H = L - 1;
+    __shared__ float col[GAGE_COLN];
+    const int p = blockIdx.x, t0 = blockIdx.y * GAGE_TILE4, tid = threadIdx.x;
+    const int T = r.T, L = r.L, H = L - 1;
+    const int g = clampi_(r.pair_gage[p], 0, r.G - 1);
+    const float inv = 1.0f / r.denom[g];
+    const float *w = uh + (int64_t)p * L;
+    for (int j = tid; j < GAGE_TILE4 + H; j += GAGE_TILE) {
+        const int ts = t0 + j;
+        col[gage_phys(j)] = (ts < T) ? goT[(int64_t)g * T + ts] * inv : 0.0f;
+    }
+    __syncthreads();
+    const int i0 = tid * 4;       // column index of (output 0, tap 0)
+    float r0 = col[gage_phys(i0)], r1 = col[gage_phys(i0 + 1)], r2 = col[gage_phys(i0 + 2)],
+          r3 = col[gage_phys(i0 + 3)];
+    float y0 = 0.0f, y1 = 0.0f, y2 = 0.0f, y3 = 0.0f;
+    for (int k = 0; k < L; k++) {
+        const float wk = w[k];
+        y0 += wk * r0; y1 += wk * r1; y2 += wk * r2; y3 += wk * r3;
+        r0 = r1; r1 = r2; r2 = r3;
+        r3 = col[gage_phys(min(i0 + k + 4, GAGE_TILE4 + H - 1))];
+    }
+    float *dst = lag + (int64_t)p * T + t0 + tid * 4;
+    const int t = t0 + tid * 4;
+    if (t < T) dst[0] = y0;
+    if (t + 1 < T) dst[1] = y1;
+    if (t + 2 < T) dst[2] = y2;
+    if (t + 3 < T) dst[3] = y3;
+}
+
+// grad_qsT[u][t] = areas[u] * (sum over the pairs of unit u, in CSR order, of lag[p][t])
+__global__ void __launch_bounds__(256) k_gage_sum_bwd(const hbvx_gage_desc r, const float *__restrict__ lag,
+                                                       float *__restrict__ gqsT)
+{
+    const int u = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= r.T) return;
     float acc = 0.0f;
     for (int i = r.unit_ptr[u]; i < r.unit_ptr[u + 1]; i++) {
         const int p = clampi_(r.unit_pairs[i], 0, r.NPAIR - 1);
-        const int g = clampi_(r.pair_gage[p], 0, G - 1);
-        const float inv = 1.0f / r.denom[g];
-        __syncthreads();
-        for (int j = tid; j < GAGE_TILE + H; j += GAGE_TILE) {
-            int ts = t0 + j;
-            col[j] = (ts < T) ? goT[(int64_t)g * T + ts] * inv : 0.0f;
-        }
-        if (tid < L) wl[tid] = uh[(int64_t)p * L + tid];
-        __syncthreads();
-        float y = 0.0f;
-        for (int k = 0; k < L; k++) y += wl[k] * col[tid + k];
-        acc += y;
+        acc += lag[(int64_t)p * r.T + t];
     }
-    if (t < T) gqsT[(int64_t)u * T + t] = acc * r.areas[u];
+    gqsT[(int64_t)u * r.T + t] = acc * r.areas[u];
 }
 
 // Per pair: grad_uh[k] = sum_t gon[t] * qa[t-k] (gon = grad_out/denom of the pair's gage, qa the
@@ -155,38 +207,66 @@ __global__ void __launch_bounds__(GAGE_TILE) k_gage_bwd_q(const hbvx_gage_desc r
 // route_tau) in closed form: for the normalised gamma taps w_k,
 //   d w_k / d aa = w_k (ln t_k - sum_j w_j ln t_j),  d w_k / d theta = w_k (t_k - sum_j w_j t_j) / theta^2
 // (the lgamma / theta^aa factor cancels in the normalisation, so no digamma is needed).
-// Threads: 3 interleaved time phases x 72 taps accumulate, phase partials are added in order.
+// Threads: 18 tap groups (4 taps each) x 14 contiguous time phases of a 1024-step tile.  Within its
+// phase a thread slides a 4-value window of the runoff through registers: per step one runoff value
+// and one gradient value from LDS for 4 FMAs (the 3 x 72 layout read two values per FMA).  Phase
+// partials are added in order (deterministic).
+#define GAGE_PH 14
+#define GAGE_PLEN ((GAGE_TILE4 + GAGE_PH - 1) / GAGE_PH)
 __global__ void __launch_bounds__(GAGE_TILE) k_gage_bwd_p(const hbvx_gage_desc r, const float *__restrict__ qsT,
                                                            const float *__restrict__ goT, float *__restrict__ gdp)
 {
-    __shared__ float qcol[GAGE_TILE + GAGE_L];
-    __shared__ float gcol[GAGE_TILE];
-    __shared__ float part[3][GAGE_L];
+    __shared__ float qcol[GAGE_COLN];
+    __shared__ float gcol[GAGE_TILE4];
+    __shared__ float part[GAGE_PH][GAGE_L];
     __shared__ float w[GAGE_L];
     __shared__ float guh[GAGE_L];
     const int p = blockIdx.x, tid = threadIdx.x;
     const int T = r.T, U = r.U, G = r.G, L = r.L, H = L - 1;
     const int u = clampi_(r.pair_unit[p], 0, U - 1), g = clampi_(r.pair_gage[p], 0, G - 1);
     const float ar = r.areas[u], inv = 1.0f / r.denom[g];
-    const int k = tid % GAGE_L, phase = tid / GAGE_L; // phases 0..2 work, threads >= 216 only stage
-    const bool worker = phase < 3 && k < L;
-    float acc = 0.0f;
-    for (int t0 = 0; t0 < T; t0 += GAGE_TILE) {
+    const int tg = tid % 18, phase = tid / 18;   // taps 4 tg .. 4 tg + 3; threads >= 252 only stage
+    const int k0 = 4 * tg;
+    const bool worker = phase < GAGE_PH;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int t0 = 0; t0 < T; t0 += GAGE_TILE4) {
         __syncthreads();
-        for (int i = tid; i < GAGE_TILE + H; i += GAGE_TILE) {
-            int ts = t0 - H + i;
-            qcol[i] = (ts >= 0 && ts < T) ? qsT[(int64_t)u * T + ts] * ar : 0.0f;
+        for (int i = tid; i < GAGE_TILE4 + H; i += GAGE_TILE) {
+            const int ts = t0 - H + i;
+            qcol[gage_phys(i)] = (ts >= 0 && ts < T) ? qsT[(int64_t)u * T + ts] * ar : 0.0f;
         }
-        gcol[tid] = (t0 + tid < T) ? goT[(int64_t)g * T + t0 + tid] * inv : 0.0f;
+        for (int i = tid; i < GAGE_TILE4; i += GAGE_TILE)
+            gcol[i] = (t0 + i < T) ? goT[(int64_t)g * T + t0 + i] * inv : 0.0f;
         __syncthreads();
-        if (worker)
-            for (int j = phase; j < GAGE_TILE; j += 3) acc += gcol[j] * qcol[j + H - k];
+        if (worker) {
+            const int j0 = phase * GAGE_PLEN, j1 = min(j0 + GAGE_PLEN, GAGE_TILE4);
+            // window: qa[t - k] for k = k0 .. k0+3 at step j lives at column j + H - k (>= 0: H >= 71 >= k)
+            int c = j0 + H - k0;
+            float w0 = qcol[gage_phys(max(c, 0))], w1 = qcol[gage_phys(max(c - 1, 0))],
+                  w2 = qcol[gage_phys(max(c - 2, 0))], w3 = qcol[gage_phys(max(c - 3, 0))];
+            for (int j = j0; j < j1; j++) {
+                const float gj = gcol[j];
+                acc[0] += gj * w0; acc[1] += gj * w1; acc[2] += gj * w2; acc[3] += gj * w3;
+                w3 = w2; w2 = w1; w1 = w0;
+                c++;
+                w0 = qcol[gage_phys(min(max(c, 0), GAGE_TILE4 + H - 1))];   // (c < 0 only for unused taps >= L)
+            }
+        }
     }
-    if (worker) part[phase][k] = acc;
+    if (worker) {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (k0 + q < GAGE_L) part[phase][k0 + q] = acc[q];
+    }
     GagePair gp = gage_pair(r, p);
     if (tid < L) w[tid] = gamma_tap(gp, expf(lgammaf(gp.aa)) * powf(gp.theta, gp.aa), tid);
     __syncthreads();
-    if (tid < L) guh[tid] = (part[0][tid] + part[1][tid]) + part[2][tid];
+    if (tid < L) {
+        float sacc = 0.0f;
+#pragma unroll
+        for (int ph = 0; ph < GAGE_PH; ph++) sacc += part[ph][tid];
+        guh[tid] = sacc;
+    }
     __syncthreads();
     if (tid != 0) return;
     float sum = 0.0f;

@@ -1337,8 +1337,9 @@ static int check_gage(const hbvx_gage_desc *r)
 extern "C" uint64_t hbvx_gage_route_workspace_bytes(const hbvx_gage_desc *r)
 {
     if (!r || r->T <= 0 || r->U <= 0 || r->G <= 0) return 0;
-    // transposed runoff [U,T], transposed gradient [G,T], transposed input gradient [U,T]
-    return ((uint64_t)2 * r->U + r->G) * (uint64_t)r->T * sizeof(float);
+    // transposed runoff [U,T], transposed gradient [G,T], transposed input gradient [U,T],
+    // per-pair series [NPAIR,T]
+    return ((uint64_t)2 * r->U + r->G + r->NPAIR) * (uint64_t)r->T * sizeof(float);
 }
 
 static void launch_transpose(int R, int C, const float *in, float *out, hipStream_t st)
@@ -1357,9 +1358,12 @@ extern "C" int hbvx_gage_route_forward(const hbvx_gage_desc *r, const float *qs,
     hipStream_t st = (hipStream_t)stream;
     float *qsT = (float *)workspace;
     launch_transpose(r->T, r->U, qs, qsT, st);
-    if (r->NPAIR > 0) hipLaunchKernelGGL(k_gage_uh, dim3((r->NPAIR + 63) / 64), dim3(64), 0, st, *r, uh);
-    hipLaunchKernelGGL(k_gage_fwd, dim3((r->T + GAGE_TILE - 1) / GAGE_TILE, r->G), dim3(GAGE_TILE), 0, st, *r,
-                       qsT, uh, out);
+    if (r->NPAIR > 0) hipLaunchKernelGGL(k_gage_uh, dim3(r->NPAIR), dim3(128), 0, st, *r, uh);
+    float *lag = qsT + ((int64_t)2 * r->U + r->G) * r->T;
+    if (r->NPAIR > 0)
+        hipLaunchKernelGGL(k_gage_lag_fwd, dim3(r->NPAIR, (r->T + GAGE_TILE4 - 1) / GAGE_TILE4), dim3(GAGE_TILE), 0,
+                           st, *r, qsT, uh, lag);
+    hipLaunchKernelGGL(k_gage_sum_fwd, dim3((r->T + 255) / 256, r->G), dim3(256), 0, st, *r, lag, out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "hbvx_gage_route_forward launch");
     return HBVX_OK;
@@ -1380,8 +1384,11 @@ extern "C" int hbvx_gage_route_backward(const hbvx_gage_desc *r, const float *qs
     float *gqsT = goT + (int64_t)r->G * r->T;
     launch_transpose(r->T, r->U, qs, qsT, st);
     launch_transpose(r->T, r->G, grad_out, goT, st);
-    hipLaunchKernelGGL(k_gage_bwd_q, dim3((r->T + GAGE_TILE - 1) / GAGE_TILE, r->U), dim3(GAGE_TILE), 0, st, *r,
-                       uh, goT, gqsT);
+    float *lag = gqsT + (int64_t)r->U * r->T;
+    if (r->NPAIR > 0)
+        hipLaunchKernelGGL(k_gage_lag_bwd, dim3(r->NPAIR, (r->T + GAGE_TILE4 - 1) / GAGE_TILE4), dim3(GAGE_TILE), 0,
+                           st, *r, uh, goT, lag);
+    hipLaunchKernelGGL(k_gage_sum_bwd, dim3((r->T + 255) / 256, r->U), dim3(256), 0, st, *r, lag, gqsT);
     launch_transpose(r->U, r->T, gqsT, grad_qs, st);
     if (r->NPAIR > 0)
         hipLaunchKernelGGL(k_gage_bwd_p, dim3(r->NPAIR), dim3(GAGE_TILE), 0, st, *r, qsT, goT, grad_dp);
