@@ -86,7 +86,16 @@ class GageDesc(C.Structure):
                 ("tau_lo", C.c_float), ("tau_hi", C.c_float)]
 
 
-EXPORTS = ["hbvx_version", "hbvx_last_error", "hbvx_backend", "hbvx_sizeof", "hbvx_forward",
+class LstmDesc(C.Structure):
+    """include/hbvx_lstm.h"""
+    _fields_ = [("abi_version", C.c_int32), ("T", C.c_int32), ("B", C.c_int32), ("H", C.c_int32)]
+
+
+LSTM_ABI_VERSION = 1
+LSTM_HIDDEN_SIZES = (64, 128, 256)     # what the HIP library instantiates
+
+EXPORTS = ["hbvx_lstm_workspace_bytes", "hbvx_lstm_forward", "hbvx_lstm_backward", "hbvx_lstm_check",
+           "hbvx_version", "hbvx_last_error", "hbvx_backend", "hbvx_sizeof", "hbvx_forward",
            "hbvx_backward", "hbvx_backward_workspace_bytes", "hbvx_route_forward", "hbvx_route_workspace_bytes",
            "hbvx_route_backward", "hbvx_adj_forward", "hbvx_adj_backward", "hbvx_bfi",
            "hbvx_gage_route_forward", "hbvx_gage_route_backward",
@@ -140,6 +149,16 @@ class Library:
                                                C.c_void_p]
         d.hbvx_bfi.restype = C.c_int
         d.hbvx_bfi.argtypes = [C.c_int32, C.c_int32, _fp, _fp, C.c_float, _fp, C.c_void_p]
+        d.hbvx_lstm_workspace_bytes.restype = C.c_uint64
+        d.hbvx_lstm_workspace_bytes.argtypes = [C.POINTER(LstmDesc)]
+        d.hbvx_lstm_forward.restype = C.c_int
+        d.hbvx_lstm_forward.argtypes = [C.POINTER(LstmDesc), _fp, _fp, _fp, _fp, _fp, C.c_void_p, C.c_uint64,
+                                        C.c_void_p]
+        d.hbvx_lstm_backward.restype = C.c_int
+        d.hbvx_lstm_backward.argtypes = [C.POINTER(LstmDesc), _fp, _fp, _fp, _fp, _fp, C.c_void_p, C.c_uint64,
+                                         C.c_void_p]
+        d.hbvx_lstm_check.restype = C.c_int
+        d.hbvx_lstm_check.argtypes = [C.POINTER(LstmDesc), C.c_void_p, C.c_void_p]
         if d.hbvx_version() != ABI_VERSION:
             raise HbvxError(f"{path}: ABI version {d.hbvx_version()} != {ABI_VERSION}")
         for which, st in enumerate([Desc, FwdOut, BwdIO, RouteDesc, ParamSrc, ParamGrad, GageDesc]):
@@ -188,6 +207,22 @@ class Library:
         self._check(self.dll.hbvx_gage_route_backward(C.byref(r), qs, uh, go, gqs, gdp, ws,
                                                       C.c_uint64(ws_bytes), C.c_void_p(stream)),
                     "hbvx_gage_route_backward")
+
+    def lstm_workspace_bytes(self, r: LstmDesc) -> int:
+        return int(self.dll.hbvx_lstm_workspace_bytes(C.byref(r)))
+
+    def lstm_forward(self, r: LstmDesc, w_hh: int, gx: int, gates: int, c_all: int, h_all: int, ws,
+                     ws_bytes: int, stream: int):
+        self._check(self.dll.hbvx_lstm_forward(C.byref(r), w_hh, gx, gates, c_all, h_all, ws,
+                                               C.c_uint64(ws_bytes), C.c_void_p(stream)), "hbvx_lstm_forward")
+
+    def lstm_backward(self, r: LstmDesc, w_hh: int, gates: int, c_all: int, gh: int, gg: int, ws,
+                      ws_bytes: int, stream: int):
+        self._check(self.dll.hbvx_lstm_backward(C.byref(r), w_hh, gates, c_all, gh, gg, ws,
+                                                C.c_uint64(ws_bytes), C.c_void_p(stream)), "hbvx_lstm_backward")
+
+    def lstm_check(self, r: LstmDesc, ws, stream: int):
+        self._check(self.dll.hbvx_lstm_check(C.byref(r), ws, C.c_void_p(stream)), "hbvx_lstm_check")
 
     def bfi(self, T: int, B: int, qs: int, q2: int, nearzero: float, out: int, stream: int):
         self._check(self.dll.hbvx_bfi(T, B, qs, q2, C.c_float(nearzero), out, C.c_void_p(stream)),

@@ -19,6 +19,8 @@
 #include "hbv_tiled.h"
 #include "hbv_adj_kernels.h"
 #include "hbv_gage.h"
+#include "lstm_seq.h"
+#include "../../include/hbvx_lstm.h"
 #include "hbv_chunked.h"
 #include "hbv_pipe.h"
 #include "hbv_stream.h"
@@ -1404,3 +1406,117 @@ extern "C" int hbvx_debug_pipe_probe(unsigned long long *out32)
     return e == hipSuccess ? 0 : -1;
 }
 #endif
+
+// ---------------------------------------------------------------------------
+// sequence LSTM (include/hbvx_lstm.h; kernels in lstm_seq.h)
+// ---------------------------------------------------------------------------
+static int check_lstm(const hbvx_lstm_desc *d)
+{
+    if (!d) return fail(HBVX_E_NULL, "lstm desc is NULL");
+    if (d->abi_version != HBVX_LSTM_ABI_VERSION) return fail(HBVX_E_ABI, "lstm abi_version mismatch");
+    if (d->T <= 0 || d->B <= 0) return fail(HBVX_E_SHAPE, "lstm T/B out of range");
+    if (d->H != 64 && d->H != 128 && d->H != 256)
+        return fail(HBVX_E_UNSUPPORTED, "lstm hidden size must be 64, 128 or 256");
+    return 0;
+}
+
+static uint64_t lstm_counter_bytes(const hbvx_lstm_desc *d)
+{
+    const uint64_t ntile = ((uint64_t)d->B + LSTM_ROWS - 1) / LSTM_ROWS;
+    return ((ntile + 1) * sizeof(unsigned) + 255) / 256 * 256;
+}
+
+extern "C" uint64_t hbvx_lstm_workspace_bytes(const hbvx_lstm_desc *d)
+{
+    if (!d || d->T <= 0 || d->B <= 0 || d->H <= 0) return 0;
+    const uint64_t ntile = ((uint64_t)d->B + LSTM_ROWS - 1) / LSTM_ROWS;
+    // backward slabs (4 gates per unit) are the larger ones
+    return lstm_counter_bytes(d) + (uint64_t)d->T * ntile * d->H * LSTM_ROWS * 4 * sizeof(float);
+}
+
+template <typename K>
+static hipError_t launch_lstm(K kern, LstmArgs a, int H, hipStream_t st)
+{
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+            v = 256;
+        n_cu = v;
+    }
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LSTM_LDS_PAD);
+    if (e != hipSuccess) return e;
+    // one workgroup per CU and never more workgroups than CUs: every partner of a row tile is resident
+    const int nwg = H / LSTM_UNITS;
+    const int per_launch = n_cu / nwg > 0 ? n_cu / nwg : 1;
+    for (int t0 = 0; t0 < a.ntile; t0 += per_launch) {
+        a.tile0 = t0;
+        const int nt = a.ntile - t0 < per_launch ? a.ntile - t0 : per_launch;
+        hipLaunchKernelGGL(kern, dim3(nt * nwg), dim3(256), LSTM_LDS_PAD, st, a);
+    }
+    return hipGetLastError();
+}
+
+extern "C" int hbvx_lstm_forward(const hbvx_lstm_desc *d, const float *w_hh, const float *gx, float *gates,
+                                 float *c_all, float *h_all, void *workspace, uint64_t workspace_bytes,
+                                 void *stream)
+{
+    int rc = check_lstm(d);
+    if (rc) return rc;
+    if (!w_hh || !gx || !gates || !c_all || !h_all) return fail(HBVX_E_NULL, "lstm buffer is NULL");
+    if (!workspace || workspace_bytes < hbvx_lstm_workspace_bytes(d))
+        return fail(HBVX_E_NULL, "lstm workspace missing or too small");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(workspace, 0, lstm_counter_bytes(d), st);
+    if (e != hipSuccess) return hip_fail(e, "hbvx_lstm_forward memset");
+    LstmArgs a{};
+    a.T = d->T; a.B = d->B; a.ntile = (d->B + LSTM_ROWS - 1) / LSTM_ROWS;
+    a.w_hh = w_hh; a.gx = gx; a.gates = gates; a.c_all = c_all; a.h_all = h_all;
+    a.cnt = (unsigned *)workspace;
+    a.xch = (float *)((char *)workspace + lstm_counter_bytes(d));
+    e = d->H == 64 ? launch_lstm(k_lstm_fwd<64>, a, 64, st)
+      : d->H == 128 ? launch_lstm(k_lstm_fwd<128>, a, 128, st) : launch_lstm(k_lstm_fwd<256>, a, 256, st);
+    if (e != hipSuccess) return hip_fail(e, "hbvx_lstm_forward launch");
+    return 0;
+}
+
+extern "C" int hbvx_lstm_backward(const hbvx_lstm_desc *d, const float *w_hh, const float *gates,
+                                  const float *c_all, const float *grad_h, float *grad_gates,
+                                  void *workspace, uint64_t workspace_bytes, void *stream)
+{
+    int rc = check_lstm(d);
+    if (rc) return rc;
+    if (!w_hh || !gates || !c_all || !grad_h || !grad_gates) return fail(HBVX_E_NULL, "lstm buffer is NULL");
+    if (gates == grad_gates) return fail(HBVX_E_UNSUPPORTED, "lstm grad_gates must not alias gates");
+    if (!workspace || workspace_bytes < hbvx_lstm_workspace_bytes(d))
+        return fail(HBVX_E_NULL, "lstm workspace missing or too small");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(workspace, 0, lstm_counter_bytes(d), st);
+    if (e != hipSuccess) return hip_fail(e, "hbvx_lstm_backward memset");
+    LstmArgs a{};
+    a.T = d->T; a.B = d->B; a.ntile = (d->B + LSTM_ROWS - 1) / LSTM_ROWS;
+    a.w_hh = w_hh; a.gx = gates; a.gates = grad_gates; a.c_in = c_all; a.dh = grad_h;
+    a.cnt = (unsigned *)workspace;
+    a.xch = (float *)((char *)workspace + lstm_counter_bytes(d));
+    e = d->H == 64 ? launch_lstm(k_lstm_bwd<64>, a, 64, st)
+      : d->H == 128 ? launch_lstm(k_lstm_bwd<128>, a, 128, st) : launch_lstm(k_lstm_bwd<256>, a, 256, st);
+    if (e != hipSuccess) return hip_fail(e, "hbvx_lstm_backward launch");
+    return 0;
+}
+
+extern "C" int hbvx_lstm_check(const hbvx_lstm_desc *d, const void *workspace, void *stream)
+{
+    int rc = check_lstm(d);
+    if (rc) return rc;
+    if (!workspace) return fail(HBVX_E_NULL, "lstm workspace is NULL");
+    const int ntile = (d->B + LSTM_ROWS - 1) / LSTM_ROWS;
+    unsigned word = 0;
+    hipError_t e = hipMemcpyAsync(&word, (const unsigned *)workspace + ntile, sizeof word, hipMemcpyDeviceToHost,
+                                  (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "hbvx_lstm_check");
+    if (word) return fail(HBVX_E_DEVICE, "lstm hand-off timed out: the workgroups of a row tile were not co-resident");
+    return 0;
+}

@@ -1,0 +1,235 @@
+// lstm_seq.h -- the caller side of the hot path: the parameter network that
+// feeds hbvx_forward is an LSTM over the same [T, B] grid (delta-MG's CudnnLstmModel; not part of the
+// reference repository).  Once the HBV recurrence costs well under a millisecond the per-step
+// launches of a library LSTM dominate a training step, so the recurrence is one persistent kernel
+// per direction:
+//
+//   gates_t = gx_t + h_{t-1} W_hh^T          (gx = x W_ih^T + b_ih + b_hh: one library GEMM, host side)
+//   i, f, o = sigmoid, g = tanh;  c_t = f c_{t-1} + i g;  h_t = o tanh(c_t)      (torch.nn.LSTM)
+//
+// Basins are independent, so the batch is cut into row tiles of 16 basins (the N of
+// v_mfma_f32_16x16x4_f32: exact f32 products, a k-ordered fmaf chain) and only the H/16 workgroups
+// that share a row tile ever talk to each other.  Forward: wave = 4 hidden units x 4 gates (the 16
+// MFMA rows), its W_hh rows live in registers for the whole sequence (H/4 VGPRs), h_{t-1} of the
+// tile arrives as H/16 16-byte loads per lane.  Backward: workgroup = 16 hidden units, its 4 waves
+// split the 4H gate rows of dh_{t-1} = dgates_t W_hh (again H/4 VGPRs of W_hh each), partial tiles
+// are summed through LDS in wave order, then one thread per (unit, basin) does the cell adjoint.
+// Gate vectors use the (unit, gate) layout [T,B,H,4] so that a lane's four gates are one 16-byte access.
+//
+// Hand-off between the workgroups of a row tile, once per time step (MI355X_MICROARCH.md,
+// "inter-workgroup visibility", third measured row): every storing wave writes whole 128-byte lines
+// with sc1 stores, waits vmcnt(0) and adds 1 to the tile's counter (agent scope); wave 0 of a
+// consumer polls the counter with sc1 loads, a workgroup barrier follows, then every load of the
+// handed-off bytes is an sc1 buffer load.  The exchange buffers are written once per launch (one
+// slab per time step, never reused), one workgroup per CU (LDS padding), and a launch never holds
+// more workgroups than the chip has CUs, so all partners are resident.  Every spin is bounded: on a
+// time-out the tile gives up, sets the error word (hbvx_lstm_check) and poisons its outputs.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define LSTM_ROWS 16                 // basins per row tile
+#define LSTM_UNITS 16                // hidden units per workgroup
+#define LSTM_SPIN_LIMIT (1u << 21)   // polls before a tile gives up (seconds, not minutes)
+#define LSTM_LDS_PAD (81 * 1024)     // dynamic LDS request: more than half a CU => one workgroup per CU
+#define LSTM_SC1 16                  // buffer-instruction cache-policy bit: sc1
+
+typedef float lstm_f4 __attribute__((ext_vector_type(4)));
+
+struct LstmArgs {
+    int T, B, tile0, ntile;          // this launch covers row tiles tile0 ..; ntile = tiles of the whole batch
+    const float *w_hh;               // [4H,H], torch row order (i, f, g, o blocks)
+    const float *gx;                 // forward: [T,B,H,4] input projection; backward: activated gates
+    float *gates;                    // forward: activated gates (may alias gx); backward: grad of the pre-activations
+    const float *c_in;               // backward: c_all
+    const float *dh;                 // backward: grad_h [T,B,H]
+    float *c_all, *h_all;            // forward outputs [T,B,H]
+    float *xch;                      // exchange slabs, one per time step and row tile
+    unsigned *cnt;                   // [ntile] arrival counters (zeroed by the host), cnt[ntile] = error word
+};
+
+__device__ __forceinline__ float lstm_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// wave 0 waits until `need` waves have published; the result reaches the other waves through LDS
+__device__ __forceinline__ bool lstm_wait(const LstmArgs &a, int tile, unsigned need, int *s_ok)
+{
+    if ((threadIdx.x >> 6) == 0) {
+        int ok = 1;
+        unsigned spins = 0;
+        while (__hip_atomic_load(&a.cnt[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > LSTM_SPIN_LIMIT) {
+                ok = 0;
+                break;
+            }
+        }
+        if (threadIdx.x == 0) {
+            *s_ok = ok;
+            if (!ok) __hip_atomic_store(&a.cnt[a.ntile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    return *s_ok != 0;
+}
+
+__device__ __forceinline__ void lstm_publish(const LstmArgs &a, int tile)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if ((threadIdx.x & 63) == 0)
+        __hip_atomic_fetch_add(&a.cnt[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int H>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_lstm_fwd(LstmArgs a)
+{
+    constexpr int NWG = H / LSTM_UNITS, KB = H / 16;
+    __shared__ int s_ok;
+    const int tile = a.tile0 + blockIdx.x / NWG, s = blockIdx.x % NWG;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, kq = l >> 4, n = l & 15;
+    const int u0 = s * LSTM_UNITS + w * 4;          // the wave's four units
+    const int unit = u0 + kq;                       // this lane's unit in the result tile
+    const int row = tile * LSTM_ROWS + n, rowc = row < a.B ? row : a.B - 1;
+    const bool live = row < a.B;
+
+    // A operand: MFMA row m = 4*unit_local + gate; k of block (j, i) = 16 j + 4 kq + i, like the loads
+    float wreg[KB * 4];
+    {
+        const int m = l & 15;
+        const float *wr = a.w_hh + (size_t)((m & 3) * H + u0 + (m >> 2)) * H + 4 * kq;
+#pragma unroll
+        for (int j = 0; j < KB; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wreg[j * 4 + i] = wr[16 * j + i];
+    }
+    const size_t slab = (size_t)H * LSTM_ROWS;      // floats per (step, tile): [H/4][16 rows][4 units]
+    float c = 0.0f;
+    for (int t = 0; t < a.T; ++t) {
+        const size_t e = ((size_t)t * a.B + rowc) * H + unit;
+        lstm_f4 acc = *reinterpret_cast<const lstm_f4 *>(a.gx + e * 4);
+        if (t > 0) {
+            if (!lstm_wait(a, tile, (unsigned)(NWG * 4) * (unsigned)t, &s_ok)) {
+                if (live) a.h_all[((size_t)(a.T - 1) * a.B + row) * H + unit] = __builtin_nanf("");
+                return;
+            }
+            const float *hp = a.xch + ((size_t)(t - 1) * a.ntile + tile) * slab;
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(hp), 0, (int)(slab * 4), 0x00020000);
+            lstm_f4 hv[KB];
+#pragma unroll
+            for (int j = 0; j < KB; ++j)
+                hv[j] = __builtin_bit_cast(lstm_f4, __builtin_amdgcn_raw_buffer_load_b128(r, ((4 * j + kq) * LSTM_ROWS + n) * 16, 0, LSTM_SC1));
+            __builtin_amdgcn_sched_barrier(0);      // all loads in flight before the first MFMA
+            lstm_f4 p1 = {0, 0, 0, 0}, p2 = {0, 0, 0, 0}, p3 = {0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < KB; ++j) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float av = wreg[j * 4 + i], bv = hv[j][i];
+                    if (i == 0) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+                    else if (i == 1) p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, p1, 0, 0, 0);
+                    else if (i == 2) p2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, p2, 0, 0, 0);
+                    else p3 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, p3, 0, 0, 0);
+                }
+            }
+            acc = (acc + p1) + (p2 + p3);
+        }
+        const float ig = lstm_sigmoid(acc[0]), fg = lstm_sigmoid(acc[1]), gg = tanhf(acc[2]), og = lstm_sigmoid(acc[3]);
+        c = fg * c + ig * gg;
+        const float h = og * tanhf(c);
+        if (live) {
+            const lstm_f4 act = {ig, fg, gg, og};
+            *reinterpret_cast<lstm_f4 *>(a.gates + e * 4) = act;
+            a.c_all[e] = c;
+            a.h_all[e] = h;
+        }
+        if (t + 1 < a.T) {
+            // the wave's 64 lanes cover 256 contiguous bytes: two whole lines, one store instruction
+            float *xp = a.xch + ((size_t)t * a.ntile + tile) * slab + ((size_t)(u0 >> 2) * LSTM_ROWS + n) * 4 + kq;
+            __hip_atomic_store(xp, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lstm_publish(a, tile);
+        }
+    }
+}
+
+template <int H>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_lstm_bwd(LstmArgs a)
+{
+    constexpr int NWG = H / LSTM_UNITS, KB = H / 16;
+    __shared__ int s_ok;
+    __shared__ float part[4][4][64];
+    const int tile = a.tile0 + blockIdx.x / NWG, s = blockIdx.x % NWG;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, kq = l >> 4, n = l & 15;
+    const int unit = s * LSTM_UNITS + 4 * kq + w;   // this thread's unit in the cell adjoint
+    const int row = tile * LSTM_ROWS + n, rowc = row < a.B ? row : a.B - 1;
+    const bool live = row < a.B;
+
+    // A operand: MFMA row m = hidden unit 16 s + m; the wave's quarter of the gate rows:
+    // k of block (j, i) = gate i of unit w H/4 + 4 j + kq
+    float wreg[KB * 4];
+    {
+        const int m = l & 15;
+#pragma unroll
+        for (int j = 0; j < KB; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                wreg[j * 4 + i] = a.w_hh[(size_t)(i * H + w * (H / 4) + 4 * j + kq) * H + s * LSTM_UNITS + m];
+    }
+    const size_t slab = (size_t)H * LSTM_ROWS * 4;  // floats per (step, tile): [H units][16 rows][4 gates]
+    float dc_carry = 0.0f;
+    for (int t = a.T - 1; t >= 0; --t) {
+        const size_t e = ((size_t)t * a.B + rowc) * H + unit;
+        const lstm_f4 act = *reinterpret_cast<const lstm_f4 *>(a.gx + e * 4);
+        const float ct = a.c_in[e];
+        const float cp = t > 0 ? a.c_in[e - (size_t)a.B * H] : 0.0f;
+        float dh = a.dh[e];
+        if (t + 1 < a.T) {
+            if (!lstm_wait(a, tile, (unsigned)(NWG * 4) * (unsigned)(a.T - 1 - t), &s_ok)) {
+                if (live) {
+                    const lstm_f4 bad = {__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+                    *reinterpret_cast<lstm_f4 *>(a.gates + (((size_t)0 * a.B + row) * H + unit) * 4) = bad;
+                }
+                return;
+            }
+            const float *gp = a.xch + ((size_t)(t + 1) * a.ntile + tile) * slab;
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(gp), 0, (int)(slab * 4), 0x00020000);
+            lstm_f4 gv[KB];
+#pragma unroll
+            for (int j = 0; j < KB; ++j)
+                gv[j] = __builtin_bit_cast(lstm_f4, __builtin_amdgcn_raw_buffer_load_b128(r, ((w * (H / 4) + 4 * j + kq) * LSTM_ROWS + n) * 16, 0, LSTM_SC1));
+            __builtin_amdgcn_sched_barrier(0);      // all loads in flight before the first MFMA
+            lstm_f4 p0 = {0, 0, 0, 0}, p1 = {0, 0, 0, 0}, p2 = {0, 0, 0, 0}, p3 = {0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < KB; ++j) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float av = wreg[j * 4 + i], bv = gv[j][i];
+                    if (i == 0) p0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, p0, 0, 0, 0);
+                    else if (i == 1) p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, p1, 0, 0, 0);
+                    else if (i == 2) p2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, p2, 0, 0, 0);
+                    else p3 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, p3, 0, 0, 0);
+                }
+            }
+            p0 = (p0 + p1) + (p2 + p3);
+            // result row m = 4 kq + i of the 16 units: thread (w, l) finishes i = w
+#pragma unroll
+            for (int i = 0; i < 4; ++i) part[w][i][l] = p0[i];
+            __syncthreads();
+            dh += (part[0][w][l] + part[1][w][l]) + (part[2][w][l] + part[3][w][l]);
+        }
+        const float ig = act[0], fg = act[1], gg = act[2], og = act[3];
+        const float tc = tanhf(ct);
+        const float dc = dc_carry + dh * og * (1.0f - tc * tc);
+        lstm_f4 d;
+        d[0] = dc * gg * ig * (1.0f - ig);
+        d[1] = dc * cp * fg * (1.0f - fg);
+        d[2] = dc * ig * (1.0f - gg * gg);
+        d[3] = dh * tc * og * (1.0f - og);
+        dc_carry = dc * fg;
+        if (live) *reinterpret_cast<lstm_f4 *>(a.gates + e * 4) = d;
+        if (t > 0) {
+            // 16 lanes of one store instruction cover a unit's 256-byte block: whole lines
+            float *xp = a.xch + ((size_t)t * a.ntile + tile) * slab + ((size_t)unit * LSTM_ROWS + n) * 4;
+            const lstm_f4 dx = live ? d : lstm_f4{0, 0, 0, 0};
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(xp), "v"(dx) : "memory");
+            lstm_publish(a, tile);
+        }
+    }
+}

@@ -1250,3 +1250,119 @@ int hbvx_gage_route_backward(const hbvx_gage_desc *r, const float *qs, const flo
     }
     return HBVX_OK;
 }
+
+/* ------------------------------------------------------------------------- */
+/* Sequence LSTM (include/hbvx_lstm.h): the caller side of the hot path
+ * (not in the reference repository).  Semantics are
+ * torch.nn.LSTM's, one layer, zero initial state:
+ *   gates = x W_ih^T + b_ih + h_{t-1} W_hh^T + b_hh ; i, f, o = sigmoid, g = tanh ;
+ *   c_t = f c_{t-1} + i g ; h_t = o tanh(c_t).
+ * tests/test_lstm.py pins this restatement against torch.nn.LSTM on the CPU
+ * (values and autograd gradients). */
+#include "../include/hbvx_lstm.h"
+
+static int check_lstm(const hbvx_lstm_desc *d)
+{
+    if (!d) return fail(HBVX_E_NULL, "lstm desc is NULL");
+    if (d->abi_version != HBVX_LSTM_ABI_VERSION) return fail(HBVX_E_ABI, "lstm abi_version mismatch");
+    if (d->T <= 0 || d->B <= 0 || d->H <= 0) return fail(HBVX_E_SHAPE, "lstm T/B/H out of range");
+    return 0;
+}
+
+uint64_t hbvx_lstm_workspace_bytes(const hbvx_lstm_desc *d)
+{
+    (void)d;
+    return 0;
+}
+
+static float lstm_sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+int hbvx_lstm_forward(const hbvx_lstm_desc *d, const float *w_hh, const float *gx, float *gates,
+                      float *c_all, float *h_all, void *workspace, uint64_t workspace_bytes,
+                      void *stream)
+{
+    (void)workspace; (void)workspace_bytes; (void)stream;
+    int rc = check_lstm(d);
+    if (rc) return rc;
+    if (!w_hh || !gx || !gates || !c_all || !h_all) return fail(HBVX_E_NULL, "lstm buffer is NULL");
+    const int T = d->T, B = d->B, H = d->H;
+#pragma omp parallel for schedule(static)
+    for (int b = 0; b < B; ++b) {
+        for (int t = 0; t < T; ++t) {
+            const float *hp = t ? h_all + ((size_t)(t - 1) * B + b) * H : NULL;
+            const float *cp = t ? c_all + ((size_t)(t - 1) * B + b) * H : NULL;
+            for (int u = 0; u < H; ++u) {
+                const size_t e = ((size_t)t * B + b) * H + u;
+                float pre[4];
+                for (int g = 0; g < 4; ++g) {
+                    float acc = gx[e * 4 + g];
+                    if (hp)
+                        for (int k = 0; k < H; ++k) acc += w_hh[((size_t)g * H + u) * H + k] * hp[k];
+                    pre[g] = acc;
+                }
+                const float ig = lstm_sigmoidf(pre[0]), fg = lstm_sigmoidf(pre[1]);
+                const float gg = tanhf(pre[2]), og = lstm_sigmoidf(pre[3]);
+                const float c = fg * (cp ? cp[u] : 0.0f) + ig * gg;
+                gates[e * 4 + 0] = ig; gates[e * 4 + 1] = fg; gates[e * 4 + 2] = gg; gates[e * 4 + 3] = og;
+                c_all[e] = c;
+                h_all[e] = og * tanhf(c);
+            }
+        }
+    }
+    return 0;
+}
+
+int hbvx_lstm_backward(const hbvx_lstm_desc *d, const float *w_hh, const float *gates,
+                       const float *c_all, const float *grad_h, float *grad_gates,
+                       void *workspace, uint64_t workspace_bytes, void *stream)
+{
+    (void)workspace; (void)workspace_bytes; (void)stream;
+    int rc = check_lstm(d);
+    if (rc) return rc;
+    if (!w_hh || !gates || !c_all || !grad_h || !grad_gates) return fail(HBVX_E_NULL, "lstm buffer is NULL");
+    if (gates == grad_gates) return fail(HBVX_E_UNSUPPORTED, "lstm grad_gates must not alias gates");
+    const int T = d->T, B = d->B, H = d->H;
+    int bad = 0;
+#pragma omp parallel for schedule(static)
+    for (int b = 0; b < B; ++b) {
+        float *dc = (float *)calloc((size_t)H, sizeof(float));
+        float *dhr = (float *)calloc((size_t)H, sizeof(float));
+        if (!dc || !dhr) {
+            bad = 1;
+            free(dc); free(dhr);
+            continue;
+        }
+        for (int t = T - 1; t >= 0; --t) {
+            for (int u = 0; u < H; ++u) {
+                const size_t e = ((size_t)t * B + b) * H + u;
+                const float ig = gates[e * 4], fg = gates[e * 4 + 1], gg = gates[e * 4 + 2], og = gates[e * 4 + 3];
+                const float cp = t ? c_all[e - (size_t)B * H] : 0.0f;
+                const float tc = tanhf(c_all[e]);
+                const float dh = grad_h[e] + dhr[u];
+                const float dcu = dc[u] + dh * og * (1.0f - tc * tc);
+                grad_gates[e * 4 + 0] = dcu * gg * ig * (1.0f - ig);
+                grad_gates[e * 4 + 1] = dcu * cp * fg * (1.0f - fg);
+                grad_gates[e * 4 + 2] = dcu * ig * (1.0f - gg * gg);
+                grad_gates[e * 4 + 3] = dh * tc * og * (1.0f - og);
+                dc[u] = dcu * fg;
+            }
+            /* dh_{t-1} = dgates_t W_hh */
+            for (int k = 0; k < H; ++k) dhr[k] = 0.0f;
+            if (t)
+                for (int u = 0; u < H; ++u)
+                    for (int g = 0; g < 4; ++g) {
+                        const float dg = grad_gates[(((size_t)t * B + b) * H + u) * 4 + g];
+                        const float *wr = w_hh + ((size_t)g * H + u) * H;
+                        for (int k = 0; k < H; ++k) dhr[k] += dg * wr[k];
+                    }
+        }
+        free(dc); free(dhr);
+    }
+    return bad ? fail(HBVX_E_DEVICE, "lstm: out of memory") : 0;
+}
+
+int hbvx_lstm_check(const hbvx_lstm_desc *d, const void *workspace, void *stream)
+{
+    (void)workspace; (void)stream;
+    return check_lstm(d);
+}

@@ -78,7 +78,8 @@ def test_load_states_validation():
 
 # --- the C ABI library itself (no compute: there is no GPU here) ---
 def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "hbvx.h")).read()
+    inc = os.path.join(ROOT, "include")
+    text = "\n".join(open(os.path.join(inc, f)).read() for f in sorted(os.listdir(inc)) if f.endswith(".h"))
     return sorted(set(re.findall(r"^(?:int|uint64_t|const char \*)\s*(hbvx_[a-z_0-9]+)\s*\(", text,
                                  flags=re.M)))
 
@@ -88,7 +89,7 @@ def test_header_symbols_are_exported_by_the_hip_library():
     lib_path = ge.build_hip()
     dll = C.CDLL(lib_path)
     for sym in _declared_symbols():
-        assert hasattr(dll, sym), f"{sym} declared in include/hbvx.h but not exported"
+        assert hasattr(dll, sym), f"{sym} declared in include/*.h but not exported"
     lib = _abi.Library(lib_path)           # version + struct layout checks
     assert lib.backend == "hip:gfx950"
 

@@ -1,0 +1,111 @@
+"""Sequence LSTM of the parameter network (include/hbvx_lstm.h, hydrodl2_amd/lstm.py; SURVEY.md §8f
+rank 4).  Semantics are torch.nn.LSTM's, so torch's own fp32 / fp64 LSTM on the CPU is the reference:
+CPU tier pins oracle/hbv_oracle.c's restatement against it, GPU tier the HIP kernels.
+
+Tolerances (fp32 recurrence against an fp64 torch LSTM): outputs 2e-5 absolute (|h| <= 1), gradients
+2e-4 relative to the largest entry of each gradient tensor."""
+import pytest
+import torch
+
+from hydrodl2_amd import _abi
+from hydrodl2_amd.lstm import SeqLSTM
+
+
+def _reference(mod: SeqLSTM, x, gh, dtype=torch.float64):
+    ref = torch.nn.LSTM(mod.input_size, mod.hidden_size).to(dtype)
+    ref.load_state_dict({k: v.detach().cpu().to(dtype) for k, v in mod.state_dict().items()})
+    xr = x.detach().cpu().to(dtype).requires_grad_(True)
+    out, (hn, cn) = ref(xr)
+    (out * gh.cpu().to(dtype)).sum().backward()
+    g = {k: p.grad for k, p in ref.named_parameters()}
+    g["x"] = xr.grad
+    return out, hn, cn, g
+
+
+def _run(device, T, B, I, H, seed=0):
+    torch.manual_seed(seed)
+    mod = SeqLSTM(I, H, check=True).to(device)
+    x = torch.randn(T, B, I, device=device, requires_grad=True)
+    gh = torch.randn(T, B, H, device=device)
+    out, (hn, cn) = mod(x)
+    (out * gh).sum().backward()
+    ref_out, ref_hn, ref_cn, g = _reference(mod, x, gh)
+    assert out.shape == (T, B, H) and hn.shape == (1, B, H) and cn.shape == (1, B, H)
+    assert torch.allclose(out.cpu().double(), ref_out, rtol=0, atol=2e-5), (out.cpu().double() - ref_out).abs().max()
+    assert torch.allclose(hn.cpu().double(), ref_hn, rtol=0, atol=2e-5)
+    assert torch.allclose(cn.cpu().double(), ref_cn, rtol=1e-5, atol=2e-5)
+    got = {k: p.grad for k, p in mod.named_parameters()}
+    got["x"] = x.grad
+    for k, want in g.items():
+        err = (got[k].cpu().double() - want).abs().max().item()
+        assert err <= 2e-4 * max(want.abs().max().item(), 1e-3), (k, err, want.abs().max().item())
+
+
+@pytest.mark.parametrize("T,B,I,H", [(1, 3, 5, 8), (7, 5, 4, 16), (40, 19, 11, 64)])
+def test_oracle_lstm_matches_torch(oracle_backend, T, B, I, H):
+    _run("cpu", T, B, I, H)
+
+
+def test_state_dict_interchanges_with_torch_lstm():
+    torch.manual_seed(0)
+    ref = torch.nn.LSTM(6, 64)
+    mod = SeqLSTM(6, 64)
+    mod.load_state_dict(ref.state_dict())
+    ref.load_state_dict(mod.state_dict())
+    assert [tuple(p.shape) for p in mod.parameters()] == [tuple(p.shape) for p in ref.parameters()]
+
+
+def test_lstm_fails_loudly_without_gpu_tensors():
+    from hydrodl2_amd import _lib
+    _lib._use_library_for_testing(None)
+    with pytest.raises(RuntimeError, match="GPU|HIP"):
+        SeqLSTM(4, 64)(torch.randn(3, 2, 4))
+
+
+def test_lstm_descriptor_validation():
+    import __graft_entry__ as ge
+    lib = _abi.Library(ge.build_hip())
+    r = _abi.LstmDesc(abi_version=0, T=4, B=2, H=64)
+    with pytest.raises(_abi.HbvxError, match="abi_version"):
+        lib.lstm_forward(r, 1, 1, 1, 1, 1, 1, 1 << 30, 0)
+    r.abi_version = _abi.LSTM_ABI_VERSION
+    r.H = 48
+    with pytest.raises(_abi.HbvxError, match="hidden size"):
+        lib.lstm_forward(r, 1, 1, 1, 1, 1, 1, 1 << 30, 0)
+    r.H = 64
+    with pytest.raises(_abi.HbvxError, match="workspace"):
+        lib.lstm_forward(r, 1, 1, 1, 1, 1, 1, 16, 0)
+    assert lib.lstm_workspace_bytes(r) >= 4 * 1 * 64 * 16 * 4 * 4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,B,I,H", [(1, 1, 3, 64), (2, 16, 7, 64), (50, 23, 11, 64), (33, 40, 64, 128),
+                                     (64, 100, 16, 256), (730, 100, 256, 256)])
+def test_hip_lstm_matches_torch(hip_backend, T, B, I, H):
+    _run("cuda", T, B, I, H)
+
+
+@pytest.mark.gpu
+def test_hip_lstm_more_row_tiles_than_one_launch_holds(hip_backend):
+    # 19 row tiles x 16 workgroups > 256 CUs: the host splits the batch into two launches
+    _run("cuda", 24, 300, 8, 256, seed=3)
+
+
+@pytest.mark.gpu
+def test_hip_lstm_is_deterministic_under_load(hip_backend):
+    """Same inputs, twice, with a bandwidth-heavy kernel running beside the second call on another
+    stream (uneven arrival at the hand-offs): bit-identical results."""
+    torch.manual_seed(1)
+    mod = SeqLSTM(32, 256, check=True).cuda()
+    x = torch.randn(200, 100, 32, device="cuda")
+    with torch.no_grad():
+        a, _ = mod(x)
+        big = torch.empty(64 << 20, device="cuda")
+        side = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            for _ in range(20):
+                big.mul_(1.0001)
+        b, _ = mod(x)
+        torch.cuda.synchronize()
+    assert torch.equal(a, b)

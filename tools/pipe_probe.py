@@ -18,7 +18,11 @@ lib = _lib.get_library()
 dev = torch.device("cuda:0")
 T, B, M = 7300, 671, 16
 DYN = os.environ.get("PROBE_DYN", "").split(",") if os.environ.get("PROBE_DYN") else []
-model = hydrodl2_amd.load_model("hbv", "Hbv")({"nmul": M, "dynamic_params": {"Hbv": DYN}}, dev)
+MOD, CLS = os.environ.get("PROBE_MODEL", "hbv:Hbv").split(":")
+H = hydrodl2_amd.load_model(MOD, CLS)
+if DYN == ["all"]:
+    DYN = list(H(None, dev).parameter_bounds)
+model = H({"nmul": M, "dynamic_params": {CLS: DYN}}, dev)
 print("dynamic:", DYN)
 x, g = gen(T, B, dev)
 p = torch.randn((T, B, model.learnable_param_count), generator=g, device=dev)
