@@ -3,6 +3,7 @@
 the caller side, outside the reference repository -- delta-MG style).
 
     python examples/train_dpl.py [--basins 100] [--rho 365] [--warm-up 365] [--nmul 16] [--steps 20]
+                                 [--lstm fused|torch]
     python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 examples/train_dpl.py ...
 
 A small LSTM maps normalised forcings + static attributes to the raw parameter tensor [T,B,ny];
@@ -26,15 +27,18 @@ import torch.distributed as dist  # noqa: E402
 
 import hydrodl2_amd  # noqa: E402
 from hydrodl2_amd import ops, sharding  # noqa: E402
+from hydrodl2_amd.lstm import SeqLSTM  # noqa: E402
 
 
 class ParamNet(torch.nn.Module):
     """LSTM parameterisation network: [T,B,n_in] -> raw parameters [T,B,ny]."""
 
-    def __init__(self, n_in: int, hidden: int, ny: int):
+    def __init__(self, n_in: int, hidden: int, ny: int, fused: bool = False):
         super().__init__()
         self.inp = torch.nn.Linear(n_in, hidden)
-        self.lstm = torch.nn.LSTM(hidden, hidden)
+        # fused: hydrodl2_amd.lstm.SeqLSTM (include/hbvx_lstm.h, one persistent kernel per direction);
+        # otherwise torch's own LSTM (MIOpen on the GPU).  Same parameters either way.
+        self.lstm = SeqLSTM(hidden, hidden) if fused else torch.nn.LSTM(hidden, hidden)
         self.out = torch.nn.Linear(hidden, ny)
 
     def forward(self, z):
@@ -72,6 +76,8 @@ def main():
     ap.add_argument("--hidden", type=int, default=256)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--device", default="cuda")
+    ap.add_argument("--lstm", choices=["fused", "torch"], default="fused",
+                    help="fused: the HIP sequence kernels of include/hbvx_lstm.h; torch: torch.nn.LSTM")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -103,7 +109,7 @@ def main():
         obs = Hbv(cfg, dev)({"x_phy": x}, truth(z))["streamflow"][:, :, 0]
 
     torch.manual_seed(2)                       # same initial network on every rank
-    net = ParamNet(3 + n_attr, args.hidden, ny).to(dev)
+    net = ParamNet(3 + n_attr, args.hidden, ny, fused=args.lstm == "fused").to(dev)
     opt = torch.optim.Adam(net.parameters(), lr=1e-3)
     params = [p for p in net.parameters()]
 
@@ -131,13 +137,16 @@ def main():
     if on_gpu:
         torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
-    hbv_ms = None
+    hbv_ms = lstm_ms = None
     if on_gpu:
         ev, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
-        hbv_ms = sum(e0.elapsed_time(e1) for _, e0, e1 in ev) / args.steps
+        hbv_ms = sum(e0.elapsed_time(e1) for n, e0, e1 in ev if "lstm" not in n) / args.steps
+        lstm_ms = sum(e0.elapsed_time(e1) for n, e0, e1 in ev if "lstm" in n) / args.steps
     if rank == 0:
         print(json.dumps({"basins": B, "nmul": M, "days": T, "world": world, "ms_per_step": round(dt * 1e3, 3),
+                          "lstm": args.lstm, "hidden": args.hidden,
                           "hbv_calls_ms": None if hbv_ms is None else round(hbv_ms, 3),
+                          "lstm_kernels_ms": None if not lstm_ms else round(lstm_ms, 3),
                           "loss_first": round(losses[0], 4), "loss_last": round(losses[-1], 4)}))
     if world > 1:
         dist.destroy_process_group()

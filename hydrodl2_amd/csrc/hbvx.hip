@@ -1420,18 +1420,27 @@ static int check_lstm(const hbvx_lstm_desc *d)
     return 0;
 }
 
-static uint64_t lstm_counter_bytes(const hbvx_lstm_desc *d)
+static uint64_t lstm_counter_bytes(const hbvx_lstm_desc *) { return 256; }   // the error word, on a line of its own
+
+// exchange slabs of one direction: forward [T][tiles][H][16] floats, backward four gates per unit
+static uint64_t lstm_slab_bytes(const hbvx_lstm_desc *d, bool backward)
 {
     const uint64_t ntile = ((uint64_t)d->B + LSTM_ROWS - 1) / LSTM_ROWS;
-    return ((ntile + 1) * sizeof(unsigned) + 255) / 256 * 256;
+    return (uint64_t)d->T * ntile * d->H * LSTM_ROWS * (backward ? 4 : 1) * sizeof(float);
+}
+
+static hipError_t lstm_prepare(const hbvx_lstm_desc *d, void *workspace, bool backward, hipStream_t st)
+{
+    hipError_t e = hipMemsetAsync(workspace, 0, lstm_counter_bytes(d), st);
+    if (e != hipSuccess) return e;
+    // every exchange word starts as the sentinel 0xFFFFFFFF (lstm_seq.h)
+    return hipMemsetAsync((char *)workspace + lstm_counter_bytes(d), 0xFF, lstm_slab_bytes(d, backward), st);
 }
 
 extern "C" uint64_t hbvx_lstm_workspace_bytes(const hbvx_lstm_desc *d)
 {
     if (!d || d->T <= 0 || d->B <= 0 || d->H <= 0) return 0;
-    const uint64_t ntile = ((uint64_t)d->B + LSTM_ROWS - 1) / LSTM_ROWS;
-    // backward slabs (4 gates per unit) are the larger ones
-    return lstm_counter_bytes(d) + (uint64_t)d->T * ntile * d->H * LSTM_ROWS * 4 * sizeof(float);
+    return lstm_counter_bytes(d) + lstm_slab_bytes(d, true);   // the backward slabs are the larger ones
 }
 
 template <typename K>
@@ -1469,7 +1478,7 @@ extern "C" int hbvx_lstm_forward(const hbvx_lstm_desc *d, const float *w_hh, con
     if (!workspace || workspace_bytes < hbvx_lstm_workspace_bytes(d))
         return fail(HBVX_E_NULL, "lstm workspace missing or too small");
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(workspace, 0, lstm_counter_bytes(d), st);
+    hipError_t e = lstm_prepare(d, workspace, false, st);
     if (e != hipSuccess) return hip_fail(e, "hbvx_lstm_forward memset");
     LstmArgs a{};
     a.T = d->T; a.B = d->B; a.ntile = (d->B + LSTM_ROWS - 1) / LSTM_ROWS;
@@ -1493,7 +1502,7 @@ extern "C" int hbvx_lstm_backward(const hbvx_lstm_desc *d, const float *w_hh, co
     if (!workspace || workspace_bytes < hbvx_lstm_workspace_bytes(d))
         return fail(HBVX_E_NULL, "lstm workspace missing or too small");
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(workspace, 0, lstm_counter_bytes(d), st);
+    hipError_t e = lstm_prepare(d, workspace, true, st);
     if (e != hipSuccess) return hip_fail(e, "hbvx_lstm_backward memset");
     LstmArgs a{};
     a.T = d->T; a.B = d->B; a.ntile = (d->B + LSTM_ROWS - 1) / LSTM_ROWS;
@@ -1511,12 +1520,11 @@ extern "C" int hbvx_lstm_check(const hbvx_lstm_desc *d, const void *workspace, v
     int rc = check_lstm(d);
     if (rc) return rc;
     if (!workspace) return fail(HBVX_E_NULL, "lstm workspace is NULL");
-    const int ntile = (d->B + LSTM_ROWS - 1) / LSTM_ROWS;
     unsigned word = 0;
-    hipError_t e = hipMemcpyAsync(&word, (const unsigned *)workspace + ntile, sizeof word, hipMemcpyDeviceToHost,
+    hipError_t e = hipMemcpyAsync(&word, (const unsigned *)workspace, sizeof word, hipMemcpyDeviceToHost,
                                   (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "hbvx_lstm_check");
-    if (word) return fail(HBVX_E_DEVICE, "lstm hand-off timed out: the workgroups of a row tile were not co-resident");
+    if (word) return fail(HBVX_E_DEVICE, "lstm hand-off timed out: the waves of a row tile were not co-resident");
     return 0;
 }

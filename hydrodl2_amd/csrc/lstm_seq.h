@@ -16,14 +16,17 @@
 // are summed through LDS in wave order, then one thread per (unit, basin) does the cell adjoint.
 // Gate vectors use the (unit, gate) layout [T,B,H,4] so that a lane's four gates are one 16-byte access.
 //
-// Hand-off between the workgroups of a row tile, once per time step (MI355X_MICROARCH.md,
-// "inter-workgroup visibility", third measured row): every storing wave writes whole 128-byte lines
-// with sc1 stores, waits vmcnt(0) and adds 1 to the tile's counter (agent scope); wave 0 of a
-// consumer polls the counter with sc1 loads, a workgroup barrier follows, then every load of the
-// handed-off bytes is an sc1 buffer load.  The exchange buffers are written once per launch (one
-// slab per time step, never reused), one workgroup per CU (LDS padding), and a launch never holds
-// more workgroups than the chip has CUs, so all partners are resident.  Every spin is bounded: on a
-// time-out the tile gives up, sets the error word (hbvx_lstm_check) and poisons its outputs.
+// Hand-off between the waves of a row tile, once per time step: the exchange buffer holds one slab per
+// time step and row tile, never reused inside a launch and filled with the sentinel word 0xFFFFFFFF by
+// the host (hipMemsetAsync) before the launch.  A producer writes its slice with sc1 stores (write
+// through, 4-byte granules are atomic) and goes on; a consumer re-issues its sc1 loads of the slab (L1
+// bypassed: MI355X_MICROARCH.md "inter-workgroup visibility") until none of the words it needs is the
+// sentinel -- the payload is its own flag, there are no counters, fences or barriers on the path, and a
+// word that is not the sentinel can only be the value written in this launch.  h and the gate gradients
+// are never the sentinel pattern (arithmetic NaNs are canonical 0x7FC00000).  One workgroup per CU (LDS
+// padding) and a launch never holds more workgroups than the chip has CUs, so all partners are
+// resident.  Every spin is bounded: on a time-out the wave gives up, sets the error word
+// (hbvx_lstm_check) and poisons its outputs.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -43,46 +46,47 @@ struct LstmArgs {
     const float *c_in;               // backward: c_all
     const float *dh;                 // backward: grad_h [T,B,H]
     float *c_all, *h_all;            // forward outputs [T,B,H]
-    float *xch;                      // exchange slabs, one per time step and row tile
-    unsigned *cnt;                   // [ntile] arrival counters (zeroed by the host), cnt[ntile] = error word
+    float *xch;                      // exchange slabs, one per time step and row tile, sentinel-filled by the host
+    unsigned *cnt;                   // cnt[0] = error word (zeroed by the host)
 };
 
 __device__ __forceinline__ float lstm_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// wave 0 waits until `need` waves have published; the result reaches the other waves through LDS
-__device__ __forceinline__ bool lstm_wait(const LstmArgs &a, int tile, unsigned need, int *s_ok)
-{
-    if ((threadIdx.x >> 6) == 0) {
-        int ok = 1;
-        unsigned spins = 0;
-        while (__hip_atomic_load(&a.cnt[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > LSTM_SPIN_LIMIT) {
-                ok = 0;
-                break;
-            }
-        }
-        if (threadIdx.x == 0) {
-            *s_ok = ok;
-            if (!ok) __hip_atomic_store(&a.cnt[a.ntile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    __syncthreads();
-    return *s_ok != 0;
-}
+#define LSTM_SENTINEL 0xFFFFFFFFu
+#define LSTM_AUX (LSTM_SC1 | 0x80000000)   // sc1 + volatile: the polling loads are never hoisted or merged
 
-__device__ __forceinline__ void lstm_publish(const LstmArgs &a, int tile)
+// Loads the wave's KB 16-byte granules per lane (granule g0 + 4 j + kq of row n) until none of them
+// holds a sentinel word.  false: timed out (error word set).
+template <int KB>
+__device__ __forceinline__ bool lstm_fetch(const LstmArgs &a, const float *slab_ptr, int slab_bytes, int g0,
+                                           int kq, int n, lstm_f4 (&v)[KB])
 {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if ((threadIdx.x & 63) == 0)
-        __hip_atomic_fetch_add(&a.cnt[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(slab_ptr), 0, slab_bytes, 0x00020000);
+    for (unsigned spins = 0;; ++spins) {
+#pragma unroll
+        for (int j = 0; j < KB; ++j)
+            v[j] = __builtin_bit_cast(lstm_f4, __builtin_amdgcn_raw_buffer_load_b128(r, ((g0 + 4 * j + kq) * LSTM_ROWS + n) * 16, 0, LSTM_AUX));
+        unsigned mx = 0;
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+            const auto u = __builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v[j]);
+            mx = max(max(mx, u[0]), u[1]);
+            mx = max(max(mx, u[2]), u[3]);
+        }
+        if (__ballot(mx == LSTM_SENTINEL) == 0) return true;
+        if (spins > LSTM_SPIN_LIMIT) {
+            if ((threadIdx.x & 63) == 0) __hip_atomic_store(&a.cnt[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(2);
+        asm volatile("" ::: "memory");
+    }
 }
 
 template <int H>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_lstm_fwd(LstmArgs a)
 {
     constexpr int NWG = H / LSTM_UNITS, KB = H / 16;
-    __shared__ int s_ok;
     const int tile = a.tile0 + blockIdx.x / NWG, s = blockIdx.x % NWG;
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63, kq = l >> 4, n = l & 15;
     const int u0 = s * LSTM_UNITS + w * 4;          // the wave's four units
@@ -106,17 +110,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         const size_t e = ((size_t)t * a.B + rowc) * H + unit;
         lstm_f4 acc = *reinterpret_cast<const lstm_f4 *>(a.gx + e * 4);
         if (t > 0) {
-            if (!lstm_wait(a, tile, (unsigned)(NWG * 4) * (unsigned)t, &s_ok)) {
+            lstm_f4 hv[KB];
+            if (!lstm_fetch<KB>(a, a.xch + ((size_t)(t - 1) * a.ntile + tile) * slab, (int)(slab * 4), 0, kq, n, hv)) {
                 if (live) a.h_all[((size_t)(a.T - 1) * a.B + row) * H + unit] = __builtin_nanf("");
                 return;
             }
-            const float *hp = a.xch + ((size_t)(t - 1) * a.ntile + tile) * slab;
-            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(hp), 0, (int)(slab * 4), 0x00020000);
-            lstm_f4 hv[KB];
-#pragma unroll
-            for (int j = 0; j < KB; ++j)
-                hv[j] = __builtin_bit_cast(lstm_f4, __builtin_amdgcn_raw_buffer_load_b128(r, ((4 * j + kq) * LSTM_ROWS + n) * 16, 0, LSTM_SC1));
-            __builtin_amdgcn_sched_barrier(0);      // all loads in flight before the first MFMA
             lstm_f4 p1 = {0, 0, 0, 0}, p2 = {0, 0, 0, 0}, p3 = {0, 0, 0, 0};
 #pragma unroll
             for (int j = 0; j < KB; ++j) {
@@ -144,7 +142,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             // the wave's 64 lanes cover 256 contiguous bytes: two whole lines, one store instruction
             float *xp = a.xch + ((size_t)t * a.ntile + tile) * slab + ((size_t)(u0 >> 2) * LSTM_ROWS + n) * 4 + kq;
             __hip_atomic_store(xp, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            lstm_publish(a, tile);
         }
     }
 }
@@ -153,8 +150,7 @@ template <int H>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_lstm_bwd(LstmArgs a)
 {
     constexpr int NWG = H / LSTM_UNITS, KB = H / 16;
-    __shared__ int s_ok;
-    __shared__ float part[4][4][64];
+    __shared__ float part[2][4][4][64];
     const int tile = a.tile0 + blockIdx.x / NWG, s = blockIdx.x % NWG;
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63, kq = l >> 4, n = l & 15;
     const int unit = s * LSTM_UNITS + 4 * kq + w;   // this thread's unit in the cell adjoint
@@ -181,20 +177,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         const float cp = t > 0 ? a.c_in[e - (size_t)a.B * H] : 0.0f;
         float dh = a.dh[e];
         if (t + 1 < a.T) {
-            if (!lstm_wait(a, tile, (unsigned)(NWG * 4) * (unsigned)(a.T - 1 - t), &s_ok)) {
+            lstm_f4 gv[KB];
+            if (!lstm_fetch<KB>(a, a.xch + ((size_t)(t + 1) * a.ntile + tile) * slab, (int)(slab * 4), w * (H / 4), kq, n, gv)) {
                 if (live) {
                     const lstm_f4 bad = {__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
                     *reinterpret_cast<lstm_f4 *>(a.gates + (((size_t)0 * a.B + row) * H + unit) * 4) = bad;
                 }
                 return;
             }
-            const float *gp = a.xch + ((size_t)(t + 1) * a.ntile + tile) * slab;
-            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(gp), 0, (int)(slab * 4), 0x00020000);
-            lstm_f4 gv[KB];
-#pragma unroll
-            for (int j = 0; j < KB; ++j)
-                gv[j] = __builtin_bit_cast(lstm_f4, __builtin_amdgcn_raw_buffer_load_b128(r, ((w * (H / 4) + 4 * j + kq) * LSTM_ROWS + n) * 16, 0, LSTM_SC1));
-            __builtin_amdgcn_sched_barrier(0);      // all loads in flight before the first MFMA
             lstm_f4 p0 = {0, 0, 0, 0}, p1 = {0, 0, 0, 0}, p2 = {0, 0, 0, 0}, p3 = {0, 0, 0, 0};
 #pragma unroll
             for (int j = 0; j < KB; ++j) {
@@ -210,9 +200,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             p0 = (p0 + p1) + (p2 + p3);
             // result row m = 4 kq + i of the 16 units: thread (w, l) finishes i = w
 #pragma unroll
-            for (int i = 0; i < 4; ++i) part[w][i][l] = p0[i];
-            __syncthreads();
-            dh += (part[0][w][l] + part[1][w][l]) + (part[2][w][l] + part[3][w][l]);
+            for (int i = 0; i < 4; ++i) part[t & 1][w][i][l] = p0[i];
+            __syncthreads();                        // the only barrier of a step; part[] is two deep
+            dh += (part[t & 1][0][w][l] + part[t & 1][1][w][l]) + (part[t & 1][2][w][l] + part[t & 1][3][w][l]);
         }
         const float ig = act[0], fg = act[1], gg = act[2], og = act[3];
         const float tc = tanhf(ct);
@@ -229,7 +219,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             float *xp = a.xch + ((size_t)t * a.ntile + tile) * slab + ((size_t)unit * LSTM_ROWS + n) * 4;
             const lstm_f4 dx = live ? d : lstm_f4{0, 0, 0, 0};
             asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(xp), "v"(dx) : "memory");
-            lstm_publish(a, tile);
         }
     }
 }

@@ -16,10 +16,11 @@ def _load():
     return mod
 
 
-def _run(device, monkeypatch):
+def _run(device, monkeypatch, hidden="16", lstm="fused"):
     mod = _load()
     monkeypatch.setattr(sys, "argv", ["train_dpl.py", "--basins", "6", "--rho", "40", "--warm-up", "20",
-                                      "--nmul", "4", "--hidden", "16", "--steps", "12", "--device", device])
+                                      "--nmul", "4", "--hidden", hidden, "--steps", "12", "--device", device,
+                                      "--lstm", lstm])
     losses = mod.main()
     assert all(l == l for l in losses)           # finite
     assert min(losses[-3:]) < losses[0]          # the optimiser makes progress on 1 - NSE
@@ -31,4 +32,17 @@ def test_dpl_example_learns_cpu_oracle(oracle_backend, monkeypatch):
 
 @pytest.mark.gpu
 def test_dpl_example_learns_gpu(hip_backend, monkeypatch):
-    _run("cuda", monkeypatch)
+    _run("cuda", monkeypatch, hidden="64")
+
+
+@pytest.mark.gpu
+def test_dpl_example_fused_and_torch_lstm_agree(hip_backend, monkeypatch):
+    """Same seeds, same data: the loss curve with the HIP sequence kernels follows torch.nn.LSTM's."""
+    mod = _load()
+    curves = []
+    for lstm in ("fused", "torch"):
+        monkeypatch.setattr(sys, "argv", ["train_dpl.py", "--basins", "6", "--rho", "40", "--warm-up", "20",
+                                          "--nmul", "4", "--hidden", "64", "--steps", "5", "--lstm", lstm])
+        curves.append(mod.main())
+    for a, b in zip(*curves):
+        assert abs(a - b) <= 2e-3 * max(abs(b), 1e-3), curves
