@@ -1454,16 +1454,22 @@ static hipError_t launch_lstm(K kern, LstmArgs a, int H, hipStream_t st)
             v = 256;
         n_cu = v;
     }
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LSTM_LDS_PAD);
-    if (e != hipSuccess) return e;
-    // one workgroup per CU and never more workgroups than CUs: every partner of a row tile is resident
+    // Residency: a launch never holds more workgroups than fit on the chip at once, so every partner
+    // of a row tile is running.  Up to one launch's worth (n_cu workgroups) each workgroup gets a CU of
+    // its own (LDS padding); larger batches run two workgroups per CU (the kernels are compiled for two
+    // waves per SIMD), which hides one tile's hand-off latency behind the other's MFMAs.
     const int nwg = H / LSTM_UNITS;
-    const int per_launch = n_cu / nwg > 0 ? n_cu / nwg : 1;
+    int wpc = env_int("HBVX_LSTM_WGS_PER_CU", a.ntile * nwg > n_cu ? 2 : 1);
+    wpc = wpc < 1 ? 1 : (wpc > 2 ? 2 : wpc);
+    const int lds = wpc == 1 ? LSTM_LDS_PAD : LSTM_LDS_PAD / 2;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    const int per_launch = n_cu * wpc / nwg > 0 ? n_cu * wpc / nwg : 1;
     for (int t0 = 0; t0 < a.ntile; t0 += per_launch) {
         a.tile0 = t0;
         const int nt = a.ntile - t0 < per_launch ? a.ntile - t0 : per_launch;
-        hipLaunchKernelGGL(kern, dim3(nt * nwg), dim3(256), LSTM_LDS_PAD, st, a);
+        hipLaunchKernelGGL(kern, dim3(nt * nwg), dim3(256), lds, st, a);
     }
     return hipGetLastError();
 }

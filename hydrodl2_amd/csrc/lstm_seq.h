@@ -33,7 +33,7 @@
 #define LSTM_ROWS 16                 // basins per row tile
 #define LSTM_UNITS 16                // hidden units per workgroup
 #define LSTM_SPIN_LIMIT (1u << 21)   // polls before a tile gives up (seconds, not minutes)
-#define LSTM_LDS_PAD (81 * 1024)     // dynamic LDS request: more than half a CU => one workgroup per CU
+#define LSTM_LDS_PAD (81 * 1024)     // dynamic LDS request: more than half a CU => one workgroup per CU (half of it: two)
 #define LSTM_SC1 16                  // buffer-instruction cache-policy bit: sc1
 
 typedef float lstm_f4 __attribute__((ext_vector_type(4)));
@@ -84,7 +84,7 @@ __device__ __forceinline__ bool lstm_fetch(const LstmArgs &a, const float *slab_
 }
 
 template <int H>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_lstm_fwd(LstmArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_lstm_fwd(LstmArgs a)
 {
     constexpr int NWG = H / LSTM_UNITS, KB = H / 16;
     const int tile = a.tile0 + blockIdx.x / NWG, s = blockIdx.x % NWG;
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 }
 
 template <int H>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_lstm_bwd(LstmArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_lstm_bwd(LstmArgs a)
 {
     constexpr int NWG = H / LSTM_UNITS, KB = H / 16;
     __shared__ float part[2][4][4][64];

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../include/hbvx.h"
+#include "../../include/hbvx_lstm.h"
 #include <dlfcn.h>
 
 #include "../../hydrodl2_amd/csrc/hbv_step.h"
@@ -350,6 +351,28 @@ extern "C" int hbvx_gage_route_backward(const hbvx_gage_desc *r, const float *qs
     if (!fn) { snprintf(g_err, sizeof g_err, "set HBVX_ORACLE_LIB for gage routing"); return HBVX_E_UNSUPPORTED; }
     return fn(r, qs, uh, go, gqs, gdp, ws, wsb, st);
 }
+
+// sequence LSTM (include/hbvx_lstm.h): forwarded to the oracle, like the routing entry points
+extern "C" uint64_t hbvx_lstm_workspace_bytes(const hbvx_lstm_desc *) { return 0; }
+extern "C" int hbvx_lstm_forward(const hbvx_lstm_desc *d, const float *w, const float *gx, float *g, float *c,
+                                 float *h, void *ws, uint64_t wsb, void *st)
+{
+    typedef int (*fn_t)(const hbvx_lstm_desc *, const float *, const float *, float *, float *, float *, void *,
+                        uint64_t, void *);
+    fn_t fn = (fn_t)oracle_sym("hbvx_lstm_forward");
+    if (!fn) { snprintf(g_err, sizeof g_err, "set HBVX_ORACLE_LIB for the lstm"); return HBVX_E_UNSUPPORTED; }
+    return fn(d, w, gx, g, c, h, ws, wsb, st);
+}
+extern "C" int hbvx_lstm_backward(const hbvx_lstm_desc *d, const float *w, const float *g, const float *c,
+                                  const float *gh, float *gg, void *ws, uint64_t wsb, void *st)
+{
+    typedef int (*fn_t)(const hbvx_lstm_desc *, const float *, const float *, const float *, const float *, float *,
+                        void *, uint64_t, void *);
+    fn_t fn = (fn_t)oracle_sym("hbvx_lstm_backward");
+    if (!fn) { snprintf(g_err, sizeof g_err, "set HBVX_ORACLE_LIB for the lstm"); return HBVX_E_UNSUPPORTED; }
+    return fn(d, w, g, c, gh, gg, ws, wsb, st);
+}
+extern "C" int hbvx_lstm_check(const hbvx_lstm_desc *, const void *, void *) { return 0; }
 
 // Step::jt_unit against Step::bwd with zero flux adjoints (HBV 1.0): for n random days, the worst
 // difference over the five unit adjoints, relative to the largest entry of J^T.
