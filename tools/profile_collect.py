@@ -7,6 +7,8 @@
     profiles/<tag>_pmc_fetch_size.csv    per-kernel FETCH_SIZE (KiB) of the hbvx kernels, averaged
     profiles/<tag>_pmc_write_size.csv    per-kernel WRITE_SIZE (KiB)
     profiles/<tag>_bench.json            the bench line of the profiled run
+    profiles/<tag>_lstm_kernel_stats.csv, <tag>_lstm.json   tools/bench_lstm.py (sequence LSTM beside torch's)
+    profiles/<tag>_dpl_kernel_stats.csv, <tag>_dpl.json     examples/train_dpl.py --lstm fused
     profiles/pmc_traffic.json            HBM bytes per ABI call (read by bench.py for roofline.traffic)
 """
 import csv
@@ -50,6 +52,15 @@ def main(tag):
         line = [l for l in f if l.startswith("{")][-1]
     with open(os.path.join(out, f"{tag}_bench.json"), "w") as f:
         f.write(line)
+    for extra in ("lstm", "dpl"):
+        st = glob.glob(os.path.join(raw, extra, "**", "*kernel_stats.csv"), recursive=True)
+        js = os.path.join(ROOT, "gpurun_out", f"prof_{tag}.{extra}.json")
+        if st and os.path.exists(js):
+            shutil.copy(st[0], os.path.join(out, f"{tag}_{extra}_kernel_stats.csv"))
+            with open(js) as f:
+                lines = [l for l in f if l.startswith("{")]
+            with open(os.path.join(out, f"{tag}_{extra}.json"), "w") as f:
+                f.write(lines[-1])
     tables = {}
     for kind in ("fetch", "write"):
         src = glob.glob(os.path.join(raw, kind, "**", "*counter_collection.csv"), recursive=True)[0]

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Profile bench.py on the GPU box (run through gpurun from the repo root):
 #   bash tools/profile_round.sh <tag>
-# Three rocprofv3 passes of the same command: kernel trace + stats, then the two TCC counters in
+# Three rocprofv3 passes of bench.py: kernel trace + stats, then the two TCC counters in
 # their own passes (FETCH_SIZE and WRITE_SIZE do not fit one pass).  Raw output under
 # gpurun_out/prof_<tag>/; tools/profile_collect.py turns it into profiles/<tag>_*.
 set -e
@@ -12,6 +12,9 @@ cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG/kt -o kt -- python3 $R/bench.py --steps 5 --warmup 2 > $R/gpurun_out/prof_$TAG.bench.json 2> $R/gpurun_out/prof_$TAG.kt.log
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_$TAG/fetch -o fetch -- python3 $R/bench.py --steps 3 --warmup 1 > /dev/null 2> $R/gpurun_out/prof_$TAG.fetch.log
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_$TAG/write -o write -- python3 $R/bench.py --steps 3 --warmup 1 > /dev/null 2> $R/gpurun_out/prof_$TAG.write.log
+# the caller side: sequence LSTM beside torch's, and the end-to-end training step
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG/lstm -o lstm -- python3 $R/tools/bench_lstm.py > $R/gpurun_out/prof_$TAG.lstm.json 2> $R/gpurun_out/prof_$TAG.lstm.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG/dpl -o dpl -- python3 $R/examples/train_dpl.py --lstm fused --steps 10 > $R/gpurun_out/prof_$TAG.dpl.json 2> $R/gpurun_out/prof_$TAG.dpl.log
 cd $R
 find gpurun_out/prof_$TAG -name "*.csv" | head -20
 tail -1 gpurun_out/prof_$TAG.bench.json
