@@ -9,9 +9,10 @@
 //
 // Basins are independent, so the batch is cut into row tiles of 16 basins (the N of
 // v_mfma_f32_16x16x4_f32: exact f32 products, a k-ordered fmaf chain) and only the H/16 workgroups
-// that share a row tile ever talk to each other.  Forward: wave = 4 hidden units x 4 gates (the 16
-// MFMA rows), its W_hh rows live in registers for the whole sequence (H/4 VGPRs), h_{t-1} of the
-// tile arrives as H/16 16-byte loads per lane.  Backward: workgroup = 16 hidden units, its 4 waves
+// that share a row tile ever talk to each other.  Forward: workgroup = 16 hidden units = four groups of
+// 4 units x 4 gates (the 16 MFMA rows); wave w multiplies K quarter w of h_{t-1} (H/64 16-byte loads
+// per lane) into all four groups (its W_hh entries live in H/4 VGPRs for the whole sequence), the
+// partial tiles are summed through LDS in wave order and wave w finishes unit group w.  Backward: workgroup = 16 hidden units, its 4 waves
 // split the 4H gate rows of dh_{t-1} = dgates_t W_hh (again H/4 VGPRs of W_hh each), partial tiles
 // are summed through LDS in wave order, then one thread per (unit, basin) does the cell adjoint.
 // Gate vectors use the (unit, gate) layout [T,B,H,4] so that a lane's four gates are one 16-byte access.
@@ -86,23 +87,30 @@ __device__ __forceinline__ bool lstm_fetch(const LstmArgs &a, const float *slab_
 template <int H>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_lstm_fwd(LstmArgs a)
 {
-    constexpr int NWG = H / LSTM_UNITS, KB = H / 16;
+    constexpr int NWG = H / LSTM_UNITS, KQ = H / 64;   // KQ: 16-byte loads per lane = the wave's quarter of h
+    __shared__ lstm_f4 part[2][4][4][64];              // [buffer][K quarter][unit group][lane]
     const int tile = a.tile0 + blockIdx.x / NWG, s = blockIdx.x % NWG;
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63, kq = l >> 4, n = l & 15;
-    const int u0 = s * LSTM_UNITS + w * 4;          // the wave's four units
-    const int unit = u0 + kq;                       // this lane's unit in the result tile
+    const int u0 = s * LSTM_UNITS + w * 4;          // the four units this wave finishes (unit group w)
+    const int unit = u0 + kq;
     const int row = tile * LSTM_ROWS + n, rowc = row < a.B ? row : a.B - 1;
     const bool live = row < a.B;
 
-    // A operand: MFMA row m = 4*unit_local + gate; k of block (j, i) = 16 j + 4 kq + i, like the loads
-    float wreg[KB * 4];
+    // The workgroup owns 16 units = four unit groups of 4 units x 4 gates (the 16 MFMA rows); wave w
+    // multiplies K quarter w of h_{t-1} into all four groups, so no byte of the slab is loaded twice
+    // per workgroup.  A operand of group g: MFMA row m = 4*unit_local + gate; k of block (j, i) =
+    // 4 (w H/16 + 4 j + kq) + i, like the loads.
+    float wreg[4][KQ * 4];
     {
         const int m = l & 15;
-        const float *wr = a.w_hh + (size_t)((m & 3) * H + u0 + (m >> 2)) * H + 4 * kq;
 #pragma unroll
-        for (int j = 0; j < KB; ++j)
+        for (int g = 0; g < 4; ++g) {
+            const float *wr = a.w_hh + (size_t)((m & 3) * H + s * LSTM_UNITS + 4 * g + (m >> 2)) * H + 4 * (w * (H / 16) + kq);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) wreg[j * 4 + i] = wr[16 * j + i];
+            for (int j = 0; j < KQ; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wreg[g][j * 4 + i] = wr[16 * j + i];
+        }
     }
     const size_t slab = (size_t)H * LSTM_ROWS;      // floats per (step, tile): [H/4][16 rows][4 units]
     float c = 0.0f;
@@ -110,24 +118,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const size_t e = ((size_t)t * a.B + rowc) * H + unit;
         lstm_f4 acc = *reinterpret_cast<const lstm_f4 *>(a.gx + e * 4);
         if (t > 0) {
-            lstm_f4 hv[KB];
-            if (!lstm_fetch<KB>(a, a.xch + ((size_t)(t - 1) * a.ntile + tile) * slab, (int)(slab * 4), 0, kq, n, hv)) {
+            lstm_f4 hv[KQ];
+            if (!lstm_fetch<KQ>(a, a.xch + ((size_t)(t - 1) * a.ntile + tile) * slab, (int)(slab * 4), w * (H / 16), kq, n, hv)) {
                 if (live) a.h_all[((size_t)(a.T - 1) * a.B + row) * H + unit] = __builtin_nanf("");
                 return;
             }
-            lstm_f4 p1 = {0, 0, 0, 0}, p2 = {0, 0, 0, 0}, p3 = {0, 0, 0, 0};
+            lstm_f4 p[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
-            for (int j = 0; j < KB; ++j) {
+            for (int j = 0; j < KQ; ++j)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float av = wreg[j * 4 + i], bv = hv[j][i];
-                    if (i == 0) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
-                    else if (i == 1) p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, p1, 0, 0, 0);
-                    else if (i == 2) p2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, p2, 0, 0, 0);
-                    else p3 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, p3, 0, 0, 0);
-                }
-            }
-            acc = (acc + p1) + (p2 + p3);
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        p[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[g][j * 4 + i], hv[j][i], p[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) part[t & 1][w][g][l] = p[g];
+            __syncthreads();                        // the only barrier of a step; part[] is two deep
+            acc += (part[t & 1][0][w][l] + part[t & 1][1][w][l]) + (part[t & 1][2][w][l] + part[t & 1][3][w][l]);
         }
         const float ig = lstm_sigmoid(acc[0]), fg = lstm_sigmoid(acc[1]), gg = tanhf(acc[2]), og = lstm_sigmoid(acc[3]);
         c = fg * c + ig * gg;
