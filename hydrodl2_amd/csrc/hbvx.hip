@@ -1455,17 +1455,24 @@ static hipError_t launch_lstm(K kern, LstmArgs a, int H, hipStream_t st)
         n_cu = v;
     }
     // Residency: a launch never holds more workgroups than fit on the chip at once, so every partner
-    // of a row tile is running.  Up to one launch's worth (n_cu workgroups) each workgroup gets a CU of
-    // its own (LDS padding); larger batches run two workgroups per CU (the kernels are compiled for two
-    // waves per SIMD), which hides one tile's hand-off latency behind the other's MFMAs.
+    // of a row tile is running.  The kernels are compiled for three waves per SIMD (<= 168 VGPRs), so up
+    // to three workgroups share a CU; the LDS request is sized so that exactly `wpc` fit: a batch that
+    // fits one launch at one workgroup per CU gets a CU per workgroup, larger batches interleave two or
+    // three row tiles per SIMD, which hides one tile's hand-off latency behind the others' MFMAs.
     const int nwg = H / LSTM_UNITS;
-    int wpc = env_int("HBVX_LSTM_WGS_PER_CU", a.ntile * nwg > n_cu ? 2 : 1);
-    wpc = wpc < 1 ? 1 : (wpc > 2 ? 2 : wpc);
-    const int lds = wpc == 1 ? LSTM_LDS_PAD : LSTM_LDS_PAD / 2;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const int need = a.ntile * nwg;
+    int wpc = env_int("HBVX_LSTM_WGS_PER_CU", (need + n_cu - 1) / n_cu);
+    wpc = wpc < 1 ? 1 : (wpc > 3 ? 3 : wpc);
+    hipFuncAttributes fa;
+    hipError_t e = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern));
     if (e != hipSuccess) return e;
-    const int per_launch = n_cu * wpc / nwg > 0 ? n_cu * wpc / nwg : 1;
+    const int total = wpc == 1 ? 81 * 1024 : (wpc == 2 ? 54 * 1024 + 512 : 41 * 1024);   // of 160 KB per CU
+    const int lds = total > (int)fa.sharedSizeBytes ? total - (int)fa.sharedSizeBytes : 0;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    const int cap = n_cu * wpc / nwg > 0 ? n_cu * wpc / nwg : 1;       // row tiles one launch can hold
+    const int launches = (a.ntile + cap - 1) / cap;
+    const int per_launch = (a.ntile + launches - 1) / launches;        // balanced
     for (int t0 = 0; t0 < a.ntile; t0 += per_launch) {
         a.tile0 = t0;
         const int nt = a.ntile - t0 < per_launch ? a.ntile - t0 : per_launch;

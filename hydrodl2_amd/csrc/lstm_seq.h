@@ -24,17 +24,17 @@
 // bypassed: MI355X_MICROARCH.md "inter-workgroup visibility") until none of the words it needs is the
 // sentinel -- the payload is its own flag, there are no counters, fences or barriers on the path, and a
 // word that is not the sentinel can only be the value written in this launch.  h and the gate gradients
-// are never the sentinel pattern (arithmetic NaNs are canonical 0x7FC00000).  One workgroup per CU (LDS
-// padding) and a launch never holds more workgroups than the chip has CUs, so all partners are
-// resident.  Every spin is bounded: on a time-out the wave gives up, sets the error word
-// (hbvx_lstm_check) and poisons its outputs.
+// are never the sentinel pattern (arithmetic NaNs are canonical 0x7FC00000).  One to three workgroups
+// per CU (compiled for three waves per SIMD; the host sizes the LDS request so that exactly that many
+// fit) and a launch never holds more workgroups than that, so all partners are resident.  Every spin
+// is bounded: on a time-out the wave gives up, sets the error word (hbvx_lstm_check) and poisons its
+// outputs.
 #pragma once
 #include <hip/hip_runtime.h>
 
 #define LSTM_ROWS 16                 // basins per row tile
 #define LSTM_UNITS 16                // hidden units per workgroup
 #define LSTM_SPIN_LIMIT (1u << 21)   // polls before a tile gives up (seconds, not minutes)
-#define LSTM_LDS_PAD (81 * 1024)     // dynamic LDS request: more than half a CU => one workgroup per CU (half of it: two)
 #define LSTM_SC1 16                  // buffer-instruction cache-policy bit: sc1
 
 typedef float lstm_f4 __attribute__((ext_vector_type(4)));
@@ -85,7 +85,7 @@ __device__ __forceinline__ bool lstm_fetch(const LstmArgs &a, const float *slab_
 }
 
 template <int H>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_lstm_fwd(LstmArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_lstm_fwd(LstmArgs a)
 {
     constexpr int NWG = H / LSTM_UNITS, KQ = H / 64;   // KQ: 16-byte loads per lane = the wave's quarter of h
     __shared__ lstm_f4 part[2][4][4][64];              // [buffer][K quarter][unit group][lane]
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 template <int H>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_lstm_bwd(LstmArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_lstm_bwd(LstmArgs a)
 {
     constexpr int NWG = H / LSTM_UNITS, KB = H / 16;
     __shared__ float part[2][4][4][64];
