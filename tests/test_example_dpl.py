@@ -46,3 +46,46 @@ def test_dpl_example_fused_and_torch_lstm_agree(hip_backend, monkeypatch):
         curves.append(mod.main())
     for a, b in zip(*curves):
         assert abs(a - b) <= 2e-3 * max(abs(b), 1e-3), curves
+
+
+def _dpl_worker(rank, world, port, oracle, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import torch
+    torch.set_num_threads(1)
+    from hydrodl2_amd import _lib
+    _lib._use_library_for_testing(oracle)
+    sys.argv = ["train_dpl.py", "--basins", "7", "--rho", "30", "--warm-up", "10", "--nmul", "2",
+                "--hidden", "8", "--steps", "4", "--device", "cpu"]
+    losses = _load().main()
+    if rank == 0:
+        q.put(losses)
+
+
+def test_dpl_example_two_ranks_match_one(oracle_path, oracle_backend, monkeypatch):
+    """The whole training step (LSTM -> HBV -> NSE -> Adam) sharded over two gloo ranks (7 basins: uneven
+    shards) follows the single-process loss curve: one bucketed all-reduce of loss normalisers and
+    network gradients per step is all the ranks exchange."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dpl_worker, args=(r, 2, port, oracle_path, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    two = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    monkeypatch.setattr(sys, "argv", ["train_dpl.py", "--basins", "7", "--rho", "30", "--warm-up", "10", "--nmul", "2",
+                                      "--hidden", "8", "--steps", "4", "--device", "cpu"])
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    one = _load().main()
+    assert len(one) == len(two)
+    for a, b in zip(two, one):
+        assert abs(a - b) <= 1e-4 * max(abs(b), 1e-3), (two, one)
