@@ -64,6 +64,17 @@ def main():
         ms = sum(a.elapsed_time(b) for k, a, b in ev if k == n) / steps
         res[n + "_ms"] = round(ms, 3)
         res[n + "_us_per_step"] = round(ms * 1e3 / T, 2)
+    # what bounds the recurrence kernels: MFMA work and hand-off traffic per launch against the chip's peaks
+    tiles = (B + 15) // 16
+    flops = 2.0 * T * tiles * 16 * H * 4 * H                   # padded rows; forward = backward
+    res["mfma"] = {d: {"tflops": round(flops / (res[f"hbvx_lstm_{d}_ms"] * 1e-3) / 1e12, 2),
+                       "frac_of_fp32_mfma_peak": round(flops / (res[f"hbvx_lstm_{d}_ms"] * 1e-3) / 157.3e12, 4)}
+                   for d in ("forward", "backward")}
+    wgs = H // 16
+    xch = {"forward": T * tiles * wgs * H * 16 * 4, "backward": T * tiles * wgs * H * 16 * 4 * 4}
+    res["hand_off_load_TBps"] = {d: round(xch[d] / (res[f"hbvx_lstm_{d}_ms"] * 1e-3) / 1e12, 3) for d in xch}
+    res["hbm_algorithmic_GB"] = {"forward": round(T * B * H * 4 * (4 + 4 + 1 + 1) / 1e9, 3),
+                                 "backward": round(T * B * H * 4 * (4 + 4 + 2 + 1) / 1e9, 3)}
     err = (fwd(fused) - fwd(ref)).abs().max().item()
     res["max_abs_diff_vs_torch"] = err
     print(json.dumps(res))
