@@ -46,8 +46,7 @@ namespace hbvx {
 #define PIPE_KT 8       // days per tile with at most PIPE_FEWDYN dynamic parameters (host and device)
 #define PIPE_KT_MANY 4  // ... with more: the staged parameter rows need the LDS
 #define PIPE_FEWDYN 3   // rows staged one per filler wave
-#define PIPE_MAXDYN 18  // rows staged at most (three filler waves, PIPE_ROWS_MANY rows each)
-#define PIPE_ROWS_MANY 6
+#define PIPE_MAXDYN 18  // rows staged at most (shared by the three or four filler waves)
 
 // Run `body(tt, has_next)` for the nt days of a tile; full tiles are unrolled so that every LDS
 // address is base + immediate and the loop-carried registers need no rotation moves.
@@ -128,7 +127,7 @@ __device__ unsigned long long g_pipe_probe[32];
 // TRAJ: the forward also saves the storage trajectory and the pow results (traj and aux given).
 // DYN: parameters vary per day: filler waves de-scale them (sigmoid, range, dy_drop blend) into LDS
 // tiles five deep (snow reads tile it, groundwater tile it-2, the fillers write it+2).
-// MANY: more than PIPE_FEWDYN of them: 4-day tiles, each filler wave stages up to PIPE_ROWS_MANY rows.
+// MANY: more than PIPE_FEWDYN of them: 4-day tiles, the filler waves share the rows round-robin.
 template <int MODEL, bool BETAET, bool TRAJ, bool DYN, bool MANY = false>
 __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
 {
@@ -359,7 +358,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
             if (TRAJ) o.traj[((int64_t)2 * (T + 1) + T) * N + L.n] = SM;
         }
       }
-    } else if (wave == 2) {
+    } else if (wave == 2 && !(CAP && MANY)) {
       if constexpr (CAP) {
         PIPE_BARRIER();
         for (int it = 0; it < nIt; it++) PIPE_BARRIER();
@@ -422,10 +421,12 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                                    (HBVX_F_PERC << 16);
         const int nw = blockDim.x >> 6;
         const int quad = wave & 3;   // waves with the same value share a SIMD
-        // fillers: wave 3 stages the forcings (and dynamic-parameter row 0); with dynamic parameters
-        // waves 4 and 6 stage rows 1 and 2 -- the de-scaling (sigmoid) of a row is ~140 VALU cycles
+        // fillers: wave 3 stages the forcings; with dynamic parameters waves 4, 6 and 3 (in that order)
+        // share the dynamic rows -- the de-scaling (sigmoid) of a row is ~140 VALU cycles
         // per day, too much for one wave beside the forcings.
-        const bool is_fill = wave == 3 || (DYN && (wave == 4 || wave == 6));
+        // (in the two-stage pipeline wave 2 has no stage: with many dynamic rows it is a fourth filler)
+        constexpr int NF = (CAP && MANY) ? 4 : 3;   // filler waves when DYN
+        const bool is_fill = wave == 3 || (DYN && (wave == 4 || wave == 6 || (MANY && wave == 2)));
         const int rbase = DYN ? 8 : 4;   // first reducer wave
         if (is_fill) {
             // Registers hold the tile that goes to LDS next iteration.  Straight-line code (days past
@@ -435,8 +436,8 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
             // the tile, range = the days that exist), the day offset is a scalar operand and the
             // per-lane offset a constant, so issuing a tile costs no vector address arithmetic.
             constexpr int FD = KT;
-            constexpr int NRW = MANY ? PIPE_ROWS_MANY : 1;   // dynamic rows per filler wave
-            const int fidx = wave == 3 ? 0 : (wave == 4 ? 1 : 2);
+            constexpr int NRW = MANY ? (PIPE_MAXDYN + NF - 1) / NF : 1;   // dynamic rows per filler wave
+            const int fidx = wave == 3 ? 0 : (wave == 4 ? 1 : (wave == 6 ? 2 : 3));
             const bool forc = fidx == 0;
             const int nd = __builtin_popcount(dmask);
             float fx[FD], fy[FD], fz[FD], dv[NRW][FD];
@@ -449,7 +450,10 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
             };
             const unsigned xvo = (unsigned)(L.b * d.x_b_stride * 4);
             const unsigned xcp = d.ch_prcp * 4, xct = d.ch_tmean * 4, xce = d.ch_pet * 4;
-            // this wave stages the dynamic rows fidx, fidx + 3, ... (row k = k-th set bit of dmask)
+            // this wave stages the dynamic rows frow, frow + NF, ... (row k = k-th set bit of dmask);
+            // wave 3 also stages the forcings, so with many rows it comes last in the rotation and gets the
+            // short share (with at most three rows the order 3, 4, 6 keeps them off the stage waves' SIMDs)
+            const int frow = MANY ? (fidx + NF - 1) % NF : fidx;
             const float *dsrc[NRW];
             unsigned dvo[NRW];
             int64_t dts[NRW];
@@ -457,7 +461,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
             bool duse[NRW], dyrow[NRW];
 #pragma unroll
             for (int r = 0; r < NRW; r++) {
-                const int k = fidx + 3 * r;
+                const int k = frow + NF * r;
                 dyrow[r] = DYN && k < nd;
                 dsrc[r] = d.x; dvo[r] = 0; dts[r] = 0; dlo[r] = dhi[r] = dsta[r] = 0.0f; duse[r] = false;
                 if (dyrow[r]) {
@@ -502,7 +506,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
 #pragma unroll
                 for (int r = 0; r < NRW; r++)
                     if (dyrow[r]) {
-                        float *pin = lds + P.pin + (tile % 5) * FD * PD * 64 + (fidx + 3 * r) * 64 + lane;
+                        float *pin = lds + P.pin + (tile % 5) * FD * PD * 64 + (frow + NF * r) * 64 + lane;
 #pragma unroll
                         for (int i = 0; i < FD; i++) {
                             const float u = raw ? sigmoid_dyn_(dv[r][i]) : dv[r][i];
