@@ -95,13 +95,21 @@ class LstmSeq(torch.autograd.Function):
         return (gx.view(T, B, I) if gx is not None else None), gw_ih, gw_hh, gb, gb, None
 
 
+def lstm_seq(x, w_ih, w_hh, b_ih, b_hh, check: bool = False):
+    """Functional form: returns (h [T,B,H], c [T,B,H]) for torch.nn.LSTM-layout weights."""
+    return LstmSeq.apply(x, w_ih, w_hh, b_ih, b_hh, check)
+
+
 class SeqLSTM(torch.nn.Module):
     """One-layer LSTM over [T, B, input_size]; returns (output [T,B,H], (h_n [1,B,H], c_n [1,B,H]))
     like torch.nn.LSTM called without an initial state."""
 
-    def __init__(self, input_size: int, hidden_size: int, check: bool = False):
+    def __init__(self, input_size: int, hidden_size: int, check: bool = False, dr: float = 0.0):
         super().__init__()
         self.input_size, self.hidden_size, self.check = input_size, hidden_size, check
+        # dr: weight dropout as in hydroDL / delta-MG's CudnnLstm (one Bernoulli mask on W_ih and one on
+        # W_hh per forward call, training mode only); 0 = torch.nn.LSTM behaviour
+        self.dr = dr
         k = 1.0 / math.sqrt(hidden_size)
         # same creation order and distribution as torch.nn.LSTM.reset_parameters
         self.weight_ih_l0 = torch.nn.Parameter(torch.empty(4 * hidden_size, input_size).uniform_(-k, k))
@@ -110,5 +118,9 @@ class SeqLSTM(torch.nn.Module):
         self.bias_hh_l0 = torch.nn.Parameter(torch.empty(4 * hidden_size).uniform_(-k, k))
 
     def forward(self, x):
-        h, c = LstmSeq.apply(x, self.weight_ih_l0, self.weight_hh_l0, self.bias_ih_l0, self.bias_hh_l0, self.check)
+        w_ih, w_hh = self.weight_ih_l0, self.weight_hh_l0
+        if self.training and self.dr > 0:
+            w_ih = torch.nn.functional.dropout(w_ih, self.dr, training=True)
+            w_hh = torch.nn.functional.dropout(w_hh, self.dr, training=True)
+        h, c = LstmSeq.apply(x, w_ih, w_hh, self.bias_ih_l0, self.bias_hh_l0, self.check)
         return h, (h[-1:], c[-1:])

@@ -46,6 +46,31 @@ def test_oracle_lstm_matches_torch(oracle_backend, T, B, I, H):
     _run("cpu", T, B, I, H)
 
 
+def test_weight_dropout_matches_masked_torch_lstm(oracle_backend):
+    """dr > 0 (hydroDL's CudnnLstm weight dropout): same as torch.nn.LSTM run on the masked weights, and
+    the gradient reaches the parameters through the mask; eval mode ignores dr."""
+    torch.manual_seed(3)
+    mod = SeqLSTM(4, 8, dr=0.5)
+    x = torch.randn(6, 3, 4)
+    torch.manual_seed(11)
+    out, _ = mod(x)
+    out.sum().backward()
+    torch.manual_seed(11)
+    w_ih = torch.nn.functional.dropout(mod.weight_ih_l0.detach(), 0.5, training=True)
+    w_hh = torch.nn.functional.dropout(mod.weight_hh_l0.detach(), 0.5, training=True)
+    ref = torch.nn.LSTM(4, 8)
+    ref.load_state_dict({"weight_ih_l0": w_ih, "weight_hh_l0": w_hh, "bias_ih_l0": mod.bias_ih_l0.detach(),
+                         "bias_hh_l0": mod.bias_hh_l0.detach()})
+    want, _ = ref(x)
+    assert torch.allclose(out, want, atol=1e-5)
+    g = mod.weight_hh_l0.grad
+    assert torch.all(g[w_hh == 0] == 0) and g.abs().sum() > 0
+    mod.eval()
+    a, _ = mod(x)
+    b, _ = mod(x)
+    assert torch.equal(a, b)
+
+
 def test_state_dict_interchanges_with_torch_lstm():
     torch.manual_seed(0)
     ref = torch.nn.LSTM(6, 64)
