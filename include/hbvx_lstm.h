@@ -8,6 +8,12 @@
  * caller's side (hydrodl2_amd/lstm.py); these entry points are the recurrence, which a GEMM library
  * cannot fuse.  Gate vectors use the (unit, gate) layout: element [t][b][u][g], g = 0..3 = i, f, g, o.
  *
+ * Residency: the kernels are persistent -- the workgroups of a 16-basin row tile hand data to each
+ * other inside one launch -- and each launch is sized to fit the whole GPU.  Run a call on a GPU that
+ * is not executing another large kernel at the same time (other streams, other processes): partners
+ * that cannot become resident are detected by bounded spins and reported (hbvx_lstm_check), never
+ * waited for indefinitely.
+ *
  * Errors: 0 on success, a negative HBVX_E_* (include/hbvx.h) otherwise; hbvx_last_error() has the text. */
 #ifndef HBVX_LSTM_H
 #define HBVX_LSTM_H
