@@ -3,7 +3,7 @@
 the caller side, outside the reference repository -- delta-MG style).
 
     python examples/train_dpl.py [--basins 100] [--rho 365] [--warm-up 365] [--nmul 16] [--steps 20]
-                                 [--lstm fused|torch]
+                                 [--lstm fused|torch] [--tune-gemm]
     python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 examples/train_dpl.py ...
 
 A small LSTM maps normalised forcings + static attributes to the raw parameter tensor [T,B,ny];
@@ -78,6 +78,10 @@ def main():
     ap.add_argument("--device", default="cuda")
     ap.add_argument("--lstm", choices=["fused", "torch"], default="fused",
                     help="fused: the HIP sequence kernels of include/hbvx_lstm.h; torch: torch.nn.LSTM")
+    ap.add_argument("--tune-gemm", action="store_true",
+                    help="let torch's TunableOp pick the hipBLASLt/rocBLAS solution of every GEMM shape during "
+                         "the warm-up steps (the LSTM's weight-gradient GEMMs have K = T*B: the default "
+                         "heuristic is 2x off there)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -88,6 +92,12 @@ def main():
     dev = torch.device(args.device if not on_gpu else f"cuda:{torch.cuda.current_device()}")
     if world > 1:
         dist.init_process_group("nccl" if on_gpu else "gloo")
+
+    if args.tune_gemm and on_gpu:
+        import torch.cuda.tunable as tunable
+        tunable.enable(True)
+        tunable.set_max_tuning_duration(1000)       # ms per GEMM shape
+        tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), "tunableop_dpl.csv"))
 
     T, B, M = args.warm_up + args.rho, args.basins, args.nmul
     dyn = ["parBETA", "parBETAET"]
@@ -144,7 +154,7 @@ def main():
         lstm_ms = sum(e0.elapsed_time(e1) for n, e0, e1 in ev if "lstm" in n) / args.steps
     if rank == 0:
         print(json.dumps({"basins": B, "nmul": M, "days": T, "world": world, "ms_per_step": round(dt * 1e3, 3),
-                          "lstm": args.lstm, "hidden": args.hidden,
+                          "lstm": args.lstm, "hidden": args.hidden, "tuned_gemm": bool(args.tune_gemm),
                           "hbv_calls_ms": None if hbv_ms is None else round(hbv_ms, 3),
                           "lstm_kernels_ms": None if not lstm_ms else round(lstm_ms, 3),
                           "loss_first": round(losses[0], 4), "loss_last": round(losses[-1], 4)}))
