@@ -1443,8 +1443,7 @@ extern "C" uint64_t hbvx_lstm_workspace_bytes(const hbvx_lstm_desc *d)
     return lstm_counter_bytes(d) + lstm_slab_bytes(d, true);   // the backward slabs are the larger ones
 }
 
-template <typename K>
-static hipError_t launch_lstm(K kern, LstmArgs a, int H, hipStream_t st)
+static int lstm_cu_count()
 {
     static int n_cu = 0;
     if (n_cu == 0) {
@@ -1454,12 +1453,18 @@ static hipError_t launch_lstm(K kern, LstmArgs a, int H, hipStream_t st)
             v = 256;
         n_cu = v;
     }
+    return n_cu;
+}
+
+template <typename K>
+static hipError_t launch_lstm(K kern, LstmArgs a, int nwg, hipStream_t st)
+{
+    const int n_cu = lstm_cu_count();
     // Residency: a launch never holds more workgroups than fit on the chip at once, so every partner
     // of a row tile is running.  The kernels are compiled for three waves per SIMD (<= 168 VGPRs), so up
     // to three workgroups share a CU; the LDS request is sized so that exactly `wpc` fit: a batch that
     // fits one launch at one workgroup per CU gets a CU per workgroup, larger batches interleave two or
     // three row tiles per SIMD, which hides one tile's hand-off latency behind the others' MFMAs.
-    const int nwg = H / LSTM_UNITS;
     const int need = a.ntile * nwg;
     int wpc = env_int("HBVX_LSTM_WGS_PER_CU", (need + n_cu - 1) / n_cu);
     wpc = wpc < 1 ? 1 : (wpc > 3 ? 3 : wpc);
@@ -1498,8 +1503,15 @@ extern "C" int hbvx_lstm_forward(const hbvx_lstm_desc *d, const float *w_hh, con
     a.w_hh = w_hh; a.gx = gx; a.gates = gates; a.c_all = c_all; a.h_all = h_all;
     a.cnt = (unsigned *)workspace;
     a.xch = (float *)((char *)workspace + lstm_counter_bytes(d));
-    e = d->H == 64 ? launch_lstm(k_lstm_fwd<64>, a, 64, st)
-      : d->H == 128 ? launch_lstm(k_lstm_fwd<128>, a, 128, st) : launch_lstm(k_lstm_fwd<256>, a, 256, st);
+    // 8 units per workgroup while twice the workgroups still fit one launch at one per CU, else 16
+    const int n_cu = lstm_cu_count();
+    const bool small = env_int("HBVX_LSTM_UNITS", a.ntile * (d->H / 8) <= n_cu ? 8 : 16) == 8;
+    if (small)
+        e = d->H == 64 ? launch_lstm(k_lstm_fwd<64, 2>, a, 8, st)
+          : d->H == 128 ? launch_lstm(k_lstm_fwd<128, 2>, a, 16, st) : launch_lstm(k_lstm_fwd<256, 2>, a, 32, st);
+    else
+        e = d->H == 64 ? launch_lstm(k_lstm_fwd<64, 4>, a, 4, st)
+          : d->H == 128 ? launch_lstm(k_lstm_fwd<128, 4>, a, 8, st) : launch_lstm(k_lstm_fwd<256, 4>, a, 16, st);
     if (e != hipSuccess) return hip_fail(e, "hbvx_lstm_forward launch");
     return 0;
 }
@@ -1522,8 +1534,8 @@ extern "C" int hbvx_lstm_backward(const hbvx_lstm_desc *d, const float *w_hh, co
     a.w_hh = w_hh; a.gx = gates; a.gates = grad_gates; a.c_in = c_all; a.dh = grad_h;
     a.cnt = (unsigned *)workspace;
     a.xch = (float *)((char *)workspace + lstm_counter_bytes(d));
-    e = d->H == 64 ? launch_lstm(k_lstm_bwd<64>, a, 64, st)
-      : d->H == 128 ? launch_lstm(k_lstm_bwd<128>, a, 128, st) : launch_lstm(k_lstm_bwd<256>, a, 256, st);
+    e = d->H == 64 ? launch_lstm(k_lstm_bwd<64>, a, 4, st)
+      : d->H == 128 ? launch_lstm(k_lstm_bwd<128>, a, 8, st) : launch_lstm(k_lstm_bwd<256>, a, 16, st);
     if (e != hipSuccess) return hip_fail(e, "hbvx_lstm_backward launch");
     return 0;
 }

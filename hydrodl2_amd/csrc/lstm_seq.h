@@ -51,7 +51,18 @@ struct LstmArgs {
     unsigned *cnt;                   // cnt[0] = error word (zeroed by the host)
 };
 
-__device__ __forceinline__ float lstm_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+// Gate non-linearities on the hardware transcendentals (v_exp_f32 / v_rcp_f32, about 1 ulp each): absolute
+// error <= 2e-7 on values in [-1, 1], far inside the test tolerance, and 4-5 instructions instead of the
+// ~30 of an IEEE division and the ~40 of ocml's tanhf -- the cell sits on the per-step latency chain.
+// Saturation is exact: exp2 -> inf gives rcp -> 0.
+__device__ __forceinline__ float lstm_sigmoid(float x)
+{
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896341f));
+}
+__device__ __forceinline__ float lstm_tanh(float x)
+{
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * 2.88539008177792681f));
+}
 
 #define LSTM_SENTINEL 0xFFFFFFFFu
 #define LSTM_AUX (LSTM_SC1 | 0x80000000)   // sc1 + volatile: the polling loads are never hoisted or merged
@@ -84,28 +95,31 @@ __device__ __forceinline__ bool lstm_fetch(const LstmArgs &a, const float *slab_
     }
 }
 
-template <int H>
+// UG: unit groups (4 units x 4 gates = the 16 MFMA rows) per workgroup: 4 (16 units, H/16 workgroups per
+// row tile) or, when the batch is small enough for twice the workgroups to fit one launch, 2 (8 units: half
+// the MFMAs per wave on the latency chain; waves 2 and 3 only multiply).
+template <int H, int UG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_lstm_fwd(LstmArgs a)
 {
-    constexpr int NWG = H / LSTM_UNITS, KQ = H / 64;   // KQ: 16-byte loads per lane = the wave's quarter of h
-    __shared__ lstm_f4 part[2][4][4][64];              // [buffer][K quarter][unit group][lane]
+    constexpr int NWG = H / (4 * UG), KQ = H / 64;     // KQ: 16-byte loads per lane = the wave's quarter of h
+    __shared__ lstm_f4 part[2][4][UG][64];             // [buffer][K quarter][unit group][lane]
     const int tile = a.tile0 + blockIdx.x / NWG, s = blockIdx.x % NWG;
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63, kq = l >> 4, n = l & 15;
-    const int u0 = s * LSTM_UNITS + w * 4;          // the four units this wave finishes (unit group w)
+    const bool fin = w < UG;                        // this wave finishes unit group w
+    const int u0 = (s * UG + (fin ? w : 0)) * 4;    // its four units
     const int unit = u0 + kq;
     const int row = tile * LSTM_ROWS + n, rowc = row < a.B ? row : a.B - 1;
-    const bool live = row < a.B;
+    const bool live = row < a.B && fin;
 
-    // The workgroup owns 16 units = four unit groups of 4 units x 4 gates (the 16 MFMA rows); wave w
-    // multiplies K quarter w of h_{t-1} into all four groups, so no byte of the slab is loaded twice
-    // per workgroup.  A operand of group g: MFMA row m = 4*unit_local + gate; k of block (j, i) =
+    // Wave w multiplies K quarter w of h_{t-1} into all UG groups, so no byte of the slab is loaded
+    // twice per workgroup.  A operand of group g: MFMA row m = 4*unit_local + gate; k of block (j, i) =
     // 4 (w H/16 + 4 j + kq) + i, like the loads.
-    float wreg[4][KQ * 4];
+    float wreg[UG][KQ * 4];
     {
         const int m = l & 15;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float *wr = a.w_hh + (size_t)((m & 3) * H + s * LSTM_UNITS + 4 * g + (m >> 2)) * H + 4 * (w * (H / 16) + kq);
+        for (int g = 0; g < UG; ++g) {
+            const float *wr = a.w_hh + (size_t)((m & 3) * H + (s * UG + g) * 4 + (m >> 2)) * H + 4 * (w * (H / 16) + kq);
 #pragma unroll
             for (int j = 0; j < KQ; ++j)
 #pragma unroll
@@ -116,29 +130,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     float c = 0.0f;
     for (int t = 0; t < a.T; ++t) {
         const size_t e = ((size_t)t * a.B + rowc) * H + unit;
-        lstm_f4 acc = *reinterpret_cast<const lstm_f4 *>(a.gx + e * 4);
+        lstm_f4 acc = {0, 0, 0, 0};
+        if (fin) acc = *reinterpret_cast<const lstm_f4 *>(a.gx + e * 4);
         if (t > 0) {
             lstm_f4 hv[KQ];
             if (!lstm_fetch<KQ>(a, a.xch + ((size_t)(t - 1) * a.ntile + tile) * slab, (int)(slab * 4), w * (H / 16), kq, n, hv)) {
                 if (live) a.h_all[((size_t)(a.T - 1) * a.B + row) * H + unit] = __builtin_nanf("");
                 return;
             }
-            lstm_f4 p[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+            lstm_f4 p[UG];
+#pragma unroll
+            for (int g = 0; g < UG; ++g) p[g] = lstm_f4{0, 0, 0, 0};
 #pragma unroll
             for (int j = 0; j < KQ; ++j)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
+                    for (int g = 0; g < UG; ++g)
                         p[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[g][j * 4 + i], hv[j][i], p[g], 0, 0, 0);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) part[t & 1][w][g][l] = p[g];
+            for (int g = 0; g < UG; ++g) part[t & 1][w][g][l] = p[g];
             __syncthreads();                        // the only barrier of a step; part[] is two deep
-            acc += (part[t & 1][0][w][l] + part[t & 1][1][w][l]) + (part[t & 1][2][w][l] + part[t & 1][3][w][l]);
+            if (fin)
+                acc += (part[t & 1][0][w][l] + part[t & 1][1][w][l]) + (part[t & 1][2][w][l] + part[t & 1][3][w][l]);
         }
-        const float ig = lstm_sigmoid(acc[0]), fg = lstm_sigmoid(acc[1]), gg = tanhf(acc[2]), og = lstm_sigmoid(acc[3]);
+        if (!fin) continue;
+        const float ig = lstm_sigmoid(acc[0]), fg = lstm_sigmoid(acc[1]), gg = lstm_tanh(acc[2]), og = lstm_sigmoid(acc[3]);
         c = fg * c + ig * gg;
-        const float h = og * tanhf(c);
+        const float h = og * lstm_tanh(c);
         if (live) {
             const lstm_f4 act = {ig, fg, gg, og};
             *reinterpret_cast<lstm_f4 *>(a.gates + e * 4) = act;
@@ -212,7 +231,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             dh += (part[t & 1][0][w][l] + part[t & 1][1][w][l]) + (part[t & 1][2][w][l] + part[t & 1][3][w][l]);
         }
         const float ig = act[0], fg = act[1], gg = act[2], og = act[3];
-        const float tc = tanhf(ct);
+        const float tc = lstm_tanh(ct);
         const float dc = dc_carry + dh * og * (1.0f - tc * tc);
         lstm_f4 d;
         d[0] = dc * gg * ig * (1.0f - ig);
