@@ -1,8 +1,11 @@
+"""Dev tool: A/B two builds of libhbvx.so on the same box.
+
+    AB_CFGS="hourly cfg3" python tools/ab_libs.py libhbvx_A.so libhbvx_B.so
+
+runs tools/bench_configs.py with each library (separate processes, three interleaved rounds) and prints
+(config, forward ms, backward ms) per round; the libraries are looked up in hydrodl2_amd/csrc/."""
 import os, sys, shutil, subprocess, json
-sys.path.insert(0,'/root/repo')
-# A/B: run bench_configs with each library build (separate processes), several rounds interleaved
-import itertools
-root=os.environ.get('GRAFT_REPO_ROOT','/root/repo')
+root=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 libs=sys.argv[1:]
 cfgs=os.environ.get('AB_CFGS','cfg2').split()
 csrc=os.path.join(root,'hydrodl2_amd','csrc')
