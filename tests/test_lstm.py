@@ -111,6 +111,17 @@ def test_hip_lstm_matches_torch(hip_backend, T, B, I, H):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"HBVX_LSTM_UNITS": "16"}, {"HBVX_LSTM_WGS_PER_CU": "3"}])
+def test_hip_lstm_other_kernel_forms(hip_backend, monkeypatch, env):
+    """The forms the host does not pick by itself at this size: 16-unit forward workgroups, three
+    workgroups per CU."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    _run("cuda", 90, 100, 12, 256, seed=5)
+    _run("cuda", 20, 37, 5, 64, seed=6)
+
+
+@pytest.mark.gpu
 def test_hip_lstm_more_row_tiles_than_one_launch_holds(hip_backend):
     # 19 row tiles x 16 workgroups > 256 CUs: the host splits the batch into two launches
     _run("cuda", 24, 300, 8, 256, seed=3)
