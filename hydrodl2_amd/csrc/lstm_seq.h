@@ -242,6 +242,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         if (live) *reinterpret_cast<lstm_f4 *>(a.gates + e * 4) = d;
         if (t > 0) {
             // 16 lanes of one store instruction cover a unit's 256-byte block: whole lines
+            // (d comes out of VALU instructions: an inline-asm store placed straight after MFMAs would read the
+            // accumulators before their write-back -- the compiler pads only the stores it can see)
             float *xp = a.xch + ((size_t)t * a.ntile + tile) * slab + ((size_t)unit * LSTM_ROWS + n) * 4;
             const lstm_f4 dx = live ? d : lstm_f4{0, 0, 0, 0};
             asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(xp), "v"(dx) : "memory");
