@@ -120,7 +120,16 @@ __device__ unsigned long long g_pipe_probe[32];
 // the forcings), DY_USE moves it into the parameter array.
 // Branch-free: a static parameter reads row 0 of the tile (always valid) and keeps its value through
 // a select, so the stepper loop has no scalar branches.
-#define DY_DECL(X) const bool dy_##X = DYN && ((dmask >> X) & 1u); const int ix_##X = dy_##X ? dyn_index(dmask, X) * 64 : 0; float pn_##X = 0.0f
+// SC (slot combo, like the adjoint's SlotCombo): when the dynamic set is known at compile time -- 1:
+// {BETA, BETAET}, 2: {BETA, K0, BETAET}, the delta-MG defaults -- the flags fold, the static parameters'
+// reciprocals and products leave the day loop and the stages without a dynamic parameter run their
+// static code.  0: flags from the descriptor.
+template <int SC>
+__device__ __forceinline__ constexpr int pipe_sc_flag(int X)
+{
+    return SC == 0 ? -1 : ((X == P_BETA || X == P_BETAET || (SC == 2 && X == P_K0)) ? 1 : 0);
+}
+#define DY_DECL(X) const bool dy_##X = DYN && (pipe_sc_flag<SC>(X) >= 0 ? pipe_sc_flag<SC>(X) != 0 : (((dmask >> X) & 1u) != 0)); const int ix_##X = dy_##X ? dyn_index(dmask, X) * 64 : 0; float pn_##X = 0.0f
 #define DY_LOAD(X, ptr) do { pn_##X = (ptr)[ix_##X]; } while (0)
 #define DY_USE(X) do { p[X] = dy_##X ? pn_##X : p[X]; } while (0)
 
@@ -128,7 +137,7 @@ __device__ unsigned long long g_pipe_probe[32];
 // DYN: parameters vary per day: filler waves de-scale them (sigmoid, range, dy_drop blend) into LDS
 // tiles five deep (snow reads tile it, groundwater tile it-2, the fillers write it+2).
 // MANY: more than PIPE_FEWDYN of them: 4-day tiles, the filler waves share the rows round-robin.
-template <int MODEL, bool BETAET, bool TRAJ, bool DYN, bool MANY = false>
+template <int MODEL, bool BETAET, bool TRAJ, bool DYN, bool MANY = false, int SC = 0>
 __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
 {
     constexpr bool CAP = MODEL != MODEL_HBV10;   // two-stage pipeline (see the header comment)

@@ -782,25 +782,33 @@ extern "C" int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *s
             const bool be = d->n_param == 13, tr = out->traj != nullptr, dy = nd > 0;
             hipStream_t st = (hipStream_t)stream;
             hipError_t e;
-#define PIPE_GO(MODEL, BE, TR, DY, MANY) e = launch_tiled_one(k_fwd_pipe<MODEL, BE, TR, DY, MANY>, pa, grid_p, pthreads, lds, st)
-#define PIPE_GO4(MODEL, BE)                                                                        \
+            // compile-time dynamic sets (hbv_pipe.h, SC): {BETA, BETAET} and {BETA, K0, BETAET}
+            unsigned dmask = 0;
+            for (int i = 0; i < d->n_param; i++) dmask |= d->p[i].dyn ? (1u << i) : 0u;
+            const int sc = env_int("HBVX_PIPE_SC", 1) == 0 ? 0
+                         : dmask == ((1u << P_BETA) | (1u << P_BETAET)) ? 1
+                         : dmask == ((1u << P_BETA) | (1u << P_K0) | (1u << P_BETAET)) ? 2 : 0;
+#define PIPE_GO(MODEL, BE, TR, DY, MANY, SC) e = launch_tiled_one(k_fwd_pipe<MODEL, BE, TR, DY, MANY, SC>, pa, grid_p, pthreads, lds, st)
+#define PIPE_GO3(MODEL, BE, TR, S1, S2)                                                            \
     do {                                                                                           \
-        if (tr) {                                                                                  \
-            if (many) PIPE_GO(MODEL, BE, true, true, true);                                        \
-            else if (dy) PIPE_GO(MODEL, BE, true, true, false);                                    \
-            else PIPE_GO(MODEL, BE, true, false, false);                                           \
-        } else {                                                                                   \
-            if (many) PIPE_GO(MODEL, BE, false, true, true);                                       \
-            else if (dy) PIPE_GO(MODEL, BE, false, true, false);                                   \
-            else PIPE_GO(MODEL, BE, false, false, false);                                          \
-        }                                                                                          \
+        if (many) PIPE_GO(MODEL, BE, TR, true, true, 0);                                           \
+        else if (dy && sc == 1 && S1) PIPE_GO(MODEL, BE, TR, true, false, (S1 ? 1 : 0));           \
+        else if (dy && sc == 2 && S2) PIPE_GO(MODEL, BE, TR, true, false, (S2 ? 2 : 0));           \
+        else if (dy) PIPE_GO(MODEL, BE, TR, true, false, 0);                                       \
+        else PIPE_GO(MODEL, BE, TR, false, false, 0);                                              \
     } while (0)
-            if (d->model == HBVX_MODEL_HBV11P) PIPE_GO4(MODEL_HBV11P, true);
-            else if (d->model == HBVX_MODEL_HBV20) PIPE_GO4(MODEL_HBV20, true);
-            else if (d->model == HBVX_MODEL_HOURLY) PIPE_GO4(MODEL_HOURLY, true);
-            else if (be) PIPE_GO4(MODEL_HBV10, true);
-            else PIPE_GO4(MODEL_HBV10, false);
+#define PIPE_GO4(MODEL, BE, S1, S2)                                                                \
+    do {                                                                                           \
+        if (tr) PIPE_GO3(MODEL, BE, true, S1, S2);                                                 \
+        else PIPE_GO3(MODEL, BE, false, S1, S2);                                                   \
+    } while (0)
+            if (d->model == HBVX_MODEL_HBV11P) PIPE_GO4(MODEL_HBV11P, true, true, false);
+            else if (d->model == HBVX_MODEL_HBV20) PIPE_GO4(MODEL_HBV20, true, false, true);
+            else if (d->model == HBVX_MODEL_HOURLY) PIPE_GO4(MODEL_HOURLY, true, false, true);
+            else if (be) PIPE_GO4(MODEL_HBV10, true, true, true);
+            else PIPE_GO4(MODEL_HBV10, false, false, false);
 #undef PIPE_GO4
+#undef PIPE_GO3
 #undef PIPE_GO
             if (e != hipSuccess) return hip_fail(e, "hbvx_forward (pipelined) launch");
             return HBVX_OK;
