@@ -123,8 +123,10 @@ def test_hip_lstm_other_kernel_forms(hip_backend, monkeypatch, env):
 
 @pytest.mark.gpu
 def test_hip_lstm_more_row_tiles_than_one_launch_holds(hip_backend):
-    # 19 row tiles x 16 workgroups > 256 CUs: the host splits the batch into two launches
+    # 19 row tiles x 16 workgroups > 256 CUs: two workgroups per CU
     _run("cuda", 24, 300, 8, 256, seed=3)
+    # 63 row tiles x 16 workgroups > 3 x 256: three per CU and two balanced launches
+    _run("cuda", 12, 1000, 8, 256, seed=4)
 
 
 @pytest.mark.gpu
