@@ -268,26 +268,54 @@ __global__ void __launch_bounds__(GAGE_TILE) k_gage_bwd_p(const hbvx_gage_desc r
         guh[tid] = sacc;
     }
     __syncthreads();
-    if (tid != 0) return;
-    float sum = 0.0f;
-    for (int j = 0; j < L; j++) sum += w[j];
-    float mlt = 0.0f, mt = 0.0f;
-    for (int j = 0; j < L; j++) {
-        float wj = w[j] / sum, tj = (float)j + 0.5f;
-        mlt += wj * logf(tj);
-        mt += wj * tj;
+    // Closed-form chain shifted UH -> (taps, lag fraction) -> (route_a, route_b, route_tau): one lane per
+    // tap for the terms, thread 0 adds them in tap order (the sums the serial loop formed, bit for bit).
+    __shared__ float t1[GAGE_L], t2[GAGE_L], t3[GAGE_L];
+    __shared__ float s_sc[3];
+    if (tid == 0) {
+        float sum = 0.0f;
+        for (int j = 0; j < L; j++) sum += w[j];
+        s_sc[0] = sum;
     }
-    const int kk = (int)gp.kk;
+    __syncthreads();
+    const bool tap = tid < L;
+    const float tj = (float)tid + 0.5f;
+    float wj = 0.0f, lt = 0.0f;
+    if (tap) {
+        wj = w[tid] / s_sc[0];
+        lt = logf(tj);
+        t1[tid] = wj * lt;
+        t2[tid] = wj * tj;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float mlt = 0.0f, mt = 0.0f;
+        for (int j = 0; j < L; j++) {
+            mlt += t1[j];
+            mt += t2[j];
+        }
+        s_sc[1] = mlt;
+        s_sc[2] = mt;
+    }
+    __syncthreads();
+    if (tap) {
+        const float mlt = s_sc[1], mt = s_sc[2];
+        const int kk = (int)gp.kk;
+        // tap j feeds shifted taps j+kk (weight 1-f) and j+kk+1 (weight f)
+        const int k0s = tid + kk, k1s = tid + kk + 1;
+        const float g0 = (k0s <= L - 1) ? guh[k0s] : 0.0f, g1 = (k1s <= L - 1) ? guh[k1s] : 0.0f;
+        const float gw = r.lag_uh ? (1.0f - gp.f) * g0 + gp.f * g1 : guh[tid];
+        t3[tid] = wj * (g1 - g0);
+        t1[tid] = gw * wj * (lt - mlt);
+        t2[tid] = gw * wj * (tj - mt) / (gp.theta * gp.theta);
+    }
+    __syncthreads();
+    if (tid != 0) return;
     float gaa = 0.0f, gth = 0.0f, gf = 0.0f;
     for (int j = 0; j < L; j++) {
-        float wj = w[j] / sum, tj = (float)j + 0.5f;
-        // tap j feeds shifted taps j+kk (weight 1-f) and j+kk+1 (weight f)
-        int k0 = j + kk, k1 = j + kk + 1;
-        float g0 = (k0 <= L - 1) ? guh[k0] : 0.0f, g1 = (k1 <= L - 1) ? guh[k1] : 0.0f;
-        float gw = r.lag_uh ? (1.0f - gp.f) * g0 + gp.f * g1 : guh[j];
-        gf += wj * (g1 - g0);
-        gaa += gw * wj * (logf(tj) - mlt);
-        gth += gw * wj * (tj - mt) / (gp.theta * gp.theta);
+        gf += t3[j];
+        gaa += t1[j];
+        gth += t2[j];
     }
     gdp[p * 3 + 0] = ((gp.a > 0.0f) ? gaa : 0.0f) * (r.a_hi - r.a_lo);
     gdp[p * 3 + 1] = ((gp.b > 0.0f) ? gth : 0.0f) * (r.b_hi - r.b_lo);
