@@ -1561,3 +1561,38 @@ extern "C" int hbvx_lstm_check(const hbvx_lstm_desc *d, const void *workspace, v
     if (word) return fail(HBVX_E_DEVICE, "lstm hand-off timed out: the waves of a row tile were not co-resident");
     return 0;
 }
+
+// ---------------------------------------------------------------------------
+// zero fill of the dense gradient buffers (the autograd contract wants grad tensors shaped like the raw
+// parameter tensor [T,B,ny], of which static parameters touch one row): streaming 16-byte non-temporal
+// stores, grid-stride, no read-for-ownership
+// ---------------------------------------------------------------------------
+typedef float zero_f4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) k_zero_nt(zero_f4 *__restrict__ p, uint64_t n16)
+{
+    const zero_f4 z = {0.f, 0.f, 0.f, 0.f};
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * 256)
+        __builtin_nontemporal_store(z, &p[i]);
+}
+
+extern "C" int hbvx_zero(void *ptr, uint64_t bytes, void *stream)
+{
+    if (!ptr && bytes) return fail(HBVX_E_NULL, "hbvx_zero: buffer is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    const uint64_t head = ((uintptr_t)ptr & 15) ? 16 - ((uintptr_t)ptr & 15) : 0;
+    if (bytes < 4096 || head >= bytes) {
+        hipError_t e = hipMemsetAsync(ptr, 0, bytes, st);
+        return e == hipSuccess ? 0 : hip_fail(e, "hbvx_zero");
+    }
+    hipError_t e = hipSuccess;
+    if (head) e = hipMemsetAsync(ptr, 0, head, st);
+    const uint64_t n16 = (bytes - head) / 16, tail = (bytes - head) - n16 * 16;
+    // one 16-byte store per thread: on MI355X 6.6 TB/s against 5.3 for a grid-stride loop on a few thousand
+    // workgroups (3.8 GB: 0.58 ms against 0.72 ms for torch's fill)
+    const uint64_t want = n16 / 256 + 1;
+    const int blocks = (int)(want < 0x7fffffffull ? want : 0x7fffffffull);
+    hipLaunchKernelGGL(k_zero_nt, dim3(blocks), dim3(256), 0, st, (zero_f4 *)((char *)ptr + head), n16);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess && tail) e = hipMemsetAsync((char *)ptr + head + n16 * 16, 0, tail, st);
+    return e == hipSuccess ? 0 : hip_fail(e, "hbvx_zero");
+}

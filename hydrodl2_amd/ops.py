@@ -100,6 +100,15 @@ def _out(shape, device) -> torch.Tensor:
     return torch.empty(shape, dtype=torch.float32, device=device)
 
 
+def _zeros_like(lib, t: torch.Tensor) -> torch.Tensor:
+    """Dense zero gradient shaped like `t`, filled through hbvx_zero (6.6 TB/s on MI355X against 5.3 for
+    torch's fill kernel: the [T,B,ny] gradient of config 2 is 3.8 GB per step)."""
+    out = torch.empty_like(t)           # dense like t (same strides when t is dense): numel elements of storage
+    if out.numel():
+        _call(lib, 'hbvx_zero', lib.zero, out.data_ptr(), out.numel() * out.element_size(), _stream_of(lib, out))
+    return out
+
+
 def _ptr(t: Optional[torch.Tensor], off: int = 0) -> Optional[int]:
     if t is None:
         return None
@@ -236,7 +245,7 @@ class HbvPath(torch.autograd.Function):
         T, B, M = cfg.T, cfg.B, cfg.M
         stream = _stream_of(lib, x)
 
-        gp = [torch.zeros_like(p) if ctx.needs_input_grad[6 + i] else None
+        gp = [_zeros_like(lib, p) if ctx.needs_input_grad[6 + i] else None
               for i, p in enumerate(ptensors)]
 
         gq = None
@@ -259,7 +268,7 @@ class HbvPath(torch.autograd.Function):
         io.n_flux = cfg.n_flux
         gx = gmu = None
         if ctx.needs_input_grad[1]:
-            gx = torch.zeros_like(x)
+            gx = _zeros_like(lib, x)
             if gx.stride() != x.stride():
                 raise ValueError("x_phy must be dense for a forcing gradient")
             io.grad_x = _ptr(gx, cfg.t0 * x.stride(0))
@@ -337,7 +346,7 @@ class HbvAdjPath(torch.autograd.Function):
         dev = x.device
         T, B, M = cfg.T, cfg.B, cfg.M
         stream = _stream_of(lib, x)
-        gp = [torch.zeros_like(p) if ctx.needs_input_grad[3 + i] else None
+        gp = [_zeros_like(lib, p) if ctx.needs_input_grad[3 + i] else None
               for i, p in enumerate(ptensors)]
         gq = None
         if g_routed is not None and cfg.route is not None:

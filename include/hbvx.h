@@ -254,6 +254,11 @@ int hbvx_gage_route_backward(const hbvx_gage_desc *r, const float *qs, const flo
 int hbvx_adj_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream);
 int hbvx_adj_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *stream);
 
+/* Zero `bytes` bytes at `ptr` (streaming non-temporal stores).  The autograd contract of the plug-in wants
+ * gradient tensors shaped like the raw parameter tensor [T,B,ny] (hbv.py:211-246: static parameters read
+ * one row of it), so the dense zero fill is part of every backward step. */
+int hbvx_zero(void *ptr, uint64_t bytes, void *stream);
+
 /* Diagnostics (tests only): out[i] = the device pow used for (SM/FC)**BETA on x[i], y[i]. */
 int hbvx_selftest_pow(const float *x, const float *y, float *out, int n, void *stream);
 /* Diagnostics (tests only): out[i] = the device quotient used for SM/FC on x[i] / y[i]. */

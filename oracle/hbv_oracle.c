@@ -1366,3 +1366,12 @@ int hbvx_lstm_check(const hbvx_lstm_desc *d, const void *workspace, void *stream
     (void)workspace; (void)stream;
     return check_lstm(d);
 }
+
+/* include/hbvx.h: zero fill of the dense gradient buffers. */
+int hbvx_zero(void *ptr, uint64_t bytes, void *stream)
+{
+    (void)stream;
+    if (!ptr && bytes) return fail(HBVX_E_NULL, "hbvx_zero: buffer is NULL");
+    if (bytes) memset(ptr, 0, (size_t)bytes);
+    return 0;
+}

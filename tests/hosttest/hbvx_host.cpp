@@ -373,6 +373,7 @@ extern "C" int hbvx_lstm_backward(const hbvx_lstm_desc *d, const float *w, const
     return fn(d, w, g, c, gh, gg, ws, wsb, st);
 }
 extern "C" int hbvx_lstm_check(const hbvx_lstm_desc *, const void *, void *) { return 0; }
+extern "C" int hbvx_zero(void *ptr, uint64_t bytes, void *) { if (bytes) memset(ptr, 0, (size_t)bytes); return 0; }
 
 // Step::jt_unit against Step::bwd with zero flux adjoints (HBV 1.0): for n random days, the worst
 // difference over the five unit adjoints, relative to the largest entry of J^T.
