@@ -208,7 +208,8 @@ def main():
         except Exception:
             pmc = {}
     calls = {}
-    for call, nbytes in (("hbvx_forward", bytes_fwd), ("hbvx_backward", bytes_bwd)):
+    bytes_zero = 4.0 * T * B * ny      # the dense [T,B,ny] gradient the autograd contract returns (hbvx_zero)
+    for call, nbytes in (("hbvx_forward", bytes_fwd), ("hbvx_backward", bytes_bwd), ("hbvx_zero", bytes_zero)):
         if call in kavg:
             calls[call] = {"avg_ms": round(kavg[call], 4), "algorithmic_bytes": nbytes,
                            "achieved_GBps": round(nbytes / (kavg[call] * 1e-3) / 1e9, 2),
