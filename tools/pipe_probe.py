@@ -13,7 +13,13 @@ import hydrodl2_amd  # noqa: E402
 from hydrodl2_amd import _lib  # noqa: E402
 from tools.bench_configs import gen  # noqa: E402
 
-_lib._use_library_for_testing(os.path.join(ROOT, "hydrodl2_amd", "csrc", "libhbvx_probe.so"))
+PROBE_LIB = os.path.join(ROOT, "hydrodl2_amd", "csrc", "libhbvx_probe.so")
+SRC = os.path.join(ROOT, "hydrodl2_amd", "csrc", "hbvx.hip")
+if not os.path.exists(PROBE_LIB) or os.path.getmtime(PROBE_LIB) < os.path.getmtime(os.path.join(ROOT, "hydrodl2_amd", "csrc", "libhbvx.so")):
+    import subprocess
+    import __graft_entry__ as ge
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + ge.HIPCC_FLAGS + ["-DPIPE_PROBE", "-o", PROBE_LIB, SRC])
+_lib._use_library_for_testing(PROBE_LIB)
 lib = _lib.get_library()
 dev = torch.device("cuda:0")
 T, B, M = 7300, 671, 16
