@@ -30,6 +30,23 @@ struct Step<MODEL_HOURLY, BETAET_UNUSED> {
 
     static HBVX_HDM float dt_() { return (float)(1.0 / 24.0); } // self.dt (:58)
 
+    // x / dt, correctly rounded like the reference's IEEE division: RN(1/dt) is exactly 24, so one
+    // Newton step with the exact residual gives the correctly rounded quotient (Markstein; checked over
+    // all 2^23 mantissas).  It has to be exact: the model divides by dt and multiplies by dt again all
+    // over (tosoil, excess, ET, capillary rise, percolation), the round trips land within an ulp of the
+    // thresholds the next hour compares against (storage >= 0, SM/FC <= 1), and a quotient one ulp off
+    // flips those gradient masks -- isolated wrong forcing gradients in dry hours with the rcp-based div_.
+    static HBVX_HDM float div_dt_(float a)
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const float q = a * 24.0f;
+        const float r = __builtin_fmaf(-dt_(), q, a);
+        return __builtin_fmaf(r, 24.0f, q);
+#else
+        return a / dt_();
+#endif
+    }
+
     // The step in two parts, split where the pipelined forward splits it (hbv_pipe.h): the snow
     // routine (needs SP, MW, P, Tf; produces RAIN, tosoil) and everything else (needs SM, SUZ, SLZ,
     // PET, RAIN, tosoil).  fwd() is the two in order -- the same operations in the same order as the
@@ -38,7 +55,7 @@ struct Step<MODEL_HOURLY, BETAET_UNUSED> {
     {
         const float dt = dt_();
         const float TT = p[P_TT], CFMAX = p[P_CFMAX], CFR = p[P_CFR], CWH = p[P_CWH];
-        Pr = div_(P, dt);      // :485
+        Pr = div_dt_(P);      // :485
         // :529-533
         SPc = fmax_(SP, 0.0f);  g0 = (SP >= 0.0f) ? 1.0f : 0.0f;
         MWc = fmax_(MW, 0.0f);  g1 = (MW >= 0.0f) ? 1.0f : 0.0f;
@@ -65,7 +82,7 @@ struct Step<MODEL_HOURLY, BETAET_UNUSED> {
         refr = fmin_(rpcdt, MW1);
         SP3 = SP2 + refr;
         MW2 = MW1 - refr;
-        ts0 = div_(MW2 - CWH * SP3, dt);
+        ts0 = div_dt_(MW2 - CWH * SP3);
         tosoil = fmax_(ts0, 0.0f);
         MW3 = MW2 - tosoil * dt;
     }
@@ -77,7 +94,7 @@ struct Step<MODEL_HOURLY, BETAET_UNUSED> {
         const float BETA = p[P_BETA], FC = p[P_FC], K0 = p[P_K0], K1 = p[P_K1], K2 = p[P_K2],
                     LP = p[P_LP], PERCp = p[P_PERC], UZL = p[P_UZL], BE = p[P_BETAET], C = p[P_C],
                     RT = p[P_RT], AC = p[P_AC], F0 = p[P_F0], FMIN = p[P_FMIN], ALPHA = p[P_ALPHA];
-        PETr = div_(PET, dt);  // :487
+        PETr = div_dt_(PET);  // :487
         SMc = fmax_(SM, nz);    g2 = (SM >= nz) ? 1.0f : 0.0f;   // :529-533
         SUZc = fmax_(SUZ, nz);  g3 = (SUZ >= nz) ? 1.0f : 0.0f;
         SLZc = fmax_(SLZ, nz);  g4 = (SLZ >= nz) ? 1.0f : 0.0f;
@@ -97,7 +114,7 @@ struct Step<MODEL_HOURLY, BETAET_UNUSED> {
         rech = infil * sw;
         SM1 = SMc + (infil - rech) * dt;
         // :603-613
-        e0 = div_(SM1 - FC, dt);
+        e0 = div_dt_(SM1 - FC);
         exc = fmax_(e0, 0.0f);
         SM2 = SM1 - exc * dt;
         lpfc = LP * FC;
@@ -107,7 +124,7 @@ struct Step<MODEL_HOURLY, BETAET_UNUSED> {
         pe = PETr * ef;
         pedt = pe * dt;
         ETm = fmin_(SM2, pedt);
-        ET = div_(ETm, dt);
+        ET = div_dt_(ETm);
         dd = SM2 - ET * dt;
         SM3 = fmax_(dd, nz);
         // :616-628
@@ -117,7 +134,7 @@ struct Step<MODEL_HOURLY, BETAET_UNUSED> {
         om = 1.0f - rc;
         capp = (cs * om) * dt;
         capm = fmin_(SLZc, capp);
-        cap = div_(capm, dt);
+        cap = div_dt_(capm);
         smc = SM3 + cap * dt;
         SM4 = fmax_(smc, nz);
         slc = SLZc - cap * dt;
@@ -126,7 +143,7 @@ struct Step<MODEL_HOURLY, BETAET_UNUSED> {
         SUZ1 = SUZc + (rech + exc) * dt;
         pdt = PERCp * dt;
         PERCm = fmin_(SUZ1, pdt);
-        PERC = div_(PERCm, dt);
+        PERC = div_dt_(PERCm);
         SUZ2 = SUZ1 - PERC * dt;
         u0 = SUZ2 - UZL;
         u0c = fmax_(u0, 0.0f);

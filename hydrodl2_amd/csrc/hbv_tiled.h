@@ -540,6 +540,10 @@ __global__ void __launch_bounds__(512) k_bwd_tiled(const BwdTArgs A)
             }
             lds_barrier();
         }
+        // The static row is row T-1 of the same tensor the helpers write the dynamic rows into: wait
+        // until they have drained the last tile (with a single tile that is the one holding T-1, and
+        // their zero / dynamic store would race with the += below).
+        lds_barrier();
         if (L.active) {
 #pragma unroll
             for (int i = 0; i < NP; i++) {
@@ -673,6 +677,9 @@ __global__ void __launch_bounds__(512) k_bwd_tiled(const BwdTArgs A)
             lds_barrier();
         }
         if (nT > 0) drain(nT - 1);
+        // stores of the last drain have left this wave before the stepper adds the static gradient
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
     }
 }
 

@@ -36,6 +36,12 @@ ORACLE_CASES = [
     dict(model="Hbv", T=31, B=1, M=2, dyn=("parBETA",)),
     dict(model="Hbv_2", T=3, B=2, M=3, dyn=("parK0",)),
     dict(model="Hbv", T=129, B=3, M=16, dyn=("parBETA", "parBETAET", "parK0")),
+    # a record that fits one tile of the tiled adjoint, dynamic parameters with a dy_drop mask: the static
+    # row (T-1) and the dynamic rows share a tensor, and the helper waves' drain of that only tile used to
+    # race with the stepper's += into the static row (found by tools/fuzz_parity.py)
+    dict(model="Hbv_2_hourly", T=2, B=37, M=2, drop_frac=0.3,
+         dyn=tuple(n for n in gc.PHY_NAMES["Hbv_2_hourly"] if n != "parCFMAX")),
+    dict(model="Hbv", T=3, B=21, M=4, drop_frac=0.5, dyn=("parBETA", "parFC", "parK1", "parTT", "parCWH")),
 ]
 
 
