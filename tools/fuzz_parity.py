@@ -47,11 +47,13 @@ def main():
         kw = dict(model=model, T=T, B=B, M=M, dyn=tuple(dyn), seed=rng.randint(1, 10 ** 6),
                   drop_frac=rng.choice([0.0, 0.0, 0.3]) if dyn else 0.0,
                   muwts=(rng.random() < 0.2 and model == "Hbv"), cold=rng.random() < 0.3,
-                  betaet=("parBETAET" in names and model == "Hbv"))
+                  betaet=("parBETAET" in names and model == "Hbv"),
+                  routing=rng.random() < 0.8, raw_scale=rng.choice([1.0, 1.0, 2.5]))
+        t0 = rng.randint(1, max(1, T // 2)) if (rng.random() < 0.3 and T > 4) else 0   # warm-up offset
         try:
             prob = make_problem(**kw)
-            got = run_problem(prob, None, device="cuda:0", x_grad=True)
-            want = run_problem(prob, ge.ORACLE_LIB, device="cpu", x_grad=True)
+            got = run_problem(prob, None, device="cuda:0", x_grad=True, t0=t0)
+            want = run_problem(prob, ge.ORACLE_LIB, device="cpu", x_grad=True, t0=t0)
             for k in ("flux", "routed", "state_out"):
                 if k in want:
                     assert_close(k, got[k], want[k], 1e-4, 1e-5)
@@ -66,7 +68,7 @@ def main():
             bad += 1
             status = "ERROR " + repr(e)[:300]
         print(f"[{case:3d}] {status:12.300s} {model} T={T} B={B} M={M} dyn={len(dyn)}:{mode} drop={kw['drop_frac']} "
-              f"muwts={kw['muwts']} cold={kw['cold']} seed={kw['seed']}", flush=True)
+              f"muwts={kw['muwts']} cold={kw['cold']} routing={kw['routing']} scale={kw['raw_scale']} t0={t0} seed={kw['seed']}", flush=True)
     print(f"{n_cases - bad}/{n_cases} cases agree, {time.time() - t_start:.0f} s", flush=True)
     return 1 if bad else 0
 
