@@ -5,10 +5,9 @@ The product has exactly one compute path: the HIP library built in-tree by
 fallback: if the library is missing, or a tensor is not on the GPU, the call
 fails loudly.
 
-`_use_library_for_testing()` exists so that tests/ can drive the *host-side*
-logic of this package (parameter unpacking, warm-up orchestration, autograd
-plumbing) against the CPU oracle on machines without a GPU.  It is never
-called from the package itself and there is no environment switch for it.
+`_lib` is the one module-level handle; nothing in this package assigns it except
+`get_library()` (the CPU tier's substitution of a host implementation of the ABI
+lives in tests/seam.py, not here).
 """
 from __future__ import annotations
 
@@ -21,7 +20,6 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libhbvx.so")
 
 _lib: Optional[Library] = None
-_testing_override = False
 
 
 def get_library() -> Library:
@@ -38,12 +36,3 @@ def get_library() -> Library:
             raise RuntimeError(f"{LIB_PATH}: backend {lib.backend!r} is not a HIP build")
         _lib = lib
     return _lib
-
-
-def _use_library_for_testing(path: Optional[str]) -> None:
-    """tests/ only: route calls to another implementation of the ABI (the oracle)."""
-    global _lib, _testing_override
-    if path is None:
-        _lib, _testing_override = None, False
-    else:
-        _lib, _testing_override = Library(path), True

@@ -6,6 +6,7 @@ import numpy as np
 import torch
 
 from hydrodl2_amd import _abi, _lib
+from tests import seam
 from hydrodl2_amd.ops import HbvPath, ParamSource, RouteSource, StepConfig
 
 from . import synth
@@ -52,7 +53,7 @@ def make_problem(model="Hbv", T=40, B=5, M=4, dyn=(), betaet=False, drop_frac=0.
 
 def run_problem(prob, lib_path, device="cpu", x_grad=False, backward=True, t0=0):
     """Run forward (+backward with fixed output gradients) under `lib_path` (None = product)."""
-    _lib._use_library_for_testing(lib_path)
+    seam.use_library(lib_path)
     try:
         dev = torch.device(device)
         T, B, M, n, ny = prob["T"], prob["B"], prob["M"], prob["n"], prob["ny"]
@@ -102,7 +103,7 @@ def run_problem(prob, lib_path, device="cpu", x_grad=False, backward=True, t0=0)
                 res["g_muwts"] = mu.grad.cpu().numpy()
         return res
     finally:
-        _lib._use_library_for_testing(None)
+        seam.use_library(None)
 
 
 def assert_close(name, a, b, rtol, atol_rel):

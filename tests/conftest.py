@@ -33,10 +33,10 @@ def oracle_path():
 @pytest.fixture()
 def oracle_backend(oracle_path):
     """Route the package's host logic to the CPU oracle (tests only)."""
-    from hydrodl2_amd import _lib
-    _lib._use_library_for_testing(oracle_path)
+    from tests import seam
+    seam.use_library(oracle_path)
     yield
-    _lib._use_library_for_testing(None)
+    seam.use_library(None)
 
 
 @pytest.fixture(scope="session")
@@ -44,8 +44,9 @@ def hip_backend():
     """The product path: the HIP library on cuda:0.  Fails loudly if absent."""
     import torch
     from hydrodl2_amd import _lib
+    from tests import seam
     assert torch.cuda.is_available(), "gpu tests need a GPU"
-    _lib._use_library_for_testing(None)
+    seam.use_library(None)
     lib = _lib.get_library()
     assert lib.is_device
     return lib

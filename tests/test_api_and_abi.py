@@ -114,7 +114,8 @@ def test_hip_library_rejects_bad_descriptors():
 
 def test_product_fails_loudly_without_gpu_tensors():
     from hydrodl2_amd import _lib
-    _lib._use_library_for_testing(None)
+    from tests import seam
+    seam.use_library(None)
     m = load_model("hbv", "Hbv")(None, torch.device("cpu"))
     with pytest.raises(RuntimeError, match="GPU|HIP"):
         m({"x_phy": torch.rand(6, 2, 3)}, torch.randn(6, 2, 14))

@@ -53,8 +53,8 @@ def _dpl_worker(rank, world, port, oracle, q):
                       LOCAL_RANK=str(rank))
     import torch
     torch.set_num_threads(1)
-    from hydrodl2_amd import _lib
-    _lib._use_library_for_testing(oracle)
+    from tests import seam
+    seam.use_library(oracle)
     sys.argv = ["train_dpl.py", "--basins", "7", "--rho", "30", "--warm-up", "10", "--nmul", "2",
                 "--hidden", "8", "--steps", "4", "--device", "cpu"]
     losses = _load().main()

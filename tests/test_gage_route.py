@@ -10,6 +10,7 @@ import pytest
 import torch
 
 from hydrodl2_amd import _lib
+from tests import seam
 from hydrodl2_amd.ops import GageRoute, GageTopology
 
 from . import synth
@@ -68,7 +69,7 @@ def _restatement(pb, lag_uh):
 
 
 def _run(pb, lag_uh, lib_path, device):
-    _lib._use_library_for_testing(lib_path)
+    seam.use_library(lib_path)
     try:
         dev = torch.device(device)
         topo = GageTopology.from_outlet_topo(torch.tensor(pb["topo"], device=dev),
@@ -80,7 +81,7 @@ def _run(pb, lag_uh, lib_path, device):
         (out * torch.tensor(pb["wt"], device=dev)).sum().backward()
         return out.detach().cpu().numpy(), qs.grad.cpu().numpy(), dp.grad.cpu().numpy()
     finally:
-        _lib._use_library_for_testing(None)
+        seam.use_library(None)
 
 
 SHAPES = [(130, 9, 3, True), (40, 5, 2, True), (90, 6, 4, False), (300, 12, 5, True)]

@@ -82,11 +82,11 @@ def _run_case(device, case, tight):
 
 @pytest.fixture()
 def host_math_backend(steptest_lib, oracle_path, monkeypatch):  # noqa: F811
-    from hydrodl2_amd import _lib
+    from tests import seam
     monkeypatch.setenv("HBVX_ORACLE_LIB", oracle_path)
-    _lib._use_library_for_testing(steptest_lib)
+    seam.use_library(steptest_lib)
     yield
-    _lib._use_library_for_testing(None)
+    seam.use_library(None)
 
 
 def test_oracle_gradient_is_the_implicit_function_derivative():

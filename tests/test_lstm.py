@@ -82,7 +82,8 @@ def test_state_dict_interchanges_with_torch_lstm():
 
 def test_lstm_fails_loudly_without_gpu_tensors():
     from hydrodl2_amd import _lib
-    _lib._use_library_for_testing(None)
+    from tests import seam
+    seam.use_library(None)
     with pytest.raises(RuntimeError, match="GPU|HIP"):
         SeqLSTM(4, 64)(torch.randn(3, 2, 4))
 

@@ -43,8 +43,9 @@ def _worker(rank, world, port, oracle, T, B, M, seed, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
-    from hydrodl2_amd import _lib, sharding
-    _lib._use_library_for_testing(oracle)
+    from hydrodl2_amd import sharding
+    from tests import seam
+    seam.use_library(oracle)
     cfg = {"nmul": M, "dynamic_params": {"Hbv": ["parBETA", "parBETAET"]}, "warm_up": 5}
     x, p, w = _make(T, B, M, seed)
     xs, ps = sharding.shard_inputs({"x_phy": x}, p, world, rank)

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Per-kernel register / spill / LDS figures of a built HIP library, read from the gfx950 code
+object's metadata notes (no GPU needed).
+
+    python tools/kernel_resources.py [lib.so] [substring ...]
+
+Used by tests/test_code_object.py (no kernel may spill) and when tuning occupancy: waves per SIMD
+allowed by registers = min(8, 512 // (ceil((vgpr + agpr) / 8) * 8))  (MI355X_MICROARCH.md, register
+files)."""
+from __future__ import annotations
+
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEFAULT_LIB = os.path.join(ROOT, "hydrodl2_amd", "csrc", "libhbvx.so")
+
+
+def code_object(lib: str, out_dir: str) -> str:
+    """Extract the gfx950 code object of `lib` into out_dir; returns its path."""
+    fat = os.path.join(out_dir, "fatbin")
+    co = os.path.join(out_dir, "gfx950.co")
+    subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, fat])
+    subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o",
+                           "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}",
+                           f"--output={co}"])
+    return co
+
+
+def kernel_table(lib: str = DEFAULT_LIB) -> list[dict]:
+    with tempfile.TemporaryDirectory() as td:
+        co = code_object(lib, td)
+        notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], check=True,
+                               capture_output=True, text=True).stdout
+    rows = []
+    for blk in re.split(r"\n\s+- \.agpr_count:", notes)[1:]:
+        def field(key, _b=blk):
+            m = re.search(r"\.%s:\s+(\S+)" % key, _b)
+            return m.group(1) if m else "0"
+        rows.append({"symbol": field("name"), "agpr": int(blk.split()[0]), "vgpr": int(field("vgpr_count")),
+                     "sgpr": int(field("sgpr_count")), "vgpr_spill": int(field("vgpr_spill_count")),
+                     "sgpr_spill": int(field("sgpr_spill_count")), "lds": int(field("group_segment_fixed_size")),
+                     "scratch": int(field("private_segment_fixed_size")),
+                     "max_threads": int(field("max_flat_workgroup_size"))})
+    names = subprocess.run(["c++filt"], input="\n".join(r["symbol"] for r in rows), capture_output=True,
+                           text=True, check=True).stdout.split("\n")
+    for r, n in zip(rows, names):
+        r["name"] = n.replace("hbvx::", "")
+        alloc = -(-(r["vgpr"] + r["agpr"]) // 8) * 8
+        r["waves_per_simd"] = min(8, 512 // max(alloc, 8))
+    return rows
+
+
+def main():
+    args = sys.argv[1:]
+    lib = DEFAULT_LIB
+    if args and args[0].endswith(".so"):
+        lib = args.pop(0)
+    rows = kernel_table(lib)
+    for r in rows:
+        if args and not any(a in r["name"] for a in args):
+            continue
+        print(f"{r['name'][:110]:110s} v={r['vgpr']:3d} a={r['agpr']:3d} w/simd={r['waves_per_simd']} "
+              f"spill={r['vgpr_spill']:3d} sgpr={r['sgpr']:3d} scratch={r['scratch']}")
+    print(f"{len(rows)} kernels, {sum(1 for r in rows if r['vgpr_spill'] or r['sgpr_spill'])} with spills")
+
+
+if __name__ == "__main__":
+    main()

@@ -11,6 +11,7 @@ import torch  # noqa: E402
 
 import hydrodl2_amd  # noqa: E402
 from hydrodl2_amd import _lib  # noqa: E402
+from tests import seam  # noqa: E402
 from tools.bench_configs import gen  # noqa: E402
 
 PROBE_LIB = os.path.join(ROOT, "hydrodl2_amd", "csrc", "libhbvx_probe.so")
@@ -19,7 +20,7 @@ if not os.path.exists(PROBE_LIB) or os.path.getmtime(PROBE_LIB) < os.path.getmti
     import subprocess
     import __graft_entry__ as ge
     subprocess.check_call(["/opt/rocm/bin/hipcc"] + ge.HIPCC_FLAGS + ["-DPIPE_PROBE", "-o", PROBE_LIB, SRC])
-_lib._use_library_for_testing(PROBE_LIB)
+seam.use_library(PROBE_LIB)
 lib = _lib.get_library()
 dev = torch.device("cuda:0")
 T, B, M = 7300, 671, 16
