@@ -94,7 +94,7 @@ class LstmDesc(C.Structure):
 LSTM_ABI_VERSION = 1
 LSTM_HIDDEN_SIZES = (64, 128, 256)     # what the HIP library instantiates
 
-EXPORTS = ["hbvx_zero", "hbvx_lstm_workspace_bytes", "hbvx_lstm_forward", "hbvx_lstm_backward", "hbvx_lstm_check",
+EXPORTS = ["hbvx_zero", "hbvx_zero_except", "hbvx_lstm_workspace_bytes", "hbvx_lstm_forward", "hbvx_lstm_backward", "hbvx_lstm_check",
            "hbvx_version", "hbvx_last_error", "hbvx_backend", "hbvx_sizeof", "hbvx_forward",
            "hbvx_backward", "hbvx_backward_workspace_bytes", "hbvx_route_forward", "hbvx_route_workspace_bytes",
            "hbvx_route_backward", "hbvx_adj_forward", "hbvx_adj_backward", "hbvx_bfi",
@@ -151,6 +151,9 @@ class Library:
         d.hbvx_bfi.argtypes = [C.c_int32, C.c_int32, _fp, _fp, C.c_float, _fp, C.c_void_p]
         d.hbvx_zero.restype = C.c_int
         d.hbvx_zero.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+        d.hbvx_zero_except.restype = C.c_int
+        d.hbvx_zero_except.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_int32,
+                                       C.c_uint32, C.c_void_p]
         d.hbvx_lstm_workspace_bytes.restype = C.c_uint64
         d.hbvx_lstm_workspace_bytes.argtypes = [C.POINTER(LstmDesc)]
         d.hbvx_lstm_forward.restype = C.c_int
@@ -212,6 +215,11 @@ class Library:
 
     def zero(self, ptr: int, nbytes: int, stream: int):
         self._check(self.dll.hbvx_zero(ptr, C.c_uint64(nbytes), C.c_void_p(stream)), "hbvx_zero")
+
+    def zero_except(self, ptr: int, rows: int, width: int, r0: int, r1: int, group_w: int, keep: int,
+                    stream: int):
+        self._check(self.dll.hbvx_zero_except(ptr, rows, width, r0, r1, group_w, C.c_uint32(keep),
+                                              C.c_void_p(stream)), "hbvx_zero_except")
 
     def lstm_workspace_bytes(self, r: LstmDesc) -> int:
         return int(self.dll.hbvx_lstm_workspace_bytes(C.byref(r)))

@@ -78,31 +78,28 @@ class HbvModule(torch.nn.Module):
         self._set_parameters()
 
     # -- configuration --------------------------------------------------
+    # config key -> attribute of the same name; absent keys keep the constructor default
+    _CONFIG_KEYS = ('warm_up', 'warm_up_states', 'dy_drop', 'variables', 'routing', 'comprout',
+                    'nearzero', 'nmul', 'cache_states')
+
     def _read_config(self, config: dict) -> None:
-        """hbv.py:110-125 (same keys, same defaults, `dynamic_params` keyed by class name)."""
-        self.warm_up = config.get('warm_up', self.warm_up)
-        self.warm_up_states = config.get('warm_up_states', self.warm_up_states)
-        self.dy_drop = config.get('dy_drop', self.dy_drop)
-        self.dynamic_params = config['dynamic_params'].get(
-            self.__class__.__name__, self.dynamic_params)
-        self.variables = config.get('variables', self.variables)
-        self.routing = config.get('routing', self.routing)
-        self.comprout = config.get('comprout', self.comprout)
-        self.nearzero = config.get('nearzero', self.nearzero)
-        self.nmul = config.get('nmul', self.nmul)
-        self.cache_states = config.get('cache_states', False)
+        """Same keys and defaults as hbv.py:110-125; `dynamic_params` is REQUIRED once a config is
+        given and is keyed by the class name (hbv.py:115-117)."""
+        for key in self._CONFIG_KEYS:
+            if key in config:
+                setattr(self, key, config[key])
+        per_class = config['dynamic_params']
+        self.dynamic_params = per_class.get(type(self).__name__, self.dynamic_params)
         if self._model_id == _abi.MODEL_HBV10 and 'parBETAET' in self.dynamic_params:
             self.parameter_bounds['parBETAET'] = [0.3, 5]  # hbv.py:124-125
 
     def _set_parameters(self) -> None:
-        """hbv.py:170-180."""
+        """Name views and the width of the raw NN output: n_phys * nmul (+ 2 routing columns),
+        hbv.py:170-180."""
         self.phy_param_names = self.parameter_bounds.keys()
-        if self.routing:
-            self.routing_param_names = self.routing_parameter_bounds.keys()
-        else:
-            self.routing_param_names = []
-        self.learnable_param_count = len(self.phy_param_names) * self.nmul + len(
-            self.routing_param_names)
+        self.routing_param_names = self.routing_parameter_bounds.keys() if self.routing else []
+        n_phys, n_route = len(self.phy_param_names), len(self.routing_param_names)
+        self.learnable_param_count = n_phys * self.nmul + n_route
 
     # -- state API (hbv.py:128-168) --------------------------------------
     def _init_states(self, ngrid: int):
@@ -113,12 +110,12 @@ class HbvModule(torch.nn.Module):
         return self._states_cache
 
     def load_states(self, states: tuple[torch.Tensor, ...]) -> None:
-        for state in states:
-            if not isinstance(state, torch.Tensor):
-                raise ValueError("Each element in `states` must be a tensor.")
-        nstates = len(self.state_names)
-        if not (isinstance(states, tuple) and len(states) == nstates):
-            raise ValueError(f"`states` must be a tuple of {nstates} tensors.")
+        """Same checks and messages as hbv.py:150-168; stored detached, fp32, on the model device."""
+        want = len(self.state_names)
+        if any(not isinstance(s, torch.Tensor) for s in states):
+            raise ValueError("Each element in `states` must be a tensor.")
+        if not isinstance(states, tuple) or len(states) != want:
+            raise ValueError(f"`states` must be a tuple of {want} tensors.")
         self.states = tuple(s.detach().to(self.device, dtype=torch.float32) for s in states)
 
     # -- helpers ---------------------------------------------------------
@@ -145,10 +142,17 @@ class HbvModule(torch.nn.Module):
                           for s in states])
         return st.contiguous()
 
-    def _expand_muwts(self, muwts, T: int, B: int):
+    def _expand_muwts(self, muwts, T: int, T_total: int, B: int):
+        """Ensemble weights for the T simulated (post warm-up) days, dense [T,B,nmul].
+        The reference multiplies `muwts` against Qsimmu of length T (hbv.py:497-511): broadcast
+        shapes ([B,nmul], [1,B,nmul]) and a time-resolved [T,B,nmul] are what it accepts; a
+        [T_total,B,nmul] tensor (rows aligned with x_phy) is accepted here too and cut at warm_up."""
         if muwts is None:
             return None
-        return muwts.to(torch.float32).expand(T, B, self.nmul).contiguous()
+        mu = muwts.to(torch.float32)
+        if mu.dim() == 3 and mu.shape[0] == T_total and T_total != T:
+            mu = mu[T_total - T:]
+        return mu.expand(T, B, self.nmul).contiguous()
 
     def _param_sources(self, T_total: int, B: int, ny: int, t_first: int, sta_row: int,
                        dy_list, device):
@@ -223,7 +227,8 @@ class HbvModule(torch.nn.Module):
             cfg.route = RouteSource(0, off, off + 1, ny,
                                     self.routing_parameter_bounds['route_a'],
                                     self.routing_parameter_bounds['route_b'])
-        muwts = self._expand_muwts(self.muwts, T_total, ngrid)
+        muwts = self._expand_muwts(self.muwts, T, T_total, ngrid)
+        cfg.mu_t0 = 0                      # muwts rows are post-warm-up days already
         flux, routed, state_out, _ = HbvPath.apply(cfg, x, state_in, muwts, None, None,
                                                    parameters)
 

@@ -357,6 +357,7 @@ __global__ void __launch_bounds__(64) k_bwd_chunk_phi(const ChunkArgs A)
     }
 }
 
+#ifndef HBVX_CHUNK_NO_SHARED_KERNELS   // non-template kernels: defined in launch_chunked.hip only
 // ---- B2 -------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_bwd_chunk_scan(const ChunkArgs A)
 {
@@ -400,6 +401,8 @@ __global__ void __launch_bounds__(64) k_bwd_chunk_scan(const ChunkArgs A)
         for (int k = 0; k < 5; k++) A.io.grad_state_in[k * N + n] = a[k];
     }
 }
+
+#endif
 
 // ---- B3 -------------------------------------------------------------------------------------
 __device__ __forceinline__ float chunk_ens_sum(float v, int lgMp)
@@ -507,6 +510,7 @@ __global__ void __launch_bounds__(64) k_bwd_chunk_sweep(const ChunkArgs A)
     }
 }
 
+#ifndef HBVX_CHUNK_NO_SHARED_KERNELS
 // ---- B4 -------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_bwd_chunk_reduce(const ChunkArgs A, int NP)
 {
@@ -536,5 +540,7 @@ __global__ void __launch_bounds__(256) k_bwd_chunk_reduce(const ChunkArgs A, int
     float *dst = io.g[i].sta + (int64_t)b * io.g[i].sta_b_stride + j;
     *dst += gsum;
 }
+
+#endif
 
 } // namespace hbvx

@@ -21,7 +21,6 @@
 #include "../../include/hbvx.h"
 #include "hbv_step.h"
 #include "hbv_tiled.h"
-#include "hbv_chunked.h"
 
 namespace hbvx {
 

@@ -7,38 +7,25 @@
 // The time axis is strictly serial per lane (explicit Euler recurrence).
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared
-#include <hip/hip_runtime.h>
-
-#include <cstdio>
-#include <cstring>
-
-#include <cstdlib>
-
-#include "../../include/hbvx.h"
+#include "hbvx_host.h"
 #include "hbv_step.h"
-#include "hbv_tiled.h"
-#include "hbv_adj_kernels.h"
 #include "hbv_gage.h"
-#include "lstm_seq.h"
-#include "../../include/hbvx_lstm.h"
-#include "hbv_chunked.h"
-#include "hbv_pipe.h"
-#include "hbv_stream.h"
 
 using namespace hbvx;
+using namespace hbvx_host;
 
 // ---------------------------------------------------------------------------
 // error plumbing
 // ---------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
 
-static int fail(int code, const char *msg)
+int hbvx_host::fail(int code, const char *msg)
 {
     snprintf(g_err, sizeof g_err, "%s", msg);
     return code;
 }
 
-static int hip_fail(hipError_t e, const char *what)
+int hbvx_host::hip_fail(hipError_t e, const char *what)
 {
     snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
     return HBVX_E_DEVICE;
@@ -586,7 +573,7 @@ __global__ void __launch_bounds__(1024) k_route_bwd_params(const hbvx_route_desc
 // ---------------------------------------------------------------------------
 // host side of the C ABI
 // ---------------------------------------------------------------------------
-static int check_desc(const hbvx_desc *d)
+int hbvx_host::check_desc(const hbvx_desc *d)
 {
     if (!d) return fail(HBVX_E_NULL, "desc is NULL");
     if (d->abi_version != HBVX_ABI_VERSION) return fail(HBVX_E_ABI, "abi_version mismatch");
@@ -609,7 +596,7 @@ static int check_desc(const hbvx_desc *d)
     return HBVX_OK;
 }
 
-static int lg_members(int M)
+int hbvx_host::lg_members(int M)
 {
     int lg = 0;
     while ((1 << lg) < M) lg++;
@@ -631,107 +618,28 @@ static hipError_t launch_variant(const hbvx_desc *d, const Args &a, dim3 grid, h
     return hipGetLastError();
 }
 
-// ---------------------------------------------------------------------------
-// tile geometry + launch of the wave-specialised kernels (hbv_tiled.h)
-// ---------------------------------------------------------------------------
-static const int LDS_BUDGET = 160 * 1024 - 512; // gfx950: 160 KiB per CU, one workgroup may take it all
 
-static int env_int(const char *name, int dflt)
+int hbvx_host::env_int(const char *name, int dflt)
 {
     const char *v = getenv(name);
     return (v && *v) ? atoi(v) : dflt;
 }
 
-// HBVX_KERNEL=simple selects the one-wave kernels (kept for very large grids and as a
-// cross-check); default is the tiled, wave-specialised path.
-static bool use_tiled(const hbvx_desc *d)
+// HBVX_KERNEL=simple selects the one-wave kernels (kept as a cross-check); default is the
+// wave-specialised / streaming / time-parallel families.
+bool hbvx_host::use_tiled(const hbvx_desc *d)
 {
     const char *v = getenv("HBVX_KERNEL");
     if (v && !strcmp(v, "simple")) return false;
     return d->T > 0;
 }
 
-static int count_dyn(const hbvx_desc *d)
+int hbvx_host::count_dyn(const hbvx_desc *d)
 {
     int nd = 0;
     for (int i = 0; i < d->n_param; i++) nd += d->p[i].dyn ? 1 : 0;
     return nd;
 }
-
-static bool geom_fwd(const hbvx_desc *d, const hbvx_fwd_out *o, TileGeom &g)
-{
-    g = TileGeom{};
-    g.lgMp = lg_members(d->M);
-    g.ND = count_dyn(d);
-    g.NDm = g.ND + (d->muwts ? 1 : 0);
-    const int NF = (d->model == HBVX_MODEL_HBV10) ? 11 : (d->model == HBVX_MODEL_HBVADJ ? 1 : 12);
-    // Few workgroups (cfg2: 168 on 256 CUs): deep tiles, one workgroup owns its CU.  Many
-    // workgroups (cfg5: 3125): shallow tiles so that several steppers share a CU (LDS decides how
-    // many) -- measured at cfg5: Kt 16/8 -> 7.4 ms, Kt 4 -> 5.8 ms.
-    const int wgs = (d->B + (64 >> g.lgMp) - 1) / (64 >> g.lgMp);
-    const int ktmax = env_int("HBVX_KT", wgs >= 1024 ? 4 : 16);
-    for (int Kt = 16; Kt >= 1; Kt >>= 1) {
-        if (Kt > ktmax) continue;
-        g.Kt = Kt;
-        g.off_pin = Kt * 256;
-        g.in_sz = Kt * (256 + g.NDm * 64);
-        g.off_tout = Kt * 64 * (o->flux ? NF : 0);
-        g.out_sz = g.off_tout + Kt * 64 * (o->traj ? 7 : 0);
-        if (g.out_sz == 0) g.out_sz = 4;
-        if (2 * (g.in_sz + g.out_sz) * 4 <= LDS_BUDGET) return true;
-    }
-    return false;
-}
-
-static bool geom_bwd(const hbvx_desc *d, const hbvx_bwd_io *io, TileGeom &g)
-{
-    g = TileGeom{};
-    g.lgMp = lg_members(d->M);
-    g.ND = count_dyn(d);
-    g.NDm = g.ND + (d->muwts ? 1 : 0);
-    const int NF = io->grad_flux ? ((d->model == HBVX_MODEL_HBV10) ? 11 : 12) : 4; // staged series
-    const int bpw = 64 >> g.lgMp;
-    const int ktmax = env_int("HBVX_KT", 16);
-    for (int Kt = 16; Kt >= 1; Kt >>= 1) {
-        if (Kt > ktmax) continue;
-        g.Kt = Kt;
-        g.off_pin = Kt * 256;
-        g.off_tin = g.off_pin + Kt * g.NDm * 64;
-        g.off_gin = g.off_tin + Kt * 7 * 64;
-        g.in_sz = (g.off_gin + Kt * NF * bpw + 3) & ~3;
-        g.off_xout = Kt * 64 * g.ND;
-        g.off_mout = g.off_xout + Kt * 64 * (io->grad_x ? 3 : 0);
-        g.out_sz = g.off_mout + Kt * 64 * (io->grad_muwts ? 1 : 0);
-        if (g.out_sz == 0) g.out_sz = 4;
-        if (2 * (g.in_sz + g.out_sz) * 4 <= LDS_BUDGET) return true;
-    }
-    return false;
-}
-
-template <typename Args, typename K>
-static hipError_t launch_tiled_one(K kern, const Args &a, dim3 grid, int threads, size_t lds,
-                                   hipStream_t st)
-{
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, grid, dim3(threads), lds, st, a);
-    return hipGetLastError();
-}
-
-#define LAUNCH_TILED_V(K, d, a, grid, lds, st, ...)                                                \
-    ([&]() -> hipError_t {                                                                        \
-        int nh = env_int("HBVX_NH", (grid).x >= 1024 ? 3 : 7);                                    \
-        nh = nh < 1 ? 1 : (nh > 7 ? 7 : nh);                                                      \
-        const int threads = 64 * (1 + nh);                                                        \
-        const int m = (d)->model;                                                                 \
-        const bool be = (d)->n_param == 13;                                                       \
-        if (m == HBVX_MODEL_HBV10 && !be) return launch_tiled_one(K<MODEL_HBV10, false, __VA_ARGS__>, a, grid, threads, lds, st); \
-        if (m == HBVX_MODEL_HBV10) return launch_tiled_one(K<MODEL_HBV10, true, __VA_ARGS__>, a, grid, threads, lds, st);         \
-        if (m == HBVX_MODEL_HBV11P) return launch_tiled_one(K<MODEL_HBV11P, true, __VA_ARGS__>, a, grid, threads, lds, st);       \
-        if (m == HBVX_MODEL_HOURLY) return launch_tiled_one(K<MODEL_HOURLY, true, __VA_ARGS__>, a, grid, threads, lds, st);       \
-        return launch_tiled_one(K<MODEL_HBV20, true, __VA_ARGS__>, a, grid, threads, lds, st);    \
-    })()
 
 extern "C" int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream)
 {
@@ -741,139 +649,10 @@ extern "C" int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *s
     if (!out || !out->state_out) return fail(HBVX_E_NULL, "state_out is NULL");
     const int want_nf = (d->model == HBVX_MODEL_HBV10) ? 11 : 12;
     if (out->flux && out->n_flux != want_nf) return fail(HBVX_E_SHAPE, "n_flux does not match model");
-    {
-        // HBV 1.0 / 1.1p / 2.0, at most PIPE_MAXDYN dynamic parameters, flux requested: pipelined
-        // forward (hbv_pipe.h; three stages for HBV 1.0, two for the capillary models)
-        const char *fv = getenv("HBVX_FWD");
-        const int nd = count_dyn(d);
-        const bool many = nd > PIPE_FEWDYN;          // 4-day tiles, several staged rows per filler wave
-        const int Kt = many ? PIPE_KT_MANY : PIPE_KT;
-        const bool cap = d->model != HBVX_MODEL_HBV10;
-        const int nfl = cap ? 12 : 11;
-        // per-lane and per-tile byte offsets are 32-bit in the pipelined kernel
-        bool off32 = ((int64_t)d->B * d->x_b_stride + (int64_t)Kt * d->x_t_stride) * 4 < (int64_t)1 << 31;
-        for (int i = 0; i < d->n_param; i++)
-            if (d->p[i].dyn)
-                off32 = off32 && ((int64_t)d->B * d->p[i].dyn_b_stride + (int64_t)Kt * d->p[i].dyn_t_stride) * 4 <
-                                     (int64_t)1 << 31;
-        const int64_t wgs_p = ((int64_t)d->B + (64 >> lg_members(d->M)) - 1) / (64 >> lg_members(d->M));
-        // HBV 1.0: the pipelined kernel (one workgroup per CU) holds up to ~1000 wavefronts; the
-        // two-stage variant gives way to the streaming kernel at its cross-over (512); with more
-        // than three dynamic parameters there is no streaming kernel to give way to
-        const bool large = nd <= 3 && wgs_p >= (cap ? env_int("HBVX_STREAM_MIN", 512) : 1024) &&
-                           env_int("HBVX_STREAM", 1) != 0;
-        const bool pmodel = d->model == HBVX_MODEL_HBV10 || d->model == HBVX_MODEL_HBV11P ||
-                            d->model == HBVX_MODEL_HBV20 || d->model == HBVX_MODEL_HOURLY;
-        const size_t lds = (size_t)PipeLds(Kt, nd > 0 ? (many ? nd : PIPE_FEWDYN) : 0, cap).total * 4;
-        if (use_tiled(d) && !(fv && !strcmp(fv, "tiled")) && pmodel && off32 && !large &&
-            nd <= PIPE_MAXDYN && (int)lds <= LDS_BUDGET && wgs_p < 4096 && !d->muwts && out->flux && d->T >= 4 * Kt &&
-            (out->traj != nullptr) == (out->aux != nullptr) && (int64_t)d->B * d->M * 4 * Kt < (int64_t)1 << 31 &&
-            (int64_t)nfl * d->T * d->B * 4 < (int64_t)1 << 31) {
-            PipeArgs pa;
-            pa.d = *d;
-            pa.o = *out;
-            pa.lgMp = lg_members(d->M);
-            pa.Kt = Kt;
-            const int bpw_p = 64 >> pa.lgMp;
-            dim3 grid_p((d->B + bpw_p - 1) / bpw_p);
-            int pthreads = env_int("HBVX_PIPE_THREADS", 1024); // 3 steppers + filler + drainers (hbv_pipe.h)
-            pthreads = pthreads < 512 ? 512 : (pthreads > 1024 ? 1024 : (pthreads / 64) * 64);
-            if (nd > 0) pthreads = 1024;   // the dynamic-parameter roles assume all 16 waves
-            const bool be = d->n_param == 13, tr = out->traj != nullptr, dy = nd > 0;
-            hipStream_t st = (hipStream_t)stream;
-            hipError_t e;
-            // compile-time dynamic sets (hbv_pipe.h, SC): {BETA, BETAET} and {BETA, K0, BETAET}
-            unsigned dmask = 0;
-            for (int i = 0; i < d->n_param; i++) dmask |= d->p[i].dyn ? (1u << i) : 0u;
-            const int sc = env_int("HBVX_PIPE_SC", 1) == 0 ? 0
-                         : dmask == ((1u << P_BETA) | (1u << P_BETAET)) ? 1
-                         : dmask == ((1u << P_BETA) | (1u << P_K0) | (1u << P_BETAET)) ? 2 : 0;
-#define PIPE_GO(MODEL, BE, TR, DY, MANY, SC) e = launch_tiled_one(k_fwd_pipe<MODEL, BE, TR, DY, MANY, SC>, pa, grid_p, pthreads, lds, st)
-#define PIPE_GO3(MODEL, BE, TR, S1, S2)                                                            \
-    do {                                                                                           \
-        if (many) PIPE_GO(MODEL, BE, TR, true, true, 0);                                           \
-        else if (dy && sc == 1 && S1) PIPE_GO(MODEL, BE, TR, true, false, (S1 ? 1 : 0));           \
-        else if (dy && sc == 2 && S2) PIPE_GO(MODEL, BE, TR, true, false, (S2 ? 2 : 0));           \
-        else if (dy) PIPE_GO(MODEL, BE, TR, true, false, 0);                                       \
-        else PIPE_GO(MODEL, BE, TR, false, false, 0);                                              \
-    } while (0)
-#define PIPE_GO4(MODEL, BE, S1, S2)                                                                \
-    do {                                                                                           \
-        if (tr) PIPE_GO3(MODEL, BE, true, S1, S2);                                                 \
-        else PIPE_GO3(MODEL, BE, false, S1, S2);                                                   \
-    } while (0)
-            if (d->model == HBVX_MODEL_HBV11P) PIPE_GO4(MODEL_HBV11P, true, true, false);
-            else if (d->model == HBVX_MODEL_HBV20) PIPE_GO4(MODEL_HBV20, true, false, true);
-            else if (d->model == HBVX_MODEL_HOURLY) PIPE_GO4(MODEL_HOURLY, true, false, true);
-            else if (be) PIPE_GO4(MODEL_HBV10, true, true, true);
-            else PIPE_GO4(MODEL_HBV10, false, false, false);
-#undef PIPE_GO4
-#undef PIPE_GO3
-#undef PIPE_GO
-            if (e != hipSuccess) return hip_fail(e, "hbvx_forward (pipelined) launch");
-            return HBVX_OK;
-        }
-    }
-    {
-        // large grids: streaming one-wave kernel (hbv_stream.h)
-        const int lg = lg_members(d->M);
-        const int bpw_s = 64 >> lg;
-        const int64_t wgs = ((int64_t)d->B + bpw_s - 1) / bpw_s;
-        const int64_t N = (int64_t)d->B * d->M, lim = (int64_t)1 << 32;
-        const int nd = count_dyn(d);
-        const int nf = (d->model == HBVX_MODEL_HBV10) ? 11 : 12;
-        bool ok = use_tiled(d) && env_int("HBVX_STREAM", 1) != 0 && wgs >= env_int("HBVX_STREAM_MIN", 512) && nd <= 3 && !d->muwts &&
-                  out->flux && (out->traj != nullptr) == (out->aux != nullptr) && d->T > 0 &&
-                  5 * (int64_t)(d->T + 1) * N * 4 < lim && (int64_t)nf * d->T * d->B * 4 < lim &&
-                  ((int64_t)d->T * d->x_t_stride + (int64_t)d->B * d->x_b_stride) * 4 < lim;
-        for (int i = 0; i < d->n_param && ok; i++)
-            if (d->p[i].dyn)
-                ok = ((int64_t)d->T * d->p[i].dyn_t_stride + (int64_t)d->B * d->p[i].dyn_b_stride) * 4 < lim;
-        if (ok) {
-            StreamArgs sa;
-            sa.d = *d;
-            sa.o = *out;
-            sa.lgMp = lg;
-            sa.nd = 0;
-            sa.dslot[0] = sa.dslot[1] = sa.dslot[2] = 0;
-            for (int i = 0; i < d->n_param; i++)
-                if (d->p[i].dyn) sa.dslot[sa.nd++] = i;
-            const bool tr = out->traj != nullptr, few = nd > 0;
-            dim3 grid_s((unsigned)wgs);
-            hipStream_t st = (hipStream_t)stream;
-#define STREAM_GO(MODEL, BE)                                                                          \
-    do {                                                                                              \
-        if (tr) { if (few) hipLaunchKernelGGL((k_fwd_stream<MODEL, BE, true, true>), grid_s, dim3(64), 0, st, sa);   \
-                  else hipLaunchKernelGGL((k_fwd_stream<MODEL, BE, true, false>), grid_s, dim3(64), 0, st, sa); }   \
-        else { if (few) hipLaunchKernelGGL((k_fwd_stream<MODEL, BE, false, true>), grid_s, dim3(64), 0, st, sa);    \
-               else hipLaunchKernelGGL((k_fwd_stream<MODEL, BE, false, false>), grid_s, dim3(64), 0, st, sa); }     \
-    } while (0)
-            if (d->model == HBVX_MODEL_HBV10 && d->n_param == 12) STREAM_GO(MODEL_HBV10, false);
-            else if (d->model == HBVX_MODEL_HBV10) STREAM_GO(MODEL_HBV10, true);
-            else if (d->model == HBVX_MODEL_HBV11P) STREAM_GO(MODEL_HBV11P, true);
-            else if (d->model == HBVX_MODEL_HOURLY) STREAM_GO(MODEL_HOURLY, true);
-            else STREAM_GO(MODEL_HBV20, true);
-#undef STREAM_GO
-            hipError_t e = hipGetLastError();
-            if (e != hipSuccess) return hip_fail(e, "hbvx_forward (stream) launch");
-            return HBVX_OK;
-        }
-    }
-    {
-        FwdTArgs ta;
-        if (use_tiled(d) && geom_fwd(d, out, ta.g)) {
-            ta.d = *d;
-            ta.o = *out;
-            const int bpw_t = 64 >> ta.g.lgMp;
-            dim3 grid_t((d->B + bpw_t - 1) / bpw_t);
-            const size_t lds = (size_t)2 * (ta.g.in_sz + ta.g.out_sz) * 4;
-            const bool dyn = ta.g.NDm > 0;
-            hipError_t e = dyn ? LAUNCH_TILED_V(k_fwd_tiled, d, ta, grid_t, lds, (hipStream_t)stream, true)
-                               : LAUNCH_TILED_V(k_fwd_tiled, d, ta, grid_t, lds, (hipStream_t)stream, false);
-            if (e != hipSuccess) return hip_fail(e, "hbvx_forward (tiled) launch");
-            return HBVX_OK;
-        }
-    }
+    // kernel families in order of preference ("Which kernel runs when")
+    if (try_fwd_pipe(d, out, stream, &rc)) return rc;
+    if (try_fwd_stream(d, out, stream, &rc)) return rc;
+    if (try_fwd_tiled(d, out, stream, &rc)) return rc;
     FwdArgs a;
     a.d = *d;
     a.o = *out;
@@ -887,107 +666,6 @@ extern "C" int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *s
     return HBVX_OK;
 }
 
-// ---------------------------------------------------------------------------
-// time-parallel adjoint (hbv_chunked.h)
-// ---------------------------------------------------------------------------
-static int chunk_days() { int c = env_int("HBVX_CHUNK", 64); return c < 2 ? 2 : c; }
-
-static bool chunked_applicable(const hbvx_desc *d)
-{
-    const char *v = getenv("HBVX_BWD");
-    if (v && !strcmp(v, "tiled")) return false;
-    return d->T >= 2 * chunk_days();
-}
-
-static int np_of(const hbvx_desc *d) { return d->n_param; }
-
-extern "C" uint64_t hbvx_backward_workspace_bytes(const hbvx_desc *d)
-{
-    if (!d || d->T <= 0 || d->B <= 0 || d->M <= 0 || !chunked_applicable(d)) return 0;
-    const int C = chunk_days();
-    const uint64_t nchunk = (uint64_t)(d->T + C - 1) / C;
-    return nchunk * (uint64_t)d->B * (uint64_t)d->M * (uint64_t)(35 + np_of(d)) * sizeof(float);
-}
-
-template <int MODEL, bool BETAET, int DYN, bool GFULL>
-static hipError_t launch_chunked_t(const ChunkArgs &a, hipStream_t st)
-{
-    const hbvx_desc &d = a.d;
-    const int bpw = 64 >> a.lgMp;
-    const int64_t N = (int64_t)d.B * d.M;
-    dim3 g2((d.B + bpw - 1) / bpw, a.nchunk);
-    // the two slot lists users actually run get compile-time slots (hbv_chunked.h::SlotCombo)
-    int sc = 0;
-    if (DYN == 1 && MODEL == MODEL_HBV10 && BETAET && a.nd == 2 && a.dslot[0] == P_BETA && a.dslot[1] == P_BETAET) sc = 1;
-    if (DYN == 1 && (MODEL == MODEL_HBV20 || MODEL == MODEL_HOURLY) && a.nd == 3 && a.dslot[0] == P_BETA && a.dslot[1] == P_K0 &&
-        a.dslot[2] == P_BETAET)
-        sc = 2;
-    if constexpr (DYN == 1 && MODEL == MODEL_HBV10 && BETAET) {
-        if (sc == 1) {
-            hipLaunchKernelGGL((k_bwd_chunk_phi<MODEL, BETAET, DYN, GFULL, 1>), g2, dim3(64), 0, st, a);
-            hipLaunchKernelGGL(k_bwd_chunk_scan, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, st, a);
-            hipLaunchKernelGGL((k_bwd_chunk_sweep<MODEL, BETAET, DYN, GFULL, 1>), g2, dim3(64), 0, st, a);
-        }
-    }
-    if constexpr (DYN == 1 && (MODEL == MODEL_HBV20 || MODEL == MODEL_HOURLY)) {
-        if (sc == 2) {
-            hipLaunchKernelGGL((k_bwd_chunk_phi<MODEL, BETAET, DYN, GFULL, 2>), g2, dim3(64), 0, st, a);
-            hipLaunchKernelGGL(k_bwd_chunk_scan, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, st, a);
-            hipLaunchKernelGGL((k_bwd_chunk_sweep<MODEL, BETAET, DYN, GFULL, 2>), g2, dim3(64), 0, st, a);
-        }
-    }
-    if (sc != 0) {
-        hipLaunchKernelGGL(k_bwd_chunk_reduce, dim3((unsigned)((N + 255) / 256), d.n_param), dim3(256), 0, st,
-                           a, d.n_param);
-        return hipGetLastError();
-    }
-    hipLaunchKernelGGL((k_bwd_chunk_phi<MODEL, BETAET, DYN, GFULL>), g2, dim3(64), 0, st, a);
-    hipLaunchKernelGGL(k_bwd_chunk_scan, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, st, a);
-    hipLaunchKernelGGL((k_bwd_chunk_sweep<MODEL, BETAET, DYN, GFULL>), g2, dim3(64), 0, st, a);
-    if (DYN == 3) return hipGetLastError();   // every parameter dynamic: the static gradient is zero
-    hipLaunchKernelGGL(k_bwd_chunk_reduce, dim3((unsigned)((N + 255) / 256), d.n_param), dim3(256), 0, st,
-                       a, d.n_param);
-    return hipGetLastError();
-}
-
-template <int DYN, bool GFULL>
-static hipError_t launch_chunked_v(const hbvx_desc *d, const ChunkArgs &a, hipStream_t st)
-{
-    if (d->model == HBVX_MODEL_HBV10 && d->n_param == 12) return launch_chunked_t<MODEL_HBV10, false, DYN, GFULL>(a, st);
-    if (d->model == HBVX_MODEL_HBV10) return launch_chunked_t<MODEL_HBV10, true, DYN, GFULL>(a, st);
-    if (d->model == HBVX_MODEL_HBV11P) return launch_chunked_t<MODEL_HBV11P, true, DYN, GFULL>(a, st);
-    if (d->model == HBVX_MODEL_HOURLY) return launch_chunked_t<MODEL_HOURLY, true, DYN, GFULL>(a, st);
-    return launch_chunked_t<MODEL_HBV20, true, DYN, GFULL>(a, st);
-}
-
-static hipError_t launch_chunked(const hbvx_desc *d, const hbvx_bwd_io *io, hipStream_t st)
-{
-    ChunkArgs a;
-    a.d = *d;
-    a.io = *io;
-    a.lgMp = lg_members(d->M);
-    a.C = chunk_days();
-    a.nchunk = (d->T + a.C - 1) / a.C;
-    const int64_t N = (int64_t)d->B * d->M;
-    a.phi = (float *)io->workspace;
-    a.abnd = a.phi + (int64_t)a.nchunk * 30 * N;
-    a.gpart = a.abnd + (int64_t)a.nchunk * 5 * N;
-    const bool gfull = io->grad_flux != nullptr;
-    a.nd = 0;
-    a.dslot[0] = a.dslot[1] = a.dslot[2] = 0;
-    const int ndyn = count_dyn(d);
-    if (ndyn > 0 && ndyn <= CHUNK_FEW && !d->muwts) {   // few dynamic parameters: slot-list kernels
-        for (int i = 0; i < d->n_param; i++)
-            if (d->p[i].dyn) a.dslot[a.nd++] = i;
-        return gfull ? launch_chunked_v<1, true>(d, a, st) : launch_chunked_v<1, false>(d, a, st);
-    }
-    bool alldyn = ndyn == d->n_param && !d->muwts;
-    for (int i = 0; i < d->n_param && alldyn; i++) alldyn = d->p[i].drop == nullptr;
-    if (alldyn) return gfull ? launch_chunked_v<3, true>(d, a, st) : launch_chunked_v<3, false>(d, a, st);
-    if (ndyn > 0 || d->muwts) return gfull ? launch_chunked_v<2, true>(d, a, st) : launch_chunked_v<2, false>(d, a, st);
-    return gfull ? launch_chunked_v<0, true>(d, a, st) : launch_chunked_v<0, false>(d, a, st);
-}
-
 extern "C" int hbvx_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *stream)
 {
     int rc = check_desc(d);
@@ -997,80 +675,9 @@ extern "C" int hbvx_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *st
     const int want_nf = (d->model == HBVX_MODEL_HBV10) ? 11 : 12;
     if (io->n_flux != want_nf) return fail(HBVX_E_SHAPE, "n_flux does not match model");
     if (d->T == 0) return HBVX_OK;
-    {
-        // large grids: single-pass streaming adjoint (hbv_stream.h), no workspace.  Measured cross-over
-        // against the time-parallel kernels: ~1500 wavefronts (forward stream vs tiled: ~400)
-        const int lg = lg_members(d->M);
-        const int bpw_s = 64 >> lg;
-        const int64_t wgs = ((int64_t)d->B + bpw_s - 1) / bpw_s;
-        const int64_t N = (int64_t)d->B * d->M, lim = (int64_t)1 << 32;
-        const int nd = count_dyn(d);
-        const int nf = (d->model == HBVX_MODEL_HBV10) ? 11 : 12;
-        bool ok = use_tiled(d) && env_int("HBVX_STREAM", 1) != 0 && wgs >= env_int("HBVX_STREAM_MIN_BWD", 2048) && nd <= 3 && !d->muwts &&
-                  (io->grad_flux || io->grad_flux4) && 5 * (int64_t)(d->T + 1) * N * 4 < lim &&
-                  (int64_t)nf * d->T * d->B * 4 < lim &&
-                  ((int64_t)d->T * d->x_t_stride + (int64_t)d->B * d->x_b_stride) * 4 < lim;
-        for (int i = 0; i < d->n_param && ok; i++)
-            if (d->p[i].dyn) {
-                ok = ((int64_t)d->T * d->p[i].dyn_t_stride + (int64_t)d->B * d->p[i].dyn_b_stride) * 4 < lim;
-                if (ok && io->g[i].dyn)
-                    ok = ((int64_t)d->T * io->g[i].dyn_t_stride + (int64_t)d->B * io->g[i].dyn_b_stride) * 4 < lim;
-            }
-        if (ok) {
-            StreamBwdArgs sa;
-            sa.d = *d;
-            sa.io = *io;
-            sa.lgMp = lg;
-            sa.nd = 0;
-            sa.dslot[0] = sa.dslot[1] = sa.dslot[2] = 0;
-            for (int i = 0; i < d->n_param; i++)
-                if (d->p[i].dyn) sa.dslot[sa.nd++] = i;
-            const bool few = nd > 0, gfull = io->grad_flux != nullptr;
-            dim3 grid_s((unsigned)wgs);
-            hipStream_t st = (hipStream_t)stream;
-#define STREAM_GO(MODEL, BE)                                                                              \
-    do {                                                                                                  \
-        if (few) { if (gfull) hipLaunchKernelGGL((k_bwd_stream<MODEL, BE, true, true>), grid_s, dim3(64), 0, st, sa);    \
-                   else hipLaunchKernelGGL((k_bwd_stream<MODEL, BE, true, false>), grid_s, dim3(64), 0, st, sa); }      \
-        else { if (gfull) hipLaunchKernelGGL((k_bwd_stream<MODEL, BE, false, true>), grid_s, dim3(64), 0, st, sa);       \
-               else hipLaunchKernelGGL((k_bwd_stream<MODEL, BE, false, false>), grid_s, dim3(64), 0, st, sa); }         \
-    } while (0)
-            if (d->model == HBVX_MODEL_HBV10 && d->n_param == 12) STREAM_GO(MODEL_HBV10, false);
-            else if (d->model == HBVX_MODEL_HBV10) STREAM_GO(MODEL_HBV10, true);
-            else if (d->model == HBVX_MODEL_HBV11P) STREAM_GO(MODEL_HBV11P, true);
-            else if (d->model == HBVX_MODEL_HOURLY) STREAM_GO(MODEL_HOURLY, true);
-            else STREAM_GO(MODEL_HBV20, true);
-#undef STREAM_GO
-            hipError_t e = hipGetLastError();
-            if (e != hipSuccess) return hip_fail(e, "hbvx_backward (stream) launch");
-            return HBVX_OK;
-        }
-    }
-    if (io->workspace && chunked_applicable(d) &&
-        io->workspace_bytes >= hbvx_backward_workspace_bytes(d)) {
-        hipError_t e = launch_chunked(d, io, (hipStream_t)stream);
-        if (e != hipSuccess) return hip_fail(e, "hbvx_backward (chunked) launch");
-        return HBVX_OK;
-    }
-    {
-        BwdTArgs ta;
-        if (use_tiled(d) && geom_bwd(d, io, ta.g)) {
-            ta.d = *d;
-            ta.io = *io;
-            const int bpw_t = 64 >> ta.g.lgMp;
-            dim3 grid_t((d->B + bpw_t - 1) / bpw_t);
-            const size_t lds = (size_t)2 * (ta.g.in_sz + ta.g.out_sz) * 4;
-            const bool dyn = ta.g.NDm > 0, gfull = io->grad_flux != nullptr;
-            hipStream_t st_ = (hipStream_t)stream;
-            hipError_t e =
-                dyn ? (gfull ? LAUNCH_TILED_V(k_bwd_tiled, d, ta, grid_t, lds, st_, true, true)
-                             : LAUNCH_TILED_V(k_bwd_tiled, d, ta, grid_t, lds, st_, true, false))
-                    : (gfull ? LAUNCH_TILED_V(k_bwd_tiled, d, ta, grid_t, lds, st_, false, true)
-                             : LAUNCH_TILED_V(k_bwd_tiled, d, ta, grid_t, lds, st_, false, false));
-            if (e != hipSuccess) return hip_fail(e, "hbvx_backward (tiled) launch");
-            return HBVX_OK;
-        }
-    }
+    if (try_bwd_stream(d, io, stream, &rc)) return rc;
+    if (try_bwd_chunked(d, io, stream, &rc)) return rc;
+    if (try_bwd_tiled(d, io, stream, &rc)) return rc;
     BwdArgs a;
     a.d = *d;
     a.io = *io;
@@ -1174,106 +781,6 @@ extern "C" int hbvx_selftest_div(const float *x, const float *y, float *out, int
                        out, n);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "selftest_div launch");
-    return HBVX_OK;
-}
-
-// ---------------------------------------------------------------------------
-// implicit HBV ("HBV adjoint", hbv_adj.py)
-// ---------------------------------------------------------------------------
-static int check_adj(const hbvx_desc *d)
-{
-    int rc = check_desc(d);
-    if (rc) return rc;
-    if (d->model != HBVX_MODEL_HBVADJ) return fail(HBVX_E_UNSUPPORTED, "hbvx_adj_* needs model HBVADJ");
-    if (!(d->adj_gtol >= 0.0f) || d->adj_max_iter < 0 || d->adj_max_iter > 64)
-        return fail(HBVX_E_SHAPE, "bad Newton policy (adj_gtol / adj_max_iter)");
-    return HBVX_OK;
-}
-
-extern "C" int hbvx_adj_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream)
-{
-    int rc = check_adj(d);
-    if (rc) return rc;
-    if (!out || !out->state_out) return fail(HBVX_E_NULL, "state_out is NULL");
-    if (out->flux && out->n_flux != 1) return fail(HBVX_E_SHAPE, "hbvx_adj_forward writes n_flux = 1");
-    {
-        FwdTArgs ta;
-        if (use_tiled(d) && geom_fwd(d, out, ta.g)) {
-            ta.d = *d;
-            ta.o = *out;
-            const int bpw_t = 64 >> ta.g.lgMp;
-            dim3 grid_t((d->B + bpw_t - 1) / bpw_t);
-            const size_t lds = (size_t)2 * (ta.g.in_sz + ta.g.out_sz) * 4;
-            const bool dyn = ta.g.NDm > 0, be = d->n_param == 13;
-            int nh = env_int("HBVX_NH", 7);
-            nh = nh < 1 ? 1 : (nh > 7 ? 7 : nh);
-            const int threads = 64 * (1 + nh);
-            hipStream_t st = (hipStream_t)stream;
-            hipError_t e =
-                be ? (dyn ? launch_tiled_one(k_fwd_tiled<MODEL_HBVADJ, true, true>, ta, grid_t, threads, lds, st)
-                          : launch_tiled_one(k_fwd_tiled<MODEL_HBVADJ, true, false>, ta, grid_t, threads, lds, st))
-                   : (dyn ? launch_tiled_one(k_fwd_tiled<MODEL_HBVADJ, false, true>, ta, grid_t, threads, lds, st)
-                          : launch_tiled_one(k_fwd_tiled<MODEL_HBVADJ, false, false>, ta, grid_t, threads, lds, st));
-            if (e != hipSuccess) return hip_fail(e, "hbvx_adj_forward (tiled) launch");
-            return HBVX_OK;
-        }
-    }
-    AdjFwdArgs a;
-    a.d = *d;
-    a.o = *out;
-    a.lgMp = lg_members(d->M);
-    const int bpw = 64 >> a.lgMp;
-    dim3 grid((d->B + bpw - 1) / bpw);
-    if (d->n_param == 13) hipLaunchKernelGGL(k_adj_fwd<true>, grid, dim3(64), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(k_adj_fwd<false>, grid, dim3(64), 0, (hipStream_t)stream, a);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "hbvx_adj_forward launch");
-    return HBVX_OK;
-}
-
-extern "C" int hbvx_adj_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *stream)
-{
-    int rc = check_adj(d);
-    if (rc) return rc;
-    if (!io || !io->traj) return fail(HBVX_E_NULL, "traj is NULL");
-    if (io->n_flux != 1) return fail(HBVX_E_SHAPE, "hbvx_adj_backward expects n_flux = 1");
-    if (d->T == 0) return HBVX_OK;
-    if (io->workspace && chunked_applicable(d) && io->workspace_bytes >= hbvx_backward_workspace_bytes(d)) {
-        // time-parallel adjoint (hbv_adj_kernels.h + the scan / reduce kernels of hbv_chunked.h)
-        ChunkArgs ca;
-        ca.d = *d;
-        ca.io = *io;
-        ca.lgMp = lg_members(d->M);
-        ca.C = chunk_days();
-        ca.nchunk = (d->T + ca.C - 1) / ca.C;
-        const int64_t N = (int64_t)d->B * d->M;
-        ca.phi = (float *)io->workspace;
-        ca.abnd = ca.phi + (int64_t)ca.nchunk * 30 * N;
-        ca.gpart = ca.abnd + (int64_t)ca.nchunk * 5 * N;
-        hipStream_t st = (hipStream_t)stream;
-        const int bpw_c = 64 >> ca.lgMp;
-        dim3 g2((d->B + bpw_c - 1) / bpw_c, ca.nchunk);
-        if (d->n_param == 13) hipLaunchKernelGGL(k_adj_chunk_phi<true>, g2, dim3(64), 0, st, *d, *io, ca.lgMp, ca.C, ca.phi);
-        else hipLaunchKernelGGL(k_adj_chunk_phi<false>, g2, dim3(64), 0, st, *d, *io, ca.lgMp, ca.C, ca.phi);
-        hipLaunchKernelGGL(k_bwd_chunk_scan, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, st, ca);
-        if (d->n_param == 13) hipLaunchKernelGGL(k_adj_chunk_sweep<true>, g2, dim3(64), 0, st, *d, *io, ca.lgMp, ca.C, ca.abnd, ca.gpart);
-        else hipLaunchKernelGGL(k_adj_chunk_sweep<false>, g2, dim3(64), 0, st, *d, *io, ca.lgMp, ca.C, ca.abnd, ca.gpart);
-        hipLaunchKernelGGL(k_bwd_chunk_reduce, dim3((unsigned)((N + 255) / 256), d->n_param), dim3(256), 0, st,
-                           ca, d->n_param);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return hip_fail(e, "hbvx_adj_backward (chunked) launch");
-        return HBVX_OK;
-    }
-    AdjBwdArgs a;
-    a.d = *d;
-    a.io = *io;
-    a.lgMp = lg_members(d->M);
-    const int bpw = 64 >> a.lgMp;
-    dim3 grid((d->B + bpw - 1) / bpw);
-    if (d->n_param == 13) hipLaunchKernelGGL(k_adj_bwd<true>, grid, dim3(64), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(k_adj_bwd<false>, grid, dim3(64), 0, (hipStream_t)stream, a);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "hbvx_adj_backward launch");
     return HBVX_OK;
 }
 
@@ -1407,161 +914,6 @@ extern "C" int hbvx_gage_route_backward(const hbvx_gage_desc *r, const float *qs
     return HBVX_OK;
 }
 
-#ifdef PIPE_PROBE
-extern "C" int hbvx_debug_pipe_probe(unsigned long long *out32)
-{
-    hipError_t e = hipMemcpyFromSymbol(out32, HIP_SYMBOL(hbvx::g_pipe_probe), 32 * sizeof(unsigned long long));
-    return e == hipSuccess ? 0 : -1;
-}
-#endif
-
-// ---------------------------------------------------------------------------
-// sequence LSTM (include/hbvx_lstm.h; kernels in lstm_seq.h)
-// ---------------------------------------------------------------------------
-static int check_lstm(const hbvx_lstm_desc *d)
-{
-    if (!d) return fail(HBVX_E_NULL, "lstm desc is NULL");
-    if (d->abi_version != HBVX_LSTM_ABI_VERSION) return fail(HBVX_E_ABI, "lstm abi_version mismatch");
-    if (d->T <= 0 || d->B <= 0) return fail(HBVX_E_SHAPE, "lstm T/B out of range");
-    if (d->H != 64 && d->H != 128 && d->H != 256)
-        return fail(HBVX_E_UNSUPPORTED, "lstm hidden size must be 64, 128 or 256");
-    return 0;
-}
-
-static uint64_t lstm_counter_bytes(const hbvx_lstm_desc *) { return 256; }   // the error word, on a line of its own
-
-// exchange slabs of one direction: forward [T][tiles][H][16] floats, backward four gates per unit
-static uint64_t lstm_slab_bytes(const hbvx_lstm_desc *d, bool backward)
-{
-    const uint64_t ntile = ((uint64_t)d->B + LSTM_ROWS - 1) / LSTM_ROWS;
-    return (uint64_t)d->T * ntile * d->H * LSTM_ROWS * (backward ? 4 : 1) * sizeof(float);
-}
-
-static hipError_t lstm_prepare(const hbvx_lstm_desc *d, void *workspace, bool backward, hipStream_t st)
-{
-    hipError_t e = hipMemsetAsync(workspace, 0, lstm_counter_bytes(d), st);
-    if (e != hipSuccess) return e;
-    // every exchange word starts as the sentinel 0xFFFFFFFF (lstm_seq.h)
-    return hipMemsetAsync((char *)workspace + lstm_counter_bytes(d), 0xFF, lstm_slab_bytes(d, backward), st);
-}
-
-extern "C" uint64_t hbvx_lstm_workspace_bytes(const hbvx_lstm_desc *d)
-{
-    if (!d || d->T <= 0 || d->B <= 0 || d->H <= 0) return 0;
-    return lstm_counter_bytes(d) + lstm_slab_bytes(d, true);   // the backward slabs are the larger ones
-}
-
-static int lstm_cu_count()
-{
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
-            v = 256;
-        n_cu = v;
-    }
-    return n_cu;
-}
-
-template <typename K>
-static hipError_t launch_lstm(K kern, LstmArgs a, int nwg, hipStream_t st)
-{
-    const int n_cu = lstm_cu_count();
-    // Residency: a launch never holds more workgroups than fit on the chip at once, so every partner
-    // of a row tile is running.  The kernels are compiled for three waves per SIMD (<= 168 VGPRs), so up
-    // to three workgroups share a CU; the LDS request is sized so that exactly `wpc` fit: a batch that
-    // fits one launch at one workgroup per CU gets a CU per workgroup, larger batches interleave two or
-    // three row tiles per SIMD, which hides one tile's hand-off latency behind the others' MFMAs.
-    const int need = a.ntile * nwg;
-    int wpc = env_int("HBVX_LSTM_WGS_PER_CU", (need + n_cu - 1) / n_cu);
-    wpc = wpc < 1 ? 1 : (wpc > 3 ? 3 : wpc);
-    hipFuncAttributes fa;
-    hipError_t e = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern));
-    if (e != hipSuccess) return e;
-    const int total = wpc == 1 ? 81 * 1024 : (wpc == 2 ? 54 * 1024 + 512 : 41 * 1024);   // of 160 KB per CU
-    const int lds = total > (int)fa.sharedSizeBytes ? total - (int)fa.sharedSizeBytes : 0;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    const int cap = n_cu * wpc / nwg > 0 ? n_cu * wpc / nwg : 1;       // row tiles one launch can hold
-    const int launches = (a.ntile + cap - 1) / cap;
-    const int per_launch = (a.ntile + launches - 1) / launches;        // balanced
-    for (int t0 = 0; t0 < a.ntile; t0 += per_launch) {
-        a.tile0 = t0;
-        const int nt = a.ntile - t0 < per_launch ? a.ntile - t0 : per_launch;
-        hipLaunchKernelGGL(kern, dim3(nt * nwg), dim3(256), lds, st, a);
-    }
-    return hipGetLastError();
-}
-
-extern "C" int hbvx_lstm_forward(const hbvx_lstm_desc *d, const float *w_hh, const float *gx, float *gates,
-                                 float *c_all, float *h_all, void *workspace, uint64_t workspace_bytes,
-                                 void *stream)
-{
-    int rc = check_lstm(d);
-    if (rc) return rc;
-    if (!w_hh || !gx || !gates || !c_all || !h_all) return fail(HBVX_E_NULL, "lstm buffer is NULL");
-    if (!workspace || workspace_bytes < hbvx_lstm_workspace_bytes(d))
-        return fail(HBVX_E_NULL, "lstm workspace missing or too small");
-    hipStream_t st = (hipStream_t)stream;
-    hipError_t e = lstm_prepare(d, workspace, false, st);
-    if (e != hipSuccess) return hip_fail(e, "hbvx_lstm_forward memset");
-    LstmArgs a{};
-    a.T = d->T; a.B = d->B; a.ntile = (d->B + LSTM_ROWS - 1) / LSTM_ROWS;
-    a.w_hh = w_hh; a.gx = gx; a.gates = gates; a.c_all = c_all; a.h_all = h_all;
-    a.cnt = (unsigned *)workspace;
-    a.xch = (float *)((char *)workspace + lstm_counter_bytes(d));
-    // 8 units per workgroup while twice the workgroups still fit one launch at one per CU, else 16
-    const int n_cu = lstm_cu_count();
-    const bool small = env_int("HBVX_LSTM_UNITS", a.ntile * (d->H / 8) <= n_cu ? 8 : 16) == 8;
-    if (small)
-        e = d->H == 64 ? launch_lstm(k_lstm_fwd<64, 2>, a, 8, st)
-          : d->H == 128 ? launch_lstm(k_lstm_fwd<128, 2>, a, 16, st) : launch_lstm(k_lstm_fwd<256, 2>, a, 32, st);
-    else
-        e = d->H == 64 ? launch_lstm(k_lstm_fwd<64, 4>, a, 4, st)
-          : d->H == 128 ? launch_lstm(k_lstm_fwd<128, 4>, a, 8, st) : launch_lstm(k_lstm_fwd<256, 4>, a, 16, st);
-    if (e != hipSuccess) return hip_fail(e, "hbvx_lstm_forward launch");
-    return 0;
-}
-
-extern "C" int hbvx_lstm_backward(const hbvx_lstm_desc *d, const float *w_hh, const float *gates,
-                                  const float *c_all, const float *grad_h, float *grad_gates,
-                                  void *workspace, uint64_t workspace_bytes, void *stream)
-{
-    int rc = check_lstm(d);
-    if (rc) return rc;
-    if (!w_hh || !gates || !c_all || !grad_h || !grad_gates) return fail(HBVX_E_NULL, "lstm buffer is NULL");
-    if (gates == grad_gates) return fail(HBVX_E_UNSUPPORTED, "lstm grad_gates must not alias gates");
-    if (!workspace || workspace_bytes < hbvx_lstm_workspace_bytes(d))
-        return fail(HBVX_E_NULL, "lstm workspace missing or too small");
-    hipStream_t st = (hipStream_t)stream;
-    hipError_t e = lstm_prepare(d, workspace, true, st);
-    if (e != hipSuccess) return hip_fail(e, "hbvx_lstm_backward memset");
-    LstmArgs a{};
-    a.T = d->T; a.B = d->B; a.ntile = (d->B + LSTM_ROWS - 1) / LSTM_ROWS;
-    a.w_hh = w_hh; a.gx = gates; a.gates = grad_gates; a.c_in = c_all; a.dh = grad_h;
-    a.cnt = (unsigned *)workspace;
-    a.xch = (float *)((char *)workspace + lstm_counter_bytes(d));
-    e = d->H == 64 ? launch_lstm(k_lstm_bwd<64>, a, 4, st)
-      : d->H == 128 ? launch_lstm(k_lstm_bwd<128>, a, 8, st) : launch_lstm(k_lstm_bwd<256>, a, 16, st);
-    if (e != hipSuccess) return hip_fail(e, "hbvx_lstm_backward launch");
-    return 0;
-}
-
-extern "C" int hbvx_lstm_check(const hbvx_lstm_desc *d, const void *workspace, void *stream)
-{
-    int rc = check_lstm(d);
-    if (rc) return rc;
-    if (!workspace) return fail(HBVX_E_NULL, "lstm workspace is NULL");
-    unsigned word = 0;
-    hipError_t e = hipMemcpyAsync(&word, (const unsigned *)workspace, sizeof word, hipMemcpyDeviceToHost,
-                                  (hipStream_t)stream);
-    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
-    if (e != hipSuccess) return hip_fail(e, "hbvx_lstm_check");
-    if (word) return fail(HBVX_E_DEVICE, "lstm hand-off timed out: the waves of a row tile were not co-resident");
-    return 0;
-}
-
 // ---------------------------------------------------------------------------
 // zero fill of the dense gradient buffers (the autograd contract wants grad tensors shaped like the raw
 // parameter tensor [T,B,ny], of which static parameters touch one row): streaming 16-byte non-temporal
@@ -1596,3 +948,67 @@ extern "C" int hbvx_zero(void *ptr, uint64_t bytes, void *stream)
     if (e == hipSuccess && tail) e = hipMemsetAsync((char *)ptr + head + n16 * 16, 0, tail, st);
     return e == hipSuccess ? 0 : hip_fail(e, "hbvx_zero");
 }
+
+// Zero fill that leaves out what the adjoint overwrites (include/hbvx.h: hbvx_zero_except).  One thread
+// per 16 bytes of a slab of `srows` rows (slab elements < 2^31: 32-bit index arithmetic); a vector
+// that lies completely inside kept columns on kept rows is skipped, one that lies completely outside
+// is one non-temporal 16-byte store, a mixed one falls back to scalar stores.
+__global__ void __launch_bounds__(256) k_zero_except(float *__restrict__ p, int64_t rows, unsigned width,
+                                                      unsigned srows, int64_t r0, int64_t r1, unsigned group_w,
+                                                      unsigned keep)
+{
+    const int64_t row_base = (int64_t)blockIdx.y * srows;
+    const int64_t left = rows - row_base;
+    const unsigned nrow = left < (int64_t)srows ? (unsigned)left : srows;
+    const unsigned e0 = (blockIdx.x * 256u + threadIdx.x) * 4u;
+    const unsigned nel = nrow * width;
+    if (e0 >= nel) return;
+    float *q = p + row_base * width;
+    unsigned row = e0 / width, col = e0 - row * width;
+    bool kept[4];
+    bool any = false, all = true;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int64_t r = row_base + row;
+        const unsigned g = col / group_w;
+        kept[k] = (e0 + k < nel) && r >= r0 && r < r1 && g < 32u && ((keep >> g) & 1u);
+        const bool live = e0 + k < nel;
+        any = any || kept[k];
+        all = all && (kept[k] || !live);
+        col++;
+        if (col == width) { col = 0; row++; }
+    }
+    if (all) return;
+    if (!any && e0 + 3 < nel) {
+        const zero_f4 z = {0.f, 0.f, 0.f, 0.f};
+        __builtin_nontemporal_store(z, reinterpret_cast<zero_f4 *>(q + e0));
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (e0 + k < nel && !kept[k]) q[e0 + k] = 0.0f;
+}
+
+extern "C" int hbvx_zero_except(float *ptr, int64_t rows, int32_t width, int64_t r0, int64_t r1, int32_t group_w,
+                                uint32_t keep_groups, void *stream)
+{
+    if (rows < 0 || width <= 0 || group_w <= 0) return fail(HBVX_E_SHAPE, "hbvx_zero_except: bad shape");
+    if (!ptr && rows) return fail(HBVX_E_NULL, "hbvx_zero_except: buffer is NULL");
+    if (rows == 0) return 0;
+    if (keep_groups == 0 || r1 <= r0 || ((uintptr_t)ptr & 15))
+        return hbvx_zero(ptr, (uint64_t)rows * (uint64_t)width * sizeof(float), stream);
+    // slabs of rows: a multiple of 4 rows (16-byte vectors stay aligned), fewer than 2^30 elements each
+    int64_t srows = ((int64_t)1 << 30) / width;
+    srows = srows >= 4 ? (srows & ~(int64_t)3) : 4;
+    if ((int64_t)width * 4 >= ((int64_t)1 << 31)) return fail(HBVX_E_SHAPE, "hbvx_zero_except: width too large");
+    if (srows > rows) srows = (rows + 3) & ~(int64_t)3;
+    const int64_t nslab = (rows + srows - 1) / srows;
+    if (nslab > 65535) return hbvx_zero(ptr, (uint64_t)rows * (uint64_t)width * sizeof(float), stream);
+    const uint64_t vec = ((uint64_t)srows * (uint64_t)width + 3) / 4;
+    hipLaunchKernelGGL(k_zero_except, dim3((unsigned)((vec + 255) / 256), (unsigned)nslab), dim3(256), 0,
+                       (hipStream_t)stream, ptr, rows, (unsigned)width, (unsigned)srows, r0, r1, (unsigned)group_w,
+                       keep_groups);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "hbvx_zero_except");
+}
+

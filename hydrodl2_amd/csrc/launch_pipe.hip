@@ -1,0 +1,101 @@
+// launch_pipe.hip -- host dispatch of the pipelined forward (hbv_pipe.h).
+#include "hbvx_host.h"
+#include "hbv_pipe.h"
+
+using namespace hbvx;
+using namespace hbvx_host;
+
+template <typename Args, typename K>
+static hipError_t launch_tiled_one(K kern, const Args &a, dim3 grid, int threads, size_t lds,
+                                   hipStream_t st)
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, grid, dim3(threads), lds, st, a);
+    return hipGetLastError();
+}
+
+bool hbvx_host::try_fwd_pipe(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream, int *rc)
+{
+        // HBV 1.0 / 1.1p / 2.0, at most PIPE_MAXDYN dynamic parameters, flux requested: pipelined
+        // forward (hbv_pipe.h; three stages for HBV 1.0, two for the capillary models)
+        const char *fv = getenv("HBVX_FWD");
+        const int nd = count_dyn(d);
+        const bool many = nd > PIPE_FEWDYN;          // 4-day tiles, several staged rows per filler wave
+        const int Kt = many ? PIPE_KT_MANY : PIPE_KT;
+        const bool cap = d->model != HBVX_MODEL_HBV10;
+        const int nfl = cap ? 12 : 11;
+        // per-lane and per-tile byte offsets are 32-bit in the pipelined kernel
+        bool off32 = ((int64_t)d->B * d->x_b_stride + (int64_t)Kt * d->x_t_stride) * 4 < (int64_t)1 << 31;
+        for (int i = 0; i < d->n_param; i++)
+            if (d->p[i].dyn)
+                off32 = off32 && ((int64_t)d->B * d->p[i].dyn_b_stride + (int64_t)Kt * d->p[i].dyn_t_stride) * 4 <
+                                     (int64_t)1 << 31;
+        const int64_t wgs_p = ((int64_t)d->B + (64 >> lg_members(d->M)) - 1) / (64 >> lg_members(d->M));
+        // HBV 1.0: the pipelined kernel (one workgroup per CU) holds up to ~1000 wavefronts; the
+        // two-stage variant gives way to the streaming kernel at its cross-over (512); with more
+        // than three dynamic parameters there is no streaming kernel to give way to
+        const bool large = nd <= 3 && wgs_p >= (cap ? env_int("HBVX_STREAM_MIN", 512) : 1024) &&
+                           env_int("HBVX_STREAM", 1) != 0;
+        const bool pmodel = d->model == HBVX_MODEL_HBV10 || d->model == HBVX_MODEL_HBV11P ||
+                            d->model == HBVX_MODEL_HBV20 || d->model == HBVX_MODEL_HOURLY;
+        const size_t lds = (size_t)PipeLds(Kt, nd > 0 ? (many ? nd : PIPE_FEWDYN) : 0, cap).total * 4;
+        if (use_tiled(d) && !(fv && !strcmp(fv, "tiled")) && pmodel && off32 && !large &&
+            nd <= PIPE_MAXDYN && (int)lds <= LDS_BUDGET && wgs_p < 4096 && !d->muwts && out->flux && d->T >= 4 * Kt &&
+            (out->traj != nullptr) == (out->aux != nullptr) && (int64_t)d->B * d->M * 4 * Kt < (int64_t)1 << 31 &&
+            (int64_t)nfl * d->T * d->B * 4 < (int64_t)1 << 31) {
+            PipeArgs pa;
+            pa.d = *d;
+            pa.o = *out;
+            pa.lgMp = lg_members(d->M);
+            pa.Kt = Kt;
+            const int bpw_p = 64 >> pa.lgMp;
+            dim3 grid_p((d->B + bpw_p - 1) / bpw_p);
+            int pthreads = env_int("HBVX_PIPE_THREADS", 1024); // 3 steppers + filler + drainers (hbv_pipe.h)
+            pthreads = pthreads < 512 ? 512 : (pthreads > 1024 ? 1024 : (pthreads / 64) * 64);
+            if (nd > 0) pthreads = 1024;   // the dynamic-parameter roles assume all 16 waves
+            const bool be = d->n_param == 13, tr = out->traj != nullptr, dy = nd > 0;
+            hipStream_t st = (hipStream_t)stream;
+            hipError_t e;
+            // compile-time dynamic sets (hbv_pipe.h, SC): {BETA, BETAET} and {BETA, K0, BETAET}
+            unsigned dmask = 0;
+            for (int i = 0; i < d->n_param; i++) dmask |= d->p[i].dyn ? (1u << i) : 0u;
+            const int sc = env_int("HBVX_PIPE_SC", 1) == 0 ? 0
+                         : dmask == ((1u << P_BETA) | (1u << P_BETAET)) ? 1
+                         : dmask == ((1u << P_BETA) | (1u << P_K0) | (1u << P_BETAET)) ? 2 : 0;
+#define PIPE_GO(MODEL, BE, TR, DY, MANY, SC) e = launch_tiled_one(k_fwd_pipe<MODEL, BE, TR, DY, MANY, SC>, pa, grid_p, pthreads, lds, st)
+#define PIPE_GO3(MODEL, BE, TR, S1, S2)                                                            \
+    do {                                                                                           \
+        if (many) PIPE_GO(MODEL, BE, TR, true, true, 0);                                           \
+        else if (dy && sc == 1 && S1) PIPE_GO(MODEL, BE, TR, true, false, (S1 ? 1 : 0));           \
+        else if (dy && sc == 2 && S2) PIPE_GO(MODEL, BE, TR, true, false, (S2 ? 2 : 0));           \
+        else if (dy) PIPE_GO(MODEL, BE, TR, true, false, 0);                                       \
+        else PIPE_GO(MODEL, BE, TR, false, false, 0);                                              \
+    } while (0)
+#define PIPE_GO4(MODEL, BE, S1, S2)                                                                \
+    do {                                                                                           \
+        if (tr) PIPE_GO3(MODEL, BE, true, S1, S2);                                                 \
+        else PIPE_GO3(MODEL, BE, false, S1, S2);                                                   \
+    } while (0)
+            if (d->model == HBVX_MODEL_HBV11P) PIPE_GO4(MODEL_HBV11P, true, true, false);
+            else if (d->model == HBVX_MODEL_HBV20) PIPE_GO4(MODEL_HBV20, true, false, true);
+            else if (d->model == HBVX_MODEL_HOURLY) PIPE_GO4(MODEL_HOURLY, true, false, true);
+            else if (be) PIPE_GO4(MODEL_HBV10, true, true, true);
+            else PIPE_GO4(MODEL_HBV10, false, false, false);
+#undef PIPE_GO4
+#undef PIPE_GO3
+#undef PIPE_GO
+            *rc = e != hipSuccess ? hip_fail(e, "hbvx_forward (pipelined) launch") : HBVX_OK;
+            return true;
+        }
+    return false;
+}
+
+#ifdef PIPE_PROBE
+extern "C" int hbvx_debug_pipe_probe(unsigned long long *out32)
+{
+    hipError_t e = hipMemcpyFromSymbol(out32, HIP_SYMBOL(hbvx::g_pipe_probe), 32 * sizeof(unsigned long long));
+    return e == hipSuccess ? 0 : -1;
+}
+#endif

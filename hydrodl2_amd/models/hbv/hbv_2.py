@@ -108,7 +108,7 @@ class Hbv_2(HbvModule):
             cfg.route = RouteSource(1, off, off + 1, ws,
                                     self.routing_parameter_bounds['route_a'],
                                     self.routing_parameter_bounds['route_b'])
-        muwts = self._expand_muwts(self.muwts, T, ngrid)
+        muwts = self._expand_muwts(self.muwts, T, T, ngrid)
         flux, routed, state_out, traj = HbvPath.apply(cfg, x, state_in, muwts, ac, elev,
                                                       p_dyn, p_sta)
 

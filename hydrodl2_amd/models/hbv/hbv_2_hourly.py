@@ -126,7 +126,7 @@ class Hbv_2_hourly(HbvModule):
                          B=ngrid, M=M, raw_sigmoid=False, channels=self._channels(),
                          nearzero=float(self.nearzero), params=srcs,
                          want_flux=not self.initialize, want_traj=True)
-        muwts = self._expand_muwts(self.muwts, T, ngrid)
+        muwts = self._expand_muwts(self.muwts, T, T, ngrid)
         flux, _, _, traj = HbvPath.apply(cfg, x, state_in, muwts, ac, elev, *ptensors)
         series = traj.detach()[:, 1:, :].reshape(5, T, ngrid, M)
         series = tuple(series[k] for k in range(5))                       # :725

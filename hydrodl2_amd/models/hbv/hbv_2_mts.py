@@ -32,56 +32,57 @@ from hydrodl2_amd.ops import ParamSource
 class Hbv_2_mts(torch.nn.Module):
     """HBV 2.0, multi timescale, distributed UH."""
 
+    # chunking keys of the hourly config (hbv_2_mts.py:65-76) -> attribute of the same name
+    _CHUNK_KEYS = ('train_spatial_chunk_size', 'simulate_spatial_chunk_size',
+                   'simulate_temporal_chunk_size', 'train_warmup')
+
     def __init__(self, low_freq_config: Optional[dict[str, Any]] = None,
                  high_freq_config: Optional[dict[str, Any]] = None,
                  device: Optional[torch.device] = None) -> None:
         super().__init__()
-        self.device = device if device is not None else torch.device('cpu')
+        self.device = torch.device('cpu') if device is None else device
         self.dtype = torch.float32
-        self.low_freq_model = Hbv_2(low_freq_config, device=device)
-        self.low_freq_model.initialize = True
-        self.high_freq_model = Hbv_2_hourly(high_freq_config, device=device)
-        self._state_cache = [None, None]
-        self.states = (None, None)
-        self.load_from_cache = False
-        self.use_from_cache = False
-        self.state_transfer_model = torch.nn.ModuleDict(        # hbv_2_mts.py:61-63
-            {name: torch.nn.Identity() for name in self.high_freq_model.state_names})
-        self.train_spatial_chunk_size = high_freq_config['train_spatial_chunk_size']
-        self.simulate_spatial_chunk_size = high_freq_config['simulate_spatial_chunk_size']
-        self.simulate_temporal_chunk_size = high_freq_config['simulate_temporal_chunk_size']
-        self.spatial_chunk_size = self.train_spatial_chunk_size
-        self.simulate_mode = False
-        self.train_warmup = high_freq_config['train_warmup']
-        if self.low_freq_model.nmul != self.high_freq_model.nmul:
+        daily, hourly = Hbv_2(low_freq_config, device=device), Hbv_2_hourly(high_freq_config, device=device)
+        if daily.nmul != hourly.nmul:
             raise ValueError("low- and high-frequency models must share nmul "
                              "(the static parameters are concatenated, hbv_2_mts.py:326-329)")
+        daily.initialize = True            # the daily run only warms the storages up
+        self.low_freq_model, self.high_freq_model = daily, hourly
+        self.state_transfer_model = torch.nn.ModuleDict(
+            {name: torch.nn.Identity() for name in hourly.state_names})
+        for key in self._CHUNK_KEYS:
+            setattr(self, key, high_freq_config[key])
+        self._state_cache = [None, None]   # [daily series, hourly series]
+        self.states = (None, None)
+        self.load_from_cache = self.use_from_cache = False
+        self.set_mode(False)
 
     # -- state API (hbv_2_mts.py:78-98) -------------------------------------------------------
     def get_states(self):
         """(daily state series, hourly state series).  The hourly series is the one `_forward`
         cached: the hourly sub-model is driven through `_PBM`, which does not fill its own cache
         (upstream returns None there, so `load_states(get_states())` could not round-trip)."""
-        hif = self.high_freq_model.get_states()
-        return (self.low_freq_model.get_states(), hif if hif is not None else self._state_cache[1])
+        hourly = self.high_freq_model.get_states()
+        if hourly is None:
+            hourly = self._state_cache[1]
+        return (self.low_freq_model.get_states(), hourly)
 
     def load_states(self, state_tuple) -> None:
-        if not isinstance(state_tuple, tuple) or len(state_tuple) != 2:
+        if not (isinstance(state_tuple, tuple) and len(state_tuple) == 2):
             raise ValueError("`states` must be a tuple of two tuples of tensors.")
-        self._state_cache = tuple(
-            tuple(s[-1].detach().to(self.device, dtype=self.dtype) for s in states)
-            for states in state_tuple)
+
+        def last_step(series):
+            return tuple(s[-1].detach().to(self.device, dtype=self.dtype) for s in series)
+
+        self._state_cache = (last_step(state_tuple[0]), last_step(state_tuple[1]))
         if self.load_from_cache:
             self.low_freq_model.load_states(state_tuple[0])
 
     def set_mode(self, is_simulate: bool):
-        """hbv_2_mts.py:283-290."""
-        if is_simulate:
-            self.spatial_chunk_size = self.simulate_spatial_chunk_size
-            self.simulate_mode = True
-        else:
-            self.spatial_chunk_size = self.train_spatial_chunk_size
-            self.simulate_mode = False
+        """Training blocks vs simulation blocks of units (hbv_2_mts.py:283-290)."""
+        self.simulate_mode = bool(is_simulate)
+        self.spatial_chunk_size = (self.simulate_spatial_chunk_size if self.simulate_mode
+                                   else self.train_spatial_chunk_size)
 
     # -- hand-offs ----------------------------------------------------------------------------
     def state_transfer(self, states):
@@ -168,66 +169,72 @@ class Hbv_2_mts(torch.nn.Module):
         return predictions
 
     # -- chunked driver -----------------------------------------------------------------------
-    def forward(self, x_dict, parameters):
-        """hbv_2_mts.py:176-281.  `x_dict` / `parameters` may live on the host in simulate mode;
-        each block of units is moved to the device when its turn comes."""
-        device = self.device
-        hi = self.high_freq_model
-        n_units = x_dict['areas'].shape[0]
-        spatial_chunk_size = self.spatial_chunk_size
-        temporal_chunk_size = self.simulate_temporal_chunk_size
-        train_warmup = self.train_warmup
+    @staticmethod
+    def _unit_blocks(n_units: int, size: int):
+        """Consecutive [lo, hi) blocks of units."""
+        for lo in range(0, n_units, size):
+            yield lo, min(lo + size, n_units)
 
-        hi.use_distr_routing = False
-        if (not self.simulate_mode) and (n_units <= spatial_chunk_size):
+    @staticmethod
+    def _routing_windows(n_steps: int, warmup: int, size: int):
+        """(first row read, one past the last row, rows to drop) per temporal routing window:
+        every window re-reads `warmup` rows of history; only the first keeps them in its output
+        (hbv_2_mts.py:254-278)."""
+        for start in range(warmup, n_steps, size):
+            yield start - warmup, min(start + size, n_steps), (0 if start == warmup else warmup)
+
+    def _block_inputs(self, x_dict, parameters, lo, hi, pair_unit):
+        """Unit block [lo, hi) of every input, on the compute device.  `pair_unit[k]` = unit of
+        gage-unit pair k, so the block's pair parameters are the rows with lo <= unit < hi."""
+        dev = self.device
+        (day_dyn, day_sta), (hr_dyn, hr_sta, hr_pair) = parameters[0][:2], parameters[1][:3]
+        xs = {k: x_dict[k][:, lo:hi].to(dev) for k in ('x_phy_low_freq', 'x_phy_high_freq', 'outlet_topo')}
+        xs.update({k: x_dict[k][lo:hi].to(dev) for k in ('ac_all', 'elev_all', 'areas')})
+        in_block = (pair_unit >= lo) & (pair_unit < hi)
+        ps = ([day_dyn[:, lo:hi].to(dev), day_sta[lo:hi].to(dev)],
+              [hr_dyn[:, lo:hi].to(dev), hr_sta[lo:hi].to(dev), hr_pair[in_block].to(dev)])
+        return xs, ps
+
+    def forward(self, x_dict, parameters):
+        """Whole-domain run (hbv_2_mts.py:176-281).  Small training batches go through `_forward`
+        in one piece.  Otherwise the unit runoff is produced block by block (inputs may live on
+        the host; a block is moved to the device when its turn comes) without gage routing, and
+        the gage routing then runs over the assembled runoff in temporal windows."""
+        hourly = self.high_freq_model
+        n_units = x_dict['areas'].shape[0]
+        hourly.use_distr_routing = False
+        if not self.simulate_mode and n_units <= self.spatial_chunk_size:
             return self._forward(x_dict, parameters)
 
-        reach_idx = (x_dict['outlet_topo'] == 1).nonzero(as_tuple=False)
-        preds_list = []
-        for i in tqdm(range(0, n_units, spatial_chunk_size), desc="Spatial runoff chunks"):
-            end_idx = min(i + spatial_chunk_size, n_units)
-            idxs_in_chunk = (reach_idx[:, 1] >= i) & (reach_idx[:, 1] < end_idx)
-            chunk_x_dict = {
-                'x_phy_low_freq': x_dict['x_phy_low_freq'][:, i:end_idx].to(device),
-                'x_phy_high_freq': x_dict['x_phy_high_freq'][:, i:end_idx].to(device),
-                'ac_all': x_dict['ac_all'][i:end_idx].to(device),
-                'elev_all': x_dict['elev_all'][i:end_idx].to(device),
-                'areas': x_dict['areas'][i:end_idx].to(device),
-                'outlet_topo': x_dict['outlet_topo'][:, i:end_idx].to(device),
-            }
-            chunk_parameters = (
-                [parameters[0][0][:, i:end_idx].to(device), parameters[0][1][i:end_idx].to(device)],
-                [parameters[1][0][:, i:end_idx].to(device), parameters[1][1][i:end_idx].to(device),
-                 parameters[1][2][idxs_in_chunk].to(device)],
-            )
-            preds_list.append(self._forward(chunk_x_dict, chunk_parameters))
+        pair_unit = (x_dict['outlet_topo'] == 1).nonzero(as_tuple=False)[:, 1]   # once, not per block
+        blocks = list(self._unit_blocks(n_units, self.spatial_chunk_size))
+        per_block = [self._forward(*self._block_inputs(x_dict, parameters, lo, hi, pair_unit))
+                     for lo, hi in tqdm(blocks, desc="Spatial runoff chunks")]
+        predictions = self.concat_spatial_chunks(per_block)
 
-        predictions = self.concat_spatial_chunks(preds_list)
         runoff = predictions['Qs']
-        high_freq_length = runoff.shape[0]
-
-        p_distr = parameters[1][2].to(device)
-        outlet_topo = x_dict['outlet_topo'].to(device)
-        areas = x_dict['areas'].to(device)
-        routed = []
-        for t in tqdm(range(train_warmup, high_freq_length, temporal_chunk_size),
-                      desc="Temporal routing chunks"):
-            end_t = min(t + temporal_chunk_size, high_freq_length)
-            chunk = hi.distr_routing(runoff[t - train_warmup:end_t], p_distr, outlet_topo, areas)
-            if t > train_warmup:           # routing warm-up is kept for the first chunk only
-                chunk = chunk[train_warmup:]
-            routed.append({'Qs_rout': chunk})
-        predictions['streamflow'] = self.concat_temporal_chunks(routed)['Qs_rout']
+        topo, areas = x_dict['outlet_topo'].to(self.device), x_dict['areas'].to(self.device)
+        pair_params = parameters[1][2].to(self.device)
+        windows = list(self._routing_windows(runoff.shape[0], self.train_warmup,
+                                             self.simulate_temporal_chunk_size))
+        pieces = []
+        for first, stop, drop in tqdm(windows, desc="Temporal routing chunks"):
+            q = hourly.distr_routing(runoff[first:stop], pair_params, topo, areas)
+            pieces.append({'Qs_rout': q[drop:]})
+        predictions['streamflow'] = self.concat_temporal_chunks(pieces)['Qs_rout']
         return predictions
 
     @staticmethod
     def concat_spatial_chunks(pred_list):
-        """hbv_2_mts.py:351-364."""
-        return {k: torch.cat([p[k] for p in pred_list], dim=1 if pred_list[0][k].ndim == 3 else 0)
-                for k in pred_list[0]}
+        """Join per-block outputs on the unit axis: [T, units, 1] series on dim 1, per-unit
+        vectors on dim 0 (hbv_2_mts.py:351-364)."""
+        first = pred_list[0]
+        return {k: torch.cat([p[k] for p in pred_list], dim=(1 if first[k].ndim == 3 else 0)) for k in first}
 
     @staticmethod
     def concat_temporal_chunks(pred_list):
-        """hbv_2_mts.py:366-377."""
-        return {k: (torch.cat([p[k] for p in pred_list], dim=0) if pred_list[0][k].ndim == 3
-                    else pred_list[0][k]) for k in pred_list[0]}
+        """Join per-window outputs on the time axis; anything that is not a [T, ., 1] series is
+        taken from the first window (hbv_2_mts.py:366-377)."""
+        first = pred_list[0]
+        return {k: (torch.cat([p[k] for p in pred_list], dim=0) if first[k].ndim == 3 else first[k])
+                for k in first}

@@ -70,6 +70,7 @@ class StepConfig:
     want_traj: bool = False    # keep the state trajectory even without autograd
     adj_gtol: float = 1e-3     # implicit scheme only (hbv_adj.py:519)
     adj_max_iter: int = 3      # implicit scheme only (hbv_adj.py:518)
+    mu_t0: Optional[int] = None  # first row of muwts used by this call (None: same as t0)
 
 
 # bench.py sets this to a list to collect (abi_call, start_event, end_event) per launch,
@@ -109,6 +110,33 @@ def _zeros_like(lib, t: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def _grad_like(lib, p: torch.Tensor, cfg: "StepConfig", tensor_idx: int) -> torch.Tensor:
+    """Gradient buffer for parameter tensor `p`: zero wherever the adjoint accumulates (static rows,
+    routing columns) or never writes, left alone where it STORES -- the nmul columns of every dynamic
+    parameter on the days of this call (hbvx_backward writes each of those elements exactly once,
+    0 for a dy_drop-masked basin).  Falls back to the dense fill when the layout is not the plain
+    [T,B,width] one.  Under HBVX_DEBUG_POISON the left-alone part is NaN: an element a kernel skipped
+    cannot pass."""
+    dyn = [ps for ps in cfg.params if ps.dyn_off >= 0 and ps.dyn_tensor_idx == tensor_idx]
+    M, B, T = cfg.M, cfg.B, cfg.T
+    if not dyn or p.dim() != 3 or not p.is_contiguous() or p.shape[1] != B:
+        return _zeros_like(lib, p)
+    W = p.shape[2]
+    keep, t_first = 0, None
+    for ps in dyn:
+        tf, rem = divmod(ps.dyn_off, B * W)
+        k, j0 = divmod(rem, M)
+        if (ps.dyn_ts != B * W or ps.dyn_bs != W or rem >= W or j0 != 0 or (k + 1) * M > W or k >= 32
+                or (t_first is not None and tf != t_first) or tf + T > p.shape[0]):
+            return _zeros_like(lib, p)
+        t_first = tf
+        keep |= 1 << k
+    out = torch.full_like(p, float("nan")) if _POISON else torch.empty_like(p)
+    _call(lib, 'hbvx_zero', lib.zero_except, out.data_ptr(), p.shape[0] * B, W, t_first * B, (t_first + T) * B,
+          M, keep, _stream_of(lib, out))
+    return out
+
+
 def _ptr(t: Optional[torch.Tensor], off: int = 0) -> Optional[int]:
     if t is None:
         return None
@@ -131,6 +159,10 @@ def _check_tensor(lib, t: torch.Tensor, name: str):
         raise RuntimeError(f"{name}: test library expects host tensors")
 
 
+def _mu_t0(cfg: StepConfig) -> int:
+    return cfg.t0 if cfg.mu_t0 is None else cfg.mu_t0
+
+
 def _fill_desc(cfg: StepConfig, x, state_in, muwts, ac, elev, ptensors) -> _abi.Desc:
     d = _abi.Desc()
     d.abi_version = _abi.ABI_VERSION
@@ -145,7 +177,7 @@ def _fill_desc(cfg: StepConfig, x, state_in, muwts, ac, elev, ptensors) -> _abi.
     d.ac = _ptr(ac)
     d.elev = _ptr(elev)
     if muwts is not None:  # full [Tx,B,M] contiguous (the module expands broadcasts)
-        d.muwts = _ptr(muwts, cfg.t0 * cfg.B * cfg.M)
+        d.muwts = _ptr(muwts, _mu_t0(cfg) * cfg.B * cfg.M)
         d.mu_t_stride, d.mu_b_stride = cfg.B * cfg.M, cfg.M
     d.state_in = _ptr(state_in)
     for ps in cfg.params:
@@ -245,7 +277,7 @@ class HbvPath(torch.autograd.Function):
         T, B, M = cfg.T, cfg.B, cfg.M
         stream = _stream_of(lib, x)
 
-        gp = [_zeros_like(lib, p) if ctx.needs_input_grad[6 + i] else None
+        gp = [_grad_like(lib, p, cfg, i) if ctx.needs_input_grad[6 + i] else None
               for i, p in enumerate(ptensors)]
 
         gq = None
@@ -274,7 +306,7 @@ class HbvPath(torch.autograd.Function):
             io.grad_x = _ptr(gx, cfg.t0 * x.stride(0))
         if muwts is not None and ctx.needs_input_grad[3]:
             gmu = torch.zeros_like(muwts)
-            io.grad_muwts = _ptr(gmu, cfg.t0 * B * M)
+            io.grad_muwts = _ptr(gmu, _mu_t0(cfg) * B * M)
         for ps in cfg.params:
             g = io.g[ps.slot]
             gs = gp[ps.tensor_idx]

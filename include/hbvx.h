@@ -259,6 +259,16 @@ int hbvx_adj_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *stream);
  * one row of it), so the dense zero fill is part of every backward step. */
 int hbvx_zero(void *ptr, uint64_t bytes, void *stream);
 
+/* The same for a gradient buffer of which hbvx_backward will overwrite a part: `ptr` is a dense
+ * [rows, width] float matrix (rows = T*B of the raw parameter tensor, width = ny); every element is zeroed
+ * EXCEPT those with r0 <= row < r1 and column in a kept group -- column c belongs to group c / group_w,
+ * group g (< 32) is kept when bit g of `keep_groups` is set.  Those are exactly the elements the
+ * adjoint stores (never accumulates) for a dynamic parameter: rows = the days of the call, group =
+ * the parameter's nmul columns (hbv.py:201-208).  With every parameter dynamic (BASELINE config 3)
+ * this removes a 4.4 GB fill per step.  keep_groups == 0 is hbvx_zero. */
+int hbvx_zero_except(float *ptr, int64_t rows, int32_t width, int64_t r0, int64_t r1, int32_t group_w,
+                     uint32_t keep_groups, void *stream);
+
 /* Diagnostics (tests only): out[i] = the device pow used for (SM/FC)**BETA on x[i], y[i]. */
 int hbvx_selftest_pow(const float *x, const float *y, float *out, int n, void *stream);
 /* Diagnostics (tests only): out[i] = the device quotient used for SM/FC on x[i] / y[i]. */

@@ -1375,3 +1375,19 @@ int hbvx_zero(void *ptr, uint64_t bytes, void *stream)
     if (bytes) memset(ptr, 0, (size_t)bytes);
     return 0;
 }
+
+/* include/hbvx.h: zero everything except the kept column groups on rows [r0, r1). */
+int hbvx_zero_except(float *ptr, int64_t rows, int32_t width, int64_t r0, int64_t r1, int32_t group_w,
+                     uint32_t keep_groups, void *stream)
+{
+    (void)stream;
+    if (rows < 0 || width <= 0 || group_w <= 0) return fail(HBVX_E_SHAPE, "hbvx_zero_except: bad shape");
+    if (!ptr && rows) return fail(HBVX_E_NULL, "hbvx_zero_except: buffer is NULL");
+    for (int64_t r = 0; r < rows; r++)
+        for (int32_t c = 0; c < width; c++) {
+            const int32_t g = c / group_w;
+            const int kept = r >= r0 && r < r1 && g < 32 && ((keep_groups >> g) & 1u);
+            if (!kept) ptr[r * width + c] = 0.0f;
+        }
+    return 0;
+}

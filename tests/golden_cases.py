@@ -59,6 +59,11 @@ CASES = {
     # learned ensemble weights.
     "hbv_muwts": dict(model="Hbv", config=_cfg("Hbv", 4), T=64, B=5, seed=19, loss="all",
                       muwts=True),
+    # weights with a state warm-up.  The reference multiplies muwts against the series of the
+    # call at hand -- also in the warm-up call (hbv.py:497-511 runs before the `initialize`
+    # return) -- so only shapes that broadcast over time ([B,nmul], [1,B,nmul]) run there.
+    "hbv_muwts_warmup": dict(model="Hbv", config=_cfg("Hbv", 4, ("parBETA",), warm_up=12), T=60, B=5,
+                             seed=32, loss="all", muwts="bcast"),
     # cold dry start: melt = SNOWPACK = 0 ties, SM hitting FC, SUZ < PERC.
     "hbv_ties": dict(model="Hbv", config=_cfg("Hbv", 2), T=48, B=9, seed=20, loss="all",
                      cold=True, raw_scale=2.5),
@@ -159,7 +164,8 @@ def build_inputs(name: str) -> dict:
         ny = n * nmul + 2
         out["parameters"] = synth.raw_parameters(T, B, ny, seed, spec.get("raw_scale", 1.0))
     if spec.get("muwts"):
-        u = synth.uniform((T, B, nmul), seed, 9).astype(np.float64) + 0.25
+        Tmu = 1 if spec["muwts"] == "bcast" else T
+        u = synth.uniform((Tmu, B, nmul), seed, 9).astype(np.float64) + 0.25
         out["muwts"] = (u / u.sum(-1, keepdims=True)).astype(np.float32)
     return out
 

@@ -374,6 +374,16 @@ extern "C" int hbvx_lstm_backward(const hbvx_lstm_desc *d, const float *w, const
 }
 extern "C" int hbvx_lstm_check(const hbvx_lstm_desc *, const void *, void *) { return 0; }
 extern "C" int hbvx_zero(void *ptr, uint64_t bytes, void *) { if (bytes) memset(ptr, 0, (size_t)bytes); return 0; }
+extern "C" int hbvx_zero_except(float *ptr, int64_t rows, int32_t width, int64_t r0, int64_t r1, int32_t group_w,
+                                uint32_t keep, void *)
+{
+    for (int64_t r = 0; r < rows; r++)
+        for (int32_t c = 0; c < width; c++) {
+            const int32_t g = c / group_w;
+            if (!(r >= r0 && r < r1 && g < 32 && ((keep >> g) & 1u))) ptr[r * width + c] = 0.0f;
+        }
+    return 0;
+}
 
 // Step::jt_unit against Step::bwd with zero flux adjoints (HBV 1.0): for n random days, the worst
 // difference over the five unit adjoints, relative to the largest entry of J^T.

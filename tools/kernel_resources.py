@@ -20,22 +20,32 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEFAULT_LIB = os.path.join(ROOT, "hydrodl2_amd", "csrc", "libhbvx.so")
 
 
-def code_object(lib: str, out_dir: str) -> str:
-    """Extract the gfx950 code object of `lib` into out_dir; returns its path."""
+def code_objects(lib: str, out_dir: str) -> list[str]:
+    """Extract the gfx950 code objects of `lib` (one offload bundle per translation unit) into out_dir."""
     fat = os.path.join(out_dir, "fatbin")
-    co = os.path.join(out_dir, "gfx950.co")
     subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, fat])
-    subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o",
-                           "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}",
-                           f"--output={co}"])
-    return co
+    blob = open(fat, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
+    out = []
+    for k, st in enumerate(starts):
+        end = starts[k + 1] if k + 1 < len(starts) else len(blob)
+        part = os.path.join(out_dir, f"bundle{k}")
+        with open(part, "wb") as f:
+            f.write(blob[st:end])
+        co = os.path.join(out_dir, f"gfx950_{k}.co")
+        subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o",
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={part}",
+                               f"--output={co}"])
+        out.append(co)
+    return out
 
 
 def kernel_table(lib: str = DEFAULT_LIB) -> list[dict]:
     with tempfile.TemporaryDirectory() as td:
-        co = code_object(lib, td)
-        notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], check=True,
-                               capture_output=True, text=True).stdout
+        notes = "".join(subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], check=True,
+                                       capture_output=True, text=True).stdout
+                        for co in code_objects(lib, td))
     rows = []
     for blk in re.split(r"\n\s+- \.agpr_count:", notes)[1:]:
         def field(key, _b=blk):
