@@ -1,61 +1,227 @@
 #!/usr/bin/env python3
-"""bench.py -- BASELINE.json's metric on BASELINE.json's config.
+"""bench.py -- BASELINE.json's metric on BASELINE.json's configs.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config cfg2|cfg5]
 
-A "step" is one forward + backward pass of the HBV hot path over one batch of
-synthetic CAMELS-shaped input (configs[1]: hbv, 671 basins x 16 members x 7300
-days, static parameters) through the drop-in module (`hydrodl2_amd.load_model
-('hbv')`): raw NN output [T,B,ny] -> flux dictionary -> a linear loss on
-`streamflow` (a fixed N(0,1) tensor stands in for the NSE-loss gradient) ->
-gradient w.r.t. the raw NN output.  Inputs are resident in HBM before the timed
-region.
+A "step" is one forward + backward pass of the HBV hot path over one batch of synthetic
+CAMELS-shaped input through the drop-in module (`hydrodl2_amd.load_model`): raw NN output ->
+flux dictionary -> a linear loss on `streamflow` (a fixed N(0,1) tensor stands in for the NSE-loss
+gradient) -> gradient w.r.t. the raw NN output.  Inputs are resident in HBM before the timed region.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): every rank owns its
-own 671-basin shard (weak scaling; basins are independent); the
-only collective is an RCCL all-reduce of the loss and of the basin-summed
-gradient row that a shared parameterisation network would receive.
+--config cfg2 (default, the headline; BASELINE.json configs[1]): `hbv`, 671 basins x 16 members x
+    7300 days, static parameters.  N > 1: WEAK scaling, every rank owns its own 671-basin shard.
+--config cfg5 (configs[4]): `hbv_2`, 100 000 basins x 16 members x 730 days, three dynamic
+    parameters.  N > 1: STRONG scaling, rank r owns basins [r*ceil(B/N), ...).
+Basins are independent, so the data path has no collective; the only exchange is one RCCL
+all-reduce per step of the loss and of the basin-summed static-parameter gradient a shared
+parameterisation network would receive.
 
-Rank 0 prints ONE JSON line.  `value` = whole-job basin-ensemble-timesteps/s.
+N > 1 is one process per GPU.  Either the driver starts the ranks (torch.distributed.run: RANK /
+LOCAL_RANK / WORLD_SIZE set) or `python bench.py --gpus N` does it itself: the parent starts N
+children BEFORE touching the GPU and relays rank 0's JSON line.
+
+Rank 0 prints ONE JSON line.  `value` = whole-job basin-ensemble-timesteps/s.  At N = 1 the line also
+carries `secondary` (configs 2-dyn, 3, 4 and one GPU's share of 5, driver-timed in the same run) and
+`cpu_baseline` (the C/OpenMP oracle port and the pure-torch eager restatement on the host cores).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+CKPT_K = 64             # checkpoint interval assumed by SURVEY.md §8d's algorithmic byte count
 
 
-def synth_inputs(T, B, ny, dev, seed):
-    """CAMELS-shaped forcings and raw N(0,1) parameters, generated on the GPU."""
-    g = torch.Generator(device=dev)
-    g.manual_seed(seed)
+# --------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` without a launcher
+# --------------------------------------------------------------------------------------------
+def self_launch(n: int, argv: list[str]) -> int:
+    """Start n ranks of this script (one per GPU) and relay rank 0's output.  Runs before the
+    parent has made any GPU call (it never makes one)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
+# --------------------------------------------------------------------------------------------
+# synthetic workloads
+# --------------------------------------------------------------------------------------------
+def synth_forcing(T, B, dev, g):
+    """CAMELS-shaped forcings, generated on the compute device."""
+    import torch
     day = torch.arange(T, device=dev, dtype=torch.float32)[:, None]
     season = torch.sin(2 * torch.pi * day / 365.0)
     u = torch.rand((T, B), generator=g, device=dev)
     P = torch.clamp((u - 0.7) * 60.0, min=0.0)
     boff = torch.rand((1, B), generator=g, device=dev) * 25.0 - 10.0
     Tm = 10.0 * season + 5.0 * torch.randn((T, B), generator=g, device=dev) + boff
-    PET = torch.clamp(3.0 + 2.5 * season + 0.3 * torch.randn((T, B), generator=g, device=dev),
-                      min=0.0)
-    x = torch.stack([P, Tm, PET], dim=-1).contiguous()
-    params = torch.randn((T, B, ny), generator=g, device=dev)
-    w = torch.randn((T, B, 1), generator=g, device=dev)
-    return x, params, w
+    PET = torch.clamp(3.0 + 2.5 * season + 0.3 * torch.randn((T, B), generator=g, device=dev), min=0.0)
+    return torch.stack([P, Tm, PET], dim=-1).contiguous()
 
 
-def cpu_baseline(B, M, T_sample, seed=0):
-    """The CPU oracle (oracle/, OpenMP over basins) on a bounded sample of the same workload,
-    called through the same C ABI; reported next to the GPU number, never the target."""
+WORKLOADS = {
+    # name: (model file, class, T, B, M, dynamic parameters or "all", routed series with gradient)
+    "cfg2": ("hbv", "Hbv", 7300, 671, 16, []),
+    "cfg2dyn": ("hbv", "Hbv", 7300, 671, 16, ["parBETA", "parBETAET"]),
+    "cfg3": ("hbv_1_1p", "Hbv_1_1p", 7300, 671, 16, "all"),
+    "cfg4": ("hbv_adj", "HbvAdj", 7300, 671, 16, ["parBETAET"]),
+    "cfg5": ("hbv_2", "Hbv_2", 730, 100000, 16, ["parBETA", "parK0", "parBETAET"]),
+    "cfg5share": ("hbv_2", "Hbv_2", 730, 12500, 16, ["parBETA", "parK0", "parBETAET"]),
+}
+
+
+class Workload:
+    """One model + resident synthetic inputs + the step closure."""
+
+    def __init__(self, name, dev, seed, B=None, T=None, M=None):
+        import torch
+        import hydrodl2_amd
+        fam, cls, T0, B0, M0, dyn = WORKLOADS[name]
+        self.name, self.T, self.B, self.M = name, T or T0, B or B0, M or M0
+        T, B, M = self.T, self.B, self.M
+        C = hydrodl2_amd.load_model(fam, cls)
+        if dyn == "all":
+            dyn = list(C(None, dev).parameter_bounds)
+        self.model = C({"nmul": M, "dynamic_params": {cls: list(dyn)}}, dev)
+        self.n_dyn = len(dyn)
+        self.routed = bool(self.model.routing)
+        self.n_flux = {"Hbv": 11, "HbvAdj": 1}.get(cls, 12)
+        g = torch.Generator(device=dev)
+        g.manual_seed(seed)
+        x = synth_forcing(T, B, dev, g)
+        self.xd = {"x_phy": x}
+        if cls == "Hbv_2":
+            pd = torch.rand((T, B, self.n_dyn * M), generator=g, device=dev).requires_grad_(True)
+            ps = torch.rand((B, (16 - self.n_dyn) * M), generator=g, device=dev).requires_grad_(True)
+            self.params, self.leaves, self.shared = (pd, ps), [pd, ps], ps
+            self.xd["ac_all"] = torch.rand(B, generator=g, device=dev) * 5000
+            self.xd["elev_all"] = torch.rand(B, generator=g, device=dev) * 3000
+        else:
+            p = torch.randn((T, B, self.model.learnable_param_count), generator=g, device=dev).requires_grad_(True)
+            self.params, self.leaves, self.shared = p, [p], p
+        self.key = "flow_sim" if cls == "HbvAdj" else "streamflow"
+        self.w = torch.randn((T, B, 1), generator=g, device=dev)
+        self.cls = cls
+
+    @property
+    def lane_steps(self):
+        return self.B * self.M * self.T
+
+    def step(self):
+        for leaf in self.leaves:
+            leaf.grad = None
+        out = self.model(self.xd, self.params)
+        loss = (out[self.key] * self.w).sum()
+        loss.backward()
+        self.last_loss = loss.detach()
+        return loss
+
+    def shared_grad(self):
+        """What a shared parameterisation network would receive from this shard, basin-summed:
+        the last-row gradient of the raw NN output (hbv) or the static-parameter gradient (hbv_2)."""
+        g = self.shared.grad
+        return g[-1].sum(0) if g.dim() == 3 else g.sum(0)
+
+    def alg_bytes(self):
+        """SURVEY.md §8d algorithmic HBM bytes per lane-step (fp32, K-day checkpoints, n_g = the
+        series with incoming gradient): (forward kernel, backward kernel, routing fwd, routing bwd)."""
+        M, nd = self.M, self.n_dyn
+        n_g = 4 if self.routed else 1
+        fwd = 12.0 / M + 4.0 * nd + 4.0 * self.n_flux / M + 20.0 / CKPT_K
+        bwd = 12.0 / M + 4.0 * nd + 4.0 * nd + 4.0 * n_g / M + 20.0 / CKPT_K
+        rt = 32.0 / M if self.routed else 0.0
+        return fwd, bwd, rt, rt
+
+    def design_bytes(self):
+        """Bytes this build's kernels move per lane-step by construction: the forward
+        saves the whole trajectory + two pow results (28 B) instead of K-day checkpoints, the
+        time-parallel adjoint reads its inputs twice."""
+        M, nd = self.M, self.n_dyn
+        n_g = 4 if self.routed else 1
+        fwd = 12.0 / M + 4.0 * nd + 4.0 * self.n_flux / M + 28.0
+        one = 12.0 / M + 4.0 * nd + 28.0 + 4.0 * n_g / M
+        return fwd, one + 4.0 * nd
+
+
+def timed_steps(wl, steps, warmup, dev, world, after_step=None):
+    """W untimed + K timed steps with per-launch HIP events; returns (seconds, per-call avg ms)."""
+    import torch
+    import torch.distributed as dist
+    from hydrodl2_amd import ops
+    for _ in range(warmup):
+        wl.step()
+        if after_step:
+            after_step()
+    ops.KERNEL_EVENTS = []          # per-launch HIP events on the launch stream
+    if world > 1:
+        dist.barrier()
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wl.step()
+        if after_step:
+            after_step()
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
+    per = {}
+    for name, e0, e1 in events:
+        per.setdefault(name, []).append(e0.elapsed_time(e1))
+    # a step may launch a call twice (warm-up + main forward): report time per STEP
+    return dt, {k: sum(v) / steps for k, v in per.items()}
+
+
+def roofline_entry(wl, kms, ms_per_step):
+    """HBM roofline figures of one workload from its per-call kernel times."""
+    ls = wl.lane_steps
+    f8, b8, rf8, rb8 = wl.alg_bytes()
+    fd, bd = wl.design_bytes()
+    fk = "hbvx_adj_forward" if wl.cls == "HbvAdj" else "hbvx_forward"
+    bk = "hbvx_adj_backward" if wl.cls == "HbvAdj" else "hbvx_backward"
+    out = {"bytes_per_lane_step_8d": {"fwd": round(f8, 3), "bwd": round(b8, 3), "route": round(rf8 + rb8, 3),
+                                      "K": CKPT_K},
+           "kernel_ms": {k: round(v, 4) for k, v in kms.items()}}
+    if fk in kms and bk in kms:
+        gf = f8 * ls / (kms[fk] * 1e-3) / 1e9
+        gb = b8 * ls / (kms[bk] * 1e-3) / 1e9
+        whole = (f8 + b8 + rf8 + rb8) * ls / (ms_per_step * 1e-3) / 1e9
+        out.update({"fwd_GBps_8d": round(gf, 1), "bwd_GBps_8d": round(gb, 1), "step_GBps_8d": round(whole, 1),
+                    "frac_fwd": round(gf / HBM_PEAK_GBPS, 4), "frac_bwd": round(gb / HBM_PEAK_GBPS, 4),
+                    "frac_step": round(whole / HBM_PEAK_GBPS, 4),
+                    "fwd_GBps_design": round(fd * ls / (kms[fk] * 1e-3) / 1e9, 1),
+                    "bwd_GBps_design": round(bd * ls / (kms[bk] * 1e-3) / 1e9, 1)})
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# CPU baselines (rank 0, N = 1 only): bounded samples of the same workload on the host cores
+# --------------------------------------------------------------------------------------------
+def cpu_baseline_port(B, M, T_sample, seed=0):
+    """The CPU oracle (oracle/, C, OpenMP over basins) through the same C ABI."""
     import ctypes as C
     import numpy as np
     import __graft_entry__ as ge
@@ -83,7 +249,6 @@ def cpu_baseline(B, M, T_sample, seed=0):
     gflux = np.zeros((11, T, B), np.float32)
     gflux[0] = rng.standard_normal((T, B), dtype=np.float32)
     grow = np.zeros_like(row)
-
     bounds = [[1, 6], [50, 1000], [.05, .9], [.01, .5], [.001, .2], [.2, 1], [0, 10], [0, 100],
               [-2.5, 2.5], [.5, 10], [0, .1], [0, .2]]
     d = _abi.Desc()
@@ -103,7 +268,7 @@ def cpu_baseline(B, M, T_sample, seed=0):
     io.traj, io.aux, io.grad_flux, io.n_flux = traj.ctypes.data, aux.ctypes.data, gflux.ctypes.data, 11
     lib.forward(d, out, 0)  # warm-up (page faults)
     reps, dt = 0, 0.0
-    while reps < 3 or (dt < 2.0 and reps < 20):   # a few passes: one pass is well under a second on a big host
+    while reps < 3 or (dt < 2.0 and reps < 20):   # one pass is well under a second on a big host
         t0 = time.perf_counter()
         lib.forward(d, out, 0)
         lib.backward(d, io, 0)
@@ -115,128 +280,206 @@ def cpu_baseline(B, M, T_sample, seed=0):
                       f"lane-steps, {dt:.2f} s wall on {threads} threads"}
 
 
+def cpu_baseline_eager(B, M, T_sample, budget_s=40.0):
+    """The reference's kind of CPU path: PyTorch eager, one ATen call per operator per day plus the
+    autograd tape (oracle/hbv_torch_eager.py, pinned to the reference's fixtures in the CPU tests;
+    the reference itself cannot travel to this box).  One fwd+bwd pass at 671 x 16 x 365 (the
+    dMG window; the eager backward is O(T^2) for static parameters).  If the first
+    of the two halves already exceeds the budget the sample is cut to what ran."""
+    import importlib.util
+    import torch
+    spec = importlib.util.spec_from_file_location("hbv_torch_eager", os.path.join(ROOT, "oracle", "hbv_torch_eager.py"))
+    eager = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(eager)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(0)
+    T = T_sample
+    x = synth_forcing(T, B, torch.device("cpu"), g)
+    p = torch.randn((T, B, 12 * M + 2), generator=g).requires_grad_(True)
+    w = torch.randn((T, B, 1), generator=g)
+    t0 = time.perf_counter()
+    out = eager.hbv_eager(x, p, M)
+    t1 = time.perf_counter()
+    done = "fwd"
+    if t1 - t0 < budget_s:
+        (out["streamflow"] * w).sum().backward()
+        done = "fwd+bwd"
+    t2 = time.perf_counter()
+    return {"value": B * M * T / (t2 - t0), "unit": "basin-ensemble-timesteps/s", "cores": cores, "kind": "port",
+            "what": "pure-torch eager restatement of hbv.py:363-596 (reference-equivalent CPU path)",
+            "sample": f"{done}, one pass over {B}x{M}x{T} lane-steps: fwd {t1 - t0:.2f} s + bwd {t2 - t1:.2f} s "
+                      f"on {cores} torch threads"}
+
+
+# --------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--basins", type=int, default=671)
-    ap.add_argument("--nmul", type=int, default=16)
-    ap.add_argument("--days", type=int, default=7300)
+    ap.add_argument("--config", choices=["cfg2", "cfg5"], default="cfg2")
+    ap.add_argument("--basins", type=int, default=None)
+    ap.add_argument("--nmul", type=int, default=None)
+    ap.add_argument("--days", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--cpu-sample-days", type=int, default=1825)
+    ap.add_argument("--device", choices=["cuda", "cpu"], default="cuda",
+                    help="cpu exists for the launcher's own test (tests/test_bench_launch.py swaps in a host "
+                         "implementation of the ABI); the product library refuses host tensors")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+
+    import torch
+    import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with torch.distributed.run (one rank per GPU)")
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.device == "cuda":
+        assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path)"
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    else:
+        dev = torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if dev.type == "cuda":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
-    import hydrodl2_amd
-    from hydrodl2_amd import ops, sharding
-    B, M, T = args.basins, args.nmul, args.days
-    Hbv = hydrodl2_amd.load_model("hbv", "Hbv")
-    model = Hbv({"nmul": M, "dynamic_params": {"Hbv": []}}, dev)
-    ny = model.learnable_param_count
-    x, params, w = synth_inputs(T, B, ny, dev, seed=1000 + rank)
-    params.requires_grad_(True)
-    bucket = torch.zeros(ny + 1, device=dev)
+    from hydrodl2_amd import sharding
+    strong = args.config == "cfg5"
+    _, _, T0, B0, M0, _ = WORKLOADS[args.config]
+    B_total = args.basins or B0
+    if strong:
+        b0, b1 = sharding.basin_range(B_total, world, rank)
+        B_rank = b1 - b0
+    else:
+        B_rank = B_total
+    wl = Workload(args.config, dev, seed=1000 + rank, B=B_rank, T=args.days or T0, M=args.nmul or M0)
 
-    def step():
-        params.grad = None
-        out = model({"x_phy": x}, params)
-        loss = (out["streamflow"] * w).sum()
-        loss.backward()
-        # what a shared parameterisation network would receive: basin-summed last-row gradient
-        bucket[:ny] = params.grad[-1].sum(0)
-        bucket[ny] = loss.detach()
-        sharding.all_reduce_sum_([bucket])   # the path's only collective (RCCL over xGMI)
-        return loss
+    nshared = wl.shared.shape[-1]
+    bucket = torch.zeros(nshared + 1, device=dev)
+    ar_events = []
 
-    for _ in range(args.warmup):
-        step()
-    ops.KERNEL_EVENTS = []          # per-launch HIP events on the launch stream
+    def exchange():
+        # the path's only collective (RCCL over xGMI): loss + shared-network gradient, one bucket
+        bucket[:nshared] = wl.shared_grad()
+        bucket[nshared] = wl.last_loss
+        if world > 1 and dev.type == "cuda":
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            sharding.all_reduce_sum_([bucket])
+            e1.record()
+            ar_events.append((e0, e1))
+        else:
+            sharding.all_reduce_sum_([bucket])
+
+    dt, kavg = timed_steps(wl, args.steps, args.warmup, dev, world, after_step=exchange)
+    my_ms = 1e3 * dt / args.steps
+    rank_ms = [my_ms]
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
-    if world > 1:
-        tmax = torch.tensor([dt], device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        t = torch.zeros(world, device=dev)
+        t[rank] = dt
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        rank_ms = [round(1e3 * float(v) / args.steps, 4) for v in t]
+        dt = float(t.max().item())
+    ar_ms = None
+    if ar_events:
+        v = [a.elapsed_time(b) for a, b in ar_events[-args.steps:]]
+        ar_ms = round(sum(v) / len(v), 4)
 
-    lane_steps = B * M * T
-    value = world * lane_steps * args.steps / dt
+    lane_steps_job = (B_total if strong else B_total * world) * wl.M * wl.T
+    value = lane_steps_job * args.steps / dt
+    ms_per_step = 1e3 * dt / args.steps
 
-    # per-kernel durations (ms) from the events recorded around each ABI call
-    kt = {}
-    for name, e0, e1 in events:
-        kt.setdefault(name, []).append(e0.elapsed_time(e1))
-    kavg = {k: sum(v) / len(v) for k, v in kt.items()}
-
-    # Algorithmic HBM bytes per launch ("bytes per lane-step", fp32):
-    #   forward : forcings 12/M + 11 mean series 4*11/M + saved trajectory/aux 28   = 31.5  B
-    #   adjoint : time-parallel, two passes over (forcings 12/M + trajectory/aux 28 + routed-Q
-    #             gradients 4*4/M = 29.75 B) + per-chunk maps/partials (35+12 floats per lane and
-    #             64-day chunk, written and read: 5.9 B)                               = 65.4  B
-    n_flux = 11
-    bytes_fwd = lane_steps * (12.0 / M + 4.0 * n_flux / M + 28.0)
-    bytes_bwd = lane_steps * (2.0 * (12.0 / M + 28.0 + 4.0 * 4 / M) + 2.0 * 4.0 * (35 + 12) / 64.0)
-    # Dominant kernel: k_fwd_pipe, the one kernel behind hbvx_forward (rocprofv3 --stats,
-    # profiles/r01_kernel_stats.csv: the largest single kernel; hbvx_backward is four kernels, the two
-    # big ones ~0.65 ms each).  The adjoint call is reported beside it in `calls`.
-    tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    pmc = {}
-    if os.path.exists(tj):
-        try:
-            pmc = json.load(open(tj))
-        except Exception:
-            pmc = {}
-    calls = {}
-    bytes_zero = 4.0 * T * B * ny      # the dense [T,B,ny] gradient the autograd contract returns (hbvx_zero)
-    for call, nbytes in (("hbvx_forward", bytes_fwd), ("hbvx_backward", bytes_bwd), ("hbvx_zero", bytes_zero)):
-        if call in kavg:
-            calls[call] = {"avg_ms": round(kavg[call], 4), "algorithmic_bytes": nbytes,
-                           "achieved_GBps": round(nbytes / (kavg[call] * 1e-3) / 1e9, 2),
-                           "traffic": pmc.get(call, {}).get("hbm_bytes_raw")}
-    dom = "hbvx_forward"
-    achieved = bytes_fwd / (kavg[dom] * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "k_fwd_pipe (hbv_pipe.h), the kernel of hbvx_forward",
-                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": calls[dom]["traffic"],
-                "avg_ms": round(kavg[dom], 4), "calls": calls,
-                "kernel_ms": {k: round(v, 4) for k, v in kavg.items()}}
-
+    res = None
     if rank == 0:
+        fam, cls = WORKLOADS[args.config][:2]
+        what = (f"{fam} ({cls}) {B_total} basins x {wl.M} members x {wl.T} days, "
+                + ("static parameters" if wl.n_dyn == 0 else f"{wl.n_dyn} dynamic parameters")
+                + ", fwd+bwd, raw parameters resident in HBM")
         res = {
             "metric": "basin-ensemble-timesteps/sec fwd+bwd", "value": value,
             "unit": "basin-ensemble-timesteps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": f"hbv (HBV 1.0) {B} basins x {M} members x {T} days, static "
-                                   "parameters, fwd+bwd, raw parameters [T,B,ny] in HBM",
-                       "basins_per_gpu": B, "nmul": M, "days": T, "parallelism": f"basin-shard x{world}"},
-            "roofline": roofline,
+            "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": what, "name": args.config, "basins_total": B_total if strong else B_total * world,
+                       "basins_per_gpu": B_rank, "nmul": wl.M, "days": wl.T,
+                       "parallelism": f"basin-shard x{world}"},
+            "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+            "rank_ms_per_step": rank_ms, "allreduce_ms": ar_ms,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(B, M, min(args.cpu_sample_days, T))
+        if dev.type == "cuda" and "hbvx_forward" in kavg:
+            # Dominant kernel = the one kernel behind hbvx_forward (rocprofv3 --stats: the largest single
+            # kernel of the step; hbvx_backward is 4 kernels).  `achieved` follows SURVEY.md §8d: algorithmic
+            # bytes per lane-step (K = 64-day checkpoints; routing is a separate kernel and not counted
+            # here) x lane-steps per launch / the launch's HIP-event duration.  `frac_design` prices the
+            # bytes this build moves by construction (full trajectory instead of checkpoints).
+            f8, b8, rf8, rb8 = wl.alg_bytes()
+            fd, bd = wl.design_bytes()
+            ls = wl.lane_steps
+            ach = f8 * ls / (kavg["hbvx_forward"] * 1e-3) / 1e9
+            ach_d = fd * ls / (kavg["hbvx_forward"] * 1e-3) / 1e9
+            pmc, src = {}, os.path.join("profiles", "pmc_traffic.json")
+            try:
+                pmc = json.load(open(os.path.join(ROOT, src)))
+            except Exception:
+                pmc = {}
+            traffic = pmc.get("hbvx_forward", {}).get("hbm_bytes") if args.config == "cfg2" else None
+            res["roofline"] = {
+                "bound": "hbm", "kernel": "the kernel of hbvx_forward (k_fwd_pipe at cfg2, k_fwd_stream at cfg5)",
+                "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBPS, 5), "frac_8d": round(ach / HBM_PEAK_GBPS, 5),
+                "frac_design": round(ach_d / HBM_PEAK_GBPS, 5),
+                "bytes_per_lane_step": {"8d_fwd": round(f8, 3), "8d_bwd": round(b8, 3), "8d_route": round(rf8 + rb8, 3),
+                                        "design_fwd": round(fd, 3), "design_bwd": round(bd, 3), "K": CKPT_K},
+                "traffic": traffic, "traffic_source": src + " (committed rocprofv3 --pmc passes of this command, "
+                                                            "corrected as DESIGN.md §5 states; not re-measured in this run)",
+                "avg_ms": round(kavg["hbvx_forward"], 4),
+                "whole_step": roofline_entry(wl, kavg, ms_per_step),
+            }
+    del wl
+    if dev.type == "cuda":
+        torch.cuda.empty_cache()
+
+    if rank == 0 and world == 1 and dev.type == "cuda" and not args.no_secondary:
+        # the other BASELINE configs under the same clock: 5 timed steps each, same event timing
+        sec = []
+        for name in ("cfg2dyn", "cfg3", "cfg4", "cfg5share"):
+            if name == args.config:
+                continue
+            try:
+                w2 = Workload(name, dev, seed=7)
+                dt2, k2 = timed_steps(w2, 5, 2, dev, 1)
+                ms2 = 1e3 * dt2 / 5
+                e = {"config": name, "T": w2.T, "B": w2.B, "M": w2.M, "n_dyn": w2.n_dyn, "steps": 5,
+                     "ms_per_step": round(ms2, 4), "lane_steps_per_s": w2.lane_steps / (ms2 * 1e-3)}
+                e.update(roofline_entry(w2, k2, ms2))
+                sec.append(e)
+                del w2
+            except Exception as ex:  # a secondary config must not take the headline down
+                sec.append({"config": name, "error": repr(ex)[:200]})
+            torch.cuda.empty_cache()
+        res["secondary"] = sec
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cb = cpu_baseline_port(671, 16, min(args.cpu_sample_days, 7300))
+        try:
+            cb["eager"] = cpu_baseline_eager(671, 16, 365)
+        except Exception as ex:
+            cb["eager"] = {"error": repr(ex)[:200]}
+        res["cpu_baseline"] = cb
+    if rank == 0:
         print(json.dumps(res))
+        sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
 
