@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_PARAM = 20
 GAGE_MAXLEN = 72
 NSTATE = 5
@@ -18,6 +18,9 @@ UH_MAXLEN = 15
 
 # enum hbvx_model
 MODEL_HBV10, MODEL_HBV11P, MODEL_HBV20, MODEL_HBVADJ, MODEL_HOURLY = 0, 1, 2, 3, 4
+
+# enum hbvx_traj_layout
+TRAJ_ROWS, TRAJ_PACKED = 0, 1
 
 # enum hbvx_flux
 (F_QSIM, F_Q0, F_Q1, F_Q2, F_AET, F_SWE, F_RECHARGE, F_EXCS, F_EVAPFACTOR, F_TOSOIL, F_PERC,
@@ -56,14 +59,14 @@ class Desc(C.Structure):
 
 class FwdOut(C.Structure):
     _fields_ = [("flux", _fp), ("state_out", _fp), ("traj", _fp), ("aux", _fp),
-                ("n_flux", C.c_int32), ("reserved0", C.c_int32)]
+                ("n_flux", C.c_int32), ("traj_layout", C.c_int32)]
 
 
 class BwdIO(C.Structure):
     _fields_ = [("traj", _fp), ("aux", _fp), ("grad_flux", _fp), ("grad_flux4", _fp),
                 ("grad_state_out", _fp), ("grad_x", _fp),
                 ("grad_muwts", _fp), ("grad_state_in", _fp),
-                ("n_flux", C.c_int32), ("reserved0", C.c_int32),
+                ("n_flux", C.c_int32), ("traj_layout", C.c_int32),
                 ("g", ParamGrad * MAX_PARAM),
                 ("workspace", _fp), ("workspace_bytes", C.c_uint64)]
 
@@ -94,7 +97,7 @@ class LstmDesc(C.Structure):
 LSTM_ABI_VERSION = 1
 LSTM_HIDDEN_SIZES = (64, 128, 256)     # what the HIP library instantiates
 
-EXPORTS = ["hbvx_zero", "hbvx_zero_except", "hbvx_lstm_workspace_bytes", "hbvx_lstm_forward", "hbvx_lstm_backward", "hbvx_lstm_check",
+EXPORTS = ["hbvx_zero", "hbvx_zero_except", "hbvx_preferred_traj_layout", "hbvx_lstm_workspace_bytes", "hbvx_lstm_forward", "hbvx_lstm_backward", "hbvx_lstm_check",
            "hbvx_version", "hbvx_last_error", "hbvx_backend", "hbvx_sizeof", "hbvx_forward",
            "hbvx_backward", "hbvx_backward_workspace_bytes", "hbvx_route_forward", "hbvx_route_workspace_bytes",
            "hbvx_route_backward", "hbvx_adj_forward", "hbvx_adj_backward", "hbvx_bfi",
@@ -149,6 +152,8 @@ class Library:
                                                C.c_void_p]
         d.hbvx_bfi.restype = C.c_int
         d.hbvx_bfi.argtypes = [C.c_int32, C.c_int32, _fp, _fp, C.c_float, _fp, C.c_void_p]
+        d.hbvx_preferred_traj_layout.restype = C.c_int
+        d.hbvx_preferred_traj_layout.argtypes = [C.POINTER(Desc)]
         d.hbvx_zero.restype = C.c_int
         d.hbvx_zero.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
         d.hbvx_zero_except.restype = C.c_int
@@ -188,6 +193,9 @@ class Library:
     def backward(self, desc: Desc, io: BwdIO, stream: int):
         self._check(self.dll.hbvx_backward(C.byref(desc), C.byref(io), C.c_void_p(stream)),
                     "hbvx_backward")
+
+    def preferred_traj_layout(self, desc: Desc) -> int:
+        return int(self.dll.hbvx_preferred_traj_layout(C.byref(desc)))
 
     def backward_workspace_bytes(self, desc: Desc) -> int:
         return int(self.dll.hbvx_backward_workspace_bytes(C.byref(desc)))

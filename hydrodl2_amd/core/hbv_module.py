@@ -15,7 +15,7 @@ from typing import Any, Optional, Union
 import torch
 
 from .. import _abi
-from ..ops import Bfi, HbvPath, ParamSource, RouteSource, StepConfig
+from ..ops import Bfi, ParamSource, RouteSource, StepConfig, hbv_path
 
 
 class HbvModule(torch.nn.Module):
@@ -214,7 +214,7 @@ class HbvModule(torch.nn.Module):
                 cfg_w = StepConfig(T=warm_up, t0=0, want_flux=False, **base)
                 cfg_w.params = self._param_sources(T_total, ngrid, ny, 0, warm_up - 1, [],
                                                    x.device)
-                _, _, state_in, _ = HbvPath.apply(cfg_w, x, state_in, None, None, None,
+                _, _, state_in, _ = hbv_path(cfg_w, x, state_in, None, None, None,
                                                   parameters.detach())
 
         # hbv.py:349-353
@@ -229,7 +229,7 @@ class HbvModule(torch.nn.Module):
                                     self.routing_parameter_bounds['route_b'])
         muwts = self._expand_muwts(self.muwts, T, T_total, ngrid)
         cfg.mu_t0 = 0                      # muwts rows are post-warm-up days already
-        flux, routed, state_out, _ = HbvPath.apply(cfg, x, state_in, muwts, None, None,
+        flux, routed, state_out, _ = hbv_path(cfg, x, state_in, muwts, None, None,
                                                    parameters)
 
         # hbv.py:356-359

@@ -25,6 +25,9 @@
 namespace hbvx {
 
 #define STREAM_D 4
+#ifndef STREAM_EXP
+#define STREAM_EXP 0   // dev experiments: 1 no flux stores, 2 no ensemble reduction, 4 no trajectory stores
+#endif
 
 struct StreamArgs {
     hbvx_desc d;
@@ -174,7 +177,7 @@ __global__ void __launch_bounds__(64) k_fwd_stream(const StreamArgs A)
         s.SP = st[0]; s.MW = st[1]; s.SM = st[2]; s.SUZ = st[3]; s.SLZ = st[4];
         s.template fwd<false>(p, nz, ac, elev, 0.0f, 0.0f);
         const unsigned so = (unsigned)t * row4;
-        if (TRAJ) {
+        if (TRAJ && !(STREAM_EXP & 4)) {
 #pragma unroll
             for (int k = 0; k < 5; k++) bstore(rtraj, tvo[k], so, st[k]);
             bstore(raux, avo[0], so, s.sw0);
@@ -189,12 +192,19 @@ __global__ void __launch_bounds__(64) k_fwd_stream(const StreamArgs A)
         f[HBVX_F_CAPILLARY] = s.cap;
 #pragma unroll
         for (int k = 0; k < NF; k++) f[k] *= act;
-        ens_sum_dpp<NF>(f, lgMp);
+        if (!(STREAM_EXP & 2)) ens_sum_dpp<NF>(f, lgMp);
         unsigned fso = (unsigned)t * fB;
+        if (STREAM_EXP & 1) {
+            float acc = 0.0f;
 #pragma unroll
-        for (int k = 0; k < NF; k++) {
-            bstore(rflux, fvo, fso, f[k] * invM);
-            fso += fT;
+            for (int k = 0; k < NF; k++) acc += f[k];
+            if (acc == 123.456f) bstore(rflux, fvo, fso, acc);
+        } else {
+#pragma unroll
+            for (int k = 0; k < NF; k++) {
+                bstore(rflux, fvo, fso, f[k] * invM);
+                fso += fT;
+            }
         }
     };
 

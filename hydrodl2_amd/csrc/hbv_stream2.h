@@ -1,0 +1,499 @@
+// hbv_stream2.h -- streaming forward / adjoint for large grids, second generation.
+//
+// Measured on MI355X (profiles/r02_*): the first streaming kernels (hbv_stream.h) were bound by the
+// NUMBER of vector-memory instructions, stores above all -- a wave-store costs the CU ~20 cycles of
+// issue whatever its width (12 flux stores of 16 useful bytes cost as much as 7 trajectory stores of
+// 256 bytes: 0.85 ms each of a 2.2 ms forward at 3 waves per SIMD) -- and by dependent-instruction
+// latency at low occupancy (one wave alone issues a dependent fp32 chain at ~10 cycles per
+// instruction, independent work at ~2.9; tools/micro/issue_rate.hip).  Hence:
+//
+//   * packed trajectory (HBVX_TRAJ_PACKED): per lane-day one 16-byte record (SP, MW, SM, SUZ), one
+//     4-byte SLZ row and one 8-byte record of the two saved powers -- 3 stores in the forward and 3
+//     loads in the adjoint instead of 7 + 7, inside the same two caller buffers;
+//   * one flux store per day: after the ensemble butterflies every lane of a basin holds every mean;
+//     member lane j keeps series j and the wave writes 12 series x 4 basins with ONE store;
+//   * the three forcings of a basin in one 12-byte load when their channels are adjacent;
+//   * the dynamic-parameter set is a template constant (the sets users run: none, {BETA, BETAET},
+//     {BETA, K0, BETAET}); any other set of up to three stays on hbv_stream.h;
+//   * the adjoint keeps one day of inputs in flight, accumulates the static-parameter gradients in
+//     place, and is compiled for three or more waves per SIMD.
+//
+// Numerics: the same Step<> code and the same ensemble add tree as every other kernel family.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/hbvx.h"
+#include "hbv_step.h"
+#include "hbv_tiled.h"
+#include "hbv_stream.h"
+
+namespace hbvx {
+
+// compile-time dynamic-parameter sets (slot lists in parameter order)
+template <int SC> struct StreamDyn { static constexpr int nd = 0; };
+template <> struct StreamDyn<1> { static constexpr int nd = 2; };
+template <> struct StreamDyn<2> { static constexpr int nd = 3; };
+template <int SC>
+__host__ __device__ constexpr int stream_slot(int k)
+{
+    return SC == 1 ? (k == 0 ? P_BETA : P_BETAET) : (k == 0 ? P_BETA : (k == 1 ? P_K0 : P_BETAET));
+}
+
+#ifndef STREAM2_D
+#define STREAM2_D 4      // days of forward inputs in flight (register ring)
+#endif
+
+typedef float s2_f2 __attribute__((ext_vector_type(2)));
+typedef float s2_f3 __attribute__((ext_vector_type(3)));
+typedef float s2_f4 __attribute__((ext_vector_type(4)));
+
+struct S2Buf {
+    static __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void *base)
+    {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, -1, 0x00020000);
+    }
+    static __device__ __forceinline__ float ld(__amdgpu_buffer_rsrc_t r, unsigned vo, unsigned so)
+    {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, vo, so, 0));
+    }
+    static __device__ __forceinline__ s2_f2 ld2(__amdgpu_buffer_rsrc_t r, unsigned vo, unsigned so)
+    {
+        return __builtin_bit_cast(s2_f2, __builtin_amdgcn_raw_buffer_load_b64(r, vo, so, 0));
+    }
+    static __device__ __forceinline__ s2_f3 ld3(__amdgpu_buffer_rsrc_t r, unsigned vo, unsigned so)
+    {
+        return __builtin_bit_cast(s2_f3, __builtin_amdgcn_raw_buffer_load_b96(r, vo, so, 0));
+    }
+    static __device__ __forceinline__ s2_f4 ld4(__amdgpu_buffer_rsrc_t r, unsigned vo, unsigned so)
+    {
+        return __builtin_bit_cast(s2_f4, __builtin_amdgcn_raw_buffer_load_b128(r, vo, so, 0));
+    }
+    static __device__ __forceinline__ void st(__amdgpu_buffer_rsrc_t r, unsigned vo, unsigned so, float v)
+    {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, vo, so, 0);
+    }
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u3 __attribute__((ext_vector_type(3)));
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ void st2(__amdgpu_buffer_rsrc_t r, unsigned vo, unsigned so, s2_f2 v)
+    {
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), r, vo, so, 0);
+    }
+    static __device__ __forceinline__ void st3(__amdgpu_buffer_rsrc_t r, unsigned vo, unsigned so, s2_f3 v)
+    {
+        __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(u3, v), r, vo, so, 0);
+    }
+    static __device__ __forceinline__ void st4(__amdgpu_buffer_rsrc_t r, unsigned vo, unsigned so, s2_f4 v)
+    {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), r, vo, so, 0);
+    }
+};
+
+// one of three forcing values by a wave-uniform channel number
+__device__ __forceinline__ float s2_pick(const s2_f3 v, int ch)
+{
+    return ch == 0 ? v.x : (ch == 1 ? v.y : v.z);
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward.  TRJ: 0 nothing kept, 1 trajectory rows [5,T+1,N] + aux [2,T,N], 2 packed.
+// XVEC: forcing channels are {0,1,2} and a basin's three values are adjacent (one 12-byte load).
+// ---------------------------------------------------------------------------------------------
+template <int MODEL, bool BETAET, int TRJ, int SC, bool XVEC>
+__global__ void __launch_bounds__(64) k_fwd_stream2(const StreamArgs A)
+{
+    constexpr int NP = NParamT<MODEL, BETAET>::value;
+    constexpr int NF = MODEL == MODEL_HBV10 ? 11 : 12;
+    constexpr int ND = StreamDyn<SC>::nd;
+    constexpr int D = STREAM2_D;
+    const hbvx_desc &d = A.d;
+    const hbvx_fwd_out &o = A.o;
+    const int lgMp = A.lgMp;
+    const LaneT L = lane_t(d, lgMp);
+    const int T = d.T, B = d.B;
+    const int64_t N = (int64_t)B * d.M;
+    const bool raw = d.raw_sigmoid != 0;
+    const float nz = d.nearzero, invM = 1.0f / (float)d.M;
+    const float ac = (MODEL == MODEL_HBV20 || MODEL == MODEL_HOURLY) ? d.ac[L.b] : 0.0f;
+    const float elev = (MODEL == MODEL_HBV20 || MODEL == MODEL_HOURLY) ? d.elev[L.b] : 0.0f;
+    const unsigned OOB = 0xFFFFFFFFu;
+
+    float p[NPARAM_MAX];
+#pragma unroll
+    for (int i = 0; i < NPARAM_MAX; i++) p[i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        const hbvx_param_src &s = d.p[i];
+        float v = s.sta[(int64_t)L.b * s.sta_b_stride + L.j];
+        v = raw ? sigmoid_(v) : v;
+        p[i] = descale_(v, s.lo, s.hi);
+    }
+
+    // inputs
+    const auto rx = S2Buf::rsrc(d.x);
+    const unsigned xvo = (unsigned)(L.b * d.x_b_stride * 4);
+    const unsigned xts = (unsigned)(d.x_t_stride * 4);
+    const int cp = d.ch_prcp, ct = d.ch_tmean, ce = d.ch_pet;
+    __amdgpu_buffer_rsrc_t rd[ND > 0 ? ND : 1];
+    unsigned dvo[ND > 0 ? ND : 1], dts[ND > 0 ? ND : 1];
+    float dlo[ND > 0 ? ND : 1], dsc[ND > 0 ? ND : 1], dsta[ND > 0 ? ND : 1];
+    bool duse[ND > 0 ? ND : 1];
+#pragma unroll
+    for (int k = 0; k < ND; k++) {
+        const hbvx_param_src &ps = d.p[stream_slot<SC>(k)];
+        rd[k] = S2Buf::rsrc(ps.dyn);
+        dvo[k] = (unsigned)((L.b * ps.dyn_b_stride + L.j) * 4);
+        dts[k] = (unsigned)(ps.dyn_t_stride * 4);
+        dlo[k] = ps.lo;
+        dsc[k] = ps.hi - ps.lo;
+        dsta[k] = p[stream_slot<SC>(k)];
+        duse[k] = !(ps.drop && ps.drop[L.b]);
+    }
+    // outputs
+    const auto rflux = S2Buf::rsrc(o.flux);
+    const auto rtraj = S2Buf::rsrc(o.traj), raux = S2Buf::rsrc(o.aux ? o.aux : o.traj);
+    const auto rslz = S2Buf::rsrc(TRJ == 2 ? o.traj + 4 * (int64_t)(T + 1) * N : o.traj);
+    unsigned tvo[5], avo[2];
+#pragma unroll
+    for (int k = 0; k < 5; k++) tvo[k] = (TRJ == 1 && L.active) ? (unsigned)((k * (int64_t)(T + 1) * N + L.n) * 4) : OOB;
+#pragma unroll
+    for (int k = 0; k < 2; k++) avo[k] = (TRJ == 1 && L.active && o.aux) ? (unsigned)((k * (int64_t)T * N + L.n) * 4) : OOB;
+    const unsigned pvo4 = (TRJ == 2 && L.active) ? (unsigned)(L.n * 16) : OOB;
+    const unsigned pvo1 = (TRJ == 2 && L.active) ? (unsigned)(L.n * 4) : OOB;
+    const unsigned pvo2 = (TRJ == 2 && L.active && o.aux) ? (unsigned)(L.n * 8) : OOB;
+    const unsigned row4 = (unsigned)(N * 4);
+    const unsigned fT = (unsigned)((int64_t)T * B * 4), fB = (unsigned)(B * 4);
+    // flux: with >= 16 lanes per basin, member lane j owns series j (one store per day); with fewer
+    // lanes the basin leader stores the NF series one by one
+    const bool roles = lgMp >= 4;
+    const bool bvalid = (blockIdx.x * (64 >> lgMp) + L.bl) < B;
+    const unsigned fvo_role = (roles && bvalid && L.jm < NF) ? (unsigned)(((int64_t)L.jm * T * B + L.b) * 4) : OOB;
+    const unsigned fvo_lead = (!roles && L.active && L.jm == 0) ? (unsigned)(L.b * 4) : OOB;
+
+    float st[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) st[k] = d.state_in ? d.state_in[k * N + L.n] : 0.001f;
+
+    float fx[D][3], dv[D][ND > 0 ? ND : 1];
+    auto issue = [&](int t, int j) {
+        const unsigned tc = (unsigned)min(t, T - 1);
+        const unsigned so = tc * xts;
+        if (XVEC) {
+            const s2_f3 v = S2Buf::ld3(rx, xvo, so);
+            fx[j][0] = v.x; fx[j][1] = v.y; fx[j][2] = v.z;
+        } else {
+            fx[j][0] = S2Buf::ld(rx, xvo, so + cp * 4);
+            fx[j][1] = S2Buf::ld(rx, xvo, so + ct * 4);
+            fx[j][2] = S2Buf::ld(rx, xvo, so + ce * 4);
+        }
+#pragma unroll
+        for (int k = 0; k < ND; k++) dv[j][k] = S2Buf::ld(rd[k], dvo[k], tc * dts[k]);
+    };
+    auto day = [&](int t, int j) {
+        Step<MODEL, BETAET> s;
+        if (XVEC) {
+            const s2_f3 v = {fx[j][0], fx[j][1], fx[j][2]};
+            s.P = s2_pick(v, cp); s.Tf = s2_pick(v, ct); s.PET = s2_pick(v, ce);
+        } else {
+            s.P = fx[j][0]; s.Tf = fx[j][1]; s.PET = fx[j][2];
+        }
+#pragma unroll
+        for (int k = 0; k < ND; k++) {
+            const float u = raw ? sigmoid_dyn_(dv[j][k]) : dv[j][k];
+            p[stream_slot<SC>(k)] = duse[k] ? u * dsc[k] + dlo[k] : dsta[k];
+        }
+        s.SP = st[0]; s.MW = st[1]; s.SM = st[2]; s.SUZ = st[3]; s.SLZ = st[4];
+        s.template fwd<false>(p, nz, ac, elev, 0.0f, 0.0f);
+        if (TRJ == 1) {
+            const unsigned so = (unsigned)t * row4;
+#pragma unroll
+            for (int k = 0; k < 5; k++) S2Buf::st(rtraj, tvo[k], so, st[k]);
+            S2Buf::st(raux, avo[0], so, s.sw0);
+            S2Buf::st(raux, avo[1], so, s.ef0);
+        }
+        if (TRJ == 2) {
+            const s2_f4 rec = {st[0], st[1], st[2], st[3]};
+            const s2_f2 pw = {s.sw0, s.ef0};
+            S2Buf::st4(rtraj, pvo4, (unsigned)t * row4 * 4u, rec);
+            S2Buf::st(rslz, pvo1, (unsigned)t * row4, st[4]);
+            S2Buf::st2(raux, pvo2, (unsigned)t * row4 * 2u, pw);
+        }
+        st[0] = s.SP3; st[1] = s.MW3; st[2] = s.SM4; st[3] = s.SUZ4; st[4] = s.SLZ2;
+        const float act = L.active ? 1.0f : 0.0f;
+        float f[HBVX_MAX_FLUX];
+        f[HBVX_F_QSIM] = s.Q; f[HBVX_F_Q0] = s.Q0; f[HBVX_F_Q1] = s.Q1; f[HBVX_F_Q2] = s.Q2;
+        f[HBVX_F_AET] = s.ET; f[HBVX_F_SWE] = s.SP3; f[HBVX_F_RECHARGE] = s.rech; f[HBVX_F_EXCS] = s.exc;
+        f[HBVX_F_EVAPFACTOR] = s.ef; f[HBVX_F_TOSOIL] = s.tosoil; f[HBVX_F_PERC] = s.PERC;
+        f[HBVX_F_CAPILLARY] = s.cap;
+#pragma unroll
+        for (int k = 0; k < NF; k++) f[k] *= act;
+        ens_sum_dpp<NF>(f, lgMp);
+        const unsigned fso = (unsigned)t * fB;
+        if (roles) {
+            float v = f[0];
+#pragma unroll
+            for (int k = 1; k < NF; k++) v = (L.jm == k) ? f[k] : v;
+            S2Buf::st(rflux, fvo_role, fso, v * invM);
+        } else {
+            unsigned so = fso;
+#pragma unroll
+            for (int k = 0; k < NF; k++) {
+                S2Buf::st(rflux, fvo_lead, so, f[k] * invM);
+                so += fT;
+            }
+        }
+    };
+
+#pragma unroll
+    for (int j = 0; j < D; j++) issue(j, j);
+    int t0 = 0;
+    for (; t0 + D <= T; t0 += D) {
+#pragma unroll
+        for (int j = 0; j < D; j++) {
+            day(t0 + j, j);
+            issue(t0 + j + D, j);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < D; j++)
+        if (t0 + j < T) day(t0 + j, j);
+    if (L.active) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) o.state_out[k * N + L.n] = st[k];
+        if (TRJ == 1) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) o.traj[((int64_t)k * (T + 1) + T) * N + L.n] = st[k];
+        }
+        if (TRJ == 2) {
+            float *rec = o.traj + ((int64_t)T * N + L.n) * 4;
+            rec[0] = st[0]; rec[1] = st[1]; rec[2] = st[2]; rec[3] = st[3];
+            o.traj[4 * (int64_t)(T + 1) * N + (int64_t)T * N + L.n] = st[4];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// adjoint: one serial pass, one wave per 64 lanes.  TRJ: 1 rows, 2 packed.
+// ---------------------------------------------------------------------------------------------
+#ifndef STREAM2_DB
+#define STREAM2_DB 1     // days of adjoint inputs in flight
+#endif
+#ifndef STREAM2_BWD_WAVES
+#define STREAM2_BWD_WAVES 3
+#endif
+
+template <int MODEL, bool BETAET, int TRJ, int SC, bool GFULL, bool XVEC>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STREAM2_BWD_WAVES)))
+k_bwd_stream2(const StreamBwdArgs A)
+{
+    constexpr int NP = NParamT<MODEL, BETAET>::value;
+    constexpr int NF = MODEL == MODEL_HBV10 ? 11 : 12;
+    constexpr int NG = GFULL ? NF : 4;
+    constexpr int ND = StreamDyn<SC>::nd;
+    constexpr int D = STREAM2_DB;
+    const hbvx_desc &d = A.d;
+    const hbvx_bwd_io &io = A.io;
+    const int lgMp = A.lgMp;
+    const LaneT L = lane_t(d, lgMp);
+    const int T = d.T, B = d.B;
+    const int64_t N = (int64_t)B * d.M;
+    const bool raw = d.raw_sigmoid != 0;
+    const float nz = d.nearzero, invM = 1.0f / (float)d.M;
+    const float ac = (MODEL == MODEL_HBV20 || MODEL == MODEL_HOURLY) ? d.ac[L.b] : 0.0f;
+    const float elev = (MODEL == MODEL_HBV20 || MODEL == MODEL_HOURLY) ? d.elev[L.b] : 0.0f;
+    const bool leader = L.active && L.jm == 0;
+    const unsigned OOB = 0xFFFFFFFFu;
+
+    // p[]: physical values of the day; gacc[]: sum over days of dL/d(physical value) per slot
+    float p[NPARAM_MAX], gacc[NP];
+#pragma unroll
+    for (int i = 0; i < NPARAM_MAX; i++) p[i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        const hbvx_param_src &s = d.p[i];
+        float v = s.sta[(int64_t)L.b * s.sta_b_stride + L.j];
+        v = raw ? sigmoid_(v) : v;
+        p[i] = descale_(v, s.lo, s.hi);
+        gacc[i] = 0.0f;
+    }
+
+    const auto rx = S2Buf::rsrc(d.x), rtraj = S2Buf::rsrc(io.traj), raux = S2Buf::rsrc(io.aux);
+    const auto rslz = S2Buf::rsrc(TRJ == 2 ? io.traj + 4 * (int64_t)(T + 1) * N : io.traj);
+    const auto rgf = S2Buf::rsrc(io.grad_flux ? io.grad_flux : io.grad_flux4);
+    const auto rg4 = S2Buf::rsrc(io.grad_flux4 ? io.grad_flux4 : io.grad_flux);
+    const bool has_gf = io.grad_flux != nullptr, has_g4 = io.grad_flux4 != nullptr;
+    const unsigned xvo = (unsigned)(L.b * d.x_b_stride * 4), xts = (unsigned)(d.x_t_stride * 4);
+    const int cp = d.ch_prcp, ct = d.ch_tmean, ce = d.ch_pet;
+    unsigned tvo[5], avo[2];
+#pragma unroll
+    for (int k = 0; k < 5; k++) tvo[k] = (unsigned)((k * (int64_t)(T + 1) * N + L.n) * 4);
+#pragma unroll
+    for (int k = 0; k < 2; k++) avo[k] = (unsigned)((k * (int64_t)T * N + L.n) * 4);
+    const unsigned pvo4 = (unsigned)(L.n * 16), pvo1 = (unsigned)(L.n * 4), pvo2 = (unsigned)(L.n * 8);
+    const unsigned row4 = (unsigned)(N * 4);
+    const unsigned gvo = (unsigned)(L.b * 4);
+    const unsigned fT = (unsigned)((int64_t)T * B * 4), fB = (unsigned)(B * 4);
+
+    __amdgpu_buffer_rsrc_t rd[ND > 0 ? ND : 1], rgd[ND > 0 ? ND : 1];
+    unsigned dvo[ND > 0 ? ND : 1], dts[ND > 0 ? ND : 1], gdvo[ND > 0 ? ND : 1], gdts[ND > 0 ? ND : 1];
+    float dlo[ND > 0 ? ND : 1], dsc[ND > 0 ? ND : 1], dsta[ND > 0 ? ND : 1];
+    bool duse[ND > 0 ? ND : 1];
+#pragma unroll
+    for (int k = 0; k < ND; k++) {
+        const int sl = stream_slot<SC>(k);
+        const hbvx_param_src &ps = d.p[sl];
+        rd[k] = S2Buf::rsrc(ps.dyn);
+        dvo[k] = (unsigned)((L.b * ps.dyn_b_stride + L.j) * 4);
+        dts[k] = (unsigned)(ps.dyn_t_stride * 4);
+        dlo[k] = ps.lo;
+        dsc[k] = ps.hi - ps.lo;
+        dsta[k] = p[sl];
+        duse[k] = !(ps.drop && ps.drop[L.b]);
+        const bool dg = io.g[sl].dyn != nullptr;
+        rgd[k] = S2Buf::rsrc(dg ? (const void *)io.g[sl].dyn : (const void *)d.x);
+        gdvo[k] = (dg && L.active) ? (unsigned)((L.b * io.g[sl].dyn_b_stride + L.j) * 4) : OOB;
+        gdts[k] = (unsigned)(io.g[sl].dyn_t_stride * 4);
+    }
+    const auto rgx = S2Buf::rsrc(io.grad_x ? io.grad_x : const_cast<float *>(d.x));
+    const bool has_gx = io.grad_x != nullptr;
+    const unsigned gxvo = leader ? xvo : OOB;
+
+    float a[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) a[k] = io.grad_state_out ? io.grad_state_out[k * N + L.n] : 0.0f;
+
+    struct In {
+        float fx[3], st[5], ax[2], gf[NG], dv[ND > 0 ? ND : 1];
+    };
+    auto issue = [&](int t, In &I) {
+        const unsigned tc = (unsigned)max(t, 0);
+        const unsigned so = tc * xts, sr = tc * row4, sg = tc * fB;
+        if (XVEC) {
+            const s2_f3 v = S2Buf::ld3(rx, xvo, so);
+            I.fx[0] = v.x; I.fx[1] = v.y; I.fx[2] = v.z;
+        } else {
+            I.fx[0] = S2Buf::ld(rx, xvo, so + cp * 4);
+            I.fx[1] = S2Buf::ld(rx, xvo, so + ct * 4);
+            I.fx[2] = S2Buf::ld(rx, xvo, so + ce * 4);
+        }
+        if (TRJ == 2) {
+            const s2_f4 rec = S2Buf::ld4(rtraj, pvo4, sr * 4u);
+            I.st[0] = rec.x; I.st[1] = rec.y; I.st[2] = rec.z; I.st[3] = rec.w;
+            I.st[4] = S2Buf::ld(rslz, pvo1, sr);
+            const s2_f2 pw = S2Buf::ld2(raux, pvo2, sr * 2u);
+            I.ax[0] = pw.x; I.ax[1] = pw.y;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 5; k++) I.st[k] = S2Buf::ld(rtraj, tvo[k], sr);
+            I.ax[0] = S2Buf::ld(raux, avo[0], sr); I.ax[1] = S2Buf::ld(raux, avo[1], sr);
+        }
+#pragma unroll
+        for (int k = 0; k < NG; k++) {
+            float v = 0.0f;
+            if (GFULL) { if (has_gf) v = S2Buf::ld(rgf, gvo, sg + (unsigned)k * fT); }
+            if (k < 4) { if (has_g4) v += S2Buf::ld(rg4, gvo, sg + (unsigned)k * fT); }
+            I.gf[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < ND; k++) I.dv[k] = S2Buf::ld(rd[k], dvo[k], tc * dts[k]);
+    };
+    auto day = [&](int t, const In &I) {
+        Step<MODEL, BETAET> s;
+        if (XVEC) {
+            const s2_f3 v = {I.fx[0], I.fx[1], I.fx[2]};
+            s.P = s2_pick(v, cp); s.Tf = s2_pick(v, ct); s.PET = s2_pick(v, ce);
+        } else {
+            s.P = I.fx[0]; s.Tf = I.fx[1]; s.PET = I.fx[2];
+        }
+        s.SP = I.st[0]; s.MW = I.st[1]; s.SM = I.st[2]; s.SUZ = I.st[3]; s.SLZ = I.st[4];
+        float ud[ND > 0 ? ND : 1];
+#pragma unroll
+        for (int k = 0; k < ND; k++) {
+            ud[k] = raw ? sigmoid_dyn_(I.dv[k]) : I.dv[k];
+            p[stream_slot<SC>(k)] = duse[k] ? ud[k] * dsc[k] + dlo[k] : dsta[k];
+        }
+        s.template fwd<true>(p, nz, ac, elev, I.ax[0], I.ax[1]);
+        FluxGrad g;
+        auto GF = [&](int k) -> float { return k < NG ? I.gf[k] * invM : 0.0f; };
+        g.gQ = GF(HBVX_F_QSIM); g.gQ0 = GF(HBVX_F_Q0); g.gQ1 = GF(HBVX_F_Q1); g.gQ2 = GF(HBVX_F_Q2);
+        g.gET = GF(HBVX_F_AET); g.gSWE = GF(HBVX_F_SWE); g.grech = GF(HBVX_F_RECHARGE);
+        g.gexc = GF(HBVX_F_EXCS); g.gef = GF(HBVX_F_EVAPFACTOR); g.gtosoil = GF(HBVX_F_TOSOIL);
+        g.gPERC = GF(HBVX_F_PERC); g.gcap = (NF > HBVX_F_CAPILLARY) ? GF(HBVX_F_CAPILLARY) : 0.0f;
+        float gp[NPARAM_MAX], gx[3];
+#pragma unroll
+        for (int i = 0; i < NPARAM_MAX; i++) gp[i] = 0.0f;
+        s.bwd(p, nz, g, a, gp, gx);
+        // static slots: physical-space sums (the range factor and sigmoid' are applied once, at the
+        // end); a dynamic slot contributes to the static row only where dy_drop masked the basin
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            bool dyn_slot = false;
+            int kd = 0;
+#pragma unroll
+            for (int k = 0; k < ND; k++)
+                if (stream_slot<SC>(k) == i) { dyn_slot = true; kd = k; }
+            if (!dyn_slot) {
+                gacc[i] += gp[i];
+            } else {
+                const float gu = gp[i] * dsc[kd];
+                const float gr = raw ? gu * (ud[kd] * (1.0f - ud[kd])) : gu;
+                S2Buf::st(rgd[kd], gdvo[kd], (unsigned)t * gdts[kd], duse[kd] ? gr : 0.0f);
+                gacc[i] += duse[kd] ? 0.0f : gp[i];
+            }
+        }
+        if (has_gx) {
+            const float act = L.active ? 1.0f : 0.0f;
+            float gs[3] = {gx[0] * act, gx[1] * act, gx[2] * act};
+            ens_sum_dpp<3>(gs, lgMp);
+            const unsigned so = (unsigned)t * xts;
+            S2Buf::st(rgx, gxvo, so + cp * 4, gs[0]);
+            S2Buf::st(rgx, gxvo, so + ct * 4, gs[1]);
+            S2Buf::st(rgx, gxvo, so + ce * 4, gs[2]);
+        }
+    };
+
+    if (D == 1) {
+        // one day in flight: the landed inputs move to `cur`, the next day's loads are issued, then
+        // the day is computed
+        In nxt;
+        issue(T - 1, nxt);
+        for (int t = T - 1; t >= 0; t--) {
+            const In cur = nxt;
+            issue(t - 1, nxt);
+            day(t, cur);
+        }
+    } else {
+        In ring[D];
+#pragma unroll
+        for (int j = 0; j < D; j++) issue(T - 1 - j, ring[j]);
+        for (int t0 = T - 1; t0 >= 0; t0 -= D) {
+#pragma unroll
+            for (int j = 0; j < D; j++) {
+                const int t = t0 - j;
+                if (t >= 0) day(t, ring[j]);
+                issue(t - D, ring[j]);
+            }
+        }
+    }
+    if (L.active) {
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            if (!io.g[i].sta) continue;
+            const hbvx_param_src &s = d.p[i];
+            float gr = gacc[i] * (s.hi - s.lo);
+            if (raw) {
+                const float u = sigmoid_(s.sta[(int64_t)L.b * s.sta_b_stride + L.j]);
+                gr = gr * (u * (1.0f - u));
+            }
+            float *dst = io.g[i].sta + (int64_t)L.b * io.g[i].sta_b_stride + L.j;
+            *dst += gr;
+        }
+        if (io.grad_state_in) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) io.grad_state_in[k * N + L.n] = a[k];
+        }
+    }
+}
+
+} // namespace hbvx

@@ -649,6 +649,12 @@ extern "C" int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *s
     if (!out || !out->state_out) return fail(HBVX_E_NULL, "state_out is NULL");
     const int want_nf = (d->model == HBVX_MODEL_HBV10) ? 11 : 12;
     if (out->flux && out->n_flux != want_nf) return fail(HBVX_E_SHAPE, "n_flux does not match model");
+    if (out->traj && out->traj_layout != HBVX_TRAJ_ROWS) {
+        // packed trajectory: the streaming family only (hbvx_preferred_traj_layout said so)
+        if (out->traj_layout != HBVX_TRAJ_PACKED) return fail(HBVX_E_SHAPE, "unknown traj_layout");
+        if (try_fwd_stream(d, out, stream, &rc)) return rc;
+        return fail(HBVX_E_UNSUPPORTED, "packed trajectory: no forward kernel for this call");
+    }
     // kernel families in order of preference ("Which kernel runs when")
     if (try_fwd_pipe(d, out, stream, &rc)) return rc;
     if (try_fwd_stream(d, out, stream, &rc)) return rc;
@@ -675,6 +681,11 @@ extern "C" int hbvx_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *st
     const int want_nf = (d->model == HBVX_MODEL_HBV10) ? 11 : 12;
     if (io->n_flux != want_nf) return fail(HBVX_E_SHAPE, "n_flux does not match model");
     if (d->T == 0) return HBVX_OK;
+    if (io->traj_layout != HBVX_TRAJ_ROWS) {
+        if (io->traj_layout != HBVX_TRAJ_PACKED) return fail(HBVX_E_SHAPE, "unknown traj_layout");
+        if (try_bwd_stream(d, io, stream, &rc)) return rc;
+        return fail(HBVX_E_UNSUPPORTED, "packed trajectory: no adjoint kernel for this call");
+    }
     if (try_bwd_stream(d, io, stream, &rc)) return rc;
     if (try_bwd_chunked(d, io, stream, &rc)) return rc;
     if (try_bwd_tiled(d, io, stream, &rc)) return rc;
@@ -949,44 +960,25 @@ extern "C" int hbvx_zero(void *ptr, uint64_t bytes, void *stream)
     return e == hipSuccess ? 0 : hip_fail(e, "hbvx_zero");
 }
 
-// Zero fill that leaves out what the adjoint overwrites (include/hbvx.h: hbvx_zero_except).  One thread
-// per 16 bytes of a slab of `srows` rows (slab elements < 2^31: 32-bit index arithmetic); a vector
-// that lies completely inside kept columns on kept rows is skipped, one that lies completely outside
-// is one non-temporal 16-byte store, a mixed one falls back to scalar stores.
-__global__ void __launch_bounds__(256) k_zero_except(float *__restrict__ p, int64_t rows, unsigned width,
-                                                      unsigned srows, int64_t r0, int64_t r1, unsigned group_w,
-                                                      unsigned keep)
+// Zero fill that leaves out what the adjoint overwrites (include/hbvx.h: hbvx_zero_except).
+// Rows outside [r0, r1) are contiguous memory: plain hbvx_zero.  Inside, only the gaps between
+// the kept column groups are written: 16 lanes per row walk the (few, short) gap ranges.  When less
+// than half of a row is kept the dense fill is cheaper than the gap walk and is used instead (the
+// adjoint's stores then land on zeros).
+struct ZeroGaps {
+    int n;
+    int start[34], len[34];
+};
+
+__global__ void __launch_bounds__(256) k_zero_gaps(float *__restrict__ p, int64_t r0, int64_t r1, int width,
+                                                    const ZeroGaps G)
 {
-    const int64_t row_base = (int64_t)blockIdx.y * srows;
-    const int64_t left = rows - row_base;
-    const unsigned nrow = left < (int64_t)srows ? (unsigned)left : srows;
-    const unsigned e0 = (blockIdx.x * 256u + threadIdx.x) * 4u;
-    const unsigned nel = nrow * width;
-    if (e0 >= nel) return;
-    float *q = p + row_base * width;
-    unsigned row = e0 / width, col = e0 - row * width;
-    bool kept[4];
-    bool any = false, all = true;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int64_t r = row_base + row;
-        const unsigned g = col / group_w;
-        kept[k] = (e0 + k < nel) && r >= r0 && r < r1 && g < 32u && ((keep >> g) & 1u);
-        const bool live = e0 + k < nel;
-        any = any || kept[k];
-        all = all && (kept[k] || !live);
-        col++;
-        if (col == width) { col = 0; row++; }
-    }
-    if (all) return;
-    if (!any && e0 + 3 < nel) {
-        const zero_f4 z = {0.f, 0.f, 0.f, 0.f};
-        __builtin_nontemporal_store(z, reinterpret_cast<zero_f4 *>(q + e0));
-        return;
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-        if (e0 + k < nel && !kept[k]) q[e0 + k] = 0.0f;
+    const int64_t row = r0 + (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (row >= r1) return;
+    float *q = p + row * width;
+    const int lane = threadIdx.x & 15;
+    for (int g = 0; g < G.n; g++)
+        for (int c = lane; c < G.len[g]; c += 16) q[G.start[g] + c] = 0.0f;
 }
 
 extern "C" int hbvx_zero_except(float *ptr, int64_t rows, int32_t width, int64_t r0, int64_t r1, int32_t group_w,
@@ -995,19 +987,32 @@ extern "C" int hbvx_zero_except(float *ptr, int64_t rows, int32_t width, int64_t
     if (rows < 0 || width <= 0 || group_w <= 0) return fail(HBVX_E_SHAPE, "hbvx_zero_except: bad shape");
     if (!ptr && rows) return fail(HBVX_E_NULL, "hbvx_zero_except: buffer is NULL");
     if (rows == 0) return 0;
-    if (keep_groups == 0 || r1 <= r0 || ((uintptr_t)ptr & 15))
+    r0 = r0 < 0 ? 0 : r0;
+    r1 = r1 > rows ? rows : r1;
+    // gap ranges = complement of the kept groups inside [0, width)
+    ZeroGaps G;
+    G.n = 0;
+    int kept_cols = 0, c = 0;
+    while (c < width) {
+        const int g = c / group_w;
+        const bool kept = g < 32 && ((keep_groups >> g) & 1u);
+        int e = (g + 1) * group_w;
+        e = e > width ? width : e;
+        if (kept) kept_cols += e - c;
+        else if (G.n > 0 && G.start[G.n - 1] + G.len[G.n - 1] == c) G.len[G.n - 1] += e - c;
+        else if (G.n < 34) { G.start[G.n] = c; G.len[G.n] = e - c; G.n++; }
+        c = e;
+    }
+    if (r1 <= r0 || 2 * kept_cols < width)
         return hbvx_zero(ptr, (uint64_t)rows * (uint64_t)width * sizeof(float), stream);
-    // slabs of rows: a multiple of 4 rows (16-byte vectors stay aligned), fewer than 2^30 elements each
-    int64_t srows = ((int64_t)1 << 30) / width;
-    srows = srows >= 4 ? (srows & ~(int64_t)3) : 4;
-    if ((int64_t)width * 4 >= ((int64_t)1 << 31)) return fail(HBVX_E_SHAPE, "hbvx_zero_except: width too large");
-    if (srows > rows) srows = (rows + 3) & ~(int64_t)3;
-    const int64_t nslab = (rows + srows - 1) / srows;
-    if (nslab > 65535) return hbvx_zero(ptr, (uint64_t)rows * (uint64_t)width * sizeof(float), stream);
-    const uint64_t vec = ((uint64_t)srows * (uint64_t)width + 3) / 4;
-    hipLaunchKernelGGL(k_zero_except, dim3((unsigned)((vec + 255) / 256), (unsigned)nslab), dim3(256), 0,
-                       (hipStream_t)stream, ptr, rows, (unsigned)width, (unsigned)srows, r0, r1, (unsigned)group_w,
-                       keep_groups);
+    int rc = 0;
+    if (r0 > 0) rc = hbvx_zero(ptr, (uint64_t)r0 * (uint64_t)width * sizeof(float), stream);
+    if (!rc && r1 < rows)
+        rc = hbvx_zero(ptr + r1 * width, (uint64_t)(rows - r1) * (uint64_t)width * sizeof(float), stream);
+    if (rc || G.n == 0) return rc;
+    const int64_t nblk = (r1 - r0 + 15) / 16;
+    if (nblk > 0x7fffffff) return hbvx_zero(ptr, (uint64_t)rows * (uint64_t)width * sizeof(float), stream);
+    hipLaunchKernelGGL(k_zero_gaps, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, ptr, r0, r1, (int)width, G);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "hbvx_zero_except");
 }

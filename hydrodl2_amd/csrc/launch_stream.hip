@@ -1,38 +1,142 @@
-// launch_stream.hip -- host dispatch of the streaming forward / adjoint for large grids (hbv_stream.h).
+// launch_stream.hip -- host dispatch of the streaming forward / adjoint for large grids
+// (hbv_stream2.h; hbv_stream.h for dynamic sets or forcing layouts the second generation does not
+// instantiate).
 #include "hbvx_host.h"
-#include "hbv_stream.h"
+#include "hbv_stream2.h"
 
 using namespace hbvx;
 using namespace hbvx_host;
 
+namespace {
+
+struct StreamPlan {
+    bool ok;        // the streaming family can take this problem at all
+    int lg;
+    int64_t wgs;    // wavefronts of state
+    int nd;
+    int sc;         // compile-time dynamic set of hbv_stream2.h (0 none, 1, 2) or -1: first generation only
+    bool xvec;      // three adjacent forcing channels
+    bool packed_ok; // packed trajectory offsets fit 32 bits
+    int dslot[3];
+};
+
+StreamPlan plan_stream(const hbvx_desc *d)
+{
+    StreamPlan P{};
+    P.lg = lg_members(d->M);
+    const int bpw = 64 >> P.lg;
+    P.wgs = ((int64_t)d->B + bpw - 1) / bpw;
+    const int64_t N = (int64_t)d->B * d->M, lim = (int64_t)1 << 32;
+    P.nd = count_dyn(d);
+    const int nf = (d->model == HBVX_MODEL_HBV10) ? 11 : 12;
+    P.ok = use_tiled(d) && env_int("HBVX_STREAM", 1) != 0 && P.nd <= 3 && !d->muwts && d->T > 0 &&
+           5 * (int64_t)(d->T + 1) * N * 4 < lim && (int64_t)nf * d->T * d->B * 4 < lim &&
+           ((int64_t)d->T * d->x_t_stride + (int64_t)d->B * d->x_b_stride) * 4 < lim;
+    unsigned mask = 0;
+    int k = 0;
+    for (int i = 0; i < d->n_param; i++)
+        if (d->p[i].dyn) {
+            mask |= 1u << i;
+            if (k < 3) P.dslot[k++] = i;
+            P.ok = P.ok && ((int64_t)d->T * d->p[i].dyn_t_stride + (int64_t)d->B * d->p[i].dyn_b_stride) * 4 < lim;
+        }
+    const bool be = d->n_param >= 13;
+    P.sc = mask == 0 ? 0
+         : (mask == ((1u << P_BETA) | (1u << P_BETAET)) && be &&
+            (d->model == HBVX_MODEL_HBV10 || d->model == HBVX_MODEL_HBV11P)) ? 1
+         : (mask == ((1u << P_BETA) | (1u << P_K0) | (1u << P_BETAET)) &&
+            (d->model == HBVX_MODEL_HBV20 || d->model == HBVX_MODEL_HOURLY)) ? 2 : -1;
+    const int c0 = d->ch_prcp, c1 = d->ch_tmean, c2 = d->ch_pet;
+    P.xvec = c0 >= 0 && c0 < 3 && c1 >= 0 && c1 < 3 && c2 >= 0 && c2 < 3 && c0 != c1 && c0 != c2 && c1 != c2 &&
+             d->x_b_stride >= 3;
+    if (env_int("HBVX_STREAM2", 1) == 0 || !P.xvec) P.sc = -1;
+    P.packed_ok = (int64_t)(d->T + 1) * N * 16 < lim;
+    return P;
+}
+
+int stream_min_fwd(const hbvx_desc *d)
+{
+    // the pipelined forward holds ~1000 wavefronts of HBV 1.0 state (one workgroup per CU); its
+    // two-stage variant gives way at 512
+    return d->model == HBVX_MODEL_HBV10 ? env_int("HBVX_STREAM_MIN", 1024) : env_int("HBVX_STREAM_MIN", 512);
+}
+int stream_min_bwd() { return env_int("HBVX_STREAM_MIN_BWD", 2048); }
+
+template <int MODEL, bool BE, int SC>
+void go_fwd2(int trj, const StreamArgs &sa, dim3 grid, hipStream_t st)
+{
+    if (trj == 2) hipLaunchKernelGGL((k_fwd_stream2<MODEL, BE, 2, SC, true>), grid, dim3(64), 0, st, sa);
+    else if (trj == 1) hipLaunchKernelGGL((k_fwd_stream2<MODEL, BE, 1, SC, true>), grid, dim3(64), 0, st, sa);
+    else hipLaunchKernelGGL((k_fwd_stream2<MODEL, BE, 0, SC, true>), grid, dim3(64), 0, st, sa);
+}
+
+template <int MODEL, bool BE, int SC>
+void go_bwd2(int trj, bool gfull, const StreamBwdArgs &sa, dim3 grid, hipStream_t st)
+{
+    if (trj == 2) {
+        if (gfull) hipLaunchKernelGGL((k_bwd_stream2<MODEL, BE, 2, SC, true, true>), grid, dim3(64), 0, st, sa);
+        else hipLaunchKernelGGL((k_bwd_stream2<MODEL, BE, 2, SC, false, true>), grid, dim3(64), 0, st, sa);
+    } else {
+        if (gfull) hipLaunchKernelGGL((k_bwd_stream2<MODEL, BE, 1, SC, true, true>), grid, dim3(64), 0, st, sa);
+        else hipLaunchKernelGGL((k_bwd_stream2<MODEL, BE, 1, SC, false, true>), grid, dim3(64), 0, st, sa);
+    }
+}
+
+// second-generation kernels exist for these (model, BETAET, dynamic set) combinations
+#define STREAM2_DISPATCH(GO, d, sc, ...)                                                             \
+    do {                                                                                             \
+        const int m_ = (d)->model;                                                                   \
+        const bool be_ = (d)->n_param == 13;                                                         \
+        if (m_ == HBVX_MODEL_HBV10 && !be_) GO<MODEL_HBV10, false, 0>(__VA_ARGS__);                  \
+        else if (m_ == HBVX_MODEL_HBV10 && (sc) == 0) GO<MODEL_HBV10, true, 0>(__VA_ARGS__);         \
+        else if (m_ == HBVX_MODEL_HBV10) GO<MODEL_HBV10, true, 1>(__VA_ARGS__);                      \
+        else if (m_ == HBVX_MODEL_HBV11P && (sc) == 0) GO<MODEL_HBV11P, true, 0>(__VA_ARGS__);       \
+        else if (m_ == HBVX_MODEL_HBV11P) GO<MODEL_HBV11P, true, 1>(__VA_ARGS__);                    \
+        else if (m_ == HBVX_MODEL_HBV20 && (sc) == 0) GO<MODEL_HBV20, true, 0>(__VA_ARGS__);         \
+        else if (m_ == HBVX_MODEL_HBV20) GO<MODEL_HBV20, true, 2>(__VA_ARGS__);                      \
+        else if ((sc) == 0) GO<MODEL_HOURLY, true, 0>(__VA_ARGS__);                                  \
+        else GO<MODEL_HOURLY, true, 2>(__VA_ARGS__);                                                 \
+    } while (0)
+
+} // namespace
+
+// include/hbvx.h: the trajectory layout hbvx_forward / hbvx_backward want for this problem
+extern "C" int hbvx_preferred_traj_layout(const hbvx_desc *d)
+{
+    if (!d || check_desc(d) || d->model == HBVX_MODEL_HBVADJ) return HBVX_TRAJ_ROWS;
+    const StreamPlan P = plan_stream(d);
+    const bool stream_both = P.ok && P.sc >= 0 && P.packed_ok && P.wgs >= stream_min_bwd() &&
+                             P.wgs >= stream_min_fwd(d);
+    return stream_both ? HBVX_TRAJ_PACKED : HBVX_TRAJ_ROWS;
+}
+
 bool hbvx_host::try_fwd_stream(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream, int *rc)
 {
-        // large grids: streaming one-wave kernel (hbv_stream.h)
-        const int lg = lg_members(d->M);
-        const int bpw_s = 64 >> lg;
-        const int64_t wgs = ((int64_t)d->B + bpw_s - 1) / bpw_s;
-        const int64_t N = (int64_t)d->B * d->M, lim = (int64_t)1 << 32;
-        const int nd = count_dyn(d);
-        const int nf = (d->model == HBVX_MODEL_HBV10) ? 11 : 12;
-        bool ok = use_tiled(d) && env_int("HBVX_STREAM", 1) != 0 && wgs >= env_int("HBVX_STREAM_MIN", 512) && nd <= 3 && !d->muwts &&
-                  out->flux && (out->traj != nullptr) == (out->aux != nullptr) && d->T > 0 &&
-                  5 * (int64_t)(d->T + 1) * N * 4 < lim && (int64_t)nf * d->T * d->B * 4 < lim &&
-                  ((int64_t)d->T * d->x_t_stride + (int64_t)d->B * d->x_b_stride) * 4 < lim;
-        for (int i = 0; i < d->n_param && ok; i++)
-            if (d->p[i].dyn)
-                ok = ((int64_t)d->T * d->p[i].dyn_t_stride + (int64_t)d->B * d->p[i].dyn_b_stride) * 4 < lim;
-        if (ok) {
-            StreamArgs sa;
-            sa.d = *d;
-            sa.o = *out;
-            sa.lgMp = lg;
-            sa.nd = 0;
-            sa.dslot[0] = sa.dslot[1] = sa.dslot[2] = 0;
-            for (int i = 0; i < d->n_param; i++)
-                if (d->p[i].dyn) sa.dslot[sa.nd++] = i;
-            const bool tr = out->traj != nullptr, few = nd > 0;
-            dim3 grid_s((unsigned)wgs);
-            hipStream_t st = (hipStream_t)stream;
+    const StreamPlan P = plan_stream(d);
+    const bool packed = out->traj && out->traj_layout == HBVX_TRAJ_PACKED;
+    // the second generation also takes a trajectory without the saved powers (inference that keeps the state series)
+    bool ok = P.ok && out->flux && (P.sc >= 0 ? (out->traj || !out->aux) : (out->traj != nullptr) == (out->aux != nullptr));
+    if (packed) {
+        if (!(ok && P.sc >= 0 && P.packed_ok)) {
+            *rc = fail(HBVX_E_UNSUPPORTED, "packed trajectory asked for a problem hbvx_preferred_traj_layout does not pack");
+            return true;
+        }
+    } else if (!(ok && P.wgs >= stream_min_fwd(d))) {
+        return false;
+    }
+    StreamArgs sa;
+    sa.d = *d;
+    sa.o = *out;
+    sa.lgMp = P.lg;
+    sa.nd = P.nd;
+    for (int k = 0; k < 3; k++) sa.dslot[k] = k < P.nd ? P.dslot[k] : 0;
+    const bool tr = out->traj != nullptr, few = P.nd > 0;
+    dim3 grid_s((unsigned)P.wgs);
+    hipStream_t st = (hipStream_t)stream;
+    if (P.sc >= 0) {
+        const int trj = !tr ? 0 : (packed ? 2 : 1);
+        STREAM2_DISPATCH(go_fwd2, d, P.sc, trj, sa, grid_s, st);
+    } else {
 #define STREAM_GO(MODEL, BE)                                                                          \
     do {                                                                                              \
         if (tr) { if (few) hipLaunchKernelGGL((k_fwd_stream<MODEL, BE, true, true>), grid_s, dim3(64), 0, st, sa);   \
@@ -40,51 +144,48 @@ bool hbvx_host::try_fwd_stream(const hbvx_desc *d, const hbvx_fwd_out *out, void
         else { if (few) hipLaunchKernelGGL((k_fwd_stream<MODEL, BE, false, true>), grid_s, dim3(64), 0, st, sa);    \
                else hipLaunchKernelGGL((k_fwd_stream<MODEL, BE, false, false>), grid_s, dim3(64), 0, st, sa); }     \
     } while (0)
-            if (d->model == HBVX_MODEL_HBV10 && d->n_param == 12) STREAM_GO(MODEL_HBV10, false);
-            else if (d->model == HBVX_MODEL_HBV10) STREAM_GO(MODEL_HBV10, true);
-            else if (d->model == HBVX_MODEL_HBV11P) STREAM_GO(MODEL_HBV11P, true);
-            else if (d->model == HBVX_MODEL_HOURLY) STREAM_GO(MODEL_HOURLY, true);
-            else STREAM_GO(MODEL_HBV20, true);
+        if (d->model == HBVX_MODEL_HBV10 && d->n_param == 12) STREAM_GO(MODEL_HBV10, false);
+        else if (d->model == HBVX_MODEL_HBV10) STREAM_GO(MODEL_HBV10, true);
+        else if (d->model == HBVX_MODEL_HBV11P) STREAM_GO(MODEL_HBV11P, true);
+        else if (d->model == HBVX_MODEL_HOURLY) STREAM_GO(MODEL_HOURLY, true);
+        else STREAM_GO(MODEL_HBV20, true);
 #undef STREAM_GO
-            hipError_t e = hipGetLastError();
-            *rc = e != hipSuccess ? hip_fail(e, "hbvx_forward (stream) launch") : HBVX_OK;
-            return true;
-        }
-    return false;
+    }
+    hipError_t e = hipGetLastError();
+    *rc = e != hipSuccess ? hip_fail(e, "hbvx_forward (stream) launch") : HBVX_OK;
+    return true;
 }
 
 bool hbvx_host::try_bwd_stream(const hbvx_desc *d, const hbvx_bwd_io *io, void *stream, int *rc)
 {
-        // large grids: single-pass streaming adjoint (hbv_stream.h), no workspace.  Measured cross-over
-        // against the time-parallel kernels: ~1500 wavefronts (forward stream vs tiled: ~400)
-        const int lg = lg_members(d->M);
-        const int bpw_s = 64 >> lg;
-        const int64_t wgs = ((int64_t)d->B + bpw_s - 1) / bpw_s;
-        const int64_t N = (int64_t)d->B * d->M, lim = (int64_t)1 << 32;
-        const int nd = count_dyn(d);
-        const int nf = (d->model == HBVX_MODEL_HBV10) ? 11 : 12;
-        bool ok = use_tiled(d) && env_int("HBVX_STREAM", 1) != 0 && wgs >= env_int("HBVX_STREAM_MIN_BWD", 2048) && nd <= 3 && !d->muwts &&
-                  (io->grad_flux || io->grad_flux4) && 5 * (int64_t)(d->T + 1) * N * 4 < lim &&
-                  (int64_t)nf * d->T * d->B * 4 < lim &&
-                  ((int64_t)d->T * d->x_t_stride + (int64_t)d->B * d->x_b_stride) * 4 < lim;
-        for (int i = 0; i < d->n_param && ok; i++)
-            if (d->p[i].dyn) {
-                ok = ((int64_t)d->T * d->p[i].dyn_t_stride + (int64_t)d->B * d->p[i].dyn_b_stride) * 4 < lim;
-                if (ok && io->g[i].dyn)
-                    ok = ((int64_t)d->T * io->g[i].dyn_t_stride + (int64_t)d->B * io->g[i].dyn_b_stride) * 4 < lim;
-            }
-        if (ok) {
-            StreamBwdArgs sa;
-            sa.d = *d;
-            sa.io = *io;
-            sa.lgMp = lg;
-            sa.nd = 0;
-            sa.dslot[0] = sa.dslot[1] = sa.dslot[2] = 0;
-            for (int i = 0; i < d->n_param; i++)
-                if (d->p[i].dyn) sa.dslot[sa.nd++] = i;
-            const bool few = nd > 0, gfull = io->grad_flux != nullptr;
-            dim3 grid_s((unsigned)wgs);
-            hipStream_t st = (hipStream_t)stream;
+    // single-pass streaming adjoint, no workspace
+    StreamPlan P = plan_stream(d);
+    const int64_t lim = (int64_t)1 << 32;
+    const bool packed = io->traj_layout == HBVX_TRAJ_PACKED;
+    bool ok = P.ok && (io->grad_flux || io->grad_flux4);
+    for (int i = 0; i < d->n_param && ok; i++)
+        if (d->p[i].dyn && io->g[i].dyn)
+            ok = ((int64_t)d->T * io->g[i].dyn_t_stride + (int64_t)d->B * io->g[i].dyn_b_stride) * 4 < lim;
+    if (packed) {
+        if (!(ok && P.sc >= 0 && P.packed_ok)) {
+            *rc = fail(HBVX_E_UNSUPPORTED, "packed trajectory: no adjoint kernel for this call");
+            return true;
+        }
+    } else if (!(ok && P.wgs >= stream_min_bwd())) {
+        return false;
+    }
+    StreamBwdArgs sa;
+    sa.d = *d;
+    sa.io = *io;
+    sa.lgMp = P.lg;
+    sa.nd = P.nd;
+    for (int k = 0; k < 3; k++) sa.dslot[k] = k < P.nd ? P.dslot[k] : 0;
+    const bool few = P.nd > 0, gfull = io->grad_flux != nullptr;
+    dim3 grid_s((unsigned)P.wgs);
+    hipStream_t st = (hipStream_t)stream;
+    if (P.sc >= 0) {
+        STREAM2_DISPATCH(go_bwd2, d, P.sc, packed ? 2 : 1, gfull, sa, grid_s, st);
+    } else {
 #define STREAM_GO(MODEL, BE)                                                                              \
     do {                                                                                                  \
         if (few) { if (gfull) hipLaunchKernelGGL((k_bwd_stream<MODEL, BE, true, true>), grid_s, dim3(64), 0, st, sa);    \
@@ -92,15 +193,14 @@ bool hbvx_host::try_bwd_stream(const hbvx_desc *d, const hbvx_bwd_io *io, void *
         else { if (gfull) hipLaunchKernelGGL((k_bwd_stream<MODEL, BE, false, true>), grid_s, dim3(64), 0, st, sa);       \
                else hipLaunchKernelGGL((k_bwd_stream<MODEL, BE, false, false>), grid_s, dim3(64), 0, st, sa); }         \
     } while (0)
-            if (d->model == HBVX_MODEL_HBV10 && d->n_param == 12) STREAM_GO(MODEL_HBV10, false);
-            else if (d->model == HBVX_MODEL_HBV10) STREAM_GO(MODEL_HBV10, true);
-            else if (d->model == HBVX_MODEL_HBV11P) STREAM_GO(MODEL_HBV11P, true);
-            else if (d->model == HBVX_MODEL_HOURLY) STREAM_GO(MODEL_HOURLY, true);
-            else STREAM_GO(MODEL_HBV20, true);
+        if (d->model == HBVX_MODEL_HBV10 && d->n_param == 12) STREAM_GO(MODEL_HBV10, false);
+        else if (d->model == HBVX_MODEL_HBV10) STREAM_GO(MODEL_HBV10, true);
+        else if (d->model == HBVX_MODEL_HBV11P) STREAM_GO(MODEL_HBV11P, true);
+        else if (d->model == HBVX_MODEL_HOURLY) STREAM_GO(MODEL_HOURLY, true);
+        else STREAM_GO(MODEL_HBV20, true);
 #undef STREAM_GO
-            hipError_t e = hipGetLastError();
-            *rc = e != hipSuccess ? hip_fail(e, "hbvx_backward (stream) launch") : HBVX_OK;
-            return true;
-        }
-    return false;
+    }
+    hipError_t e = hipGetLastError();
+    *rc = e != hipSuccess ? hip_fail(e, "hbvx_backward (stream) launch") : HBVX_OK;
+    return true;
 }

@@ -12,7 +12,7 @@ import torch
 
 from hydrodl2_amd import _abi
 from hydrodl2_amd.core.hbv_module import HbvModule
-from hydrodl2_amd.ops import HbvPath, ParamSource, RouteSource, StepConfig
+from hydrodl2_amd.ops import hbv_path, state_series, ParamSource, RouteSource, StepConfig
 
 
 class Hbv_2(HbvModule):
@@ -109,12 +109,11 @@ class Hbv_2(HbvModule):
                                     self.routing_parameter_bounds['route_a'],
                                     self.routing_parameter_bounds['route_b'])
         muwts = self._expand_muwts(self.muwts, T, T, ngrid)
-        flux, routed, state_out, traj = HbvPath.apply(cfg, x, state_in, muwts, ac, elev,
-                                                      p_dyn, p_sta)
+        flux, routed, state_out, traj = hbv_path(cfg, x, state_in, muwts, ac, elev, p_dyn, p_sta)
 
-        # hbv_2.py:385-388,628: the state cache is the full series [T,B,nmul] x 5
-        series = traj.detach()[:, 1:, :].reshape(5, T, ngrid, M)
-        self._state_cache = tuple(series[k] for k in range(5))
+        # hbv_2.py:385-388,628: the state cache is the full series [T,B,nmul] x 5 (views of the
+        # saved trajectory: storages after day t = storages entering day t + 1)
+        self._state_cache = tuple(s[1:] for s in state_series(traj.detach(), cfg.traj_layout, T, ngrid, M))
         if self.cache_states:
             self.states = tuple(s[-1].detach() for s in self._state_cache)
 

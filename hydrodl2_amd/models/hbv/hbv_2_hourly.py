@@ -18,7 +18,7 @@ import torch
 
 from hydrodl2_amd import _abi
 from hydrodl2_amd.core.hbv_module import HbvModule
-from hydrodl2_amd.ops import GageRoute, GageTopology, HbvPath, ParamSource, StepConfig
+from hydrodl2_amd.ops import GageRoute, GageTopology, ParamSource, StepConfig, hbv_path, state_series
 
 
 class Hbv_2_hourly(HbvModule):
@@ -127,9 +127,8 @@ class Hbv_2_hourly(HbvModule):
                          nearzero=float(self.nearzero), params=srcs,
                          want_flux=not self.initialize, want_traj=True)
         muwts = self._expand_muwts(self.muwts, T, T, ngrid)
-        flux, _, _, traj = HbvPath.apply(cfg, x, state_in, muwts, ac, elev, *ptensors)
-        series = traj.detach()[:, 1:, :].reshape(5, T, ngrid, M)
-        series = tuple(series[k] for k in range(5))                       # :725
+        flux, _, _, traj = hbv_path(cfg, x, state_in, muwts, ac, elev, *ptensors)
+        series = tuple(s[1:] for s in state_series(traj.detach(), cfg.traj_layout, T, ngrid, M))   # :725
         if self.initialize:
             return {}, series
 

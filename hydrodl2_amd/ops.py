@@ -71,6 +71,7 @@ class StepConfig:
     adj_gtol: float = 1e-3     # implicit scheme only (hbv_adj.py:519)
     adj_max_iter: int = 3      # implicit scheme only (hbv_adj.py:518)
     mu_t0: Optional[int] = None  # first row of muwts used by this call (None: same as t0)
+    traj_layout: int = 0       # set by HbvPath.forward: enum hbvx_traj_layout of the saved trajectory
 
 
 # bench.py sets this to a list to collect (abi_call, start_event, end_event) per launch,
@@ -210,11 +211,16 @@ def _route_desc(cfg: StepConfig, ptensors, S: int = 4) -> _abi.RouteDesc:
 
 
 class HbvPath(torch.autograd.Function):
-    """flux, routed, state_out, traj = HbvPath.apply(cfg, x, state_in, muwts, ac, elev, *ptensors)
+    """routed, state_out, traj, *flux_rows = HbvPath.apply(cfg, x, state_in, muwts, ac, elev, *ptensors)
+    (use `hbv_path`, which regroups the outputs).
 
-    flux   [n_flux, T, B]  ensemble means (enum hbvx_flux order)
-    routed [4, T, B]       UH-routed Qsim, Q0, Q1, Q2 (None when cfg.route is None)
-    state_out [5, B, M]; traj [5, T+1, B*M] or None.
+    flux_rows  n_flux tensors [T, B]: the ensemble-mean series (enum hbvx_flux order), views of one
+               [n_flux, T, B] buffer.  Separate autograd outputs, so that the adjoint learns WHICH
+               series carry gradient (a loss on streamflow touches 1-4 of 12) instead of receiving a
+               dense, mostly zero [n_flux, T, B] gradient.
+    routed     [4, T, B] UH-routed Qsim, Q0, Q1, Q2 (None when cfg.route is None)
+    state_out  [5, B, M]
+    traj       saved trajectory or None; layout `cfg.traj_layout` (see `state_series`).
     """
 
     @staticmethod
@@ -237,16 +243,18 @@ class HbvPath(torch.autograd.Function):
         keep = needs_grad or cfg.want_traj
         stream = _stream_of(lib, x)
 
+        desc = _fill_desc(cfg, x, state_in, muwts, ac, elev, ptensors)
         out = _abi.FwdOut()
         flux = _out((cfg.n_flux, T, B), dev) \
             if cfg.want_flux else None
         state_out = _out((5, B, M), dev)
+        # same two buffers whatever the layout the library asks for (include/hbvx.h, hbvx_traj_layout)
         traj = _out((5, T + 1, B * M), dev) if keep else None
         aux = _out((2, T, B * M), dev) if needs_grad else None
+        cfg.traj_layout = lib.preferred_traj_layout(desc) if (keep and cfg.want_flux) else _abi.TRAJ_ROWS
         out.flux, out.state_out = _ptr(flux), _ptr(state_out)
         out.traj, out.aux = _ptr(traj), _ptr(aux)
-        out.n_flux = cfg.n_flux
-        desc = _fill_desc(cfg, x, state_in, muwts, ac, elev, ptensors)
+        out.n_flux, out.traj_layout = cfg.n_flux, cfg.traj_layout
         _call(lib, 'hbvx_forward', lib.forward, desc, out, stream)
 
         routed = uh = None
@@ -257,6 +265,7 @@ class HbvPath(torch.autograd.Function):
             _call(lib, 'hbvx_route_forward', lib.route_forward, r, _ptr(flux), _ptr(uh), _ptr(routed), stream)
 
         ctx.cfg = cfg
+        ctx.traj_layout = cfg.traj_layout
         ctx.set_materialize_grads(False)
         if needs_grad:
             ctx.save_for_backward(x, state_in, muwts, ac, elev, traj, aux, flux, uh, *ptensors)
@@ -264,10 +273,11 @@ class HbvPath(torch.autograd.Function):
         if traj is not None:
             nondiff.append(traj)
         ctx.mark_non_differentiable(*nondiff)
-        return flux, routed, state_out, traj
+        rows = tuple(flux.unbind(0)) if flux is not None else ()
+        return (routed, state_out, traj) + rows
 
     @staticmethod
-    def backward(ctx, g_flux, g_routed, _g_state, _g_traj):
+    def backward(ctx, g_routed, _g_state, _g_traj, *g_rows):
         lib = get_library()
         cfg: StepConfig = ctx.cfg
         saved = ctx.saved_tensors
@@ -288,16 +298,29 @@ class HbvPath(torch.autograd.Function):
             gt = gp[rs.tensor_idx]
             ws_bytes = lib.route_workspace_bytes(r)
             ws = torch.empty((max(ws_bytes, 4) + 3) // 4, dtype=torch.float32, device=dev)
+            g_routed = g_routed.contiguous()
             _call(lib, 'hbvx_route_backward', lib.route_backward, r, _ptr(flux), _ptr(uh),
-                  _ptr(g_routed.contiguous()), _ptr(gq), _ptr(gt, rs.a_off), _ptr(gt, rs.b_off),
+                  _ptr(g_routed), _ptr(gq), _ptr(gt, rs.a_off), _ptr(gt, rs.b_off),
                   _ptr(ws), ws_bytes, stream)
-        if g_flux is not None:
-            g_flux = g_flux.contiguous()
+        # Which series carry gradient?  Only the four runoff series (the usual losses: streamflow,
+        # with or without routing) -> a [4,T,B] buffer and the adjoint's 4-series kernels; anything
+        # else -> the dense [n_flux,T,B] form.
+        have = [k for k, g in enumerate(g_rows) if g is not None]
+        g_flux = None
+        if have and max(have) < 4:
+            if gq is None:
+                gq = torch.zeros((4, T, B), dtype=torch.float32, device=dev)
+            for k in have:
+                gq[k] += g_rows[k]
+        elif have:
+            g_flux = torch.zeros((cfg.n_flux, T, B), dtype=torch.float32, device=dev)
+            for k in have:
+                g_flux[k] = g_rows[k]
 
         io = _abi.BwdIO()
         io.traj, io.aux = _ptr(traj), _ptr(aux)
         io.grad_flux, io.grad_flux4 = _ptr(g_flux), _ptr(gq)
-        io.n_flux = cfg.n_flux
+        io.n_flux, io.traj_layout = cfg.n_flux, ctx.traj_layout
         gx = gmu = None
         if ctx.needs_input_grad[1]:
             gx = _zeros_like(lib, x)
@@ -317,13 +340,40 @@ class HbvPath(torch.autograd.Function):
                 g.dyn = _ptr(gp[ps.dyn_tensor_idx], ps.dyn_off)
                 g.dyn_t_stride, g.dyn_b_stride = ps.dyn_ts, ps.dyn_bs
         desc = _fill_desc(cfg, x, state_in, muwts, ac, elev, ptensors)
-        ws_bytes = lib.backward_workspace_bytes(desc)
+        if g_flux is None and gq is None:
+            # nothing flows back through the series (a loss on nothing): gradients are zero
+            for ps in cfg.params:
+                if ps.dyn_off >= 0 and gp[ps.dyn_tensor_idx] is not None:
+                    gp[ps.dyn_tensor_idx].zero_()
+            return (None, gx, None, gmu, None, None, *gp)
+        ws_bytes = lib.backward_workspace_bytes(desc) if ctx.traj_layout == _abi.TRAJ_ROWS else 0
         if ws_bytes:
             ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
             io.workspace, io.workspace_bytes = _ptr(ws), ws_bytes
         _call(lib, 'hbvx_backward', lib.backward, desc, io, stream)
 
         return (None, gx, None, gmu, None, None, *gp)
+
+
+def hbv_path(cfg: StepConfig, x, state_in, muwts, ac, elev, *ptensors):
+    """flux, routed, state_out, traj = hbv_path(...): `flux` is the tuple of n_flux series [T,B]
+    (index it with the hbvx_flux enum) or None when cfg.want_flux is False."""
+    outs = HbvPath.apply(cfg, x, state_in, muwts, ac, elev, *ptensors)
+    routed, state_out, traj = outs[:3]
+    return (outs[3:] or None), routed, state_out, traj
+
+
+def state_series(traj: torch.Tensor, layout: int, T: int, B: int, M: int):
+    """The five storages entering day t, t = 0..T (t = T: after the last day), as [T+1, B, M] views of
+    the saved trajectory, whatever its layout (include/hbvx.h, hbvx_traj_layout).  Zero-copy."""
+    flat = traj.reshape(-1)
+    N = B * M
+    if layout == _abi.TRAJ_PACKED:
+        rec = flat[: 4 * (T + 1) * N].view(T + 1, B, M, 4)
+        slz = flat[4 * (T + 1) * N: 5 * (T + 1) * N].view(T + 1, B, M)
+        return tuple(rec[..., k] for k in range(4)) + (slz,)
+    rows = flat.view(5, T + 1, B, M)
+    return tuple(rows[k] for k in range(5))
 
 
 class HbvAdjPath(torch.autograd.Function):

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define HBVX_ABI_VERSION 6
+#define HBVX_ABI_VERSION 7
 #define HBVX_MAX_PARAM 20
 #define HBVX_NSTATE 5   /* SNOWPACK, MELTWATER, SM, SUZ, SLZ  (hbv.py:61-67) */
 #define HBVX_MAX_FLUX 12
@@ -134,6 +134,14 @@ typedef struct hbvx_desc {
     int32_t adj_max_iter;  /* updates allowed = max_iter + 1; reference max_iter = 3 */
 } hbvx_desc;
 
+/* Layout of the saved trajectory (hbvx_fwd_out.traj / .aux, same two buffers and sizes either way):
+ *   ROWS    traj [5,T+1,N] (storage k entering day t at traj[(k*(T+1)+t)*N + n]), aux [2,T,N]
+ *   PACKED  traj = records [T+1,N,4] (SNOWPACK, MELTWATER, SM, SUZ) followed by SLZ rows [T+1,N];
+ *           aux = records [T,N,2].  Three wide stores / loads per lane-day instead of seven: what the
+ *           streaming kernels for large grids use (a vector-memory instruction costs the same issue
+ *           time whatever its width).  N = B*M, lane n = b*M + j. */
+enum hbvx_traj_layout { HBVX_TRAJ_ROWS = 0, HBVX_TRAJ_PACKED = 1 };
+
 typedef struct hbvx_fwd_out {
     float *flux;      /* [n_flux,T,B] or NULL (state warm-up: hbv.py:557-559) */
     float *state_out; /* [5,B,M] storages after the last step, required */
@@ -143,7 +151,8 @@ typedef struct hbvx_fwd_out {
     float *aux;       /* optional [2,T,B*M]: (SM/FC)^BETA and the evap factor before
                          their clamps; saved for hbvx_backward */
     int32_t n_flux;   /* 11 (HBV 1.0) or 12 */
-    int32_t reserved0;
+    int32_t traj_layout; /* enum hbvx_traj_layout: how traj / aux are laid out.  Must be what
+                            hbvx_preferred_traj_layout() returns for this desc, or HBVX_TRAJ_ROWS */
 } hbvx_fwd_out;
 
 typedef struct hbvx_bwd_io {
@@ -157,7 +166,7 @@ typedef struct hbvx_bwd_io {
     float *grad_muwts;       /* optional [T,B,M] contiguous (overwritten) */
     float *grad_state_in;    /* optional [5,B,M] (overwritten) */
     int32_t n_flux;
-    int32_t reserved0;
+    int32_t traj_layout;     /* the layout the forward call wrote traj / aux in */
     hbvx_param_grad g[HBVX_MAX_PARAM];
     void *workspace;          /* optional caller-owned scratch of hbvx_backward_workspace_bytes();
                                  enables the time-parallel (chunked) adjoint */
@@ -181,6 +190,10 @@ const char *hbvx_last_error(void);
 const char *hbvx_backend(void);         /* "hip:gfx950" or "cpu-oracle" */
 uint64_t hbvx_sizeof(int which);        /* 0 desc, 1 fwd_out, 2 bwd_io, 3 route_desc,
                                            4 param_src, 5 param_grad, 6 gage_desc: layout check */
+
+/* The trajectory layout this library wants for the problem (grid size, dynamic set): pass the
+ * value in hbvx_fwd_out.traj_layout and hbvx_bwd_io.traj_layout.  HBVX_TRAJ_ROWS is always accepted. */
+int hbvx_preferred_traj_layout(const hbvx_desc *d);
 
 int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream);
 int hbvx_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *stream);

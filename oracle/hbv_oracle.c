@@ -40,6 +40,8 @@ static int fail(int code, const char *msg)
 }
 
 int hbvx_version(void) { return HBVX_ABI_VERSION; }
+/* the oracle keeps the plain row layout of the trajectory */
+int hbvx_preferred_traj_layout(const hbvx_desc *d) { (void)d; return HBVX_TRAJ_ROWS; }
 const char *hbvx_last_error(void) { return g_err; }
 const char *hbvx_backend(void) { return "cpu-oracle"; }
 
@@ -753,6 +755,8 @@ int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream)
     int rc = check_desc(d);
     if (rc) return rc;
     if (!out || !out->state_out) return fail(HBVX_E_NULL, "state_out is NULL");
+    if (out->traj && out->traj_layout != HBVX_TRAJ_ROWS)
+        return fail(HBVX_E_UNSUPPORTED, "the oracle keeps the trajectory in rows (HBVX_TRAJ_ROWS)");
     const int T = d->T, B = d->B, M = d->M;
     const int64_t N = (int64_t)B * M;
     const int nf = out->n_flux;
@@ -840,6 +844,8 @@ int hbvx_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *stream)
     int rc = check_desc(d);
     if (rc) return rc;
     if (!io || !io->traj) return fail(HBVX_E_NULL, "traj is NULL");
+    if (io->traj_layout != HBVX_TRAJ_ROWS)
+        return fail(HBVX_E_UNSUPPORTED, "the oracle keeps the trajectory in rows (HBVX_TRAJ_ROWS)");
     const int T = d->T, B = d->B, M = d->M;
     const int64_t N = (int64_t)B * M;
     const int nf = io->n_flux;

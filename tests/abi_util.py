@@ -7,7 +7,7 @@ import torch
 
 from hydrodl2_amd import _abi, _lib
 from tests import seam
-from hydrodl2_amd.ops import HbvPath, ParamSource, RouteSource, StepConfig
+from hydrodl2_amd.ops import ParamSource, RouteSource, StepConfig, hbv_path, state_series
 
 from . import synth
 from .golden_cases import PHY_NAMES
@@ -84,12 +84,14 @@ def run_problem(prob, lib_path, device="cpu", x_grad=False, backward=True, t0=0)
         if prob["routing"]:
             off = (T - 1) * B * ny + n * M
             cfg.route = RouteSource(0, off, off + 1, ny, [0, 2.9], [0, 6.5])
-        flux, routed, state_out, traj = HbvPath.apply(cfg, x, None, mu, ac, elev, p)
+        rows, routed, state_out, traj = hbv_path(cfg, x, None, mu, ac, elev, p)
+        flux = torch.stack(rows)
         res = {"flux": flux.detach().cpu().numpy(), "state_out": state_out.cpu().numpy()}
         if routed is not None:
             res["routed"] = routed.detach().cpu().numpy()
-        if traj is not None:
-            res["traj"] = traj.cpu().numpy()
+        if traj is not None:    # always compared in the row layout [5, T+1, N]
+            res["traj"] = torch.stack([v.reshape(Tc + 1, B * M) for v in
+                                       state_series(traj, cfg.traj_layout, Tc, B, M)]).cpu().numpy()
         if backward:
             gf = torch.from_numpy(prob["gflux"][:, t0:]).to(dev)
             loss = (flux * gf).sum()
