@@ -35,6 +35,7 @@ struct StreamArgs {
     int lgMp;
     int nd;
     int dslot[3];
+    int per_xcd;   // hbv_stream2.h: basin groups per XCD (grid = 8 * per_xcd)
 };
 
 template <int CTRL>
@@ -248,6 +249,7 @@ struct StreamBwdArgs {
     int lgMp;
     int nd;
     int dslot[3];
+    int per_xcd;
 };
 
 template <int MODEL, bool BETAET, bool FEW, bool GFULL>

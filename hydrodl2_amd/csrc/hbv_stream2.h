@@ -41,7 +41,15 @@ __host__ __device__ constexpr int stream_slot(int k)
 }
 
 #ifndef STREAM2_D
-#define STREAM2_D 4      // days of forward inputs in flight (register ring)
+#define STREAM2_D 2      // days of forward inputs in flight (register ring; 2 measured best: 1.77 vs 1.93 ms at config 5)
+#endif
+#ifndef FWPE
+// four waves per SIMD (<= 128 VGPRs; the {BETA, K0, BETAET} instance needs 103 without spilling): a
+// 12 500-basin share is 3 125 waves, more than the 3 072 slots of three per SIMD
+#define FWPE __attribute__((amdgpu_waves_per_eu(4)))
+#endif
+#ifndef STREAM2_EXP
+#define STREAM2_EXP 0    // dev experiments: 1 no flux store, 4 no trajectory stores
 #endif
 
 typedef float s2_f2 __attribute__((ext_vector_type(2)));
@@ -84,11 +92,68 @@ struct S2Buf {
     {
         __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(u3, v), r, vo, so, 0);
     }
-    static __device__ __forceinline__ void st4(__amdgpu_buffer_rsrc_t r, unsigned vo, unsigned so, s2_f4 v)
+    // 16-byte store.  NOT the builtin: on gfx950 a buffer_store_dwordx4 whose soffset is an SGPR reads
+    // its data registers late, and a VALU write to them in the very next issue slot corrupts the last
+    // four lanes of every row of 16 (observed: `v_pk_mov_b32` right behind the store replaced the SUZ
+    // word of the packed record; tests/test_gpu_parity.py::test_stream_forward_equals_tiled_forward).
+    // LLVM's hazard recognizer covers >8-byte stores only when soffset is NOT a register, so the wait
+    // state is issued here, inside the same asm block as the store (nothing can be scheduled between).
+    // The compiler does not count this store in vmcnt: its waits only become more conservative
+    // (in-order retirement: an uncounted younger operation never lets an older load be read early).
+    static __device__ __forceinline__ u4 words(const void *base)
     {
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), r, vo, so, 0);
+        const unsigned long long b = (unsigned long long)base;
+        const u4 w = {(unsigned)b, (unsigned)(b >> 32) & 0xFFFFu, 0xFFFFFFFFu, 0x00020000u};
+        return w;
+    }
+    static __device__ __forceinline__ void st4(const u4 rsrc_words, unsigned vo, unsigned so, s2_f4 v)
+    {
+        asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1"
+                     :
+                     : "v"(v), "v"(vo), "s"(rsrc_words), "s"(so)
+                     : "memory");
     }
 };
+
+// XCD-aware wave -> basin-group map.  Workgroups are dealt round-robin over the 8 XCDs (block i runs
+// on XCD i % 8: observed, not guaranteed -- it only matters for speed), each with its own L2.  A wave
+// touches 16-byte pieces of the flux / forcing / gradient rows (4 basins x 4 bytes); with the plain
+// map the 8 pieces of one 128-byte line are written by 8 different L2s and reach HBM as 8 masked
+// partial writes.  Here XCD c owns the contiguous run of groups [c * per, (c + 1) * per), so the
+// pieces of a line meet in one L2 and leave it as whole lines.  The grid is 8 * per blocks; groups
+// past the end return at once.
+struct S2Lane : LaneT {
+    bool valid;    // the wave has at least one basin
+    bool bvalid;   // this lane's basin exists (its member may be padding)
+};
+__device__ __forceinline__ S2Lane s2_lane(const hbvx_desc &d, int lgMp, int per_xcd)
+{
+    S2Lane L;
+    const int i = blockIdx.x;
+    const int group = (i & 7) * per_xcd + (i >> 3);
+    L.lane = threadIdx.x & 63;
+    const int Mp = 1 << lgMp;
+    L.jm = L.lane & (Mp - 1);
+    L.bl = L.lane >> lgMp;
+    const int b = group * (64 >> lgMp) + L.bl;
+    L.valid = group * (64 >> lgMp) < d.B;
+    L.bvalid = b < d.B;
+    L.active = (b < d.B) && (L.jm < d.M);
+    L.b = b < d.B ? b : d.B - 1;
+    L.j = L.jm < d.M ? L.jm : d.M - 1;
+    L.n = (int64_t)L.b * d.M + L.j;
+    return L;
+}
+
+// fire-and-forget fp32 add into an LDS word this lane owns (ds_add_f32)
+__device__ __forceinline__ void s2_lds_add(float *w, float v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_ds_faddf((__attribute__((address_space(3))) float *)w, v, 0, 0, false);
+#else
+    *w += v;
+#endif
+}
 
 // one of three forcing values by a wave-uniform channel number
 __device__ __forceinline__ float s2_pick(const s2_f3 v, int ch)
@@ -101,7 +166,7 @@ __device__ __forceinline__ float s2_pick(const s2_f3 v, int ch)
 // XVEC: forcing channels are {0,1,2} and a basin's three values are adjacent (one 12-byte load).
 // ---------------------------------------------------------------------------------------------
 template <int MODEL, bool BETAET, int TRJ, int SC, bool XVEC>
-__global__ void __launch_bounds__(64) k_fwd_stream2(const StreamArgs A)
+__global__ void __launch_bounds__(64) FWPE k_fwd_stream2(const StreamArgs A)
 {
     constexpr int NP = NParamT<MODEL, BETAET>::value;
     constexpr int NF = MODEL == MODEL_HBV10 ? 11 : 12;
@@ -110,7 +175,8 @@ __global__ void __launch_bounds__(64) k_fwd_stream2(const StreamArgs A)
     const hbvx_desc &d = A.d;
     const hbvx_fwd_out &o = A.o;
     const int lgMp = A.lgMp;
-    const LaneT L = lane_t(d, lgMp);
+    const S2Lane L = s2_lane(d, lgMp, A.per_xcd);
+    if (!L.valid) return;
     const int T = d.T, B = d.B;
     const int64_t N = (int64_t)B * d.M;
     const bool raw = d.raw_sigmoid != 0;
@@ -153,6 +219,7 @@ __global__ void __launch_bounds__(64) k_fwd_stream2(const StreamArgs A)
     // outputs
     const auto rflux = S2Buf::rsrc(o.flux);
     const auto rtraj = S2Buf::rsrc(o.traj), raux = S2Buf::rsrc(o.aux ? o.aux : o.traj);
+    const S2Buf::u4 wtraj = S2Buf::words(o.traj);
     const auto rslz = S2Buf::rsrc(TRJ == 2 ? o.traj + 4 * (int64_t)(T + 1) * N : o.traj);
     unsigned tvo[5], avo[2];
 #pragma unroll
@@ -167,7 +234,7 @@ __global__ void __launch_bounds__(64) k_fwd_stream2(const StreamArgs A)
     // flux: with >= 16 lanes per basin, member lane j owns series j (one store per day); with fewer
     // lanes the basin leader stores the NF series one by one
     const bool roles = lgMp >= 4;
-    const bool bvalid = (blockIdx.x * (64 >> lgMp) + L.bl) < B;
+    const bool bvalid = L.bvalid;
     const unsigned fvo_role = (roles && bvalid && L.jm < NF) ? (unsigned)(((int64_t)L.jm * T * B + L.b) * 4) : OOB;
     const unsigned fvo_lead = (!roles && L.active && L.jm == 0) ? (unsigned)(L.b * 4) : OOB;
 
@@ -205,17 +272,17 @@ __global__ void __launch_bounds__(64) k_fwd_stream2(const StreamArgs A)
         }
         s.SP = st[0]; s.MW = st[1]; s.SM = st[2]; s.SUZ = st[3]; s.SLZ = st[4];
         s.template fwd<false>(p, nz, ac, elev, 0.0f, 0.0f);
-        if (TRJ == 1) {
+        if (TRJ == 1 && !(STREAM2_EXP & 4)) {
             const unsigned so = (unsigned)t * row4;
 #pragma unroll
             for (int k = 0; k < 5; k++) S2Buf::st(rtraj, tvo[k], so, st[k]);
             S2Buf::st(raux, avo[0], so, s.sw0);
             S2Buf::st(raux, avo[1], so, s.ef0);
         }
-        if (TRJ == 2) {
+        if (TRJ == 2 && !(STREAM2_EXP & 4)) {
             const s2_f4 rec = {st[0], st[1], st[2], st[3]};
             const s2_f2 pw = {s.sw0, s.ef0};
-            S2Buf::st4(rtraj, pvo4, (unsigned)t * row4 * 4u, rec);
+            S2Buf::st4(wtraj, pvo4, (unsigned)t * row4 * 4u, rec);
             S2Buf::st(rslz, pvo1, (unsigned)t * row4, st[4]);
             S2Buf::st2(raux, pvo2, (unsigned)t * row4 * 2u, pw);
         }
@@ -230,7 +297,12 @@ __global__ void __launch_bounds__(64) k_fwd_stream2(const StreamArgs A)
         for (int k = 0; k < NF; k++) f[k] *= act;
         ens_sum_dpp<NF>(f, lgMp);
         const unsigned fso = (unsigned)t * fB;
-        if (roles) {
+        if (STREAM2_EXP & 1) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < NF; k++) acc += f[k];
+            if (acc == 123.456f) S2Buf::st(rflux, fvo_role, fso, acc);
+        } else if (roles) {
             float v = f[0];
 #pragma unroll
             for (int k = 1; k < NF; k++) v = (L.jm == k) ? f[k] : v;
@@ -282,9 +354,20 @@ __global__ void __launch_bounds__(64) k_fwd_stream2(const StreamArgs A)
 #ifndef STREAM2_BWD_WAVES
 #define STREAM2_BWD_WAVES 3
 #endif
+#ifndef STREAM2_LDS_ACC
+#define STREAM2_LDS_ACC 1   // static-parameter gradient sums live in LDS (ds_add_f32, one owner per word)
+#endif
+
+// waves per SIMD the adjoint is compiled for: three (<= 168 VGPRs) wherever that needs no spill; the
+// hourly step and the capillary models with all twelve gradient series live keep two
+template <int MODEL, bool GFULL>
+constexpr int s2_bwd_waves()
+{
+    return (MODEL == MODEL_HOURLY || ((MODEL == MODEL_HBV20 || MODEL == MODEL_HBV11P) && GFULL)) ? 2 : STREAM2_BWD_WAVES;
+}
 
 template <int MODEL, bool BETAET, int TRJ, int SC, bool GFULL, bool XVEC>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STREAM2_BWD_WAVES)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(s2_bwd_waves<MODEL, GFULL>())))
 k_bwd_stream2(const StreamBwdArgs A)
 {
     constexpr int NP = NParamT<MODEL, BETAET>::value;
@@ -295,7 +378,8 @@ k_bwd_stream2(const StreamBwdArgs A)
     const hbvx_desc &d = A.d;
     const hbvx_bwd_io &io = A.io;
     const int lgMp = A.lgMp;
-    const LaneT L = lane_t(d, lgMp);
+    const S2Lane L = s2_lane(d, lgMp, A.per_xcd);
+    if (!L.valid) return;
     const int T = d.T, B = d.B;
     const int64_t N = (int64_t)B * d.M;
     const bool raw = d.raw_sigmoid != 0;
@@ -305,8 +389,20 @@ k_bwd_stream2(const StreamBwdArgs A)
     const bool leader = L.active && L.jm == 0;
     const unsigned OOB = 0xFFFFFFFFu;
 
-    // p[]: physical values of the day; gacc[]: sum over days of dL/d(physical value) per slot
-    float p[NPARAM_MAX], gacc[NP];
+    // p[]: physical values of the day; gacc[]: sum over days of dL/d(physical value) per slot --
+    // in LDS (each lane owns its word: no contention, plain fp32 adds in day order) so that the
+    // sixteen accumulators do not cost registers the step needs
+    float p[NPARAM_MAX];
+#if STREAM2_LDS_ACC
+    __shared__ float s_acc[NP][64];
+    float *const gacc_lds = &s_acc[0][threadIdx.x & 63];
+#define S2_ACC_ADD(i, v) s2_lds_add(gacc_lds + (i) * 64, (v))
+#define S2_ACC_GET(i) gacc_lds[(i) * 64]
+#else
+    float gacc[NP];
+#define S2_ACC_ADD(i, v) gacc[i] += (v)
+#define S2_ACC_GET(i) gacc[i]
+#endif
 #pragma unroll
     for (int i = 0; i < NPARAM_MAX; i++) p[i] = 0.0f;
 #pragma unroll
@@ -315,7 +411,11 @@ k_bwd_stream2(const StreamBwdArgs A)
         float v = s.sta[(int64_t)L.b * s.sta_b_stride + L.j];
         v = raw ? sigmoid_(v) : v;
         p[i] = descale_(v, s.lo, s.hi);
+#if STREAM2_LDS_ACC
+        gacc_lds[i * 64] = 0.0f;
+#else
         gacc[i] = 0.0f;
+#endif
     }
 
     const auto rx = S2Buf::rsrc(d.x), rtraj = S2Buf::rsrc(io.traj), raux = S2Buf::rsrc(io.aux);
@@ -434,12 +534,12 @@ k_bwd_stream2(const StreamBwdArgs A)
             for (int k = 0; k < ND; k++)
                 if (stream_slot<SC>(k) == i) { dyn_slot = true; kd = k; }
             if (!dyn_slot) {
-                gacc[i] += gp[i];
+                S2_ACC_ADD(i, gp[i]);
             } else {
                 const float gu = gp[i] * dsc[kd];
                 const float gr = raw ? gu * (ud[kd] * (1.0f - ud[kd])) : gu;
                 S2Buf::st(rgd[kd], gdvo[kd], (unsigned)t * gdts[kd], duse[kd] ? gr : 0.0f);
-                gacc[i] += duse[kd] ? 0.0f : gp[i];
+                S2_ACC_ADD(i, duse[kd] ? 0.0f : gp[i]);
             }
         }
         if (has_gx) {
@@ -481,7 +581,7 @@ k_bwd_stream2(const StreamBwdArgs A)
         for (int i = 0; i < NP; i++) {
             if (!io.g[i].sta) continue;
             const hbvx_param_src &s = d.p[i];
-            float gr = gacc[i] * (s.hi - s.lo);
+            float gr = S2_ACC_GET(i) * (s.hi - s.lo);
             if (raw) {
                 const float u = sigmoid_(s.sta[(int64_t)L.b * s.sta_b_stride + L.j]);
                 gr = gr * (u * (1.0f - u));
@@ -495,5 +595,8 @@ k_bwd_stream2(const StreamBwdArgs A)
         }
     }
 }
+
+#undef S2_ACC_ADD
+#undef S2_ACC_GET
 
 } // namespace hbvx

@@ -129,13 +129,16 @@ bool hbvx_host::try_fwd_stream(const hbvx_desc *d, const hbvx_fwd_out *out, void
     sa.o = *out;
     sa.lgMp = P.lg;
     sa.nd = P.nd;
+    sa.per_xcd = 0;
     for (int k = 0; k < 3; k++) sa.dslot[k] = k < P.nd ? P.dslot[k] : 0;
     const bool tr = out->traj != nullptr, few = P.nd > 0;
     dim3 grid_s((unsigned)P.wgs);
     hipStream_t st = (hipStream_t)stream;
     if (P.sc >= 0) {
         const int trj = !tr ? 0 : (packed ? 2 : 1);
-        STREAM2_DISPATCH(go_fwd2, d, P.sc, trj, sa, grid_s, st);
+        sa.per_xcd = (int)((P.wgs + 7) / 8);
+        const dim3 grid2((unsigned)(8 * sa.per_xcd));
+        STREAM2_DISPATCH(go_fwd2, d, P.sc, trj, sa, grid2, st);
     } else {
 #define STREAM_GO(MODEL, BE)                                                                          \
     do {                                                                                              \
@@ -179,12 +182,15 @@ bool hbvx_host::try_bwd_stream(const hbvx_desc *d, const hbvx_bwd_io *io, void *
     sa.io = *io;
     sa.lgMp = P.lg;
     sa.nd = P.nd;
+    sa.per_xcd = 0;
     for (int k = 0; k < 3; k++) sa.dslot[k] = k < P.nd ? P.dslot[k] : 0;
     const bool few = P.nd > 0, gfull = io->grad_flux != nullptr;
     dim3 grid_s((unsigned)P.wgs);
     hipStream_t st = (hipStream_t)stream;
     if (P.sc >= 0) {
-        STREAM2_DISPATCH(go_bwd2, d, P.sc, packed ? 2 : 1, gfull, sa, grid_s, st);
+        sa.per_xcd = (int)((P.wgs + 7) / 8);
+        const dim3 grid2((unsigned)(8 * sa.per_xcd));
+        STREAM2_DISPATCH(go_bwd2, d, P.sc, packed ? 2 : 1, gfull, sa, grid2, st);
     } else {
 #define STREAM_GO(MODEL, BE)                                                                              \
     do {                                                                                                  \
