@@ -48,6 +48,9 @@ __host__ __device__ constexpr int stream_slot(int k)
 // 12 500-basin share is 3 125 waves, more than the 3 072 slots of three per SIMD
 #define FWPE __attribute__((amdgpu_waves_per_eu(4)))
 #endif
+#ifndef STREAM2_LDS_ACC
+#define STREAM2_LDS_ACC 1   // adjoint: static-parameter gradient sums live in LDS, one owner per word (0: registers)
+#endif
 #ifndef STREAM2_EXP
 #define STREAM2_EXP 0    // dev experiments: 1 no flux store, 4 no trajectory stores
 #endif
@@ -92,6 +95,19 @@ struct S2Buf {
     {
         __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(u3, v), r, vo, so, 0);
     }
+    // buffer load straight into LDS (LDS-DMA), no VGPRs: lane i's bytes land at lds + i * 4 (4-byte form)
+    // or lds + i * 16 (12- and 16-byte forms: the 12-byte form leaves every fourth word untouched --
+    // measured, tools/micro/lds_dma.hip)
+    template <int BYTES>
+    static __device__ __forceinline__ void ld_lds(__amdgpu_buffer_rsrc_t r, void *lds, unsigned vo, unsigned so)
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        auto *dst = (__attribute__((address_space(3))) void *)lds;
+        if constexpr (BYTES == 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 4, vo, so, 0, 0);
+        else if constexpr (BYTES == 12) __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 12, vo, so, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, vo, so, 0, 0);
+#endif
+    }
     // 16-byte store.  NOT the builtin: on gfx950 a buffer_store_dwordx4 whose soffset is an SGPR reads
     // its data registers late, and a VALU write to them in the very next issue slot corrupts the last
     // four lanes of every row of 16 (observed: `v_pk_mov_b32` right behind the store replaced the SUZ
@@ -125,6 +141,7 @@ struct S2Buf {
 struct S2Lane : LaneT {
     bool valid;    // the wave has at least one basin
     bool bvalid;   // this lane's basin exists (its member may be padding)
+    int b0;        // first basin of the wave
 };
 __device__ __forceinline__ S2Lane s2_lane(const hbvx_desc &d, int lgMp, int per_xcd)
 {
@@ -136,7 +153,8 @@ __device__ __forceinline__ S2Lane s2_lane(const hbvx_desc &d, int lgMp, int per_
     L.jm = L.lane & (Mp - 1);
     L.bl = L.lane >> lgMp;
     const int b = group * (64 >> lgMp) + L.bl;
-    L.valid = group * (64 >> lgMp) < d.B;
+    L.b0 = group * (64 >> lgMp);
+    L.valid = L.b0 < d.B;
     L.bvalid = b < d.B;
     L.active = (b < d.B) && (L.jm < d.M);
     L.b = b < d.B ? b : d.B - 1;
@@ -145,10 +163,11 @@ __device__ __forceinline__ S2Lane s2_lane(const hbvx_desc &d, int lgMp, int per_
     return L;
 }
 
-// fire-and-forget fp32 add into an LDS word this lane owns (ds_add_f32)
+// fp32 add into an LDS word this lane owns: plain read-modify-write (STREAM2_LDS_ACC 1) or the LDS
+// atomic ds_add_f32 (2).  Measured at config 5: the atomic form took the adjoint from 2.9 to 13 ms.
 __device__ __forceinline__ void s2_lds_add(float *w, float v)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && STREAM2_LDS_ACC == 2
     __builtin_amdgcn_ds_faddf((__attribute__((address_space(3))) float *)w, v, 0, 0, false);
 #else
     *w += v;
@@ -231,11 +250,16 @@ __global__ void __launch_bounds__(64) FWPE k_fwd_stream2(const StreamArgs A)
     const unsigned pvo2 = (TRJ == 2 && L.active && o.aux) ? (unsigned)(L.n * 8) : OOB;
     const unsigned row4 = (unsigned)(N * 4);
     const unsigned fT = (unsigned)((int64_t)T * B * 4), fB = (unsigned)(B * 4);
-    // flux: with >= 16 lanes per basin, member lane j owns series j (one store per day); with fewer
-    // lanes the basin leader stores the NF series one by one
-    const bool roles = lgMp >= 4;
-    const bool bvalid = L.bvalid;
-    const unsigned fvo_role = (roles && bvalid && L.jm < NF) ? (unsigned)(((int64_t)L.jm * T * B + L.b) * 4) : OOB;
+    // flux, Mp = 16 (the usual nmul): member lane j picks series j, one ds_bpermute hands the value of
+    // (series k, basin q) to lane 4k + q, and lanes 0..4*NF-1 store -- every quad writes 16 contiguous
+    // bytes (12 requests per day where one lane per series and basin would make 48 four-byte ones: the
+    // address FIFO of the memory pipeline was full a fifth of the time).  Other Mp: the basin leader
+    // stores the NF series one by one.
+    const bool roles = lgMp == 4;
+    const int tl = L.lane;                          // as a target: series tl / 4 of basin tl % 4
+    const int src_lane = (tl & 3) * 16 + (tl >> 2);  // who holds it: lane jm = series in basin row tl % 4
+    const int tb = L.b0 + (tl & 3);
+    const unsigned fvo_role = (roles && (tl >> 2) < NF && tb < B) ? (unsigned)(((int64_t)(tl >> 2) * T * B + tb) * 4) : OOB;
     const unsigned fvo_lead = (!roles && L.active && L.jm == 0) ? (unsigned)(L.b * 4) : OOB;
 
     float st[5];
@@ -306,7 +330,8 @@ __global__ void __launch_bounds__(64) FWPE k_fwd_stream2(const StreamArgs A)
             float v = f[0];
 #pragma unroll
             for (int k = 1; k < NF; k++) v = (L.jm == k) ? f[k] : v;
-            S2Buf::st(rflux, fvo_role, fso, v * invM);
+            v = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane * 4, __builtin_bit_cast(int, v * invM)));
+            S2Buf::st(rflux, fvo_role, fso, v);
         } else {
             unsigned so = fso;
 #pragma unroll
@@ -354,9 +379,10 @@ __global__ void __launch_bounds__(64) FWPE k_fwd_stream2(const StreamArgs A)
 #ifndef STREAM2_BWD_WAVES
 #define STREAM2_BWD_WAVES 3
 #endif
-#ifndef STREAM2_LDS_ACC
-#define STREAM2_LDS_ACC 1   // static-parameter gradient sums live in LDS (ds_add_f32, one owner per word)
+#ifndef STREAM2_LDSPF
+#define STREAM2_LDSPF 1  // adjoint: the next day's inputs travel HBM -> LDS (LDS-DMA) instead of waiting in 17-25 VGPRs
 #endif
+
 
 // waves per SIMD the adjoint is compiled for: three (<= 168 VGPRs) wherever that needs no spill; the
 // hourly step and the capillary models with all twelve gradient series live keep two
@@ -553,7 +579,85 @@ k_bwd_stream2(const StreamBwdArgs A)
         }
     };
 
-    if (D == 1) {
+    if (D == 1 && STREAM2_LDSPF) {
+        // One day in flight, staged through LDS: rows of 64 lanes x (12 | 16 | 4 | 8 | 4...) bytes.  Per
+        // day: wait for the DMA, pull the day's inputs into registers, re-arm the DMA for the day
+        // before, compute.  Only ONE set of inputs occupies registers, and it dies as the step
+        // consumes it.
+        __shared__ s2_f4 l_rec[64];
+        __shared__ float l_x[64 * 4], l_st[5][64], l_ax[2 * 64], l_gf[NG][64], l_dv[ND > 0 ? ND : 1][64];
+        const int ln = threadIdx.x & 63;
+        auto arm = [&](int t) {
+            const unsigned tc = (unsigned)max(t, 0);
+            const unsigned so = tc * xts, sr = tc * row4, sg = tc * fB;
+            if (XVEC) {
+                S2Buf::ld_lds<12>(rx, l_x, xvo, so);
+            } else {
+                S2Buf::ld_lds<4>(rx, l_x, xvo, so + cp * 4);
+                S2Buf::ld_lds<4>(rx, l_x + 64, xvo, so + ct * 4);
+                S2Buf::ld_lds<4>(rx, l_x + 128, xvo, so + ce * 4);
+            }
+            if (TRJ == 2) {
+                S2Buf::ld_lds<16>(rtraj, l_rec, pvo4, sr * 4u);
+                S2Buf::ld_lds<4>(rslz, l_st[4], pvo1, sr);
+                // 8-byte LDS-DMA does not exist: the two saved powers travel as two 4-byte rows
+                S2Buf::ld_lds<4>(raux, l_ax, pvo2, sr * 2u);
+                S2Buf::ld_lds<4>(raux, l_ax + 64, pvo2 + 4u, sr * 2u);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 5; k++) S2Buf::ld_lds<4>(rtraj, l_st[k], tvo[k], sr);
+                S2Buf::ld_lds<4>(raux, l_ax, avo[0], sr);
+                S2Buf::ld_lds<4>(raux, l_ax + 64, avo[1], sr);
+            }
+#pragma unroll
+            for (int k = 0; k < NG; k++) {
+                // one of the two gradient sources per series travels by DMA; if both exist the second
+                // is added from a plain load in `pull`
+                if (GFULL && has_gf) S2Buf::ld_lds<4>(rgf, l_gf[k], gvo, sg + (unsigned)k * fT);
+                else if (k < 4 && has_g4) S2Buf::ld_lds<4>(rg4, l_gf[k], gvo, sg + (unsigned)k * fT);
+            }
+#pragma unroll
+            for (int k = 0; k < ND; k++) S2Buf::ld_lds<4>(rd[k], l_dv[k], dvo[k], tc * dts[k]);
+        };
+        auto pull = [&](int t, In &I) {
+            if (XVEC) {
+                I.fx[0] = l_x[ln * 4]; I.fx[1] = l_x[ln * 4 + 1]; I.fx[2] = l_x[ln * 4 + 2];
+            } else {
+                I.fx[0] = l_x[ln]; I.fx[1] = l_x[64 + ln]; I.fx[2] = l_x[128 + ln];
+            }
+            if (TRJ == 2) {
+                const s2_f4 rec = l_rec[ln];
+                I.st[0] = rec.x; I.st[1] = rec.y; I.st[2] = rec.z; I.st[3] = rec.w;
+                I.st[4] = l_st[4][ln];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 5; k++) I.st[k] = l_st[k][ln];
+            }
+            I.ax[0] = l_ax[ln]; I.ax[1] = l_ax[64 + ln];
+            const unsigned sg = (unsigned)t * fB;
+#pragma unroll
+            for (int k = 0; k < NG; k++) {
+                float v = 0.0f;
+                if (GFULL && has_gf) {
+                    v = l_gf[k][ln];
+                    if (k < 4 && has_g4) v += S2Buf::ld(rg4, gvo, sg + (unsigned)k * fT);
+                } else if (k < 4 && has_g4) {
+                    v = l_gf[k][ln];
+                }
+                I.gf[k] = v;
+            }
+#pragma unroll
+            for (int k = 0; k < ND; k++) I.dv[k] = l_dv[k][ln];
+        };
+        arm(T - 1);
+        for (int t = T - 1; t >= 0; t--) {
+            In cur;
+            pull(t, cur);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the LDS reads are done before the DMA rewrites the rows
+            arm(t - 1);
+            day(t, cur);
+        }
+    } else if (D == 1) {
         // one day in flight: the landed inputs move to `cur`, the next day's loads are issued, then
         // the day is computed
         In nxt;
