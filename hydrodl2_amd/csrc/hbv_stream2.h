@@ -51,8 +51,11 @@ __host__ __device__ constexpr int stream_slot(int k)
 #ifndef STREAM2_LDS_ACC
 #define STREAM2_LDS_ACC 1   // adjoint: static-parameter gradient sums live in LDS, one owner per word (0: registers)
 #endif
+#ifndef STREAM2_ST_AUX
+#define STREAM2_ST_AUX 0   // cache policy of the forward's trajectory / flux stores (0 default, 2 nt, 17 sc0 sc1)
+#endif
 #ifndef STREAM2_EXP
-#define STREAM2_EXP 0    // dev experiments: 1 no flux store, 4 no trajectory stores
+#define STREAM2_EXP 0    // dev experiments: 1 no flux store, 4 no trajectory stores, 8 / 16 / 32 no record / SLZ / powers store
 #endif
 
 typedef float s2_f2 __attribute__((ext_vector_type(2)));
@@ -60,6 +63,9 @@ typedef float s2_f3 __attribute__((ext_vector_type(3)));
 typedef float s2_f4 __attribute__((ext_vector_type(4)));
 
 struct S2Buf {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u3 __attribute__((ext_vector_type(3)));
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
     static __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void *base)
     {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, -1, 0x00020000);
@@ -84,9 +90,15 @@ struct S2Buf {
     {
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, vo, so, 0);
     }
-    typedef unsigned u2 __attribute__((ext_vector_type(2)));
-    typedef unsigned u3 __attribute__((ext_vector_type(3)));
-    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    // streaming variants (trajectory / flux rows: written once, read by another kernel much later)
+    static __device__ __forceinline__ void sts(__amdgpu_buffer_rsrc_t r, unsigned vo, unsigned so, float v)
+    {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, vo, so, STREAM2_ST_AUX);
+    }
+    static __device__ __forceinline__ void sts2(__amdgpu_buffer_rsrc_t r, unsigned vo, unsigned so, s2_f2 v)
+    {
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), r, vo, so, STREAM2_ST_AUX);
+    }
     static __device__ __forceinline__ void st2(__amdgpu_buffer_rsrc_t r, unsigned vo, unsigned so, s2_f2 v)
     {
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), r, vo, so, 0);
@@ -124,7 +136,13 @@ struct S2Buf {
     }
     static __device__ __forceinline__ void st4(const u4 rsrc_words, unsigned vo, unsigned so, s2_f4 v)
     {
+#if STREAM2_ST_AUX == 2
+        asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1"
+#elif STREAM2_ST_AUX == 17
+        asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen sc0 sc1\n\ts_nop 1"
+#else
         asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1"
+#endif
                      :
                      : "v"(v), "v"(vo), "s"(rsrc_words), "s"(so)
                      : "memory");
@@ -306,9 +324,9 @@ __global__ void __launch_bounds__(64) FWPE k_fwd_stream2(const StreamArgs A)
         if (TRJ == 2 && !(STREAM2_EXP & 4)) {
             const s2_f4 rec = {st[0], st[1], st[2], st[3]};
             const s2_f2 pw = {s.sw0, s.ef0};
-            S2Buf::st4(wtraj, pvo4, (unsigned)t * row4 * 4u, rec);
-            S2Buf::st(rslz, pvo1, (unsigned)t * row4, st[4]);
-            S2Buf::st2(raux, pvo2, (unsigned)t * row4 * 2u, pw);
+            if (!(STREAM2_EXP & 8)) S2Buf::st4(wtraj, pvo4, (unsigned)t * row4 * 4u, rec);
+            if (!(STREAM2_EXP & 16)) S2Buf::sts(rslz, pvo1, (unsigned)t * row4, st[4]);
+            if (!(STREAM2_EXP & 32)) S2Buf::sts2(raux, pvo2, (unsigned)t * row4 * 2u, pw);
         }
         st[0] = s.SP3; st[1] = s.MW3; st[2] = s.SM4; st[3] = s.SUZ4; st[4] = s.SLZ2;
         const float act = L.active ? 1.0f : 0.0f;
@@ -331,7 +349,7 @@ __global__ void __launch_bounds__(64) FWPE k_fwd_stream2(const StreamArgs A)
 #pragma unroll
             for (int k = 1; k < NF; k++) v = (L.jm == k) ? f[k] : v;
             v = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane * 4, __builtin_bit_cast(int, v * invM)));
-            S2Buf::st(rflux, fvo_role, fso, v);
+            S2Buf::sts(rflux, fvo_role, fso, v);
         } else {
             unsigned so = fso;
 #pragma unroll
