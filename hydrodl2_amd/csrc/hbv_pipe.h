@@ -273,16 +273,26 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
         if (MODEL == MODEL_HOURLY) { OP(P_F0, ptr); OP(P_FMIN, ptr); OP(P_ALPHA, ptr); }           \
     } while (0)
 #define DY_USE2(X, unused) DY_USE(X)
-                if (DYN) DY_ALL(DY_LOAD, pin);
+                // Arbitrary dynamic sets (SC == 0) on this fused stage: up to 15 staged rows.  One-day-ahead
+                // prefetch registers for all of them pushed the wave over its 128 VGPRs (3-44 spilled
+                // values per lane); there the values are read from the LDS tile at the start of their day
+                // instead (independent reads, one wait).
+                constexpr bool PREF = SC != 0;
+#define DY_NOW(X, ptr) do { p[X] = dy_##X ? (ptr)[ix_##X] : p[X]; } while (0)
+                if (DYN && PREF) DY_ALL(DY_LOAD, pin);
                 auto day = [&](int tt, bool more) __attribute__((always_inline)) {
                     Step<MODEL, BETAET> s;
                     s.PET = npet; s.RAIN = nrain; s.tosoil = nts;
-                    if (DYN) DY_ALL(DY_USE2, 0);
+                    if (DYN && PREF) DY_ALL(DY_USE2, 0);
+                    if (DYN && !PREF) {
+                        const float *pc = pin + tt * PD * 64;
+                        DY_ALL(DY_NOW, pc);
+                    }
                     if (more) {
                         npet = in4[(tt + 1) * 64 + lane].z;
                         nrain = ab[(tt + 1) * 128];
                         nts = ab[(tt + 1) * 128 + 64];
-                        if (DYN) {
+                        if (DYN && PREF) {
                             const float *pt = pin + (tt + 1) * PD * 64;
                             DY_ALL(DY_LOAD, pt);
                         }
@@ -306,6 +316,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                 PIPE_DAYS(nt, day);
 #undef DY_ALL
 #undef DY_USE2
+#undef DY_NOW
             }
             PIPE_BARRIER();
         }

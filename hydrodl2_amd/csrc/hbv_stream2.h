@@ -410,8 +410,12 @@ constexpr int s2_bwd_waves()
     return (MODEL == MODEL_HOURLY || ((MODEL == MODEL_HBV20 || MODEL == MODEL_HBV11P) && GFULL)) ? 2 : STREAM2_BWD_WAVES;
 }
 
-template <int MODEL, bool BETAET, int TRJ, int SC, bool GFULL, bool XVEC>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(s2_bwd_waves<MODEL, GFULL>())))
+// W4: compiled for four waves per SIMD (<= 128 VGPRs, a few spilled values) instead of three.  Slower
+// per wave, but a grid that overflows the three-per-SIMD slots by a little (a 12 500-basin share: 3 125
+// waves for 3 072 slots) otherwise pays a whole extra round for the overflow: measured 2.45 -> 2.15 ms
+// there, 1.94 -> 2.20 ms at 3 072 waves.  The host picks per grid (launch_stream.hip).
+template <int MODEL, bool BETAET, int TRJ, int SC, bool GFULL, bool XVEC, bool W4 = false>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W4 ? 4 : s2_bwd_waves<MODEL, GFULL>())))
 k_bwd_stream2(const StreamBwdArgs A)
 {
     constexpr int NP = NParamT<MODEL, BETAET>::value;

@@ -423,8 +423,17 @@ struct BwdTArgs {
 // GFULL = false: only the runoff series (Qsim, Q0, Q1, Q2) carry gradient (loss on routed or
 // un-routed streamflow): the other flux adjoints are compile-time zero and are neither staged
 // nor added.
+// Workgroup size the tiled adjoint is compiled for: 8 waves (two per SIMD, 256 VGPRs each), except
+// the HBV 2.0 / hourly steps with dynamic parameters, whose stepper wave needs more than 256 registers
+// (it spilled 7-31 values): 4 waves, one per SIMD, up to 512 registers -- stepper + three helpers.
+template <int MODEL, bool DYN>
+constexpr int bwd_tiled_threads()
+{
+    return ((MODEL == MODEL_HBV20 || MODEL == MODEL_HOURLY) && DYN) ? 256 : 512;
+}
+
 template <int MODEL, bool BETAET, bool DYN, bool GFULL>
-__global__ void __launch_bounds__(512) k_bwd_tiled(const BwdTArgs A)
+__global__ void __launch_bounds__((bwd_tiled_threads<MODEL, DYN>())) k_bwd_tiled(const BwdTArgs A)
 {
     constexpr int NP = NParamT<MODEL, BETAET>::value;
     constexpr int NF = (MODEL == MODEL_HBV10) ? 11 : 12;

@@ -70,9 +70,32 @@ void go_fwd2(int trj, const StreamArgs &sa, dim3 grid, hipStream_t st)
     else hipLaunchKernelGGL((k_fwd_stream2<MODEL, BE, 0, SC, true>), grid, dim3(64), 0, st, sa);
 }
 
+// true when four waves per SIMD hold the grid in fewer rounds than three (hbv_stream2.h, W4)
+bool four_waves_pay(int64_t wgs)
+{
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+            v = 256;
+        n_cu = v;
+    }
+    const int64_t s3 = (int64_t)n_cu * 4 * 3, s4 = (int64_t)n_cu * 4 * 4;
+    const int force = env_int("HBVX_STREAM_W4", -1);
+    if (force >= 0) return force != 0;
+    return (wgs + s4 - 1) / s4 < (wgs + s3 - 1) / s3;
+}
+
 template <int MODEL, bool BE, int SC>
 void go_bwd2(int trj, bool gfull, const StreamBwdArgs &sa, dim3 grid, hipStream_t st)
 {
+    // the W4 form exists for the 4-series gradient of the explicit daily models (the hourly step and
+    // the 12-series form spill too much at 128 registers)
+    if (trj == 2 && !gfull && MODEL != MODEL_HOURLY && four_waves_pay((int64_t)sa.per_xcd * 8)) {
+        hipLaunchKernelGGL((k_bwd_stream2<MODEL, BE, 2, SC, false, true, MODEL != MODEL_HOURLY>), grid, dim3(64), 0, st, sa);
+        return;
+    }
     if (trj == 2) {
         if (gfull) hipLaunchKernelGGL((k_bwd_stream2<MODEL, BE, 2, SC, true, true>), grid, dim3(64), 0, st, sa);
         else hipLaunchKernelGGL((k_bwd_stream2<MODEL, BE, 2, SC, false, true>), grid, dim3(64), 0, st, sa);

@@ -76,10 +76,12 @@ static hipError_t launch_tiled_one(K kern, const Args &a, dim3 grid, int threads
     return hipGetLastError();
 }
 
+// LIMIT256: the kernel's HBV 2.0 / hourly instances are compiled for 256 threads (hbv_tiled.h, bwd_tiled_threads)
 #define LAUNCH_TILED_V(K, d, a, grid, lds, st, ...)                                                \
     ([&]() -> hipError_t {                                                                        \
         int nh = env_int("HBVX_NH", (grid).x >= 1024 ? 3 : 7);                                    \
         nh = nh < 1 ? 1 : (nh > 7 ? 7 : nh);                                                      \
+        if (LIMIT256 && ((d)->model == HBVX_MODEL_HBV20 || (d)->model == HBVX_MODEL_HOURLY)) nh = nh > 3 ? 3 : nh; \
         const int threads = 64 * (1 + nh);                                                        \
         const int m = (d)->model;                                                                 \
         const bool be = (d)->n_param == 13;                                                       \
@@ -100,6 +102,7 @@ bool hbvx_host::try_fwd_tiled(const hbvx_desc *d, const hbvx_fwd_out *out, void 
             dim3 grid_t((d->B + bpw_t - 1) / bpw_t);
             const size_t lds = (size_t)2 * (ta.g.in_sz + ta.g.out_sz) * 4;
             const bool dyn = ta.g.NDm > 0;
+            constexpr bool LIMIT256 = false;
             hipError_t e = dyn ? LAUNCH_TILED_V(k_fwd_tiled, d, ta, grid_t, lds, (hipStream_t)stream, true)
                                : LAUNCH_TILED_V(k_fwd_tiled, d, ta, grid_t, lds, (hipStream_t)stream, false);
             *rc = e != hipSuccess ? hip_fail(e, "hbvx_forward (tiled) launch") : HBVX_OK;
@@ -120,10 +123,16 @@ bool hbvx_host::try_bwd_tiled(const hbvx_desc *d, const hbvx_bwd_io *io, void *s
             const bool dyn = ta.g.NDm > 0, gfull = io->grad_flux != nullptr;
             hipStream_t st_ = (hipStream_t)stream;
             hipError_t e =
-                dyn ? (gfull ? LAUNCH_TILED_V(k_bwd_tiled, d, ta, grid_t, lds, st_, true, true)
-                             : LAUNCH_TILED_V(k_bwd_tiled, d, ta, grid_t, lds, st_, true, false))
-                    : (gfull ? LAUNCH_TILED_V(k_bwd_tiled, d, ta, grid_t, lds, st_, false, true)
-                             : LAUNCH_TILED_V(k_bwd_tiled, d, ta, grid_t, lds, st_, false, false));
+                [&]() -> hipError_t {
+                    if (dyn) {
+                        constexpr bool LIMIT256 = true;
+                        return gfull ? LAUNCH_TILED_V(k_bwd_tiled, d, ta, grid_t, lds, st_, true, true)
+                                     : LAUNCH_TILED_V(k_bwd_tiled, d, ta, grid_t, lds, st_, true, false);
+                    }
+                    constexpr bool LIMIT256 = false;
+                    return gfull ? LAUNCH_TILED_V(k_bwd_tiled, d, ta, grid_t, lds, st_, false, true)
+                                 : LAUNCH_TILED_V(k_bwd_tiled, d, ta, grid_t, lds, st_, false, false);
+                }();
             *rc = e != hipSuccess ? hip_fail(e, "hbvx_backward (tiled) launch") : HBVX_OK;
             return true;
         }
