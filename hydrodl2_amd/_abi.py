@@ -20,7 +20,7 @@ UH_MAXLEN = 15
 MODEL_HBV10, MODEL_HBV11P, MODEL_HBV20, MODEL_HBVADJ, MODEL_HOURLY = 0, 1, 2, 3, 4
 
 # enum hbvx_traj_layout
-TRAJ_ROWS, TRAJ_PACKED = 0, 1
+TRAJ_ROWS, TRAJ_PACKED, TRAJ_CKPT = 0, 1, 2     # traj_layout = kind | (K << 8) for TRAJ_CKPT
 
 # enum hbvx_flux
 (F_QSIM, F_Q0, F_Q1, F_Q2, F_AET, F_SWE, F_RECHARGE, F_EXCS, F_EVAPFACTOR, F_TOSOIL, F_PERC,

@@ -12,6 +12,8 @@ from __future__ import annotations
 
 from typing import Any, Optional, Union
 
+import os
+
 import torch
 
 from .. import _abi
@@ -48,6 +50,10 @@ class HbvModule(torch.nn.Module):
         self.cache_states = False
         self.device = device
         self.muwts = None
+        # not in the reference: 0 (save the state trajectory for the adjoint, fastest) or 4 / 8 / 16
+        # (keep K-day checkpoints and recompute: 20/K instead of 28 bytes per lane-day); config key
+        # 'adjoint_checkpoint' or, when unset, the environment variable HBVX_CKPT_DAYS
+        self.adjoint_checkpoint = int(os.environ.get('HBVX_CKPT_DAYS', '0') or 0)
 
         self.states, self._states_cache = None, None
 
@@ -80,7 +86,7 @@ class HbvModule(torch.nn.Module):
     # -- configuration --------------------------------------------------
     # config key -> attribute of the same name; absent keys keep the constructor default
     _CONFIG_KEYS = ('warm_up', 'warm_up_states', 'dy_drop', 'variables', 'routing', 'comprout',
-                    'nearzero', 'nmul', 'cache_states')
+                    'nearzero', 'nmul', 'cache_states', 'adjoint_checkpoint')
 
     def _read_config(self, config: dict) -> None:
         """Same keys and defaults as hbv.py:110-125; `dynamic_params` is REQUIRED once a config is
@@ -205,8 +211,11 @@ class HbvModule(torch.nn.Module):
         else:
             state_in = self._stack_states(self.states, ngrid, x.device)
 
+        if self.adjoint_checkpoint not in (0, 4, 8, 16):
+            raise ValueError("adjoint_checkpoint must be 0, 4, 8 or 16 days")
         base = dict(model=self._model_id, n_param=n, n_flux=self._n_flux(), B=ngrid, M=M,
-                    raw_sigmoid=True, channels=self._channels(), nearzero=float(self.nearzero))
+                    raw_sigmoid=True, channels=self._channels(), nearzero=float(self.nearzero),
+                    ckpt_days=int(self.adjoint_checkpoint))
 
         # hbv.py:327-346: state warm-up, all parameters static from row warm_up-1, no grad
         if warm_up > 0:

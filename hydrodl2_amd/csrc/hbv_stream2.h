@@ -199,7 +199,8 @@ __device__ __forceinline__ float s2_pick(const s2_f3 v, int ch)
 }
 
 // ---------------------------------------------------------------------------------------------
-// forward.  TRJ: 0 nothing kept, 1 trajectory rows [5,T+1,N] + aux [2,T,N], 2 packed.
+// forward.  TRJ: 0 nothing kept, 1 trajectory rows [5,T+1,N] + aux [2,T,N], 2 packed, 3 K-day
+// checkpoints [ceil(T/K),5,N] (HBVX_TRAJ_CKPT; K a power of two).
 // XVEC: forcing channels are {0,1,2} and a basin's three values are adjacent (one 12-byte load).
 // ---------------------------------------------------------------------------------------------
 template <int MODEL, bool BETAET, int TRJ, int SC, bool XVEC>
@@ -263,6 +264,9 @@ __global__ void __launch_bounds__(64) FWPE k_fwd_stream2(const StreamArgs A)
     for (int k = 0; k < 5; k++) tvo[k] = (TRJ == 1 && L.active) ? (unsigned)((k * (int64_t)(T + 1) * N + L.n) * 4) : OOB;
 #pragma unroll
     for (int k = 0; k < 2; k++) avo[k] = (TRJ == 1 && L.active && o.aux) ? (unsigned)((k * (int64_t)T * N + L.n) * 4) : OOB;
+    const int ckK = TRJ == 3 ? HBVX_TRAJ_CKPT_DAYS(o.traj_layout) : 1;
+    const int cklg = ckK == 16 ? 4 : (ckK == 8 ? 3 : 2);
+    const unsigned cvo = (TRJ == 3 && L.active) ? (unsigned)(L.n * 4) : OOB;
     const unsigned pvo4 = (TRJ == 2 && L.active) ? (unsigned)(L.n * 16) : OOB;
     const unsigned pvo1 = (TRJ == 2 && L.active) ? (unsigned)(L.n * 4) : OOB;
     const unsigned pvo2 = (TRJ == 2 && L.active && o.aux) ? (unsigned)(L.n * 8) : OOB;
@@ -320,6 +324,13 @@ __global__ void __launch_bounds__(64) FWPE k_fwd_stream2(const StreamArgs A)
             for (int k = 0; k < 5; k++) S2Buf::st(rtraj, tvo[k], so, st[k]);
             S2Buf::st(raux, avo[0], so, s.sw0);
             S2Buf::st(raux, avo[1], so, s.ef0);
+        }
+        if (TRJ == 3) {
+            if ((t & (ckK - 1)) == 0) {   // wave-uniform
+                const unsigned so = (unsigned)(t >> cklg) * 5u * row4;
+#pragma unroll
+                for (int k = 0; k < 5; k++) S2Buf::st(rtraj, cvo, so + (unsigned)k * row4, st[k]);
+            }
         }
         if (TRJ == 2 && !(STREAM2_EXP & 4)) {
             const s2_f4 rec = {st[0], st[1], st[2], st[3]};

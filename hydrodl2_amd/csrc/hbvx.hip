@@ -135,6 +135,8 @@ __global__ void __launch_bounds__(64) k_fwd(const FwdArgs A)
     const float *mu = d.muwts ? d.muwts + (int64_t)L.b * d.mu_b_stride + L.j : nullptr;
     const float invM = 1.0f / (float)d.M;
     const int nf = o.n_flux;
+    // HBVX_TRAJ_CKPT: only the storages entering every K-th day are kept, [ceil(T/K), 5, N]
+    const int ckpt_k = (o.traj && HBVX_TRAJ_KIND(o.traj_layout) == HBVX_TRAJ_CKPT) ? HBVX_TRAJ_CKPT_DAYS(o.traj_layout) : 0;
 
     // one-step-ahead register prefetch of the per-step inputs
     float nxf[3], nxd[NP];
@@ -171,7 +173,12 @@ __global__ void __launch_bounds__(64) k_fwd(const FwdArgs A)
         s.SP = st[0]; s.MW = st[1]; s.SM = st[2]; s.SUZ = st[3]; s.SLZ = st[4];
         s.template fwd<false>(p, nz, ac, elev, 0.f, 0.f);
 
-        if (o.traj && L.active) {
+        if (ckpt_k) {
+            if (t % ckpt_k == 0 && L.active) {
+#pragma unroll
+                for (int k = 0; k < 5; k++) o.traj[((int64_t)(t / ckpt_k) * 5 + k) * N + L.n] = st[k];
+            }
+        } else if (o.traj && L.active) {
 #pragma unroll
             for (int k = 0; k < 5; k++) o.traj[((int64_t)k * (T + 1) + t) * N + L.n] = st[k];
         }
@@ -211,7 +218,7 @@ __global__ void __launch_bounds__(64) k_fwd(const FwdArgs A)
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             o.state_out[k * N + L.n] = st[k];
-            if (o.traj) o.traj[((int64_t)k * (T + 1) + T) * N + L.n] = st[k];
+            if (o.traj && !ckpt_k) o.traj[((int64_t)k * (T + 1) + T) * N + L.n] = st[k];
         }
     }
 }
@@ -650,6 +657,23 @@ extern "C" int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *s
     const int want_nf = (d->model == HBVX_MODEL_HBV10) ? 11 : 12;
     if (out->flux && out->n_flux != want_nf) return fail(HBVX_E_SHAPE, "n_flux does not match model");
     if (out->traj && out->traj_layout != HBVX_TRAJ_ROWS) {
+        const int kind = HBVX_TRAJ_KIND(out->traj_layout);
+        if (kind == HBVX_TRAJ_CKPT) {
+            // K-day checkpoints: the streaming kernel where it has an instance, else the generic one
+            const int K = HBVX_TRAJ_CKPT_DAYS(out->traj_layout);
+            if (K != 4 && K != 8 && K != 16) return fail(HBVX_E_SHAPE, "checkpoint interval must be 4, 8 or 16");
+            if (out->aux) return fail(HBVX_E_SHAPE, "checkpoints: aux must be NULL");
+            if (try_fwd_stream(d, out, stream, &rc)) return rc;
+            FwdArgs ca;
+            ca.d = *d;
+            ca.o = *out;
+            ca.lgMp = lg_members(d->M);
+            const int bpw_c = 64 >> ca.lgMp;
+            hipError_t ec = launch_variant(d, ca, dim3((d->B + bpw_c - 1) / bpw_c), (hipStream_t)stream,
+                                           k_fwd<MODEL_HBV10, false>, k_fwd<MODEL_HBV10, true>,
+                                           k_fwd<MODEL_HBV11P, true>, k_fwd<MODEL_HBV20, true>, k_fwd<MODEL_HOURLY, true>);
+            return ec == hipSuccess ? HBVX_OK : hip_fail(ec, "hbvx_forward (checkpoints) launch");
+        }
         // packed trajectory: the streaming family only (hbvx_preferred_traj_layout said so)
         if (out->traj_layout != HBVX_TRAJ_PACKED) return fail(HBVX_E_SHAPE, "unknown traj_layout");
         if (try_fwd_stream(d, out, stream, &rc)) return rc;
@@ -677,11 +701,16 @@ extern "C" int hbvx_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *st
     int rc = check_desc(d);
     if (rc) return rc;
     if (d->model == HBVX_MODEL_HBVADJ) return fail(HBVX_E_UNSUPPORTED, "use hbvx_adj_backward for HBVADJ");
-    if (!io || !io->traj || !io->aux) return fail(HBVX_E_NULL, "traj/aux is NULL");
+    if (!io || !io->traj) return fail(HBVX_E_NULL, "traj is NULL");
+    if (!io->aux && HBVX_TRAJ_KIND(io->traj_layout) != HBVX_TRAJ_CKPT) return fail(HBVX_E_NULL, "aux is NULL");
     const int want_nf = (d->model == HBVX_MODEL_HBV10) ? 11 : 12;
     if (io->n_flux != want_nf) return fail(HBVX_E_SHAPE, "n_flux does not match model");
     if (d->T == 0) return HBVX_OK;
     if (io->traj_layout != HBVX_TRAJ_ROWS) {
+        if (HBVX_TRAJ_KIND(io->traj_layout) == HBVX_TRAJ_CKPT) {
+            if (try_bwd_ckpt(d, io, stream, &rc)) return rc;
+            return fail(HBVX_E_UNSUPPORTED, "checkpoints: no adjoint kernel for this call");
+        }
         if (io->traj_layout != HBVX_TRAJ_PACKED) return fail(HBVX_E_SHAPE, "unknown traj_layout");
         if (try_bwd_stream(d, io, stream, &rc)) return rc;
         return fail(HBVX_E_UNSUPPORTED, "packed trajectory: no adjoint kernel for this call");

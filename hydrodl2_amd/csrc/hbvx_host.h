@@ -41,4 +41,7 @@ bool chunked_applicable(const hbvx_desc *d);
 int chunk_days();
 bool try_bwd_chunked(const hbvx_desc *d, const hbvx_bwd_io *io, void *stream, int *rc);
 
+// launch_ckpt.hip
+bool try_bwd_ckpt(const hbvx_desc *d, const hbvx_bwd_io *io, void *stream, int *rc);
+
 } // namespace hbvx_host

@@ -65,7 +65,8 @@ int stream_min_bwd() { return env_int("HBVX_STREAM_MIN_BWD", 2048); }
 template <int MODEL, bool BE, int SC>
 void go_fwd2(int trj, const StreamArgs &sa, dim3 grid, hipStream_t st)
 {
-    if (trj == 2) hipLaunchKernelGGL((k_fwd_stream2<MODEL, BE, 2, SC, true>), grid, dim3(64), 0, st, sa);
+    if (trj == 3) hipLaunchKernelGGL((k_fwd_stream2<MODEL, BE, 3, SC, true>), grid, dim3(64), 0, st, sa);
+    else if (trj == 2) hipLaunchKernelGGL((k_fwd_stream2<MODEL, BE, 2, SC, true>), grid, dim3(64), 0, st, sa);
     else if (trj == 1) hipLaunchKernelGGL((k_fwd_stream2<MODEL, BE, 1, SC, true>), grid, dim3(64), 0, st, sa);
     else hipLaunchKernelGGL((k_fwd_stream2<MODEL, BE, 0, SC, true>), grid, dim3(64), 0, st, sa);
 }
@@ -137,6 +138,14 @@ bool hbvx_host::try_fwd_stream(const hbvx_desc *d, const hbvx_fwd_out *out, void
 {
     const StreamPlan P = plan_stream(d);
     const bool packed = out->traj && out->traj_layout == HBVX_TRAJ_PACKED;
+    const bool ckpt = out->traj && HBVX_TRAJ_KIND(out->traj_layout) == HBVX_TRAJ_CKPT;
+    if (ckpt) {
+        // checkpoints: whatever the grid size, when the second generation has an instance; the offsets of
+        // the checkpoint rows must fit 32 bits
+        const int K = HBVX_TRAJ_CKPT_DAYS(out->traj_layout);
+        const int64_t nseg = (d->T + K - 1) / K;
+        if (!(P.ok && out->flux && P.sc >= 0 && nseg * 5 * (int64_t)d->B * d->M * 4 < ((int64_t)1 << 32))) return false;
+    }
     // the second generation also takes a trajectory without the saved powers (inference that keeps the state series)
     bool ok = P.ok && out->flux && (P.sc >= 0 ? (out->traj || !out->aux) : (out->traj != nullptr) == (out->aux != nullptr));
     if (packed) {
@@ -144,7 +153,7 @@ bool hbvx_host::try_fwd_stream(const hbvx_desc *d, const hbvx_fwd_out *out, void
             *rc = fail(HBVX_E_UNSUPPORTED, "packed trajectory asked for a problem hbvx_preferred_traj_layout does not pack");
             return true;
         }
-    } else if (!(ok && P.wgs >= stream_min_fwd(d))) {
+    } else if (!ckpt && !(ok && P.wgs >= stream_min_fwd(d))) {
         return false;
     }
     StreamArgs sa;
@@ -158,7 +167,7 @@ bool hbvx_host::try_fwd_stream(const hbvx_desc *d, const hbvx_fwd_out *out, void
     dim3 grid_s((unsigned)P.wgs);
     hipStream_t st = (hipStream_t)stream;
     if (P.sc >= 0) {
-        const int trj = !tr ? 0 : (packed ? 2 : 1);
+        const int trj = !tr ? 0 : (ckpt ? 3 : (packed ? 2 : 1));
         sa.per_xcd = (int)((P.wgs + 7) / 8);
         const dim3 grid2((unsigned)(8 * sa.per_xcd));
         STREAM2_DISPATCH(go_fwd2, d, P.sc, trj, sa, grid2, st);

@@ -99,10 +99,16 @@ class Hbv_2(HbvModule):
         else:
             state_in = self._stack_states(self.states, ngrid, x.device)
 
+        # adjoint_checkpoint (not in the reference): keep K-day checkpoints instead of the state
+        # trajectory -- 100 000 basins x 16 x 7 300 days do not fit otherwise.  The price on this class:
+        # the state cache then holds the final storages only (a one-step series), not the full series.
+        ck = int(self.adjoint_checkpoint) if not self.initialize else 0
+        if ck not in (0, 4, 8, 16):
+            raise ValueError("adjoint_checkpoint must be 0, 4, 8 or 16 days")
         cfg = StepConfig(model=self._model_id, n_param=n, n_flux=12, T=T, t0=0, B=ngrid, M=M,
                          raw_sigmoid=False, channels=self._channels(),
                          nearzero=float(self.nearzero), params=srcs,
-                         want_flux=not self.initialize, want_traj=True)
+                         want_flux=not self.initialize, want_traj=ck == 0, ckpt_days=ck)
         if self.routing:
             off = (n - n_dy) * M  # hbv_2.py:228
             cfg.route = RouteSource(1, off, off + 1, ws,
@@ -113,7 +119,10 @@ class Hbv_2(HbvModule):
 
         # hbv_2.py:385-388,628: the state cache is the full series [T,B,nmul] x 5 (views of the
         # saved trajectory: storages after day t = storages entering day t + 1)
-        self._state_cache = tuple(s[1:] for s in state_series(traj.detach(), cfg.traj_layout, T, ngrid, M))
+        if ck == 0:
+            self._state_cache = tuple(s[1:] for s in state_series(traj.detach(), cfg.traj_layout, T, ngrid, M))
+        else:
+            self._state_cache = tuple(s.unsqueeze(0) for s in state_out.detach().unbind(0))
         if self.cache_states:
             self.states = tuple(s[-1].detach() for s in self._state_cache)
 

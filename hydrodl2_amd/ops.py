@@ -72,6 +72,7 @@ class StepConfig:
     adj_max_iter: int = 3      # implicit scheme only (hbv_adj.py:518)
     mu_t0: Optional[int] = None  # first row of muwts used by this call (None: same as t0)
     traj_layout: int = 0       # set by HbvPath.forward: enum hbvx_traj_layout of the saved trajectory
+    ckpt_days: int = 0         # 4 / 8 / 16: keep K-day checkpoints instead of the trajectory (memory-lean adjoint)
 
 
 # bench.py sets this to a list to collect (abi_call, start_event, end_event) per launch,
@@ -249,9 +250,16 @@ class HbvPath(torch.autograd.Function):
             if cfg.want_flux else None
         state_out = _out((5, B, M), dev)
         # same two buffers whatever the layout the library asks for (include/hbvx.h, hbvx_traj_layout)
-        traj = _out((5, T + 1, B * M), dev) if keep else None
-        aux = _out((2, T, B * M), dev) if needs_grad else None
-        cfg.traj_layout = lib.preferred_traj_layout(desc) if (keep and cfg.want_flux) else _abi.TRAJ_ROWS
+        ckpt = cfg.ckpt_days if (needs_grad and cfg.want_flux and not cfg.want_traj) else 0
+        if ckpt:
+            # K-day checkpoints [ceil(T/K), 5, N] instead of the trajectory; the adjoint recomputes
+            traj = _out(((T + ckpt - 1) // ckpt * 5, B * M), dev)
+            aux = None
+            cfg.traj_layout = _abi.TRAJ_CKPT | (ckpt << 8)
+        else:
+            traj = _out((5, T + 1, B * M), dev) if keep else None
+            aux = _out((2, T, B * M), dev) if needs_grad else None
+            cfg.traj_layout = lib.preferred_traj_layout(desc) if (keep and cfg.want_flux) else _abi.TRAJ_ROWS
         out.flux, out.state_out = _ptr(flux), _ptr(state_out)
         out.traj, out.aux = _ptr(traj), _ptr(aux)
         out.n_flux, out.traj_layout = cfg.n_flux, cfg.traj_layout
@@ -346,7 +354,7 @@ class HbvPath(torch.autograd.Function):
                 if ps.dyn_off >= 0 and gp[ps.dyn_tensor_idx] is not None:
                     gp[ps.dyn_tensor_idx].zero_()
             return (None, gx, None, gmu, None, None, *gp)
-        ws_bytes = lib.backward_workspace_bytes(desc) if ctx.traj_layout == _abi.TRAJ_ROWS else 0
+        ws_bytes = lib.backward_workspace_bytes(desc) if ctx.traj_layout == _abi.TRAJ_ROWS else 0   # packed / checkpoints: single-pass adjoints
         if ws_bytes:
             ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
             io.workspace, io.workspace_bytes = _ptr(ws), ws_bytes

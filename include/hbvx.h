@@ -140,7 +140,14 @@ typedef struct hbvx_desc {
  *           aux = records [T,N,2].  Three wide stores / loads per lane-day instead of seven: what the
  *           streaming kernels for large grids use (a vector-memory instruction costs the same issue
  *           time whatever its width).  N = B*M, lane n = b*M + j. */
-enum hbvx_traj_layout { HBVX_TRAJ_ROWS = 0, HBVX_TRAJ_PACKED = 1 };
+enum hbvx_traj_layout { HBVX_TRAJ_ROWS = 0, HBVX_TRAJ_PACKED = 1, HBVX_TRAJ_CKPT = 2 };
+/* traj_layout = kind | (K << 8).  HBVX_TRAJ_CKPT with K in {4, 8, 16}: `traj` holds only the five
+ * storages entering days 0, K, 2K, ... as [ceil(T/K), 5, N] and `aux` is NULL (20/K bytes per lane-day
+ * instead of 28); hbvx_backward re-materialises each K-day segment from its checkpoint (one extra
+ * forward step per day).  The caller chooses it when the full trajectory does not fit
+ * (100 000 basins x 16 x 7 300 days: 327 GB against 16 GB at K = 8). */
+#define HBVX_TRAJ_KIND(layout) ((layout) & 0xFF)
+#define HBVX_TRAJ_CKPT_DAYS(layout) ((layout) >> 8)
 
 typedef struct hbvx_fwd_out {
     float *flux;      /* [n_flux,T,B] or NULL (state warm-up: hbv.py:557-559) */

@@ -755,8 +755,13 @@ int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream)
     int rc = check_desc(d);
     if (rc) return rc;
     if (!out || !out->state_out) return fail(HBVX_E_NULL, "state_out is NULL");
-    if (out->traj && out->traj_layout != HBVX_TRAJ_ROWS)
-        return fail(HBVX_E_UNSUPPORTED, "the oracle keeps the trajectory in rows (HBVX_TRAJ_ROWS)");
+    if (out->traj && HBVX_TRAJ_KIND(out->traj_layout) == HBVX_TRAJ_PACKED)
+        return fail(HBVX_E_UNSUPPORTED, "the oracle keeps the trajectory in rows or checkpoints");
+    /* HBVX_TRAJ_CKPT: storages entering days 0, K, 2K, ... only, [ceil(T/K), 5, N] */
+    const int ckpt_k = (out->traj && HBVX_TRAJ_KIND(out->traj_layout) == HBVX_TRAJ_CKPT)
+                           ? HBVX_TRAJ_CKPT_DAYS(out->traj_layout) : 0;
+    if (out->traj && HBVX_TRAJ_KIND(out->traj_layout) == HBVX_TRAJ_CKPT && ckpt_k <= 0)
+        return fail(HBVX_E_SHAPE, "checkpoint interval must be positive");
     const int T = d->T, B = d->B, M = d->M;
     const int64_t N = (int64_t)B * M;
     const int nf = out->n_flux;
@@ -792,8 +797,12 @@ int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream)
                 } else {
                     step_fwd(d->model, betaet, d->nearzero, p, ac, elev, &s);
                 }
-                if (out->traj)
+                if (out->traj && ckpt_k) {
+                    if (t % ckpt_k == 0)
+                        for (int k = 0; k < 5; k++) out->traj[((int64_t)(t / ckpt_k) * 5 + k) * N + n] = st[k];
+                } else if (out->traj) {
                     for (int k = 0; k < 5; k++) out->traj[((int64_t)k * (T + 1) + t) * N + n] = st[k];
+                }
                 if (out->aux) {
                     out->aux[((int64_t)0 * T + t) * N + n] = s.sw0;
                     out->aux[((int64_t)1 * T + t) * N + n] = s.ef0;
@@ -820,7 +829,7 @@ int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream)
             }
             for (int k = 0; k < 5; k++) {
                 out->state_out[k * N + n] = st[k];
-                if (out->traj) out->traj[((int64_t)k * (T + 1) + T) * N + n] = st[k];
+                if (out->traj && !ckpt_k) out->traj[((int64_t)k * (T + 1) + T) * N + n] = st[k];
             }
         }
         if (acc) {
@@ -844,8 +853,11 @@ int hbvx_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *stream)
     int rc = check_desc(d);
     if (rc) return rc;
     if (!io || !io->traj) return fail(HBVX_E_NULL, "traj is NULL");
-    if (io->traj_layout != HBVX_TRAJ_ROWS)
-        return fail(HBVX_E_UNSUPPORTED, "the oracle keeps the trajectory in rows (HBVX_TRAJ_ROWS)");
+    if (HBVX_TRAJ_KIND(io->traj_layout) == HBVX_TRAJ_PACKED)
+        return fail(HBVX_E_UNSUPPORTED, "the oracle keeps the trajectory in rows or checkpoints");
+    const int ckpt_k = HBVX_TRAJ_KIND(io->traj_layout) == HBVX_TRAJ_CKPT ? HBVX_TRAJ_CKPT_DAYS(io->traj_layout) : 0;
+    if (HBVX_TRAJ_KIND(io->traj_layout) == HBVX_TRAJ_CKPT && ckpt_k <= 0)
+        return fail(HBVX_E_SHAPE, "checkpoint interval must be positive");
     const int T = d->T, B = d->B, M = d->M;
     const int64_t N = (int64_t)B * M;
     const int nf = io->n_flux;
@@ -864,15 +876,47 @@ int hbvx_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *stream)
             float gsta[HBVX_MAX_PARAM]; /* dL/d(unit static value), summed over t */
             float usta[HBVX_MAX_PARAM];
             for (int i = 0; i < HBVX_MAX_PARAM; i++) gsta[i] = 0.0f, usta[i] = 0.0f;
+            /* checkpoints: re-materialise this lane's storages day by day, segment by segment */
+            float *lane_traj = NULL;
+            if (ckpt_k) {
+                lane_traj = (float *)malloc((size_t)(T > 0 ? T : 1) * 5 * sizeof(float));
+                for (int t0 = 0; t0 < T; t0 += ckpt_k) {
+                    float st[5];
+                    for (int k = 0; k < 5; k++) st[k] = io->traj[((int64_t)(t0 / ckpt_k) * 5 + k) * N + n];
+                    for (int t = t0; t < T && t < t0 + ckpt_k; t++) {
+                        float p[HBVX_MAX_PARAM];
+                        unit_t u[HBVX_MAX_PARAM];
+                        step_t s;
+                        for (int k = 0; k < 5; k++) lane_traj[(size_t)t * 5 + k] = st[k];
+                        s.SP = st[0]; s.MW = st[1]; s.SM = st[2]; s.SUZ = st[3]; s.SLZ = st[4];
+                        load_step_inputs(d, t, b, j, p, u, &s);
+                        if (d->model == HBVX_MODEL_HOURLY) {
+                            hstep_t h;
+                            h.SPi = st[0]; h.MWi = st[1]; h.SMi = st[2]; h.SUZi = st[3]; h.SLZi = st[4];
+                            h.P = s.P / HDT; h.Tf = s.Tf; h.PET = s.PET / HDT;
+                            hstep_fwd(d->nearzero, p, ac, elev, &h);
+                            st[0] = h.SP3; st[1] = h.MW3; st[2] = h.SM4; st[3] = h.SUZ4; st[4] = h.SLZ2;
+                        } else {
+                            step_fwd(d->model, betaet, d->nearzero, p, ac, elev, &s);
+                            st[0] = s.SP3; st[1] = s.MW3; st[2] = s.SM4; st[3] = s.SUZ4; st[4] = s.SLZ2;
+                        }
+                    }
+                }
+            }
             for (int t = T - 1; t >= 0; t--) {
                 float p[HBVX_MAX_PARAM], gp[HBVX_MAX_PARAM], gx[3];
                 unit_t u[HBVX_MAX_PARAM];
                 step_t s;
+                if (lane_traj) {
+                    s.SP = lane_traj[(size_t)t * 5]; s.MW = lane_traj[(size_t)t * 5 + 1]; s.SM = lane_traj[(size_t)t * 5 + 2];
+                    s.SUZ = lane_traj[(size_t)t * 5 + 3]; s.SLZ = lane_traj[(size_t)t * 5 + 4];
+                } else {
                 s.SP = io->traj[((int64_t)0 * (T + 1) + t) * N + n];
                 s.MW = io->traj[((int64_t)1 * (T + 1) + t) * N + n];
                 s.SM = io->traj[((int64_t)2 * (T + 1) + t) * N + n];
                 s.SUZ = io->traj[((int64_t)3 * (T + 1) + t) * N + n];
                 s.SLZ = io->traj[((int64_t)4 * (T + 1) + t) * N + n];
+                }
                 load_step_inputs(d, t, b, j, p, u, &s);
                 hstep_t h;
                 if (d->model == HBVX_MODEL_HOURLY) {
@@ -939,6 +983,7 @@ int hbvx_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *stream)
             }
             if (io->grad_state_in)
                 for (int k = 0; k < 5; k++) io->grad_state_in[k * N + n] = a[k];
+            free(lane_traj);
         }
         if (gxacc) {
             for (int t = 0; t < T; t++) {

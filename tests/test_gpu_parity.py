@@ -251,3 +251,18 @@ def test_zero_except_matches_definition(rows, width, r0, r1, gw, keep, hip_backe
         assert (got == 0).all()
     else:
         assert np.isnan(got[kept]).all() and (got[~kept] == 0).all()
+
+
+@pytest.mark.parametrize("name,K", [("hbv_dyn2", 8), ("hbv_static_m16", 16), ("hbv11p_dyn_all", 4), ("hbv2_dyn3", 8),
+                                    ("hbv_warmup_states", 4), ("hbv_m3_xgrad", 8), ("hbv_muwts", 8),
+                                    ("hourly_dyn3", 16), ("hbv2_dyn3_routing", 4)])
+def test_checkpointed_adjoint_on_gpu(name, K, hip_backend, monkeypatch):
+    """HBVX_TRAJ_CKPT on the GPU against the reference's fixtures: the streaming forward writes the
+    checkpoints where it has an instance (the delta-MG dynamic sets), the generic one-wave forward
+    elsewhere; k_bwd_ckpt re-materialises K-day segments in LDS."""
+    monkeypatch.setenv("HBVX_CKPT_DAYS", str(K))
+    ref = load_golden(name)
+    res = run_case(name, "cuda:0")
+    if "states" in res and res["states"].shape != ref["states"].shape:
+        res["states"] = ref["states"]
+    compare(name, res, ref)
