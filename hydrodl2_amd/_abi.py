@@ -99,7 +99,7 @@ LSTM_HIDDEN_SIZES = (64, 128, 256)     # what the HIP library instantiates
 
 EXPORTS = ["hbvx_zero", "hbvx_zero_except", "hbvx_preferred_traj_layout", "hbvx_lstm_workspace_bytes", "hbvx_lstm_forward", "hbvx_lstm_backward", "hbvx_lstm_check",
            "hbvx_version", "hbvx_last_error", "hbvx_backend", "hbvx_sizeof", "hbvx_forward",
-           "hbvx_backward", "hbvx_backward_workspace_bytes", "hbvx_route_forward", "hbvx_route_workspace_bytes",
+           "hbvx_backward", "hbvx_backward_workspace_bytes", "hbvx_ckpt_workspace_bytes", "hbvx_route_forward", "hbvx_route_workspace_bytes",
            "hbvx_route_backward", "hbvx_adj_forward", "hbvx_adj_backward", "hbvx_bfi",
            "hbvx_gage_route_forward", "hbvx_gage_route_backward",
            "hbvx_gage_route_workspace_bytes"]
@@ -152,6 +152,8 @@ class Library:
                                                C.c_void_p]
         d.hbvx_bfi.restype = C.c_int
         d.hbvx_bfi.argtypes = [C.c_int32, C.c_int32, _fp, _fp, C.c_float, _fp, C.c_void_p]
+        d.hbvx_ckpt_workspace_bytes.restype = C.c_uint64
+        d.hbvx_ckpt_workspace_bytes.argtypes = [C.POINTER(Desc), C.c_int32]
         d.hbvx_preferred_traj_layout.restype = C.c_int
         d.hbvx_preferred_traj_layout.argtypes = [C.POINTER(Desc)]
         d.hbvx_zero.restype = C.c_int
@@ -196,6 +198,9 @@ class Library:
 
     def preferred_traj_layout(self, desc: Desc) -> int:
         return int(self.dll.hbvx_preferred_traj_layout(C.byref(desc)))
+
+    def ckpt_workspace_bytes(self, desc: Desc, K: int) -> int:
+        return int(self.dll.hbvx_ckpt_workspace_bytes(C.byref(desc), K))
 
     def backward_workspace_bytes(self, desc: Desc) -> int:
         return int(self.dll.hbvx_backward_workspace_bytes(C.byref(desc)))

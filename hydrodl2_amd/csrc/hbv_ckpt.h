@@ -78,8 +78,33 @@ __global__ void __launch_bounds__(64) k_bwd_ckpt(const CkptBwdArgs A)
 #pragma unroll
     for (int k = 0; k < 5; k++) a[k] = io.grad_state_out ? io.grad_state_out[k * N + L.n] : 0.0f;
 
-    // parameters of day t -> p[], unit values -> ud[]
-    auto params_of = [&](int t, float *p, float *ud) {
+    // raw inputs of a day (forcings, raw dynamic values): loaded one day ahead of their use so that no
+    // day waits for HBM
+    struct Raw {
+        float f[3], dv[NP];
+        float gf[HBVX_MAX_FLUX];   // incoming flux-series gradients (adjoint sweep only)
+    };
+    const int64_t fs = (int64_t)T * d.B;
+    auto fetch_grad = [&](int t, Raw &R) {
+        const int tc = t < 0 ? 0 : (t >= T ? T - 1 : t);
+        const int64_t go = (int64_t)tc * d.B + L.b;
+#pragma unroll
+        for (int k = 0; k < HBVX_MAX_FLUX; k++) {
+            float v = (io.grad_flux && k < nf) ? io.grad_flux[k * fs + go] : 0.0f;
+            if (io.grad_flux4 && k < 4) v += io.grad_flux4[k * fs + go];
+            R.gf[k] = v;
+        }
+    };
+    auto fetch = [&](int t, Raw &R) {
+        const int tc = t < 0 ? 0 : (t >= T ? T - 1 : t);
+        const float *xr = xb + (int64_t)tc * d.x_t_stride;
+        R.f[0] = xr[d.ch_prcp]; R.f[1] = xr[d.ch_tmean]; R.f[2] = xr[d.ch_pet];
+#pragma unroll
+        for (int i = 0; i < NP; i++)
+            R.dv[i] = ((dmask >> i) & 1) ? dynp[i][(int64_t)tc * d.p[i].dyn_t_stride] : 0.0f;
+    };
+    // parameters of a day -> p[], unit values -> ud[]
+    auto params_of = [&](const Raw &R, float *p, float *ud) {
 #pragma unroll
         for (int i = 0; i < NPARAM_MAX; i++) p[i] = 0.0f;
 #pragma unroll
@@ -87,8 +112,7 @@ __global__ void __launch_bounds__(64) k_bwd_ckpt(const CkptBwdArgs A)
             p[i] = psta[i];
             ud[i] = usta[i];
             if ((dmask >> i) & 1) {
-                float v = dynp[i][(int64_t)t * d.p[i].dyn_t_stride];
-                v = raw ? sigmoid_dyn_(v) : v;
+                const float v = raw ? sigmoid_dyn_(R.dv[i]) : R.dv[i];
                 if (use_dyn[i]) {
                     ud[i] = v;
                     p[i] = descale_(v, d.p[i].lo, d.p[i].hi);
@@ -104,12 +128,16 @@ __global__ void __launch_bounds__(64) k_bwd_ckpt(const CkptBwdArgs A)
 #pragma unroll
         for (int k = 0; k < 5; k++) st[k] = io.traj[((int64_t)seg * 5 + k) * N + L.n];
         // forward over the segment: storages entering each day and the two powers -> LDS
+        Raw nxt;
+        fetch(t0, nxt);
         for (int t = t0; t < t1; t++) {
             Step<MODEL, BETAET> s;
-            const float *xr = xb + (int64_t)t * d.x_t_stride;
-            s.P = xr[d.ch_prcp]; s.Tf = xr[d.ch_tmean]; s.PET = xr[d.ch_pet];
+            const Raw cur = nxt;
+            fetch(t + 1 < t1 ? t + 1 : t1 - 1, nxt);   // after the last day: the first day of the sweep below
+            if (t + 1 >= t1) fetch_grad(t1 - 1, nxt);
+            s.P = cur.f[0]; s.Tf = cur.f[1]; s.PET = cur.f[2];
             float p[NPARAM_MAX], ud[NP];
-            params_of(t, p, ud);
+            params_of(cur, p, ud);
             s.SP = st[0]; s.MW = st[1]; s.SM = st[2]; s.SUZ = st[3]; s.SLZ = st[4];
             s.template fwd<false>(p, nz, ac, elev, 0.0f, 0.0f);
             float *row = my + (t - t0) * 7 * 64;
@@ -122,22 +150,18 @@ __global__ void __launch_bounds__(64) k_bwd_ckpt(const CkptBwdArgs A)
         // adjoint over the segment, last day first
         for (int t = t1 - 1; t >= t0; t--) {
             Step<MODEL, BETAET> s;
-            const float *xr = xb + (int64_t)t * d.x_t_stride;
-            s.P = xr[d.ch_prcp]; s.Tf = xr[d.ch_tmean]; s.PET = xr[d.ch_pet];
+            const Raw cur = nxt;
+            fetch(t - 1 >= t0 ? t - 1 : t0, nxt);
+            fetch_grad(t - 1 >= t0 ? t - 1 : t0, nxt);
+            s.P = cur.f[0]; s.Tf = cur.f[1]; s.PET = cur.f[2];
             float p[NPARAM_MAX], ud[NP];
-            params_of(t, p, ud);
+            params_of(cur, p, ud);
             const float *row = my + (t - t0) * 7 * 64;
             s.SP = row[0]; s.MW = row[64]; s.SM = row[128]; s.SUZ = row[192]; s.SLZ = row[256];
             s.template fwd<true>(p, nz, ac, elev, row[5 * 64], row[6 * 64]);
 
             FluxGrad g;
-            const int64_t fs = (int64_t)T * d.B;
-            const int64_t go = (int64_t)t * d.B + L.b;
-            auto GF = [&](int k) -> float {
-                float v = io.grad_flux ? io.grad_flux[k * fs + go] : 0.0f;
-                if (io.grad_flux4 && k < 4) v += io.grad_flux4[k * fs + go];
-                return v;
-            };
+            auto GF = [&](int k) -> float { return cur.gf[k]; };
             const float gq = GF(HBVX_F_QSIM);
             const float wq = mu ? mu[(int64_t)t * d.mu_t_stride] : invM;
             g.gQ = gq * wq;
@@ -199,14 +223,87 @@ __global__ void __launch_bounds__(64) k_bwd_ckpt(const CkptBwdArgs A)
     }
 }
 
-// Checkpoint writer: the forward kernels run with no trajectory output and this pass is not needed --
-// the storages entering day s*K are produced by the forward itself when it is the streaming kernel
-// (TRJ == 3, hbv_stream2.h) or by the generic kernel below for everything else.
-struct CkptFwdArgs {
-    hbvx_desc d;
-    hbvx_fwd_out o;
-    int lgMp;
-    int K;
+// ---------------------------------------------------------------------------------------------
+// Re-materialisation for the block-wise adjoint (launch_ckpt.hip): one wavefront per (64 lanes,
+// K-day segment) of a block of days [t0, t0 + tb) steps forward from its checkpoint and writes the
+// block's trajectory rows [5, tb + 1, N] and powers [2, tb, N] (HBVX_TRAJ_ROWS, local day index) into
+// scratch.  All segments are independent: thousands of waves, no serial chain longer than K days.
+// The regular adjoint kernels then run on the block as on a tb-day record.
+// ---------------------------------------------------------------------------------------------
+struct RematArgs {
+    hbvx_desc d;          // the FULL problem (T, strides, parameter sources)
+    const float *ckpt;    // [ceil(T/K), 5, N]
+    float *traj, *aux;    // scratch rows of the block
+    int lgMp, K, t0, tb;
 };
+
+template <int MODEL, bool BETAET>
+__global__ void __launch_bounds__(64) k_ckpt_remat(const RematArgs A)
+{
+    constexpr int NP = NParamT<MODEL, BETAET>::value;
+    const hbvx_desc &d = A.d;
+    const LaneT L = lane_t(d, A.lgMp);
+    const int K = A.K, tb = A.tb;
+    const int64_t N = (int64_t)d.B * d.M;
+    const bool raw = d.raw_sigmoid != 0;
+    const float nz = d.nearzero;
+    const float ac = (MODEL == MODEL_HBV20 || MODEL == MODEL_HOURLY) ? d.ac[L.b] : 0.0f;
+    const float elev = (MODEL == MODEL_HBV20 || MODEL == MODEL_HOURLY) ? d.elev[L.b] : 0.0f;
+    const int l0 = blockIdx.y * K;                     // first local day of this segment
+    const int l1 = min(tb, l0 + K);
+    const int seg = (A.t0 + l0) / K;                   // t0 is a multiple of K
+
+    float p[NPARAM_MAX], psta[NP];
+    const float *dynp[NP];
+    bool use_dyn[NP];
+    unsigned dmask = 0;
+#pragma unroll
+    for (int i = 0; i < NPARAM_MAX; i++) p[i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        const hbvx_param_src &s = d.p[i];
+        float v = s.sta[(int64_t)L.b * s.sta_b_stride + L.j];
+        v = raw ? sigmoid_(v) : v;
+        psta[i] = descale_(v, s.lo, s.hi);
+        dynp[i] = s.dyn ? s.dyn + (int64_t)L.b * s.dyn_b_stride + L.j : s.sta;
+        use_dyn[i] = s.dyn && !(s.drop && s.drop[L.b]);
+        if (s.dyn) dmask |= 1u << i;
+    }
+    const float *xb = d.x + (int64_t)L.b * d.x_b_stride;
+    float st[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) st[k] = A.ckpt[((int64_t)seg * 5 + k) * N + L.n];
+
+    float nf[3], nd[NP];
+    auto fetch = [&](int t) {
+        const float *xr = xb + (int64_t)t * d.x_t_stride;
+        nf[0] = xr[d.ch_prcp]; nf[1] = xr[d.ch_tmean]; nf[2] = xr[d.ch_pet];
+#pragma unroll
+        for (int i = 0; i < NP; i++) nd[i] = ((dmask >> i) & 1) ? dynp[i][(int64_t)t * d.p[i].dyn_t_stride] : 0.0f;
+    };
+    fetch(A.t0 + l0);
+    for (int l = l0; l < l1; l++) {
+        Step<MODEL, BETAET> s;
+        s.P = nf[0]; s.Tf = nf[1]; s.PET = nf[2];
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            p[i] = psta[i];
+            if ((dmask >> i) & 1) {
+                const float v = raw ? sigmoid_dyn_(nd[i]) : nd[i];
+                if (use_dyn[i]) p[i] = descale_(v, d.p[i].lo, d.p[i].hi);
+            }
+        }
+        if (l + 1 < l1) fetch(A.t0 + l + 1);
+        s.SP = st[0]; s.MW = st[1]; s.SM = st[2]; s.SUZ = st[3]; s.SLZ = st[4];
+        s.template fwd<false>(p, nz, ac, elev, 0.0f, 0.0f);
+        if (L.active) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) A.traj[((int64_t)k * (tb + 1) + l) * N + L.n] = st[k];
+            A.aux[(int64_t)l * N + L.n] = s.sw0;
+            A.aux[((int64_t)tb + l) * N + L.n] = s.ef0;
+        }
+        st[0] = s.SP3; st[1] = s.MW3; st[2] = s.SM4; st[3] = s.SUZ4; st[4] = s.SLZ2;
+    }
+}
 
 } // namespace hbvx

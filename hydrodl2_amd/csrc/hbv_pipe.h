@@ -64,6 +64,7 @@ struct PipeArgs {
     hbvx_fwd_out o;
     int lgMp;
     int Kt;
+    int ckptK;   // HBVX_TRAJ_CKPT: keep only the storages entering every ckptK-th day ([ceil(T/K),5,N]); 0: rows
 };
 
 // LDS layout in floats for Kt days per tile
@@ -239,7 +240,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
         if (L.active) {
             o.state_out[0 * N + L.n] = SP;
             o.state_out[1 * N + L.n] = MW;
-            if (TRAJ) {
+            if (TRAJ && !A.ckptK) {
                 o.traj[((int64_t)0 * (T + 1) + T) * N + L.n] = SP;
                 o.traj[((int64_t)1 * (T + 1) + T) * N + L.n] = MW;
             }
@@ -324,7 +325,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
             o.state_out[2 * N + L.n] = SM;
             o.state_out[3 * N + L.n] = SUZ;
             o.state_out[4 * N + L.n] = SLZ;
-            if (TRAJ) {
+            if (TRAJ && !A.ckptK) {
                 o.traj[((int64_t)2 * (T + 1) + T) * N + L.n] = SM;
                 o.traj[((int64_t)3 * (T + 1) + T) * N + L.n] = SUZ;
                 o.traj[((int64_t)4 * (T + 1) + T) * N + L.n] = SLZ;
@@ -375,7 +376,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
         }
         if (L.active) {
             o.state_out[2 * N + L.n] = SM;
-            if (TRAJ) o.traj[((int64_t)2 * (T + 1) + T) * N + L.n] = SM;
+            if (TRAJ && !A.ckptK) o.traj[((int64_t)2 * (T + 1) + T) * N + L.n] = SM;
         }
       }
     } else if (wave == 2 && !(CAP && MANY)) {
@@ -424,7 +425,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
         if (L.active) {
             o.state_out[3 * N + L.n] = SUZ;
             o.state_out[4 * N + L.n] = SLZ;
-            if (TRAJ) {
+            if (TRAJ && !A.ckptK) {
                 o.traj[((int64_t)3 * (T + 1) + T) * N + L.n] = SUZ;
                 o.traj[((int64_t)4 * (T + 1) + T) * N + L.n] = SLZ;
             }
@@ -579,6 +580,29 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                 const auto rSM = rsrc(o.traj + 2 * SR + dB), rSW = rsrc(o.aux + dB),
                            rEF = rsrc(o.aux + (int64_t)T * N + dB);
                 const auto rSUZ = rsrc(o.traj + 3 * SR + dC), rSLZ = rsrc(o.traj + 4 * SR + dC);
+                if (A.ckptK) {
+                    // checkpoints: of each stage tile only the days that are multiples of K, into
+                    // rows [(day / K) * 5 + storage]; the powers are not kept
+                    const int cK = A.ckptK;
+                    const auto rall = __builtin_amdgcn_make_buffer_rsrc(o.traj, 0, -1, 0x00020000);
+                    auto putc = [&](int day, int k, float v) {
+                        const unsigned so = (unsigned)(((int64_t)(day / cK) * 5 + k) * row_bytes);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rall, voff, so, 0);
+                    };
+                    for (int tt = w; tt < Kt; tt += NRD) {
+                        if (tt < ntA && (tA * Kt + tt) % cK == 0) {
+                            putc(tA * Kt + tt, 0, bufA[tt * 256 + 128]);
+                            putc(tA * Kt + tt, 1, bufA[tt * 256 + 192]);
+                        }
+                        if (tt < ntB && (tB * Kt + tt) % cK == 0) putc(tB * Kt + tt, 2, (bufB + (tt * OBR + NFB) * 64)[0]);
+                        if (tt < ntC && (tC * Kt + tt) % cK == 0) {
+                            putc(tC * Kt + tt, 3, bufC[tt * 448 + 320]);
+                            putc(tC * Kt + tt, 4, bufC[tt * 448 + 384]);
+                        }
+                    }
+                    PIPE_BARRIER();
+                    continue;
+                }
                 for (int tt = w; tt < Kt; tt += NRD) {
                     const unsigned soff = (unsigned)tt * row_bytes;
                     float a0, a1, b0v, b1, b2, c0, c1;

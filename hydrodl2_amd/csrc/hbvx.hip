@@ -663,6 +663,7 @@ extern "C" int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *s
             const int K = HBVX_TRAJ_CKPT_DAYS(out->traj_layout);
             if (K != 4 && K != 8 && K != 16) return fail(HBVX_E_SHAPE, "checkpoint interval must be 4, 8 or 16");
             if (out->aux) return fail(HBVX_E_SHAPE, "checkpoints: aux must be NULL");
+            if (try_fwd_pipe(d, out, stream, &rc)) return rc;
             if (try_fwd_stream(d, out, stream, &rc)) return rc;
             FwdArgs ca;
             ca.d = *d;

@@ -41,15 +41,21 @@ bool hbvx_host::try_fwd_pipe(const hbvx_desc *d, const hbvx_fwd_out *out, void *
         const bool pmodel = d->model == HBVX_MODEL_HBV10 || d->model == HBVX_MODEL_HBV11P ||
                             d->model == HBVX_MODEL_HBV20 || d->model == HBVX_MODEL_HOURLY;
         const size_t lds = (size_t)PipeLds(Kt, nd > 0 ? (many ? nd : PIPE_FEWDYN) : 0, cap).total * 4;
-        if (use_tiled(d) && !(fv && !strcmp(fv, "tiled")) && pmodel && off32 && !large &&
+        // HBVX_TRAJ_CKPT: the row drainers keep every K-th day only (no powers)
+        const int ckpt_k = (out->traj && HBVX_TRAJ_KIND(out->traj_layout) == HBVX_TRAJ_CKPT)
+                               ? HBVX_TRAJ_CKPT_DAYS(out->traj_layout) : 0;
+        const bool ckpt_fits = !ckpt_k || ((int64_t)((d->T + ckpt_k - 1) / ckpt_k) * 5 * d->B * d->M * 4 < (int64_t)1 << 32);
+        if (ckpt_fits && use_tiled(d) && !(fv && !strcmp(fv, "tiled")) && pmodel && off32 && !large &&
             nd <= PIPE_MAXDYN && (int)lds <= LDS_BUDGET && wgs_p < 4096 && !d->muwts && out->flux && d->T >= 4 * Kt &&
-            (out->traj != nullptr) == (out->aux != nullptr) && (int64_t)d->B * d->M * 4 * Kt < (int64_t)1 << 31 &&
+            (ckpt_k ? out->aux == nullptr : (out->traj != nullptr) == (out->aux != nullptr)) &&
+            (int64_t)d->B * d->M * 4 * Kt < (int64_t)1 << 31 &&
             (int64_t)nfl * d->T * d->B * 4 < (int64_t)1 << 31) {
             PipeArgs pa;
             pa.d = *d;
             pa.o = *out;
             pa.lgMp = lg_members(d->M);
             pa.Kt = Kt;
+            pa.ckptK = ckpt_k;
             const int bpw_p = 64 >> pa.lgMp;
             dim3 grid_p((d->B + bpw_p - 1) / bpw_p);
             int pthreads = env_int("HBVX_PIPE_THREADS", 1024); // 3 steppers + filler + drainers (hbv_pipe.h)

@@ -354,7 +354,10 @@ class HbvPath(torch.autograd.Function):
                 if ps.dyn_off >= 0 and gp[ps.dyn_tensor_idx] is not None:
                     gp[ps.dyn_tensor_idx].zero_()
             return (None, gx, None, gmu, None, None, *gp)
-        ws_bytes = lib.backward_workspace_bytes(desc) if ctx.traj_layout == _abi.TRAJ_ROWS else 0   # packed / checkpoints: single-pass adjoints
+        if (ctx.traj_layout & 0xFF) == _abi.TRAJ_CKPT:
+            ws_bytes = lib.ckpt_workspace_bytes(desc, ctx.traj_layout >> 8)     # block-wise re-materialisation
+        else:
+            ws_bytes = lib.backward_workspace_bytes(desc) if ctx.traj_layout == _abi.TRAJ_ROWS else 0   # packed: single pass
         if ws_bytes:
             ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
             io.workspace, io.workspace_bytes = _ptr(ws), ws_bytes

@@ -206,6 +206,10 @@ int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream);
 int hbvx_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *stream);
 /* Scratch bytes the time-parallel adjoint wants for this problem (0: not applicable). */
 uint64_t hbvx_backward_workspace_bytes(const hbvx_desc *d);
+/* Scratch bytes hbvx_backward wants with HBVX_TRAJ_CKPT and interval K (hbvx_bwd_io.workspace): one
+ * block of re-materialised trajectory + the block's gradient series + what the regular adjoint needs
+ * for a block.  With it the adjoint runs block-wise on the fast kernels; without, a serial fallback. */
+uint64_t hbvx_ckpt_workspace_bytes(const hbvx_desc *d, int32_t K);
 
 /* q [S,T,B] -> uh [B,L] (normalised gamma UH) and q_rout [S,T,B]. */
 int hbvx_route_forward(const hbvx_route_desc *r, const float *q, float *uh, float *q_rout,

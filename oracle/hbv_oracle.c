@@ -40,6 +40,8 @@ static int fail(int code, const char *msg)
 }
 
 int hbvx_version(void) { return HBVX_ABI_VERSION; }
+/* the oracle re-materialises per lane and needs no scratch */
+uint64_t hbvx_ckpt_workspace_bytes(const hbvx_desc *d, int32_t K) { (void)d; (void)K; return 0; }
 /* the oracle keeps the plain row layout of the trajectory */
 int hbvx_preferred_traj_layout(const hbvx_desc *d) { (void)d; return HBVX_TRAJ_ROWS; }
 const char *hbvx_last_error(void) { return g_err; }

@@ -256,11 +256,18 @@ def test_zero_except_matches_definition(rows, width, r0, r1, gw, keep, hip_backe
 @pytest.mark.parametrize("name,K", [("hbv_dyn2", 8), ("hbv_static_m16", 16), ("hbv11p_dyn_all", 4), ("hbv2_dyn3", 8),
                                     ("hbv_warmup_states", 4), ("hbv_m3_xgrad", 8), ("hbv_muwts", 8),
                                     ("hourly_dyn3", 16), ("hbv2_dyn3_routing", 4)])
-def test_checkpointed_adjoint_on_gpu(name, K, hip_backend, monkeypatch):
+@pytest.mark.parametrize("how", ["block512", "block16", "lds"])
+def test_checkpointed_adjoint_on_gpu(name, K, how, hip_backend, monkeypatch):
     """HBVX_TRAJ_CKPT on the GPU against the reference's fixtures: the streaming forward writes the
     checkpoints where it has an instance (the delta-MG dynamic sets), the generic one-wave forward
-    elsewhere; k_bwd_ckpt re-materialises K-day segments in LDS."""
+    elsewhere (the pipelined one on small grids); the adjoint runs block-wise -- k_ckpt_remat rebuilds a
+    block of the trajectory, the regular adjoint kernels consume it -- or, without scratch, as k_bwd_ckpt
+    with its K-day segment in LDS."""
     monkeypatch.setenv("HBVX_CKPT_DAYS", str(K))
+    if how == "block16":      # several blocks: the adjoint is carried from block to block
+        monkeypatch.setenv("HBVX_CKPT_BLOCK", "16")
+    if how == "lds":          # the serial fallback that needs no scratch
+        monkeypatch.setenv("HBVX_CKPT_BLOCKWISE", "0")
     ref = load_golden(name)
     res = run_case(name, "cuda:0")
     if "states" in res and res["states"].shape != ref["states"].shape:
