@@ -158,3 +158,41 @@ def test_hbv2_many_basins(hip_backend):
     # time-parallel one; they agree to rounding (composed chunk maps vs the serial sweep)
     torch.testing.assert_close(pd.grad[:, sel], pd2.grad, rtol=1e-4, atol=1e-6 * float(pd2.grad.abs().max()))
     torch.testing.assert_close(ps.grad[sel], ps2.grad, rtol=1e-4, atol=1e-6 * float(ps2.grad.abs().max()))
+
+
+def _slice_problem(prob, pick):
+    """The sub-problem of basins `pick` (every per-basin array of tests/abi_util.make_problem)."""
+    sub = dict(prob)
+    sub["B"] = len(pick)
+    sub["x"] = np.ascontiguousarray(prob["x"][:, pick])
+    sub["params"] = np.ascontiguousarray(prob["params"][:, pick])
+    sub["gflux"] = np.ascontiguousarray(prob["gflux"][:, :, pick])
+    sub["grouted"] = np.ascontiguousarray(prob["grouted"][:, :, pick])
+    for k in ("ac", "elev"):
+        if k in prob:
+            sub[k] = np.ascontiguousarray(prob[k][pick])
+    if "drop" in prob:
+        sub["drop"] = np.ascontiguousarray(prob["drop"][:, pick])
+    return sub
+
+
+@pytest.mark.parametrize("model,M,B,T,dyn", [
+    ("Hbv_2", 16, 8200, 300, ("parBETA", "parK0", "parBETAET")),
+    ("Hbv_2_hourly", 4, 32800, 256, ("parBETA", "parK0", "parBETAET")),
+    ("Hbv", 16, 8200, 260, ("parBETA", "parBETAET")),
+    ("Hbv_1_1p", 16, 8200, 256, ()),
+])
+def test_streaming_kernels_oracle_spot_check(model, M, B, T, dyn, hip_backend, oracle_path):
+    """>= 2048 wavefronts of state, so BOTH directions take the streaming kernels (packed trajectory,
+    hbv_stream2.h): three basins pulled out of the big run -- first, middle, last (the last wave is
+    partly filled) -- against the oracle run on those basins alone.  Loss on every flux series."""
+    prob = make_problem(model=model, T=T, B=B, M=M, dyn=dyn, drop_frac=0.25 if dyn else 0.0, seed=5)
+    got = run_problem(prob, None, device="cuda:0", x_grad=True)
+    pick = [0, B // 2 + 1, B - 1]
+    want = run_problem(_slice_problem(prob, pick), oracle_path, device="cpu", x_grad=True)
+    assert_close("flux", got["flux"][:, :, pick], want["flux"], 1e-4, 1e-5)
+    if "routed" in want:
+        assert_close("routed", got["routed"][:, :, pick], want["routed"], 1e-4, 1e-5)
+    assert_close("state_out", got["state_out"][:, pick], want["state_out"], 1e-4, 1e-5)
+    assert_close("g_params", got["g_params"][:, pick], want["g_params"], 1e-3, 1e-5)
+    assert_close("g_x", got["g_x"][:, pick], want["g_x"], 1e-3, 1e-5)
