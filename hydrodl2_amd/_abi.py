@@ -49,7 +49,7 @@ class Desc(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("model", C.c_int32), ("T", C.c_int32),
                 ("B", C.c_int32), ("M", C.c_int32), ("n_param", C.c_int32),
                 ("raw_sigmoid", C.c_int32), ("ch_prcp", C.c_int32), ("ch_tmean", C.c_int32),
-                ("ch_pet", C.c_int32), ("nearzero", C.c_float), ("reserved0", C.c_int32),
+                ("ch_pet", C.c_int32), ("nearzero", C.c_float), ("adj_stop", C.c_int32),
                 ("x", _fp), ("x_t_stride", C.c_int64), ("x_b_stride", C.c_int64),
                 ("ac", _fp), ("elev", _fp), ("muwts", _fp),
                 ("mu_t_stride", C.c_int64), ("mu_b_stride", C.c_int64),

@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(64) k_adj_fwd(const AdjFwdArgs A)
 #pragma unroll
             for (int k = 0; k < 5; k++) o.traj[((int64_t)k * (T + 1) + t) * N + L.n] = x[k];
         }
-        adj_newton<BETAET>(s, p, x, 1.0f, d.adj_gtol, d.adj_max_iter, xn);
+        adj_newton<BETAET>(s, p, x, 1.0f, d.adj_gtol, d.adj_max_iter, xn, d.adj_stop != 0);
 #pragma unroll
         for (int k = 0; k < 5; k++) x[k] = xn[k];
         if (o.flux) {

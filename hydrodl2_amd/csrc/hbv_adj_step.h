@@ -15,8 +15,10 @@
 // inclusive clamps) where the reference uses an autograd Jacobian (hbv_adj.py:531,557) and
 // finite differences for dG/dtheta (hbv_adj.py:606).
 //
-// Deliberate difference: the stopping rule is evaluated PER LANE; the reference's `torch.max(resnorm)`
-// (hbv_adj.py:544) couples every basin x member of the batch through one global maximum.
+// Stopping rule: per LANE by default.  The reference's `torch.max(resnorm)` (hbv_adj.py:544) couples
+// every basin x member of the batch through one global maximum, so all lanes take as many updates
+// as the slowest; `vote` reproduces that over the 64 lanes of a wavefront (hbvx_desc.adj_stop = 1) --
+// a batch-wide maximum would cost a grid barrier per Newton update and day.
 #pragma once
 
 #include "hbv_step.h"
@@ -154,9 +156,19 @@ struct AdjStep {
 
 // One implicit day: x <- solution of G(x) = (x - xt)/dt - f(x) = 0 starting from xt.
 // Returns the number of Newton updates taken.  hbv_adj.py:516-581
+HBVX_HD bool adj_any_(bool pred, bool vote)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return vote ? __builtin_amdgcn_ballot_w64(pred) != 0 : pred;
+#else
+    (void)vote;
+    return pred;
+#endif
+}
+
 template <bool BETAET>
 HBVX_HD int adj_newton(AdjStep<BETAET> &s, const float *p, const float *xt, float idt, float gtol,
-                       int max_iter, float *x)
+                       int max_iter, float *x, bool vote = false)
 {
     float g[5], dx[5];
 #pragma unroll
@@ -175,9 +187,9 @@ HBVX_HD int adj_newton(AdjStep<BETAET> &s, const float *p, const float *xt, floa
     // refresh, the Jacobian again at the same point.
     AdjStep<BETAET> e = s;
     int it = 0;
-    while (res > gtol && it <= max_iter) {
+    while (adj_any_(res > gtol, vote) && it <= max_iter) {
         it++;
-        if (res > 0.2f * res0) {
+        if (adj_any_(res > 0.2f * res0, vote)) {
             s.F00 = e.F00; s.F01 = e.F01; s.F10 = e.F10; s.F11 = e.F11; s.F20 = e.F20; s.F21 = e.F21;
             s.F22 = e.F22; s.F30 = e.F30; s.F31 = e.F31; s.F32 = e.F32; s.F33 = e.F33; s.F43 = e.F43;
             s.F44 = e.F44;

@@ -49,6 +49,9 @@ class HbvAdj(torch.nn.Module):
         self.device = device
         self.newton_gtol = 1e-3      # hbv_adj.py:519
         self.newton_max_iter = 3     # hbv_adj.py:518
+        # 'lane': every (basin, member) stops for itself; 'global': the reference's rule (hbv_adj.py:544,546:
+        # one torch.max over the batch) applied to the 64 lanes of a wavefront (include/hbvx.h, adj_stop)
+        self.newton_stop = 'lane'
         self.parameter_bounds = {
             'parBETA': [1.0, 6.0], 'parFC': [50, 1000], 'parK0': [0.05, 0.9],
             'parK1': [0.01, 0.5], 'parK2': [0.001, 0.2], 'parLP': [0.2, 1],
@@ -71,6 +74,9 @@ class HbvAdj(torch.nn.Module):
             self.ad_efficient = config.get('ad_efficient', self.ad_efficient)
             self.newton_gtol = config.get('newton_gtol', self.newton_gtol)
             self.newton_max_iter = config.get('newton_max_iter', self.newton_max_iter)
+            self.newton_stop = config.get('newton_stop', self.newton_stop)
+            if self.newton_stop not in ('lane', 'global'):
+                raise ValueError("newton_stop must be 'lane' or 'global'")
             if 'parBETAET' in self.dynamic_params:
                 self.parameter_bounds['parBETAET'] = [0.3, 5]
         self.set_parameters()
@@ -118,7 +124,8 @@ class HbvAdj(torch.nn.Module):
               self.variables.index('pet'))
         base = dict(model=_abi.MODEL_HBVADJ, n_param=n, n_flux=1, B=B, M=M, raw_sigmoid=True,
                     channels=ch, nearzero=float(self.nearzero),
-                    adj_gtol=float(self.newton_gtol), adj_max_iter=int(self.newton_max_iter))
+                    adj_gtol=float(self.newton_gtol), adj_max_iter=int(self.newton_max_iter),
+                    adj_stop=1 if self.newton_stop == 'global' else 0)
         state = None  # zeros (hbv_adj.py:254)
         wu = self.warm_up
         if wu > 0:  # hbv_adj.py:257-274: static parameters from row warm_up-1, differentiable

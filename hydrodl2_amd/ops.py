@@ -70,6 +70,7 @@ class StepConfig:
     want_traj: bool = False    # keep the state trajectory even without autograd
     adj_gtol: float = 1e-3     # implicit scheme only (hbv_adj.py:519)
     adj_max_iter: int = 3      # implicit scheme only (hbv_adj.py:518)
+    adj_stop: int = 0          # implicit scheme only: 0 per-lane stopping rule, 1 per wavefront (hbv_adj.py:544)
     mu_t0: Optional[int] = None  # first row of muwts used by this call (None: same as t0)
     traj_layout: int = 0       # set by HbvPath.forward: enum hbvx_traj_layout of the saved trajectory
     ckpt_days: int = 0         # 4 / 8 / 16: keep K-day checkpoints instead of the trajectory (memory-lean adjoint)
@@ -192,7 +193,7 @@ def _fill_desc(cfg: StepConfig, x, state_in, muwts, ac, elev, ptensors) -> _abi.
             if ps.drop is not None:
                 s.drop = ps.drop.data_ptr()
         s.lo, s.hi = ps.lo, ps.hi
-    d.adj_gtol, d.adj_max_iter = cfg.adj_gtol, cfg.adj_max_iter
+    d.adj_gtol, d.adj_max_iter, d.adj_stop = cfg.adj_gtol, cfg.adj_max_iter, cfg.adj_stop
     return d
 
 

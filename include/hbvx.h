@@ -118,7 +118,11 @@ typedef struct hbvx_desc {
                              (hbv.py:201); 0: inputs already in [0,1] (hbv_2.py:211) */
     int32_t ch_prcp, ch_tmean, ch_pet; /* channel of each forcing (hbv.py:388-390) */
     float nearzero;       /* hbv.py:54 */
-    int32_t reserved0;
+    int32_t adj_stop;     /* hbvx_adj_* only: who decides that a day's Newton iteration stops.  0: every
+                             lane for itself.  1: the slowest lane of the WAVEFRONT (64 lanes = 64/Mp
+                             basins x Mp members) -- the reference's rule, one torch.max over the batch
+                             (hbv_adj.py:544,546), restricted to the lanes that share a wavefront: a
+                             batch-wide maximum would need a grid barrier per Newton update */
     const float *x;       /* forcings: (t,b,c) at x[t*x_t_stride + b*x_b_stride + c] */
     int64_t x_t_stride, x_b_stride;
     const float *ac;      /* [B] HBV 2.0 `ac_all`  (hbv_2.py:345), else NULL */

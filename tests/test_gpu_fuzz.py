@@ -18,7 +18,7 @@ from .abi_util import assert_close, make_problem, run_problem
 
 pytestmark = pytest.mark.gpu
 
-N_DRAWS, SEED, MAX_FLIP_DRAWS = 200, 20261004, 6
+N_DRAWS, SEED, MAX_FLIP_DRAWS = 200, 20261004, 12   # measured on MI355X: 6 draws, 1-9 elements each, all in g_x
 
 
 def _draw(rng):

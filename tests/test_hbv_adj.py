@@ -192,3 +192,63 @@ def test_hip_one_wave_kernels_still_match(hip_backend, monkeypatch):
     got, ggot, want, gwant, _ = _run_case("cuda:0", CASES[1], tight=True)
     _close("flow_sim", got, want, 2e-4, 2e-5)
     _close("grad", ggot, gwant, 2e-3, 2e-4)
+
+
+@pytest.mark.gpu
+def test_hip_global_newton_rule_is_the_oracles_global_rule(hip_backend):
+    """newton_stop='global' (hbvx_desc.adj_stop = 1): all 64 lanes of a wavefront take as many Newton
+    updates as the slowest of them -- for a batch of exactly one wavefront (4 basins x 16 members) that
+    is the reference's batch-global rule (hbv_adj.py:544,546), which the oracle implements as
+    stop='global'.  The HIP result with the global rule must match the oracle's global run, and must be
+    closer to it than the per-lane HIP result is (so the switch is shown to act)."""
+    T, B, M = 60, 4, 16
+    x, p, w = _inputs(T, B, M, 91, True)
+    cfg = dict(nmul=M, dynamic_params={"HbvAdj": ["parBETA", "parBETAET"]})
+    got_g, gg_g = _product("cuda:0", x, p, w, dict(cfg, newton_stop="global"))
+    got_l, gg_l = _product("cuda:0", x, p, w, dict(cfg, newton_stop="lane"))
+    want_g, gw_g, its_g = _oracle(x, p, w, cfg, stop="global")
+    want_l, _, its_l = _oracle(x, p, w, cfg, stop="lane")
+    assert float(its_g.max()) <= 4
+    assert np.abs(want_g - want_l).max() > 0, "the two rules coincide on this case: not a test of the switch"
+    # un-converged Newton (gtol 1e-3): float32 against float64 at the tolerances of the reference-policy tests
+    _close("flow_sim (global)", got_g, want_g, 1e-3, 5e-4)
+    # gradients of an un-converged iteration are sensitive element by element: compare in the L2 norm
+    rel = np.linalg.norm(gg_g - gw_g) / np.linalg.norm(gw_g)
+    assert rel < 2e-2, rel
+    e_g = np.abs(got_g - want_g).max()
+    e_l = np.abs(got_l - want_g).max()
+    assert e_g < e_l, (e_g, e_l)
+
+
+@pytest.mark.gpu
+def test_hip_cfg4_full_length_and_oracle_spot_check(hip_backend):
+    """BASELINE config 4 at its full size -- 671 basins x 16 members x 7300 days, tiled forward +
+    time-parallel adjoint: finite and basin-independent; and a float64-oracle spot check (values and
+    gradients) of three basins over 1460 days with the reference's Newton policy."""
+    import hydrodl2_amd
+    dev = torch.device("cuda:0")
+    H = hydrodl2_amd.load_model("hbv_adj", "HbvAdj")
+    cfg = {"nmul": 16, "dynamic_params": {"HbvAdj": ["parBETAET"]}}
+    m = H(cfg, dev)
+    T, B, M = 7300, 671, 16
+    x = torch.from_numpy(synth.forcing(T, B, 92)).to(dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(4)
+    p = torch.randn((T, B, 13 * M + 2), generator=g, device=dev).requires_grad_(True)
+    out = m({"x_phy": x}, p)["flow_sim"]
+    out.sum().backward()
+    assert out.shape == (T, B, 1) and torch.isfinite(out).all() and torch.isfinite(p.grad).all()
+    sel = [0, 335, 670]
+    pick = torch.tensor(sel, device=dev)
+    p2 = p.detach()[:, pick].contiguous().requires_grad_(True)
+    out2 = m({"x_phy": x[:, pick].contiguous()}, p2)["flow_sim"]
+    assert torch.equal(out[:, pick], out2)
+    # oracle: the first 1460 days of those three basins (a day-by-day float64 autograd loop)
+    Ts = 1460
+    xs, ps = x[:Ts, pick].cpu(), p.detach()[:Ts, pick].cpu()
+    ws = torch.from_numpy(synth.loss_weights((Ts, 3, 1), 92, 71))
+    got, ggot = _product("cuda:0", xs, ps, ws, cfg)
+    want, gwant, its = _oracle(xs, ps, ws, cfg)
+    assert float(its.max()) <= 4
+    _close("flow_sim", got, want, 5e-3, 5e-4)
+    _close("grad", ggot, gwant, 5e-2, 5e-3)
