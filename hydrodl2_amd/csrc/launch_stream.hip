@@ -74,13 +74,15 @@ void go_fwd2(int trj, const StreamArgs &sa, dim3 grid, hipStream_t st)
 // true when four waves per SIMD hold the grid in fewer rounds than three (hbv_stream2.h, W4)
 bool four_waves_pay(int64_t wgs)
 {
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
-            v = 256;
-        n_cu = v;
+    static int n_cu_of[64] = {0};
+    int dev = 0, n_cu = 256;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+        if (n_cu_of[dev] == 0) {
+            int v = 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+            n_cu_of[dev] = v;
+        }
+        n_cu = n_cu_of[dev];
     }
     const int64_t s3 = (int64_t)n_cu * 4 * 3, s4 = (int64_t)n_cu * 4 * 4;
     const int force = env_int("HBVX_STREAM_W4", -1);

@@ -40,15 +40,16 @@ extern "C" uint64_t hbvx_lstm_workspace_bytes(const hbvx_lstm_desc *d)
 
 static int lstm_cu_count()
 {
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
-            v = 256;
-        n_cu = v;
+    // per device (the caller makes the tensors' device current: hydrodl2_amd/ops.py::_device_guard)
+    static int n_cu[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (n_cu[dev] == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        n_cu[dev] = v;
     }
-    return n_cu;
+    return n_cu[dev];
 }
 
 template <typename K>
@@ -98,6 +99,8 @@ extern "C" int hbvx_lstm_forward(const hbvx_lstm_desc *d, const float *w_hh, con
     a.w_hh = w_hh; a.gx = gx; a.gates = gates; a.c_all = c_all; a.h_all = h_all;
     a.cnt = (unsigned *)workspace;
     a.xch = (float *)((char *)workspace + lstm_counter_bytes(d));
+    a.spin_limit = (unsigned)env_int("HBVX_LSTM_SPIN_LIMIT", (int)LSTM_SPIN_LIMIT);
+    a.drop_wg = env_int("HBVX_LSTM_DEBUG_DROP_WG", -1);
     // 8 units per workgroup while twice the workgroups still fit one launch at one per CU, else 16
     const int n_cu = lstm_cu_count();
     const bool small = env_int("HBVX_LSTM_UNITS", a.ntile * (d->H / 8) <= n_cu ? 8 : 16) == 8;
@@ -129,6 +132,8 @@ extern "C" int hbvx_lstm_backward(const hbvx_lstm_desc *d, const float *w_hh, co
     a.w_hh = w_hh; a.gx = gates; a.gates = grad_gates; a.c_in = c_all; a.dh = grad_h;
     a.cnt = (unsigned *)workspace;
     a.xch = (float *)((char *)workspace + lstm_counter_bytes(d));
+    a.spin_limit = (unsigned)env_int("HBVX_LSTM_SPIN_LIMIT", (int)LSTM_SPIN_LIMIT);
+    a.drop_wg = env_int("HBVX_LSTM_DEBUG_DROP_WG", -1);
     e = d->H == 64 ? launch_lstm(k_lstm_bwd<64>, a, 4, st)
       : d->H == 128 ? launch_lstm(k_lstm_bwd<128>, a, 8, st) : launch_lstm(k_lstm_bwd<256>, a, 16, st);
     if (e != hipSuccess) return hip_fail(e, "hbvx_lstm_backward launch");

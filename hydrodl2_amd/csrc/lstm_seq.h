@@ -49,6 +49,8 @@ struct LstmArgs {
     float *c_all, *h_all;            // forward outputs [T,B,H]
     float *xch;                      // exchange slabs, one per time step and row tile, sentinel-filled by the host
     unsigned *cnt;                   // cnt[0] = error word (zeroed by the host)
+    unsigned spin_limit;             // polls before a hand-off gives up (LSTM_SPIN_LIMIT; lowered by the fault-injection test)
+    int drop_wg;                     // fault injection (tests): this workgroup never publishes its slab; -1: none
 };
 
 // Gate non-linearities on the hardware transcendentals (v_exp_f32 / v_rcp_f32, about 1 ulp each): absolute
@@ -86,7 +88,7 @@ __device__ __forceinline__ bool lstm_fetch(const LstmArgs &a, const float *slab_
             mx = max(max(mx, u[2]), u[3]);
         }
         if (__ballot(mx == LSTM_SENTINEL) == 0) return true;
-        if (spins > LSTM_SPIN_LIMIT) {
+        if (spins > a.spin_limit) {
             if ((threadIdx.x & 63) == 0) __hip_atomic_store(&a.cnt[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return false;
         }
@@ -127,6 +129,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         }
     }
     const size_t slab = (size_t)H * LSTM_ROWS;      // floats per (step, tile): [H/4][16 rows][4 units]
+    // A hand-off time-out must never be silent: the wave that timed out raises this flag BEFORE the
+    // step's barrier, every wave reads it AFTER the barrier, the finishing waves poison the last output
+    // step and the whole workgroup leaves (a wave that simply returned would let the others sum stale
+    // partial tiles into finite, wrong values).  Its row-tile partners time out on its missing slab.
+    __shared__ int timed_out;
+    if (threadIdx.x == 0) timed_out = 0;
+    __syncthreads();
     float c = 0.0f;
     for (int t = 0; t < a.T; ++t) {
         const size_t e = ((size_t)t * a.B + rowc) * H + unit;
@@ -134,10 +143,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         if (fin) acc = *reinterpret_cast<const lstm_f4 *>(a.gx + e * 4);
         if (t > 0) {
             lstm_f4 hv[KQ];
-            if (!lstm_fetch<KQ>(a, a.xch + ((size_t)(t - 1) * a.ntile + tile) * slab, (int)(slab * 4), w * (H / 16), kq, n, hv)) {
-                if (live) a.h_all[((size_t)(a.T - 1) * a.B + row) * H + unit] = __builtin_nanf("");
-                return;
-            }
+            if (!lstm_fetch<KQ>(a, a.xch + ((size_t)(t - 1) * a.ntile + tile) * slab, (int)(slab * 4), w * (H / 16), kq, n, hv))
+                timed_out = 1;                      // every lane of the wave stores the same word
             lstm_f4 p[UG];
 #pragma unroll
             for (int g = 0; g < UG; ++g) p[g] = lstm_f4{0, 0, 0, 0};
@@ -151,6 +158,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
             for (int g = 0; g < UG; ++g) part[t & 1][w][g][l] = p[g];
             __syncthreads();                        // the only barrier of a step; part[] is two deep
+            if (timed_out) {
+                if (live) a.h_all[((size_t)(a.T - 1) * a.B + row) * H + unit] = __builtin_nanf("");
+                return;
+            }
             if (fin)
                 acc += (part[t & 1][0][w][l] + part[t & 1][1][w][l]) + (part[t & 1][2][w][l] + part[t & 1][3][w][l]);
         }
@@ -164,7 +175,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             a.c_all[e] = c;
             a.h_all[e] = h;
         }
-        if (t + 1 < a.T) {
+        if (t + 1 < a.T && (int)blockIdx.x != a.drop_wg) {
             // the wave's 64 lanes cover 256 contiguous bytes: two whole lines, one store instruction
             float *xp = a.xch + ((size_t)t * a.ntile + tile) * slab + ((size_t)(u0 >> 2) * LSTM_ROWS + n) * 4 + kq;
             __hip_atomic_store(xp, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -195,6 +206,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 wreg[j * 4 + i] = a.w_hh[(size_t)(i * H + w * (H / 4) + 4 * j + kq) * H + s * LSTM_UNITS + m];
     }
     const size_t slab = (size_t)H * LSTM_ROWS * 4;  // floats per (step, tile): [H units][16 rows][4 gates]
+    __shared__ int timed_out;                       // as in k_lstm_fwd: raised before the barrier, acted on after it
+    if (threadIdx.x == 0) timed_out = 0;
+    __syncthreads();
     float dc_carry = 0.0f;
     for (int t = a.T - 1; t >= 0; --t) {
         const size_t e = ((size_t)t * a.B + rowc) * H + unit;
@@ -204,13 +218,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         float dh = a.dh[e];
         if (t + 1 < a.T) {
             lstm_f4 gv[KB];
-            if (!lstm_fetch<KB>(a, a.xch + ((size_t)(t + 1) * a.ntile + tile) * slab, (int)(slab * 4), w * (H / 4), kq, n, gv)) {
-                if (live) {
-                    const lstm_f4 bad = {__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
-                    *reinterpret_cast<lstm_f4 *>(a.gates + (((size_t)0 * a.B + row) * H + unit) * 4) = bad;
-                }
-                return;
-            }
+            if (!lstm_fetch<KB>(a, a.xch + ((size_t)(t + 1) * a.ntile + tile) * slab, (int)(slab * 4), w * (H / 4), kq, n, gv))
+                timed_out = 1;
             lstm_f4 p0 = {0, 0, 0, 0}, p1 = {0, 0, 0, 0}, p2 = {0, 0, 0, 0}, p3 = {0, 0, 0, 0};
 #pragma unroll
             for (int j = 0; j < KB; ++j) {
@@ -228,6 +237,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
             for (int i = 0; i < 4; ++i) part[t & 1][w][i][l] = p0[i];
             __syncthreads();                        // the only barrier of a step; part[] is two deep
+            if (timed_out) {
+                if (live) {
+                    const lstm_f4 bad = {__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+                    *reinterpret_cast<lstm_f4 *>(a.gates + (((size_t)0 * a.B + row) * H + unit) * 4) = bad;
+                }
+                return;
+            }
             dh += (part[t & 1][0][w][l] + part[t & 1][1][w][l]) + (part[t & 1][2][w][l] + part[t & 1][3][w][l]);
         }
         const float ig = act[0], fg = act[1], gg = act[2], og = act[3];
@@ -240,7 +256,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         d[3] = dh * tc * og * (1.0f - og);
         dc_carry = dc * fg;
         if (live) *reinterpret_cast<lstm_f4 *>(a.gates + e * 4) = d;
-        if (t > 0) {
+        if (t > 0 && (int)blockIdx.x != a.drop_wg) {
             // 16 lanes of one store instruction cover a unit's 256-byte block: whole lines
             // (d comes out of VALU instructions: an inline-asm store placed straight after MFMAs would read the
             // accumulators before their write-back -- the compiler pads only the stores it can see)

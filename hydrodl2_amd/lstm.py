@@ -31,6 +31,7 @@ class LstmSeq(torch.autograd.Function):
     gradient).  `check=True` synchronises and verifies the kernels' hand-off status word."""
 
     @staticmethod
+    @ops._device_guard
     def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, check: bool = False):
         lib = get_library()
         x_c, w_hh_c = x.contiguous(), w_hh.contiguous()
@@ -64,6 +65,7 @@ class LstmSeq(torch.autograd.Function):
         return h_all, c_all
 
     @staticmethod
+    @ops._device_guard
     def backward(ctx, gh, _gc):
         lib = get_library()
         x, w_ih_p, w_hh, gates, c_all, h_all, perm = ctx.saved_tensors

@@ -13,6 +13,7 @@ only; every arithmetic step of the path runs in the HIP library.
 from __future__ import annotations
 
 from dataclasses import dataclass, field
+import functools
 import os
 from typing import List, Optional, Sequence
 
@@ -74,6 +75,21 @@ class StepConfig:
     mu_t0: Optional[int] = None  # first row of muwts used by this call (None: same as t0)
     traj_layout: int = 0       # set by HbvPath.forward: enum hbvx_traj_layout of the saved trajectory
     ckpt_days: int = 0         # 4 / 8 / 16: keep K-day checkpoints instead of the trajectory (memory-lean adjoint)
+
+
+def _device_guard(fn):
+    """Run an autograd.Function method with the CUDA device of its tensors current.  The library takes
+    the stream from the tensors' device, but HIP calls it makes besides the launch (function attributes
+    for dynamic LDS, device properties) go to the calling thread's CURRENT device: a model living on
+    cuda:k in a process that never called torch.cuda.set_device(k) would otherwise mix devices."""
+    @functools.wraps(fn)
+    def wrapped(ctx, *args):
+        dev = next((a.device for a in args if torch.is_tensor(a) and a.is_cuda), None)
+        if dev is None:
+            return fn(ctx, *args)
+        with torch.cuda.device(dev):
+            return fn(ctx, *args)
+    return wrapped
 
 
 # bench.py sets this to a list to collect (abi_call, start_event, end_event) per launch,
@@ -226,6 +242,7 @@ class HbvPath(torch.autograd.Function):
     """
 
     @staticmethod
+    @_device_guard
     def forward(ctx, cfg: StepConfig, x, state_in, muwts, ac, elev, *ptensors):
         lib = get_library()
         _check_tensor(lib, x, "x_phy")
@@ -286,6 +303,7 @@ class HbvPath(torch.autograd.Function):
         return (routed, state_out, traj) + rows
 
     @staticmethod
+    @_device_guard
     def backward(ctx, g_routed, _g_state, _g_traj, *g_rows):
         lib = get_library()
         cfg: StepConfig = ctx.cfg
@@ -397,6 +415,7 @@ class HbvAdjPath(torch.autograd.Function):
     differentiates through its warm-up, hbv_adj.py:257-274)."""
 
     @staticmethod
+    @_device_guard
     def forward(ctx, cfg: StepConfig, x, state_in, *ptensors):
         lib = get_library()
         _check_tensor(lib, x, "x_phy")
@@ -431,6 +450,7 @@ class HbvAdjPath(torch.autograd.Function):
         return flux, routed, state_out
 
     @staticmethod
+    @_device_guard
     def backward(ctx, g_flux, g_routed, g_state):
         lib = get_library()
         cfg: StepConfig = ctx.cfg
@@ -450,14 +470,19 @@ class HbvAdjPath(torch.autograd.Function):
             gt = gp[rs.tensor_idx]
             ws_bytes = lib.route_workspace_bytes(r)
             ws = torch.empty((max(ws_bytes, 4) + 3) // 4, dtype=torch.float32, device=dev)
+            g_routed_c = g_routed.contiguous()     # named: must outlive the launch that reads its pointer
             _call(lib, 'hbvx_route_backward', lib.route_backward, r, _ptr(flux), _ptr(uh),
-                  _ptr(g_routed.contiguous()), _ptr(gq), _ptr(gt, rs.a_off), _ptr(gt, rs.b_off),
+                  _ptr(g_routed_c), _ptr(gq), _ptr(gt, rs.a_off), _ptr(gt, rs.b_off),
                   _ptr(ws), ws_bytes, stream)
+        # contiguous copies of incoming gradients are bound to locals that live until after the launch:
+        # a temporary would be freed at once and the caching allocator could hand its block to gs_in / ws
+        g_flux_c = g_flux.contiguous() if g_flux is not None else None
+        g_state_c = g_state.contiguous() if g_state is not None else None
         io = _abi.BwdIO()
         io.traj = _ptr(traj)
-        io.grad_flux = _ptr(g_flux.contiguous()) if g_flux is not None else None
+        io.grad_flux = _ptr(g_flux_c)
         io.grad_flux4 = _ptr(gq)
-        io.grad_state_out = _ptr(g_state.contiguous()) if g_state is not None else None
+        io.grad_state_out = _ptr(g_state_c)
         io.n_flux = 1
         gs_in = None
         if state_in is not None and ctx.needs_input_grad[2]:
@@ -488,6 +513,7 @@ class Bfi(torch.autograd.Function):
     asks for, is two broadcasts in torch."""
 
     @staticmethod
+    @_device_guard
     def forward(ctx, qs, q2, nearzero: float):
         lib = get_library()
         qs_c, q2_c = qs.contiguous(), q2.contiguous()
@@ -500,6 +526,7 @@ class Bfi(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_device_guard
     def backward(ctx, g):
         qs, q2 = ctx.saved_tensors
         den = qs.sum(0) + ctx.nearzero
@@ -567,6 +594,7 @@ class GageRoute(torch.autograd.Function):
     (hbv_2_hourly.py:800-897)."""
 
     @staticmethod
+    @_device_guard
     def forward(ctx, topo: GageTopology, qs, dp):
         lib = get_library()
         qs_c, dp_c = qs.contiguous(), dp.contiguous()
@@ -590,6 +618,7 @@ class GageRoute(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_device_guard
     def backward(ctx, g):
         lib = get_library()
         qs, dp, uh = ctx.saved_tensors

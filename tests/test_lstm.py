@@ -148,3 +148,32 @@ def test_hip_lstm_is_deterministic_under_load(hip_backend):
         b, _ = mod(x)
         torch.cuda.synchronize()
     assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("direction", ["forward", "backward"])
+def test_handoff_timeout_is_never_silent(direction, hip_backend, monkeypatch):
+    """Fault injection: one workgroup of a row tile never publishes its slab, so its partners' polls run
+    out.  The launch must not return finite-but-wrong values: the affected rows carry NaN in the last
+    output step (forward) / the first gradient step (backward) -- also for the waves that did NOT time
+    out themselves (with 8 units per workgroup two of the four waves only multiply) -- and
+    hbvx_lstm_check reports the error word."""
+    import hydrodl2_amd._abi as _abi
+    T, B, I, H = 6, 20, 5, 64
+    torch.manual_seed(1)
+    net = SeqLSTM(I, H).cuda()
+    x = torch.randn(T, B, I, device="cuda", requires_grad=True)
+    if direction == "backward":
+        h, _ = net(x)                                    # clean forward
+    monkeypatch.setenv("HBVX_LSTM_DEBUG_DROP_WG", "1")
+    monkeypatch.setenv("HBVX_LSTM_SPIN_LIMIT", "3000")
+    if direction == "forward":
+        h, _ = net(x)
+        torch.cuda.synchronize()
+        assert torch.isnan(h[-1, :16]).any(), "rows of the starved tile must be poisoned"
+        with pytest.raises(_abi.HbvxError, match="timed out"):
+            SeqLSTM(I, H, check=True).cuda()(x)
+    else:
+        h.square().sum().backward()
+        torch.cuda.synchronize()
+        assert torch.isnan(x.grad).any() or torch.isnan(net.weight_hh_l0.grad).any()
