@@ -136,6 +136,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     __shared__ int timed_out;
     if (threadIdx.x == 0) timed_out = 0;
     __syncthreads();
+    const bool publish = (int)blockIdx.x != a.drop_wg;
     float c = 0.0f;
     for (int t = 0; t < a.T; ++t) {
         const size_t e = ((size_t)t * a.B + rowc) * H + unit;
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             a.c_all[e] = c;
             a.h_all[e] = h;
         }
-        if (t + 1 < a.T && (int)blockIdx.x != a.drop_wg) {
+        if (t + 1 < a.T && publish) {
             // the wave's 64 lanes cover 256 contiguous bytes: two whole lines, one store instruction
             float *xp = a.xch + ((size_t)t * a.ntile + tile) * slab + ((size_t)(u0 >> 2) * LSTM_ROWS + n) * 4 + kq;
             __hip_atomic_store(xp, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -209,6 +210,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     __shared__ int timed_out;                       // as in k_lstm_fwd: raised before the barrier, acted on after it
     if (threadIdx.x == 0) timed_out = 0;
     __syncthreads();
+    const bool publish = (int)blockIdx.x != a.drop_wg;
     float dc_carry = 0.0f;
     for (int t = a.T - 1; t >= 0; --t) {
         const size_t e = ((size_t)t * a.B + rowc) * H + unit;
@@ -238,9 +240,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             for (int i = 0; i < 4; ++i) part[t & 1][w][i][l] = p0[i];
             __syncthreads();                        // the only barrier of a step; part[] is two deep
             if (timed_out) {
+                // poison this step's gate gradients (nothing overwrites them: the workgroup leaves); every
+                // weight gradient sums over them, so the failure reaches the loss scaler / optimiser as NaN
                 if (live) {
                     const lstm_f4 bad = {__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
-                    *reinterpret_cast<lstm_f4 *>(a.gates + (((size_t)0 * a.B + row) * H + unit) * 4) = bad;
+                    *reinterpret_cast<lstm_f4 *>(a.gates + e * 4) = bad;
                 }
                 return;
             }
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         d[3] = dh * tc * og * (1.0f - og);
         dc_carry = dc * fg;
         if (live) *reinterpret_cast<lstm_f4 *>(a.gates + e * 4) = d;
-        if (t > 0 && (int)blockIdx.x != a.drop_wg) {
+        if (t > 0 && publish) {
             // 16 lanes of one store instruction cover a unit's 256-byte block: whole lines
             // (d comes out of VALU instructions: an inline-asm store placed straight after MFMAs would read the
             // accumulators before their write-back -- the compiler pads only the stores it can see)
