@@ -78,6 +78,9 @@ def main():
     ap.add_argument("--device", default="cuda")
     ap.add_argument("--lstm", choices=["fused", "torch"], default="fused",
                     help="fused: the HIP sequence kernels of include/hbvx_lstm.h; torch: torch.nn.LSTM")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="one blocking all-reduce after the whole backward pass instead of sending the output "
+                         "layer's gradients while the LSTM backward is still running")
     ap.add_argument("--tune-gemm", action="store_true",
                     help="let torch's TunableOp pick the hipBLASLt/rocBLAS solution of every GEMM shape during "
                          "the warm-up steps (the LSTM's weight-gradient GEMMs have K = T*B: the default "
@@ -123,15 +126,39 @@ def main():
     opt = torch.optim.Adam(net.parameters(), lr=1e-3)
     params = [p for p in net.parameters()]
 
+    # Backward produces gradients output-layer-first: net.out right after the HBV adjoint, then the
+    # LSTM (the expensive part), then net.inp.  With --overlap (default) the first bucket -- loss
+    # normalisers + net.out -- is all-reduced asynchronously from a gradient hook while the LSTM backward
+    # runs; the second bucket follows when backward returns.
+    overlap = world > 1 and not args.no_overlap
+    early = list(net.out.parameters())
+    late = [p for p in params if all(p is not q for q in early)]
+    pending = {}
+
+    def on_grad(_p):
+        if "bucket" not in pending and all(q.grad is not None for q in early):
+            pending["bucket"] = sharding.AsyncBucket([pending["stats"]] + [q.grad for q in early]).start()
+
+    if overlap:
+        for q in early:
+            q.register_post_accumulate_grad_hook(on_grad)
+
     def step():
         opt.zero_grad(set_to_none=True)
         raw = net(z)
         sim = phy({"x_phy": x}, raw)["streamflow"][:, :, 0]
         loss_sum, count = nse_loss(sim, obs)
+        stats = torch.stack([loss_sum.detach(), torch.tensor(float(count), device=dev)])
+        pending.clear()
+        pending["stats"] = stats
         loss_sum.backward()
-        # one bucketed all-reduce: [loss sum, basin count, every network gradient]
-        stats = torch.tensor([float(loss_sum.detach()), float(count)], device=dev)
-        sharding.all_reduce_sum_([stats] + [p.grad for p in params])
+        if overlap:
+            second = sharding.AsyncBucket([p.grad for p in late]).start()
+            pending["bucket"].finish()
+            second.finish()
+        else:
+            # one bucketed all-reduce: [loss sum, basin count, every network gradient]
+            sharding.all_reduce_sum_([stats] + [p.grad for p in params])
         for p in params:
             p.grad /= stats[1]
         opt.step()
@@ -155,6 +182,7 @@ def main():
     if rank == 0:
         print(json.dumps({"basins": B, "nmul": M, "days": T, "world": world, "ms_per_step": round(dt * 1e3, 3),
                           "lstm": args.lstm, "hidden": args.hidden, "tuned_gemm": bool(args.tune_gemm),
+                          "allreduce": "overlapped (2 buckets)" if overlap else "blocking (1 bucket)",
                           "hbv_calls_ms": None if hbv_ms is None else round(hbv_ms, 3),
                           "lstm_kernels_ms": None if not lstm_ms else round(lstm_ms, 3),
                           "loss_first": round(losses[0], 4), "loss_last": round(losses[-1], 4)}))

@@ -61,6 +61,38 @@ def all_reduce_sum_(tensors: Sequence[torch.Tensor], group=None) -> None:
         off += n
 
 
+class AsyncBucket:
+    """One bucket of tensors summed over ranks WHILE the caller keeps computing.
+
+    `start()` flattens the tensors and issues `all_reduce(async_op=True)` (RCCL runs it on its own
+    stream; on xGMI a few-MB bucket is latency-bound, tens of microseconds, so it hides completely behind
+    any kernel that is still running); `finish()` waits and scatters the sums back.  Used to send the
+    gradients that the backward pass produces FIRST (the output layer of the parameterisation network,
+    right after the HBV adjoint) while the part that is produced last (the LSTM) is still being
+    computed -- the overlap SURVEY.md §8f rank 4 asks for."""
+
+    def __init__(self, tensors: Sequence[torch.Tensor], group=None):
+        self.tensors, self.group = list(tensors), group
+        self.flat = self.work = None
+
+    def start(self) -> "AsyncBucket":
+        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            self.flat = torch.cat([t.reshape(-1) for t in self.tensors])
+            self.work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return self
+
+    def finish(self) -> None:
+        if self.work is None:
+            return
+        self.work.wait()
+        off = 0
+        for t in self.tensors:
+            n = t.numel()
+            t.copy_(self.flat[off:off + n].view_as(t))
+            off += n
+        self.flat = self.work = None
+
+
 def gather_basins(local: torch.Tensor, n_basins: int, dim: int, group=None) -> torch.Tensor:
     """All-gather a per-shard tensor along its basin axis (shards may be uneven)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:

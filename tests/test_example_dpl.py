@@ -48,7 +48,7 @@ def test_dpl_example_fused_and_torch_lstm_agree(hip_backend, monkeypatch):
         assert abs(a - b) <= 2e-3 * max(abs(b), 1e-3), curves
 
 
-def _dpl_worker(rank, world, port, oracle, q):
+def _dpl_worker(rank, world, port, oracle, q, extra=()):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     import torch
@@ -56,16 +56,19 @@ def _dpl_worker(rank, world, port, oracle, q):
     from tests import seam
     seam.use_library(oracle)
     sys.argv = ["train_dpl.py", "--basins", "7", "--rho", "30", "--warm-up", "10", "--nmul", "2",
-                "--hidden", "8", "--steps", "4", "--device", "cpu"]
+                "--hidden", "8", "--steps", "4", "--device", "cpu", *extra]
     losses = _load().main()
     if rank == 0:
         q.put(losses)
 
 
-def test_dpl_example_two_ranks_match_one(oracle_path, oracle_backend, monkeypatch):
+@pytest.mark.parametrize("extra", [(), ("--no-overlap",)], ids=["overlapped", "blocking"])
+def test_dpl_example_two_ranks_match_one(extra, oracle_path, oracle_backend, monkeypatch):
     """The whole training step (LSTM -> HBV -> NSE -> Adam) sharded over two gloo ranks (7 basins: uneven
-    shards) follows the single-process loss curve: one bucketed all-reduce of loss normalisers and
-    network gradients per step is all the ranks exchange."""
+    shards) follows the single-process loss curve.  All the ranks exchange per step is the loss
+    normalisers and the network gradients: by default in two buckets, the first (output layer) sent
+    asynchronously from a gradient hook while the LSTM backward is still running; --no-overlap: one
+    blocking bucket after backward."""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket()
@@ -74,7 +77,7 @@ def test_dpl_example_two_ranks_match_one(oracle_path, oracle_backend, monkeypatc
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_dpl_worker, args=(r, 2, port, oracle_path, q)) for r in range(2)]
+    procs = [ctx.Process(target=_dpl_worker, args=(r, 2, port, oracle_path, q, extra)) for r in range(2)]
     for p in procs:
         p.start()
     two = q.get(timeout=300)
