@@ -116,7 +116,31 @@ struct ChunkDay {
     float gq;       // raw dL/dQsim (before the member weight), for the muwts gradient
 };
 
-template <int NP, int DYN, bool GFULL>
+// DYN == 3 with LDSDV: the NP raw dynamic values of the next day travel HBM -> LDS by LDS-DMA
+// (chunk_dma_dyn) instead of waiting in NP registers for a whole day; chunk_pull_dyn moves them into
+// registers at the start of their day, where the de-scaling consumes them at once.  14-19 registers
+// less at the kernels' pressure peak: config 3's sweep drops under the 168 of three waves per SIMD.
+template <int NP>
+__device__ __forceinline__ void chunk_dma_dyn(const hbvx_desc &d, const ChunkLane &L, int t, float *lds)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        const hbvx_param_src &ps = d.p[i];
+        const float *src = ps.dyn + (int64_t)t * ps.dyn_t_stride + (int64_t)L.b * ps.dyn_b_stride + L.j;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(lds + i * 64), 4, 0, 0);
+    }
+#endif
+}
+template <int NP>
+__device__ __forceinline__ void chunk_pull_dyn(ChunkRaw<NP> &R, const float *lds)
+{
+#pragma unroll
+    for (int i = 0; i < NP; i++) R.dv[i] = lds[i * 64 + (threadIdx.x & 63)];
+}
+
+template <int NP, int DYN, bool GFULL, bool LDSDV = false>
 __device__ __forceinline__ void chunk_issue(const hbvx_desc &d, const hbvx_bwd_io &io,
                                             const ChunkLane &L, int t, int nf, ChunkRaw<NP> &R,
                                             int nd, const int *dslot)
@@ -151,7 +175,7 @@ __device__ __forceinline__ void chunk_issue(const hbvx_desc &d, const hbvx_bwd_i
                 R.dv[k] = ps.dyn[(int64_t)t * ps.dyn_t_stride + (int64_t)L.b * ps.dyn_b_stride + L.j];
             }
     }
-    if (DYN == 3) {
+    if (DYN == 3 && !LDSDV) {
 #pragma unroll
         for (int i = 0; i < NP; i++) {
             const hbvx_param_src &ps = d.p[i];
@@ -305,11 +329,21 @@ __global__ void __launch_bounds__(64) k_bwd_chunk_phi(const ChunkArgs A)
     FluxGrad g0;
     g0.gQ = g0.gQ0 = g0.gQ1 = g0.gQ2 = g0.gET = g0.gSWE = g0.grech = g0.gexc = g0.gef = g0.gtosoil =
         g0.gPERC = g0.gcap = 0.0f;
+    constexpr bool LDSDV = DYN == 3;
+    __shared__ float dvbuf[LDSDV ? NP * 64 : 1];
     ChunkRaw<NP> Rn;
-    chunk_issue<NP, DYN, GFULL>(d, io, L, t1 - 1, io.n_flux, Rn, nd_, ds_);
+    chunk_issue<NP, DYN, GFULL, LDSDV>(d, io, L, t1 - 1, io.n_flux, Rn, nd_, ds_);
+    if (LDSDV) chunk_dma_dyn<NP>(d, L, t1 - 1, dvbuf);
     for (int t = t1 - 1; t >= t0; t--) {
-        const ChunkRaw<NP> Rc = Rn;
-        if (t > t0) chunk_issue<NP, DYN, GFULL>(d, io, L, t - 1, io.n_flux, Rn, nd_, ds_); // next day's loads in flight
+        ChunkRaw<NP> Rc = Rn;
+        if (LDSDV) {
+            chunk_pull_dyn<NP>(Rc, dvbuf);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // LDS reads done before the DMA rewrites the rows
+        }
+        if (t > t0) {
+            chunk_issue<NP, DYN, GFULL, LDSDV>(d, io, L, t - 1, io.n_flux, Rn, nd_, ds_); // next day's loads in flight
+            if (LDSDV) chunk_dma_dyn<NP>(d, L, t - 1, dvbuf);
+        }
         ChunkDay<MODEL, BETAET, NP> D;
         chunk_finish<MODEL, BETAET, NP, DYN, GFULL>(d, Rc, raw, nz, ac, elev, usta, psta, use_dyn,
                                                     io.n_flux, invM, D, nd_, ds_);
@@ -411,11 +445,18 @@ __device__ __forceinline__ float chunk_ens_sum(float v, int lgMp)
     return v;
 }
 
-template <int MODEL, bool BETAET, int DYN, bool GFULL, int SC = 0>
+// ROWST (DYN == 3 only): the NP gradients of a lane-day are transposed through LDS and leave as whole
+// rows -- a wave's (64/Mp) basins x NP x M floats are contiguous in the [T,B,ny] gradient tensor, so
+// 8-byte stores of 512 contiguous bytes per instruction replace NP four-byte stores that each touch
+// (64/Mp) separate 64-byte pieces of misaligned 904-byte rows (partial-line writes: profiles/
+// r02_pmc_calibration.csv shows what those cost).  The host sets it when every parameter's gradient
+// lives in one tensor with the reference's column order (column = i*M + j, hbv.py:201-208).
+template <int MODEL, bool BETAET, int DYN, bool GFULL, int SC = 0, bool ROWST = false>
 __global__ void __launch_bounds__(64) k_bwd_chunk_sweep(const ChunkArgs A)
 {
     CHUNK_SLOTS(A);
     constexpr int NP = ChunkNP<MODEL, BETAET>::value;
+    __shared__ float rowbuf[ROWST ? 64 * NP : 1];
     const hbvx_desc &d = A.d;
     const hbvx_bwd_io &io = A.io;
     const ChunkLane L = chunk_lane(d, A.lgMp);
@@ -436,11 +477,21 @@ __global__ void __launch_bounds__(64) k_bwd_chunk_sweep(const ChunkArgs A)
 #pragma unroll
     for (int k = 0; k < 5; k++) a[k] = A.abnd[((int64_t)chunk * 5 + k) * N + L.n];
 
+    constexpr bool LDSDV = DYN == 3;
+    __shared__ float dvbuf[LDSDV ? NP * 64 : 1];
     ChunkRaw<NP> Rn;
-    chunk_issue<NP, DYN, GFULL>(d, io, L, t1 - 1, io.n_flux, Rn, nd_, ds_);
+    chunk_issue<NP, DYN, GFULL, LDSDV>(d, io, L, t1 - 1, io.n_flux, Rn, nd_, ds_);
+    if (LDSDV) chunk_dma_dyn<NP>(d, L, t1 - 1, dvbuf);
     for (int t = t1 - 1; t >= t0; t--) {
-        const ChunkRaw<NP> Rc = Rn;
-        if (t > t0) chunk_issue<NP, DYN, GFULL>(d, io, L, t - 1, io.n_flux, Rn, nd_, ds_);
+        ChunkRaw<NP> Rc = Rn;
+        if (LDSDV) {
+            chunk_pull_dyn<NP>(Rc, dvbuf);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        if (t > t0) {
+            chunk_issue<NP, DYN, GFULL, LDSDV>(d, io, L, t - 1, io.n_flux, Rn, nd_, ds_);
+            if (LDSDV) chunk_dma_dyn<NP>(d, L, t - 1, dvbuf);
+        }
         ChunkDay<MODEL, BETAET, NP> D;
         chunk_finish<MODEL, BETAET, NP, DYN, GFULL>(d, Rc, raw, nz, ac, elev, usta, psta, use_dyn,
                                                     io.n_flux, invM, D, nd_, ds_);
@@ -464,13 +515,34 @@ __global__ void __launch_bounds__(64) k_bwd_chunk_sweep(const ChunkArgs A)
                     gused[k] += use_dyn[k] ? gu : 0.0f;   // goes to the dynamic rows, not to the static one
                 }
         }
-        if (DYN == 3) {
+        if (DYN == 3 && !ROWST) {
 #pragma unroll
             for (int i = 0; i < NP; i++) {
                 const float gu = gp[i] * (d.p[i].hi - d.p[i].lo);
                 const float gr = raw ? gu * (D.ud[i] * (1.0f - D.ud[i])) : gu;
                 if (io.g[i].dyn && L.active)
                     io.g[i].dyn[(int64_t)t * io.g[i].dyn_t_stride + (int64_t)L.b * io.g[i].dyn_b_stride + L.j] = gr;
+            }
+        }
+        if (DYN == 3 && ROWST) {
+            // LDS image of the wave's rows: [basin in wave][i*M + j]
+            const int M = d.M, rowf = NP * M, bl = (threadIdx.x & 63) >> A.lgMp;
+            if (L.jm < M) {
+#pragma unroll
+                for (int i = 0; i < NP; i++) {
+                    const float gu = gp[i] * (d.p[i].hi - d.p[i].lo);
+                    rowbuf[bl * rowf + i * M + L.jm] = raw ? gu * (D.ud[i] * (1.0f - D.ud[i])) : gu;
+                }
+            }
+            // (one wave per workgroup: LDS traffic is ordered by the hardware, no barrier)
+            const int b0 = blockIdx.x * (64 >> A.lgMp);
+            const int nb = min(64 >> A.lgMp, d.B - b0);
+            const int half = rowf >> 1, total2 = nb * half;                 // rowf is even (host)
+            float *gbase = io.g[0].dyn + (int64_t)t * io.g[0].dyn_t_stride + (int64_t)b0 * io.g[0].dyn_b_stride;
+            for (int k = threadIdx.x & 63; k < total2; k += 64) {
+                const int rb = k / half, w2 = k - rb * half;
+                const float2 v = *reinterpret_cast<const float2 *>(&rowbuf[rb * rowf + 2 * w2]);
+                *reinterpret_cast<float2 *>(gbase + (int64_t)rb * io.g[0].dyn_b_stride + 2 * w2) = v;
             }
         }
 #pragma unroll

@@ -274,11 +274,12 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
         if (MODEL == MODEL_HOURLY) { OP(P_F0, ptr); OP(P_FMIN, ptr); OP(P_ALPHA, ptr); }           \
     } while (0)
 #define DY_USE2(X, unused) DY_USE(X)
-                // Arbitrary dynamic sets (SC == 0) on this fused stage: up to 15 staged rows.  One-day-ahead
-                // prefetch registers for all of them pushed the wave over its 128 VGPRs (3-44 spilled
-                // values per lane); there the values are read from the LDS tile at the start of their day
-                // instead (independent reads, one wait).
-                constexpr bool PREF = SC != 0;
+                // Arbitrary dynamic sets (SC == 0) of HBV 2.0 / hourly on this fused stage: up to 17 staged
+                // rows.  One-day-ahead prefetch registers for all of them pushed the wave over its 128
+                // VGPRs (3-44 spilled values per lane); there the values are read from the LDS tile at the
+                // start of their day instead (independent reads, one wait).  HBV 1.1p (14 rows) fits and
+                // keeps the prefetch: without it config 3's forward went from 2.6 to 3.8 ms.
+                constexpr bool PREF = SC != 0 || MODEL == MODEL_HBV11P;
 #define DY_NOW(X, ptr) do { p[X] = dy_##X ? (ptr)[ix_##X] : p[X]; } while (0)
                 if (DYN && PREF) DY_ALL(DY_LOAD, pin);
                 auto day = [&](int tt, bool more) __attribute__((always_inline)) {

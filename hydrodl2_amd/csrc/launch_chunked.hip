@@ -71,6 +71,19 @@ static hipError_t launch_chunked_t(const ChunkArgs &a, hipStream_t st)
     }
     hipLaunchKernelGGL((k_bwd_chunk_phi<MODEL, BETAET, DYN, GFULL>), g2, dim3(64), 0, st, a);
     hipLaunchKernelGGL(k_bwd_chunk_scan, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, st, a);
+    if constexpr (DYN == 3) {
+        // whole-row gradient stores when every parameter's gradient sits in one [T,B,ny] tensor in the
+        // reference's column order, rows 8-byte aligned (hbv_chunked.h, ROWST)
+        const hbvx_param_grad &g0 = a.io.g[0];
+        bool rows = env_int("HBVX_CHUNK_ROWST", 1) != 0 && g0.dyn && ((uintptr_t)g0.dyn & 7) == 0 &&
+                    (g0.dyn_b_stride & 1) == 0 && (g0.dyn_t_stride & 1) == 0 && ((d.n_param * d.M) & 1) == 0;
+        for (int i = 1; i < d.n_param && rows; i++)
+            rows = a.io.g[i].dyn == g0.dyn + (int64_t)i * d.M && a.io.g[i].dyn_b_stride == g0.dyn_b_stride &&
+                   a.io.g[i].dyn_t_stride == g0.dyn_t_stride;
+        if (rows) hipLaunchKernelGGL((k_bwd_chunk_sweep<MODEL, BETAET, DYN, GFULL, 0, true>), g2, dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((k_bwd_chunk_sweep<MODEL, BETAET, DYN, GFULL>), g2, dim3(64), 0, st, a);
+        return hipGetLastError();   // every parameter dynamic: the static gradient is zero
+    }
     hipLaunchKernelGGL((k_bwd_chunk_sweep<MODEL, BETAET, DYN, GFULL>), g2, dim3(64), 0, st, a);
     if (DYN == 3) return hipGetLastError();   // every parameter dynamic: the static gradient is zero
     hipLaunchKernelGGL(k_bwd_chunk_reduce, dim3((unsigned)((N + 255) / 256), d.n_param), dim3(256), 0, st,
