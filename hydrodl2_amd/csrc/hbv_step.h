@@ -38,18 +38,23 @@ HBVX_HD float fmax_(float a, float b) { return fmaxf(a, b); } // v_max_f32
 HBVX_HD float fmin_(float a, float b) { return fminf(a, b); } // v_min_f32
 
 // a / b for the forward quantities (SM/FC, SM/(LP*FC)).  The compiler's IEEE sequence is ten
-// dependent instructions (div_scale x2, rcp, 4 fma, div_fmas, div_fixup).  On the device use
-// rcp + multiply + two fused corrections: correctly rounded for normal-range operands except in
-// astronomically rare double-rounding cases, and exactly 1.0f when a == b (the inclusive clamp
-// gradients at SM == FC depend on that).  Operands here are O(1e-5 .. 1e3): no scaling needed.
+// dependent instructions (div_scale x2, rcp, 4 fma, div_fmas, div_fixup).  On the device: reciprocal,
+// ONE Newton step on the reciprocal, multiply, one fused correction of the quotient.  The numerator
+// a is a storage -- it sits on the day-to-day dependency chain, where a dependent instruction costs a
+// lone wave ~10 cycles (tools/micro/issue_rate.hip) -- while b is a parameter: its reciprocal and
+// the Newton step do not depend on the state (static b: hoisted out of the time loop; dynamic b: issued
+// beside the chain).  So only three dependent instructions follow a (mul, fma, fma) instead of the
+// five of "rcp, q, then two corrections of q".  Same instruction count.  Correctly rounded on the path's
+// operand range except in astronomically rare double-rounding cases, and exactly 1.0f when a == b (the
+// inclusive clamp gradients at SM == FC depend on that): tests/test_gpu_parity.py::test_div_on_gpu.
+// Operands here are O(1e-5 .. 1e3): no scaling needed.
 HBVX_HD float div_(float a, float b)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const float rc = __builtin_amdgcn_rcpf(b);
-    float q = a * rc;
-    float r = __builtin_fmaf(-b, q, a);
-    q = __builtin_fmaf(r, rc, q);
-    r = __builtin_fmaf(-b, q, a);
+    float rc = __builtin_amdgcn_rcpf(b);
+    rc = __builtin_fmaf(__builtin_fmaf(-b, rc, 1.0f), rc, rc);
+    const float q = a * rc;
+    const float r = __builtin_fmaf(-b, q, a);
     return __builtin_fmaf(r, rc, q);
 #else
     return a / b;

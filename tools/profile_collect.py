@@ -21,13 +21,13 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CALLS = {
-    "hbvx_forward": ["k_fwd_pipe", "k_fwd_tiled"],
+    "hbvx_forward": ["k_fwd_pipe", "k_fwd_tiled", "k_fwd_stream"],
     "hbvx_backward": ["k_bwd_chunk_phi", "k_bwd_chunk_scan", "k_bwd_chunk_sweep", "k_bwd_chunk_reduce",
-                      "k_bwd_tiled"],
+                      "k_bwd_tiled", "k_bwd_stream"],
     "hbvx_route_forward": ["k_route_fwd", "k_uh_gamma"],
     "hbvx_route_backward": ["k_route_bwd"],
     "hbvx_bfi": ["k_bfi"],
-    "hbvx_zero": ["k_zero_nt"],
+    "hbvx_zero": ["k_zero_nt", "k_zero_gaps"],
 }
 
 
@@ -45,6 +45,7 @@ def counter_table(path):
 
 
 def main(tag):
+    """(see the module docstring)"""
     raw = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     out = os.path.join(ROOT, "profiles")
     stats = glob.glob(os.path.join(raw, "kt", "**", "*kernel_stats.csv"), recursive=True)
@@ -53,6 +54,12 @@ def main(tag):
         line = [l for l in f if l.startswith("{")][-1]
     with open(os.path.join(out, f"{tag}_bench.json"), "w") as f:
         f.write(line)
+    st = glob.glob(os.path.join(raw, "cfgs", "**", "*kernel_stats.csv"), recursive=True)
+    if st:
+        shutil.copy(st[0], os.path.join(out, f"{tag}_configs_kernel_stats.csv"))
+        js = os.path.join(ROOT, "gpurun_out", f"prof_{tag}.cfgs.jsonl")
+        if os.path.exists(js):
+            shutil.copy(js, os.path.join(out, f"{tag}_bench_configs.jsonl"))
     for extra in ("lstm", "dpl"):
         st = glob.glob(os.path.join(raw, extra, "**", "*kernel_stats.csv"), recursive=True)
         js = os.path.join(ROOT, "gpurun_out", f"prof_{tag}.{extra}.json")
@@ -80,9 +87,11 @@ def main(tag):
         wb = sum(tables["write"].get(k, (0, 0.0))[1] for k in ks) * 1024
         traffic[call] = {
             "kernels": ks, "fetch_bytes_raw": fb, "write_bytes": wb, "hbm_bytes_raw": fb + wb,
+            "hbm_bytes": 2.0 * fb + wb,
             "note": "per ABI call (sum over its kernels), rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "
-                    "separate passes, KiB x1024; FETCH_SIZE is NOT doubled: the guide's x2 is calibrated "
-                    "for 16 B/lane streams, these kernels load 4 B/lane"}
+                    "separate passes, KiB x1024.  hbm_bytes = 2 x FETCH_SIZE + WRITE_SIZE: the guide's x2 for "
+                    "FETCH_SIZE also holds for 4 B/lane row loads (profiles/r02_pmc_calibration.csv); "
+                    "WRITE_SIZE is exact for row and 16-byte streams and counts 16-byte pieces of a line twice"}
     with open(os.path.join(out, "pmc_traffic.json"), "w") as f:
         json.dump(traffic, f, indent=1)
     print(json.dumps({k: (round(v["fetch_bytes_raw"] / 1e9, 3), round(v["write_bytes"] / 1e9, 3))
@@ -90,4 +99,4 @@ def main(tag):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "r01")
+    main(sys.argv[1] if len(sys.argv) > 1 else "r02")
