@@ -253,8 +253,11 @@ def cpu_baseline_port(B, M, T_sample, seed=0):
     from hydrodl2_amd import _abi
     if not os.path.exists(ge.ORACLE_LIB):
         ge.build_oracle()
-    os.environ.setdefault("OMP_NUM_THREADS", str(host_cores()))   # before libgomp starts
     lib = _abi.Library(ge.ORACLE_LIB)
+    try:    # torch has usually started the OpenMP runtime already: set the team size through its API
+        C.CDLL("libgomp.so.1").omp_set_num_threads(C.c_int(host_cores()))
+    except OSError:
+        pass
     lib.dll.hbvo_num_threads.restype = C.c_int
     threads = int(lib.dll.hbvo_num_threads())
     rng = np.random.default_rng(seed)
