@@ -1,7 +1,7 @@
 """Sequence LSTM for the parameter network that feeds the HBV plug-in (the
 caller side, delta-MG's CudnnLstmModel -- outside the reference repository).
 
-`SeqLSTM` is a drop-in for a one-layer `torch.nn.LSTM(input_size, hidden_size)` on [T, B, I] input
+`SeqLSTM` is a drop-in for `torch.nn.LSTM(input_size, hidden_size, num_layers)` on [T, B, I] input
 with zero initial state: same parameter names and shapes (`weight_ih_l0`, `weight_hh_l0`,
 `bias_ih_l0`, `bias_hh_l0`), same initialisation, same gate order, so state dicts interchange.
 
@@ -103,26 +103,42 @@ def lstm_seq(x, w_ih, w_hh, b_ih, b_hh, check: bool = False):
 
 
 class SeqLSTM(torch.nn.Module):
-    """One-layer LSTM over [T, B, input_size]; returns (output [T,B,H], (h_n [1,B,H], c_n [1,B,H]))
-    like torch.nn.LSTM called without an initial state."""
+    """LSTM over [T, B, input_size]; returns (output [T,B,H], (h_n [L,B,H], c_n [L,B,H])) like
+    torch.nn.LSTM(input_size, hidden_size, num_layers) called without an initial state.  Layers are
+    stacked on the host: layer l's output sequence is layer l+1's input, each layer one pair of
+    persistent kernels.  Parameter names follow torch (`weight_ih_l{k}` ...), so state dicts interchange."""
 
-    def __init__(self, input_size: int, hidden_size: int, check: bool = False, dr: float = 0.0):
+    def __init__(self, input_size: int, hidden_size: int, check: bool = False, dr: float = 0.0,
+                 num_layers: int = 1):
         super().__init__()
+        if num_layers < 1:
+            raise ValueError("SeqLSTM: num_layers must be >= 1")
         self.input_size, self.hidden_size, self.check = input_size, hidden_size, check
+        self.num_layers = num_layers
         # dr: weight dropout as in hydroDL / delta-MG's CudnnLstm (one Bernoulli mask on W_ih and one on
         # W_hh per forward call, training mode only); 0 = torch.nn.LSTM behaviour
         self.dr = dr
         k = 1.0 / math.sqrt(hidden_size)
         # same creation order and distribution as torch.nn.LSTM.reset_parameters
-        self.weight_ih_l0 = torch.nn.Parameter(torch.empty(4 * hidden_size, input_size).uniform_(-k, k))
-        self.weight_hh_l0 = torch.nn.Parameter(torch.empty(4 * hidden_size, hidden_size).uniform_(-k, k))
-        self.bias_ih_l0 = torch.nn.Parameter(torch.empty(4 * hidden_size).uniform_(-k, k))
-        self.bias_hh_l0 = torch.nn.Parameter(torch.empty(4 * hidden_size).uniform_(-k, k))
+        for layer in range(num_layers):
+            n_in = input_size if layer == 0 else hidden_size
+            self.register_parameter(f"weight_ih_l{layer}", torch.nn.Parameter(torch.empty(4 * hidden_size, n_in).uniform_(-k, k)))
+            self.register_parameter(f"weight_hh_l{layer}", torch.nn.Parameter(torch.empty(4 * hidden_size, hidden_size).uniform_(-k, k)))
+            self.register_parameter(f"bias_ih_l{layer}", torch.nn.Parameter(torch.empty(4 * hidden_size).uniform_(-k, k)))
+            self.register_parameter(f"bias_hh_l{layer}", torch.nn.Parameter(torch.empty(4 * hidden_size).uniform_(-k, k)))
 
     def forward(self, x):
-        w_ih, w_hh = self.weight_ih_l0, self.weight_hh_l0
-        if self.training and self.dr > 0:
-            w_ih = torch.nn.functional.dropout(w_ih, self.dr, training=True)
-            w_hh = torch.nn.functional.dropout(w_hh, self.dr, training=True)
-        h, c = LstmSeq.apply(x, w_ih, w_hh, self.bias_ih_l0, self.bias_hh_l0, self.check)
-        return h, (h[-1:], c[-1:])
+        if x.is_cuda and self.hidden_size not in _abi.LSTM_HIDDEN_SIZES:
+            raise ValueError(f"SeqLSTM: hidden_size must be one of {_abi.LSTM_HIDDEN_SIZES} (the sizes the HIP "
+                             f"kernels are instantiated for), got {self.hidden_size}")
+        hn, cn = [], []
+        for layer in range(self.num_layers):
+            w_ih, w_hh = getattr(self, f"weight_ih_l{layer}"), getattr(self, f"weight_hh_l{layer}")
+            if self.training and self.dr > 0:
+                w_ih = torch.nn.functional.dropout(w_ih, self.dr, training=True)
+                w_hh = torch.nn.functional.dropout(w_hh, self.dr, training=True)
+            x, c = LstmSeq.apply(x, w_ih, w_hh, getattr(self, f"bias_ih_l{layer}"), getattr(self, f"bias_hh_l{layer}"),
+                                 self.check)
+            hn.append(x[-1])
+            cn.append(c[-1])
+        return x, (torch.stack(hn), torch.stack(cn))

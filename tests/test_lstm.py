@@ -177,3 +177,35 @@ def test_handoff_timeout_is_never_silent(direction, hip_backend, monkeypatch):
         h.square().sum().backward()
         torch.cuda.synchronize()
         assert torch.isnan(x.grad).any() or torch.isnan(net.weight_hh_l0.grad).any()
+
+
+def _two_layer(device, T, B, I, H):
+    torch.manual_seed(3)
+    ref = torch.nn.LSTM(I, H, num_layers=2).double()
+    mod = SeqLSTM(I, H, num_layers=2)
+    mod.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    mod = mod.to(device)
+    x = torch.randn(T, B, I)
+    xr = x.double().requires_grad_(True)
+    xo = x.to(device).requires_grad_(True)
+    yr, (hr, cr) = ref(xr)
+    yo, (ho, co) = mod(xo)
+    assert ho.shape == hr.shape == (2, B, H)
+    assert torch.allclose(yo.cpu().double(), yr, rtol=1e-4, atol=2e-5)
+    assert torch.allclose(ho.cpu().double(), hr, rtol=1e-4, atol=2e-5) and torch.allclose(co.cpu().double(), cr, rtol=1e-4, atol=5e-5)
+    w = torch.randn_like(yr)
+    (yr * w).sum().backward()
+    (yo * w.float().to(device)).sum().backward()
+    for (k, p), (_, q) in zip(mod.named_parameters(), ref.named_parameters()):
+        err = (p.grad.cpu().double() - q.grad).abs().max().item()
+        assert err <= 3e-4 * max(q.grad.abs().max().item(), 1e-3), (k, err)
+    assert torch.allclose(xo.grad.cpu().double(), xr.grad, rtol=1e-3, atol=1e-5)
+
+
+def test_two_layers_match_torch_on_oracle(oracle_backend):
+    _two_layer("cpu", 12, 5, 6, 16)
+
+
+@pytest.mark.gpu
+def test_two_layers_match_torch_on_gpu(hip_backend):
+    _two_layer("cuda", 40, 21, 9, 64)
