@@ -239,16 +239,19 @@ __global__ void __launch_bounds__(64) FWPE k_fwd_stream2(const StreamArgs A)
     const unsigned xvo = (unsigned)(L.b * d.x_b_stride * 4);
     const unsigned xts = (unsigned)(d.x_t_stride * 4);
     const int cp = d.ch_prcp, ct = d.ch_tmean, ce = d.ch_pet;
-    __amdgpu_buffer_rsrc_t rd[ND > 0 ? ND : 1];
-    unsigned dvo[ND > 0 ? ND : 1], dts[ND > 0 ? ND : 1];
+    // dynamic rows: the descriptor is rebased on the day's row (64-bit scalar arithmetic), so only one
+    // row of the [T, B, ny] parameter tensor has to fit a descriptor's 4 GiB, not the tensor
+    const float *dbase[ND > 0 ? ND : 1];
+    int64_t dts[ND > 0 ? ND : 1];
+    unsigned dvo[ND > 0 ? ND : 1];
     float dlo[ND > 0 ? ND : 1], dsc[ND > 0 ? ND : 1], dsta[ND > 0 ? ND : 1];
     bool duse[ND > 0 ? ND : 1];
 #pragma unroll
     for (int k = 0; k < ND; k++) {
         const hbvx_param_src &ps = d.p[stream_slot<SC>(k)];
-        rd[k] = S2Buf::rsrc(ps.dyn);
+        dbase[k] = ps.dyn;
         dvo[k] = (unsigned)((L.b * ps.dyn_b_stride + L.j) * 4);
-        dts[k] = (unsigned)(ps.dyn_t_stride * 4);
+        dts[k] = ps.dyn_t_stride;
         dlo[k] = ps.lo;
         dsc[k] = ps.hi - ps.lo;
         dsta[k] = p[stream_slot<SC>(k)];
@@ -301,7 +304,7 @@ __global__ void __launch_bounds__(64) FWPE k_fwd_stream2(const StreamArgs A)
             fx[j][2] = S2Buf::ld(rx, xvo, so + ce * 4);
         }
 #pragma unroll
-        for (int k = 0; k < ND; k++) dv[j][k] = S2Buf::ld(rd[k], dvo[k], tc * dts[k]);
+        for (int k = 0; k < ND; k++) dv[j][k] = S2Buf::ld(S2Buf::rsrc(dbase[k] + tc * dts[k]), dvo[k], 0);
     };
     auto day = [&](int t, int j) {
         Step<MODEL, BETAET> s;
@@ -494,25 +497,28 @@ k_bwd_stream2(const StreamBwdArgs A)
     const unsigned gvo = (unsigned)(L.b * 4);
     const unsigned fT = (unsigned)((int64_t)T * B * 4), fB = (unsigned)(B * 4);
 
-    __amdgpu_buffer_rsrc_t rd[ND > 0 ? ND : 1], rgd[ND > 0 ? ND : 1];
-    unsigned dvo[ND > 0 ? ND : 1], dts[ND > 0 ? ND : 1], gdvo[ND > 0 ? ND : 1], gdts[ND > 0 ? ND : 1];
+    // dynamic rows and their gradient rows: descriptors rebased per day (see the forward)
+    const float *dbase[ND > 0 ? ND : 1];
+    float *gdbase[ND > 0 ? ND : 1];
+    int64_t dts[ND > 0 ? ND : 1], gdts[ND > 0 ? ND : 1];
+    unsigned dvo[ND > 0 ? ND : 1], gdvo[ND > 0 ? ND : 1];
     float dlo[ND > 0 ? ND : 1], dsc[ND > 0 ? ND : 1], dsta[ND > 0 ? ND : 1];
     bool duse[ND > 0 ? ND : 1];
 #pragma unroll
     for (int k = 0; k < ND; k++) {
         const int sl = stream_slot<SC>(k);
         const hbvx_param_src &ps = d.p[sl];
-        rd[k] = S2Buf::rsrc(ps.dyn);
+        dbase[k] = ps.dyn;
         dvo[k] = (unsigned)((L.b * ps.dyn_b_stride + L.j) * 4);
-        dts[k] = (unsigned)(ps.dyn_t_stride * 4);
+        dts[k] = ps.dyn_t_stride;
         dlo[k] = ps.lo;
         dsc[k] = ps.hi - ps.lo;
         dsta[k] = p[sl];
         duse[k] = !(ps.drop && ps.drop[L.b]);
         const bool dg = io.g[sl].dyn != nullptr;
-        rgd[k] = S2Buf::rsrc(dg ? (const void *)io.g[sl].dyn : (const void *)d.x);
+        gdbase[k] = dg ? io.g[sl].dyn : const_cast<float *>(d.x);
         gdvo[k] = (dg && L.active) ? (unsigned)((L.b * io.g[sl].dyn_b_stride + L.j) * 4) : OOB;
-        gdts[k] = (unsigned)(io.g[sl].dyn_t_stride * 4);
+        gdts[k] = dg ? io.g[sl].dyn_t_stride : 0;
     }
     const auto rgx = S2Buf::rsrc(io.grad_x ? io.grad_x : const_cast<float *>(d.x));
     const bool has_gx = io.grad_x != nullptr;
@@ -555,7 +561,7 @@ k_bwd_stream2(const StreamBwdArgs A)
             I.gf[k] = v;
         }
 #pragma unroll
-        for (int k = 0; k < ND; k++) I.dv[k] = S2Buf::ld(rd[k], dvo[k], tc * dts[k]);
+        for (int k = 0; k < ND; k++) I.dv[k] = S2Buf::ld(S2Buf::rsrc(dbase[k] + tc * dts[k]), dvo[k], 0);
     };
     auto day = [&](int t, const In &I) {
         Step<MODEL, BETAET> s;
@@ -597,7 +603,7 @@ k_bwd_stream2(const StreamBwdArgs A)
             } else {
                 const float gu = gp[i] * dsc[kd];
                 const float gr = raw ? gu * (ud[kd] * (1.0f - ud[kd])) : gu;
-                S2Buf::st(rgd[kd], gdvo[kd], (unsigned)t * gdts[kd], duse[kd] ? gr : 0.0f);
+                S2Buf::st(S2Buf::rsrc(gdbase[kd] + t * gdts[kd]), gdvo[kd], 0, duse[kd] ? gr : 0.0f);
                 S2_ACC_ADD(i, duse[kd] ? 0.0f : gp[i]);
             }
         }
@@ -650,7 +656,7 @@ k_bwd_stream2(const StreamBwdArgs A)
                 else if (k < 4 && has_g4) S2Buf::ld_lds<4>(rg4, l_gf[k], gvo, sg + (unsigned)k * fT);
             }
 #pragma unroll
-            for (int k = 0; k < ND; k++) S2Buf::ld_lds<4>(rd[k], l_dv[k], dvo[k], tc * dts[k]);
+            for (int k = 0; k < ND; k++) S2Buf::ld_lds<4>(S2Buf::rsrc(dbase[k] + tc * dts[k]), l_dv[k], dvo[k], 0);
         };
         auto pull = [&](int t, In &I) {
             if (XVEC) {

@@ -663,8 +663,9 @@ extern "C" int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *s
             const int K = HBVX_TRAJ_CKPT_DAYS(out->traj_layout);
             if (K != 4 && K != 8 && K != 16) return fail(HBVX_E_SHAPE, "checkpoint interval must be 4, 8 or 16");
             if (out->aux) return fail(HBVX_E_SHAPE, "checkpoints: aux must be NULL");
-            if (try_fwd_pipe(d, out, stream, &rc)) return rc;
             if (try_fwd_stream(d, out, stream, &rc)) return rc;
+            if (try_fwd_pipe(d, out, stream, &rc)) return rc;
+            if (try_fwd_stream(d, out, stream, &rc, true)) return rc;
             FwdArgs ca;
             ca.d = *d;
             ca.o = *out;
@@ -677,12 +678,14 @@ extern "C" int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *s
         }
         // packed trajectory: the streaming family only (hbvx_preferred_traj_layout said so)
         if (out->traj_layout != HBVX_TRAJ_PACKED) return fail(HBVX_E_SHAPE, "unknown traj_layout");
-        if (try_fwd_stream(d, out, stream, &rc)) return rc;
+        if (try_fwd_stream(d, out, stream, &rc, true)) return rc;
         return fail(HBVX_E_UNSUPPORTED, "packed trajectory: no forward kernel for this call");
     }
-    // kernel families in order of preference ("Which kernel runs when")
-    if (try_fwd_pipe(d, out, stream, &rc)) return rc;
+    // kernel families in order of preference ("Which kernel runs when"): the streaming
+    // kernels take the grids above their measured cross-over, the pipelined forward the rest of what
+    // it can hold, the tiled forward whatever is left
     if (try_fwd_stream(d, out, stream, &rc)) return rc;
+    if (try_fwd_pipe(d, out, stream, &rc)) return rc;
     if (try_fwd_tiled(d, out, stream, &rc)) return rc;
     FwdArgs a;
     a.d = *d;

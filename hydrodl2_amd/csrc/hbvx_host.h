@@ -31,7 +31,7 @@ static const int LDS_BUDGET = 160 * 1024 - 512; // gfx950: 160 KiB per CU, one w
 // launch_pipe.hip
 bool try_fwd_pipe(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream, int *rc);
 // launch_stream.hip
-bool try_fwd_stream(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream, int *rc);
+bool try_fwd_stream(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream, int *rc, bool any_size = false);
 bool try_bwd_stream(const hbvx_desc *d, const hbvx_bwd_io *io, void *stream, int *rc);
 // launch_tiled.hip
 bool try_fwd_tiled(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream, int *rc);

@@ -33,11 +33,6 @@ bool hbvx_host::try_fwd_pipe(const hbvx_desc *d, const hbvx_fwd_out *out, void *
                 off32 = off32 && ((int64_t)d->B * d->p[i].dyn_b_stride + (int64_t)Kt * d->p[i].dyn_t_stride) * 4 <
                                      (int64_t)1 << 31;
         const int64_t wgs_p = ((int64_t)d->B + (64 >> lg_members(d->M)) - 1) / (64 >> lg_members(d->M));
-        // HBV 1.0: the pipelined kernel (one workgroup per CU) holds up to ~1000 wavefronts; the
-        // two-stage variant gives way to the streaming kernel at its cross-over (512); with more
-        // than three dynamic parameters there is no streaming kernel to give way to
-        const bool large = nd <= 3 && wgs_p >= (cap ? env_int("HBVX_STREAM_MIN", 512) : 1024) &&
-                           env_int("HBVX_STREAM", 1) != 0;
         const bool pmodel = d->model == HBVX_MODEL_HBV10 || d->model == HBVX_MODEL_HBV11P ||
                             d->model == HBVX_MODEL_HBV20 || d->model == HBVX_MODEL_HOURLY;
         const size_t lds = (size_t)PipeLds(Kt, nd > 0 ? (many ? nd : PIPE_FEWDYN) : 0, cap).total * 4;
@@ -45,7 +40,7 @@ bool hbvx_host::try_fwd_pipe(const hbvx_desc *d, const hbvx_fwd_out *out, void *
         const int ckpt_k = (out->traj && HBVX_TRAJ_KIND(out->traj_layout) == HBVX_TRAJ_CKPT)
                                ? HBVX_TRAJ_CKPT_DAYS(out->traj_layout) : 0;
         const bool ckpt_fits = !ckpt_k || ((int64_t)((d->T + ckpt_k - 1) / ckpt_k) * 5 * d->B * d->M * 4 < (int64_t)1 << 32);
-        if (ckpt_fits && use_tiled(d) && !(fv && !strcmp(fv, "tiled")) && pmodel && off32 && !large &&
+        if (ckpt_fits && use_tiled(d) && !(fv && !strcmp(fv, "tiled")) && pmodel && off32 &&
             nd <= PIPE_MAXDYN && (int)lds <= LDS_BUDGET && wgs_p < 4096 && !d->muwts && out->flux && d->T >= 4 * Kt &&
             (ckpt_k ? out->aux == nullptr : (out->traj != nullptr) == (out->aux != nullptr)) &&
             (int64_t)d->B * d->M * 4 * Kt < (int64_t)1 << 31 &&

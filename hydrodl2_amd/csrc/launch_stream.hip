@@ -38,7 +38,8 @@ StreamPlan plan_stream(const hbvx_desc *d)
         if (d->p[i].dyn) {
             mask |= 1u << i;
             if (k < 3) P.dslot[k++] = i;
-            P.ok = P.ok && ((int64_t)d->T * d->p[i].dyn_t_stride + (int64_t)d->B * d->p[i].dyn_b_stride) * 4 < lim;
+            // one day's row per descriptor (the kernels rebase it every day): the tensor itself may exceed 4 GiB
+            P.ok = P.ok && d->p[i].dyn_t_stride >= 0 && (int64_t)d->B * d->p[i].dyn_b_stride * 4 < lim;
         }
     const bool be = d->n_param >= 13;
     P.sc = mask == 0 ? 0
@@ -54,13 +55,22 @@ StreamPlan plan_stream(const hbvx_desc *d)
     return P;
 }
 
-int stream_min_fwd(const hbvx_desc *d)
+// Grid size (wavefronts of state) from which the streaming kernels run.  Measured on MI355X with
+// tools/grid_sweep.py (profiles/r02_grid_sweep.jsonl): second generation -- a training step (packed
+// trajectory, both directions streaming) wins from 768 wavefronts for hbv and ties there for hbv_2;
+// forward alone the pipelined kernel holds on to 1024.  First generation (the dynamic sets without a
+// compiled instance): forward from 1024, adjoint from 2048 (round-1 measurements).
+// HBVX_STREAM_MIN overrides all of them at once; HBVX_BWD=<family> pins the adjoint for tests.
+int stream_min(const StreamPlan &P, bool training, bool adjoint)
 {
-    // the pipelined forward holds ~1000 wavefronts of HBV 1.0 state (one workgroup per CU); its
-    // two-stage variant gives way at 512
-    return d->model == HBVX_MODEL_HBV10 ? env_int("HBVX_STREAM_MIN", 1024) : env_int("HBVX_STREAM_MIN", 512);
+    const int dflt = P.sc >= 0 ? (training ? 768 : 1024) : (adjoint ? 2048 : 1024);
+    return env_int("HBVX_STREAM_MIN", dflt);
 }
-int stream_min_bwd() { return env_int("HBVX_STREAM_MIN_BWD", 2048); }
+bool adjoint_pinned_elsewhere()
+{
+    const char *v = getenv("HBVX_BWD");
+    return v && strcmp(v, "stream") != 0;
+}
 
 template <int MODEL, bool BE, int SC>
 void go_fwd2(int trj, const StreamArgs &sa, dim3 grid, hipStream_t st)
@@ -131,19 +141,18 @@ extern "C" int hbvx_preferred_traj_layout(const hbvx_desc *d)
 {
     if (!d || check_desc(d) || d->model == HBVX_MODEL_HBVADJ) return HBVX_TRAJ_ROWS;
     const StreamPlan P = plan_stream(d);
-    const bool stream_both = P.ok && P.sc >= 0 && P.packed_ok && P.wgs >= stream_min_bwd() &&
-                             P.wgs >= stream_min_fwd(d);
+    const bool stream_both = P.ok && P.sc >= 0 && P.packed_ok && !adjoint_pinned_elsewhere() &&
+                             P.wgs >= stream_min(P, true, true);
     return stream_both ? HBVX_TRAJ_PACKED : HBVX_TRAJ_ROWS;
 }
 
-bool hbvx_host::try_fwd_stream(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream, int *rc)
+bool hbvx_host::try_fwd_stream(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream, int *rc, bool any_size)
 {
     const StreamPlan P = plan_stream(d);
     const bool packed = out->traj && out->traj_layout == HBVX_TRAJ_PACKED;
     const bool ckpt = out->traj && HBVX_TRAJ_KIND(out->traj_layout) == HBVX_TRAJ_CKPT;
     if (ckpt) {
-        // checkpoints: whatever the grid size, when the second generation has an instance; the offsets of
-        // the checkpoint rows must fit 32 bits
+        // checkpoints: the second generation only; the offsets of the checkpoint rows must fit 32 bits
         const int K = HBVX_TRAJ_CKPT_DAYS(out->traj_layout);
         const int64_t nseg = (d->T + K - 1) / K;
         if (!(P.ok && out->flux && P.sc >= 0 && nseg * 5 * (int64_t)d->B * d->M * 4 < ((int64_t)1 << 32))) return false;
@@ -155,7 +164,7 @@ bool hbvx_host::try_fwd_stream(const hbvx_desc *d, const hbvx_fwd_out *out, void
             *rc = fail(HBVX_E_UNSUPPORTED, "packed trajectory asked for a problem hbvx_preferred_traj_layout does not pack");
             return true;
         }
-    } else if (!ckpt && !(ok && P.wgs >= stream_min_fwd(d))) {
+    } else if (!(ok && (any_size || P.wgs >= stream_min(P, out->traj != nullptr, false)))) {
         return false;
     }
     StreamArgs sa;
@@ -202,13 +211,13 @@ bool hbvx_host::try_bwd_stream(const hbvx_desc *d, const hbvx_bwd_io *io, void *
     bool ok = P.ok && (io->grad_flux || io->grad_flux4);
     for (int i = 0; i < d->n_param && ok; i++)
         if (d->p[i].dyn && io->g[i].dyn)
-            ok = ((int64_t)d->T * io->g[i].dyn_t_stride + (int64_t)d->B * io->g[i].dyn_b_stride) * 4 < lim;
+            ok = io->g[i].dyn_t_stride >= 0 && (int64_t)d->B * io->g[i].dyn_b_stride * 4 < lim;
     if (packed) {
         if (!(ok && P.sc >= 0 && P.packed_ok)) {
             *rc = fail(HBVX_E_UNSUPPORTED, "packed trajectory: no adjoint kernel for this call");
             return true;
         }
-    } else if (!(ok && P.wgs >= stream_min_bwd())) {
+    } else if (!(ok && !adjoint_pinned_elsewhere() && P.wgs >= stream_min(P, true, true))) {
         return false;
     }
     StreamBwdArgs sa;
