@@ -198,6 +198,47 @@ __device__ __forceinline__ float s2_pick(const s2_f3 v, int ch)
     return ch == 0 ? v.x : (ch == 1 ? v.y : v.z);
 }
 
+// Ensemble sums of NF series over the 16 member lanes of a basin row, leaving series jm on member lane
+// jm (the flux store wants exactly that).  A butterfly that adds every series on every lane costs 4 DPP
+// adds per series (48) plus an 11-deep select to pick the lane's series; halving the number of live
+// values at every stage costs 33, with the SAME add tree (lane pairs, quads, quad pairs, halves), so the
+// result is bit-identical to ens_sum_dpp's:
+//   stage 1  lanes l, l^1:  even lanes keep series 2i, odd lanes 2i+1 (2 selects + 1 DPP add)  12 -> 6
+//   stage 2  lanes l, l^2:  the same on bit 1                                                   6 -> 3
+//   stage 3  quads q, q^1:  one v_add_f32_dpp per input value -- row_ror brings the partner quad's
+//            value, bank_mask confines the write to the quads that keep that series             3(+0) -> 2
+//   stage 4  quads q, q^2:  likewise with row_ror:8                                             2 -> 1
+// The DPP reads of stages 3 and 4 come straight after VALU writes of their sources; the two wait states
+// that needs (ISA guide, manually inserted wait states) are the s_nop 1 at the head of each block -- the
+// compiler does not look inside inline assembly.
+template <int NF>
+__device__ __forceinline__ float s2_ens_sum16(const float *f, bool b0, bool b1)
+{
+    float g[6], h[3];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const float x = f[2 * i], y = 2 * i + 1 < NF ? f[2 * i + 1] : 0.0f;
+        g[i] = (b0 ? y : x) + dpp_<0xB1>(b0 ? x : y);          // quad_perm [1,0,3,2]
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+        h[j] = (b1 ? g[2 * j + 1] : g[2 * j]) + dpp_<0x4E>(b1 ? g[2 * j] : g[2 * j + 1]);   // quad_perm [2,3,0,1]
+    float p, r, v;
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %0, %3, %3 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %1, %4, %4 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %1, %4, %4 row_ror:4 row_mask:0xf bank_mask:0xa"
+        : "=&v"(p), "=&v"(r)
+        : "v"(h[0]), "v"(h[1]), "v"(h[2]));
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc"
+        : "=&v"(v)
+        : "v"(p), "v"(r));
+    return v;
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward.  TRJ: 0 nothing kept, 1 trajectory rows [5,T+1,N] + aux [2,T,N], 2 packed, 3 K-day
 // checkpoints [ceil(T/K),5,N] (HBVX_TRAJ_CKPT; K a power of two).
@@ -244,24 +285,23 @@ __global__ void __launch_bounds__(64) FWPE k_fwd_stream2(const StreamArgs A)
     const float *dbase[ND > 0 ? ND : 1];
     int64_t dts[ND > 0 ? ND : 1];
     unsigned dvo[ND > 0 ? ND : 1];
-    float dlo[ND > 0 ? ND : 1], dsc[ND > 0 ? ND : 1], dsta[ND > 0 ? ND : 1];
-    bool duse[ND > 0 ? ND : 1];
+    // per lane: range and offset of the day's value, or (0, static value) where dy_drop masked the basin --
+    // the reference's `dyn * (1 - mask) + static * mask` (hbv.py:246), no lane mask to keep in SGPRs
+    float dlo[ND > 0 ? ND : 1], dsc[ND > 0 ? ND : 1];
 #pragma unroll
     for (int k = 0; k < ND; k++) {
         const hbvx_param_src &ps = d.p[stream_slot<SC>(k)];
         dbase[k] = ps.dyn;
         dvo[k] = (unsigned)((L.b * ps.dyn_b_stride + L.j) * 4);
         dts[k] = ps.dyn_t_stride;
-        dlo[k] = ps.lo;
-        dsc[k] = ps.hi - ps.lo;
-        dsta[k] = p[stream_slot<SC>(k)];
-        duse[k] = !(ps.drop && ps.drop[L.b]);
+        const bool use = !(ps.drop && ps.drop[L.b]);
+        dlo[k] = use ? ps.lo : p[stream_slot<SC>(k)];
+        dsc[k] = use ? ps.hi - ps.lo : 0.0f;
     }
     // outputs
     const auto rflux = S2Buf::rsrc(o.flux);
     const auto rtraj = S2Buf::rsrc(o.traj), raux = S2Buf::rsrc(o.aux ? o.aux : o.traj);
-    const S2Buf::u4 wtraj = S2Buf::words(o.traj);
-    const auto rslz = S2Buf::rsrc(TRJ == 2 ? o.traj + 4 * (int64_t)(T + 1) * N : o.traj);
+    const float *const slz0 = o.traj + 4 * (int64_t)(T + 1) * N;   // packed layout: the SLZ rows
     unsigned tvo[5], avo[2];
 #pragma unroll
     for (int k = 0; k < 5; k++) tvo[k] = (TRJ == 1 && L.active) ? (unsigned)((k * (int64_t)(T + 1) * N + L.n) * 4) : OOB;
@@ -275,14 +315,16 @@ __global__ void __launch_bounds__(64) FWPE k_fwd_stream2(const StreamArgs A)
     const unsigned pvo2 = (TRJ == 2 && L.active && o.aux) ? (unsigned)(L.n * 8) : OOB;
     const unsigned row4 = (unsigned)(N * 4);
     const unsigned fT = (unsigned)((int64_t)T * B * 4), fB = (unsigned)(B * 4);
-    // flux, Mp = 16 (the usual nmul): member lane j picks series j, one ds_bpermute hands the value of
-    // (series k, basin q) to lane 4k + q, and lanes 0..4*NF-1 store -- every quad writes 16 contiguous
+    // flux, Mp = 16 (the usual nmul): s2_ens_sum16 leaves one series per member lane, one ds_bpermute hands the
+    // value of (series k, basin q) to lane 4k + q, and lanes 0..4*NF-1 store -- every quad writes 16 contiguous
     // bytes (12 requests per day where one lane per series and basin would make 48 four-byte ones: the
     // address FIFO of the memory pipeline was full a fifth of the time).  Other Mp: the basin leader
     // stores the NF series one by one.
     const bool roles = lgMp == 4;
     const int tl = L.lane;                          // as a target: series tl / 4 of basin tl % 4
     const int src_lane = (tl & 3) * 16 + (tl >> 2);  // who holds it: lane jm = series in basin row tl % 4
+    const bool jb0 = (L.jm & 1) != 0, jb1 = (L.jm & 2) != 0;
+    const bool all_act = __builtin_amdgcn_ballot_w64(L.active) == ~0ull;   // no padded member lanes, no basins past B
     const int tb = L.b0 + (tl & 3);
     const unsigned fvo_role = (roles && (tl >> 2) < NF && tb < B) ? (unsigned)(((int64_t)(tl >> 2) * T * B + tb) * 4) : OOB;
     const unsigned fvo_lead = (!roles && L.active && L.jm == 0) ? (unsigned)(L.b * 4) : OOB;
@@ -310,14 +352,14 @@ __global__ void __launch_bounds__(64) FWPE k_fwd_stream2(const StreamArgs A)
         Step<MODEL, BETAET> s;
         if (XVEC) {
             const s2_f3 v = {fx[j][0], fx[j][1], fx[j][2]};
-            s.P = s2_pick(v, cp); s.Tf = s2_pick(v, ct); s.PET = s2_pick(v, ce);
+            s.P = v.x; s.Tf = v.y; s.PET = v.z;   // XVEC: channels in (prcp, tmean, pet) order
         } else {
             s.P = fx[j][0]; s.Tf = fx[j][1]; s.PET = fx[j][2];
         }
 #pragma unroll
         for (int k = 0; k < ND; k++) {
             const float u = raw ? sigmoid_dyn_(dv[j][k]) : dv[j][k];
-            p[stream_slot<SC>(k)] = duse[k] ? u * dsc[k] + dlo[k] : dsta[k];
+            p[stream_slot<SC>(k)] = u * dsc[k] + dlo[k];
         }
         s.SP = st[0]; s.MW = st[1]; s.SM = st[2]; s.SUZ = st[3]; s.SLZ = st[4];
         s.template fwd<false>(p, nz, ac, elev, 0.0f, 0.0f);
@@ -330,17 +372,20 @@ __global__ void __launch_bounds__(64) FWPE k_fwd_stream2(const StreamArgs A)
         }
         if (TRJ == 3) {
             if ((t & (ckK - 1)) == 0) {   // wave-uniform
-                const unsigned so = (unsigned)(t >> cklg) * 5u * row4;
+                const auto rck = S2Buf::rsrc(o.traj + (int64_t)(t >> cklg) * 5 * N);   // this checkpoint's five rows
 #pragma unroll
-                for (int k = 0; k < 5; k++) S2Buf::st(rtraj, cvo, so + (unsigned)k * row4, st[k]);
+                for (int k = 0; k < 5; k++) S2Buf::st(rck, cvo, (unsigned)k * row4, st[k]);
             }
         }
         if (TRJ == 2 && !(STREAM2_EXP & 4)) {
             const s2_f4 rec = {st[0], st[1], st[2], st[3]};
             const s2_f2 pw = {s.sw0, s.ef0};
-            if (!(STREAM2_EXP & 8)) S2Buf::st4(wtraj, pvo4, (unsigned)t * row4 * 4u, rec);
-            if (!(STREAM2_EXP & 16)) S2Buf::sts(rslz, pvo1, (unsigned)t * row4, st[4]);
-            if (!(STREAM2_EXP & 32)) S2Buf::sts2(raux, pvo2, (unsigned)t * row4 * 2u, pw);
+            // the day's rows through descriptors rebased on them (64-bit scalar arithmetic): one row
+            // has to fit a descriptor's 4 GiB, not the trajectory
+            const int64_t tN = (int64_t)t * N;
+            if (!(STREAM2_EXP & 8)) S2Buf::st4(S2Buf::words(o.traj + tN * 4), pvo4, 0u, rec);
+            if (!(STREAM2_EXP & 16)) S2Buf::sts(S2Buf::rsrc(slz0 + tN), pvo1, 0u, st[4]);
+            if (!(STREAM2_EXP & 32)) S2Buf::sts2(S2Buf::rsrc(o.aux + tN * 2), pvo2, 0u, pw);
         }
         st[0] = s.SP3; st[1] = s.MW3; st[2] = s.SM4; st[3] = s.SUZ4; st[4] = s.SLZ2;
         const float act = L.active ? 1.0f : 0.0f;
@@ -349,9 +394,11 @@ __global__ void __launch_bounds__(64) FWPE k_fwd_stream2(const StreamArgs A)
         f[HBVX_F_AET] = s.ET; f[HBVX_F_SWE] = s.SP3; f[HBVX_F_RECHARGE] = s.rech; f[HBVX_F_EXCS] = s.exc;
         f[HBVX_F_EVAPFACTOR] = s.ef; f[HBVX_F_TOSOIL] = s.tosoil; f[HBVX_F_PERC] = s.PERC;
         f[HBVX_F_CAPILLARY] = s.cap;
+        if (!all_act) {
 #pragma unroll
-        for (int k = 0; k < NF; k++) f[k] *= act;
-        ens_sum_dpp<NF>(f, lgMp);
+            for (int k = 0; k < NF; k++) f[k] *= act;
+        }
+        if (!roles) ens_sum_dpp<NF>(f, lgMp);
         const unsigned fso = (unsigned)t * fB;
         if (STREAM2_EXP & 1) {
             float acc = 0.0f;
@@ -359,9 +406,7 @@ __global__ void __launch_bounds__(64) FWPE k_fwd_stream2(const StreamArgs A)
             for (int k = 0; k < NF; k++) acc += f[k];
             if (acc == 123.456f) S2Buf::st(rflux, fvo_role, fso, acc);
         } else if (roles) {
-            float v = f[0];
-#pragma unroll
-            for (int k = 1; k < NF; k++) v = (L.jm == k) ? f[k] : v;
+            float v = s2_ens_sum16<NF>(f, jb0, jb1);
             v = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane * 4, __builtin_bit_cast(int, v * invM)));
             S2Buf::sts(rflux, fvo_role, fso, v);
         } else {
@@ -481,7 +526,7 @@ k_bwd_stream2(const StreamBwdArgs A)
     }
 
     const auto rx = S2Buf::rsrc(d.x), rtraj = S2Buf::rsrc(io.traj), raux = S2Buf::rsrc(io.aux);
-    const auto rslz = S2Buf::rsrc(TRJ == 2 ? io.traj + 4 * (int64_t)(T + 1) * N : io.traj);
+    const float *const slz0 = io.traj + 4 * (int64_t)(T + 1) * N;   // packed layout: the SLZ rows
     const auto rgf = S2Buf::rsrc(io.grad_flux ? io.grad_flux : io.grad_flux4);
     const auto rg4 = S2Buf::rsrc(io.grad_flux4 ? io.grad_flux4 : io.grad_flux);
     const bool has_gf = io.grad_flux != nullptr, has_g4 = io.grad_flux4 != nullptr;
@@ -502,6 +547,7 @@ k_bwd_stream2(const StreamBwdArgs A)
     float *gdbase[ND > 0 ? ND : 1];
     int64_t dts[ND > 0 ? ND : 1], gdts[ND > 0 ? ND : 1];
     unsigned dvo[ND > 0 ? ND : 1], gdvo[ND > 0 ? ND : 1];
+    // the adjoint is short of VGPRs, not SGPRs: range / offset stay wave-uniform, the dy_drop mask a lane mask
     float dlo[ND > 0 ? ND : 1], dsc[ND > 0 ? ND : 1], dsta[ND > 0 ? ND : 1];
     bool duse[ND > 0 ? ND : 1];
 #pragma unroll
@@ -543,10 +589,11 @@ k_bwd_stream2(const StreamBwdArgs A)
             I.fx[2] = S2Buf::ld(rx, xvo, so + ce * 4);
         }
         if (TRJ == 2) {
-            const s2_f4 rec = S2Buf::ld4(rtraj, pvo4, sr * 4u);
+            const int64_t tN = (int64_t)tc * N;   // descriptors rebased on the day's rows (see the forward)
+            const s2_f4 rec = S2Buf::ld4(S2Buf::rsrc(io.traj + tN * 4), pvo4, 0u);
             I.st[0] = rec.x; I.st[1] = rec.y; I.st[2] = rec.z; I.st[3] = rec.w;
-            I.st[4] = S2Buf::ld(rslz, pvo1, sr);
-            const s2_f2 pw = S2Buf::ld2(raux, pvo2, sr * 2u);
+            I.st[4] = S2Buf::ld(S2Buf::rsrc(slz0 + tN), pvo1, 0u);
+            const s2_f2 pw = S2Buf::ld2(S2Buf::rsrc(io.aux + tN * 2), pvo2, 0u);
             I.ax[0] = pw.x; I.ax[1] = pw.y;
         } else {
 #pragma unroll
@@ -567,7 +614,7 @@ k_bwd_stream2(const StreamBwdArgs A)
         Step<MODEL, BETAET> s;
         if (XVEC) {
             const s2_f3 v = {I.fx[0], I.fx[1], I.fx[2]};
-            s.P = s2_pick(v, cp); s.Tf = s2_pick(v, ct); s.PET = s2_pick(v, ce);
+            s.P = v.x; s.Tf = v.y; s.PET = v.z;   // XVEC: channels in (prcp, tmean, pet) order
         } else {
             s.P = I.fx[0]; s.Tf = I.fx[1]; s.PET = I.fx[2];
         }
@@ -637,11 +684,13 @@ k_bwd_stream2(const StreamBwdArgs A)
                 S2Buf::ld_lds<4>(rx, l_x + 128, xvo, so + ce * 4);
             }
             if (TRJ == 2) {
-                S2Buf::ld_lds<16>(rtraj, l_rec, pvo4, sr * 4u);
-                S2Buf::ld_lds<4>(rslz, l_st[4], pvo1, sr);
+                const int64_t tN = (int64_t)tc * N;
+                const auto rpw = S2Buf::rsrc(io.aux + tN * 2);
+                S2Buf::ld_lds<16>(S2Buf::rsrc(io.traj + tN * 4), l_rec, pvo4, 0u);
+                S2Buf::ld_lds<4>(S2Buf::rsrc(slz0 + tN), l_st[4], pvo1, 0u);
                 // 8-byte LDS-DMA does not exist: the two saved powers travel as two 4-byte rows
-                S2Buf::ld_lds<4>(raux, l_ax, pvo2, sr * 2u);
-                S2Buf::ld_lds<4>(raux, l_ax + 64, pvo2 + 4u, sr * 2u);
+                S2Buf::ld_lds<4>(rpw, l_ax, pvo2, 0u);
+                S2Buf::ld_lds<4>(rpw, l_ax + 64, pvo2 + 4u, 0u);
             } else {
 #pragma unroll
                 for (int k = 0; k < 5; k++) S2Buf::ld_lds<4>(rtraj, l_st[k], tvo[k], sr);

@@ -16,7 +16,9 @@ struct StreamPlan {
     int nd;
     int sc;         // compile-time dynamic set of hbv_stream2.h (0 none, 1, 2) or -1: first generation only
     bool xvec;      // three adjacent forcing channels
-    bool packed_ok; // packed trajectory offsets fit 32 bits
+    bool gen1_ok;   // first generation: whole dynamic tensors within 32-bit offsets
+    bool rows_ok;   // row trajectory: every offset fits 32 bits
+    bool packed_ok; // packed trajectory / checkpoints: one day's rows fit 32 bits (descriptors rebased per day)
     int dslot[3];
 };
 
@@ -30,8 +32,9 @@ StreamPlan plan_stream(const hbvx_desc *d)
     P.nd = count_dyn(d);
     const int nf = (d->model == HBVX_MODEL_HBV10) ? 11 : 12;
     P.ok = use_tiled(d) && env_int("HBVX_STREAM", 1) != 0 && P.nd <= 3 && !d->muwts && d->T > 0 &&
-           5 * (int64_t)(d->T + 1) * N * 4 < lim && (int64_t)nf * d->T * d->B * 4 < lim &&
+           (int64_t)nf * d->T * d->B * 4 < lim &&
            ((int64_t)d->T * d->x_t_stride + (int64_t)d->B * d->x_b_stride) * 4 < lim;
+    P.gen1_ok = true;
     unsigned mask = 0;
     int k = 0;
     for (int i = 0; i < d->n_param; i++)
@@ -39,6 +42,7 @@ StreamPlan plan_stream(const hbvx_desc *d)
             mask |= 1u << i;
             if (k < 3) P.dslot[k++] = i;
             // one day's row per descriptor (the kernels rebase it every day): the tensor itself may exceed 4 GiB
+            P.gen1_ok = P.gen1_ok && ((int64_t)d->T * d->p[i].dyn_t_stride + (int64_t)d->B * d->p[i].dyn_b_stride) * 4 < lim;
             P.ok = P.ok && d->p[i].dyn_t_stride >= 0 && (int64_t)d->B * d->p[i].dyn_b_stride * 4 < lim;
         }
     const bool be = d->n_param >= 13;
@@ -48,10 +52,12 @@ StreamPlan plan_stream(const hbvx_desc *d)
          : (mask == ((1u << P_BETA) | (1u << P_K0) | (1u << P_BETAET)) &&
             (d->model == HBVX_MODEL_HBV20 || d->model == HBVX_MODEL_HOURLY)) ? 2 : -1;
     const int c0 = d->ch_prcp, c1 = d->ch_tmean, c2 = d->ch_pet;
-    P.xvec = c0 >= 0 && c0 < 3 && c1 >= 0 && c1 < 3 && c2 >= 0 && c2 < 3 && c0 != c1 && c0 != c2 && c1 != c2 &&
-             d->x_b_stride >= 3;
+    // second generation: the forcing channels in (prcp, tmean, pet) order, a basin's three values adjacent
+    P.xvec = c0 == 0 && c1 == 1 && c2 == 2 && d->x_b_stride >= 3;
     if (env_int("HBVX_STREAM2", 1) == 0 || !P.xvec) P.sc = -1;
-    P.packed_ok = (int64_t)(d->T + 1) * N * 16 < lim;
+    P.rows_ok = 5 * (int64_t)(d->T + 1) * N * 4 < lim;
+    P.packed_ok = N * 20 < lim;
+    if (P.sc < 0) P.ok = P.ok && P.gen1_ok && P.rows_ok;
     return P;
 }
 
@@ -153,12 +159,11 @@ bool hbvx_host::try_fwd_stream(const hbvx_desc *d, const hbvx_fwd_out *out, void
     const bool ckpt = out->traj && HBVX_TRAJ_KIND(out->traj_layout) == HBVX_TRAJ_CKPT;
     if (ckpt) {
         // checkpoints: the second generation only; the offsets of the checkpoint rows must fit 32 bits
-        const int K = HBVX_TRAJ_CKPT_DAYS(out->traj_layout);
-        const int64_t nseg = (d->T + K - 1) / K;
-        if (!(P.ok && out->flux && P.sc >= 0 && nseg * 5 * (int64_t)d->B * d->M * 4 < ((int64_t)1 << 32))) return false;
+        if (!(P.ok && out->flux && P.sc >= 0 && P.packed_ok)) return false;
     }
     // the second generation also takes a trajectory without the saved powers (inference that keeps the state series)
     bool ok = P.ok && out->flux && (P.sc >= 0 ? (out->traj || !out->aux) : (out->traj != nullptr) == (out->aux != nullptr));
+    if (out->traj && !packed && !ckpt) ok = ok && P.rows_ok;
     if (packed) {
         if (!(ok && P.sc >= 0 && P.packed_ok)) {
             *rc = fail(HBVX_E_UNSUPPORTED, "packed trajectory asked for a problem hbvx_preferred_traj_layout does not pack");
@@ -208,10 +213,11 @@ bool hbvx_host::try_bwd_stream(const hbvx_desc *d, const hbvx_bwd_io *io, void *
     StreamPlan P = plan_stream(d);
     const int64_t lim = (int64_t)1 << 32;
     const bool packed = io->traj_layout == HBVX_TRAJ_PACKED;
-    bool ok = P.ok && (io->grad_flux || io->grad_flux4);
+    bool ok = P.ok && (io->grad_flux || io->grad_flux4) && (packed || P.rows_ok);
     for (int i = 0; i < d->n_param && ok; i++)
         if (d->p[i].dyn && io->g[i].dyn)
-            ok = io->g[i].dyn_t_stride >= 0 && (int64_t)d->B * io->g[i].dyn_b_stride * 4 < lim;
+            ok = io->g[i].dyn_t_stride >= 0 && (int64_t)d->B * io->g[i].dyn_b_stride * 4 < lim &&
+                 (P.sc >= 0 || ((int64_t)d->T * io->g[i].dyn_t_stride + (int64_t)d->B * io->g[i].dyn_b_stride) * 4 < lim);
     if (packed) {
         if (!(ok && P.sc >= 0 && P.packed_ok)) {
             *rc = fail(HBVX_E_UNSUPPORTED, "packed trajectory: no adjoint kernel for this call");

@@ -181,6 +181,10 @@ def _slice_problem(prob, pick):
     ("Hbv_2_hourly", 4, 32800, 256, ("parBETA", "parK0", "parBETAET")),
     ("Hbv", 16, 8200, 260, ("parBETA", "parBETAET")),
     ("Hbv_1_1p", 16, 8200, 256, ()),
+    # beyond a buffer descriptor's 4 GiB: the packed trajectory (4.4 GB of records) and the raw
+    # [T, B, ny] parameter tensor (4.4 GB) -- the kernels rebase their descriptors on the day's rows
+    ("Hbv_2", 16, 24600, 700, ()),
+    ("Hbv", 16, 8200, 640, ("parBETA", "parBETAET")),
 ])
 def test_streaming_kernels_oracle_spot_check(model, M, B, T, dyn, hip_backend, oracle_path):
     """>= 2048 wavefronts of state, so BOTH directions take the streaming kernels (packed trajectory,
