@@ -156,6 +156,31 @@ def _grad_like(lib, p: torch.Tensor, cfg: "StepConfig", tensor_idx: int) -> torc
     return out
 
 
+# Parameter-gradient buffers are prepared while the forward kernel runs: the zero fill of a [T,B,ny]
+# gradient (3.8 GB, 0.55 ms at HBM speed for config 2) needs bandwidth, the pipelined forward needs
+# latency on 168 of 256 CUs -- on a second HIP stream the fill disappears behind it.  The buffers are
+# handed to backward through the autograd context (first backward only; a second one over a retained
+# graph fills its own).  HBVX_EARLY_ZERO=0 restores the fill at backward time.
+_EARLY_ZERO = os.environ.get("HBVX_EARLY_ZERO", "1") not in ("", "0")
+_SIDE_STREAMS: dict = {}
+
+
+def _early_grad_buffers(lib, cfg: "StepConfig", ptensors, needs) -> Optional[tuple]:
+    dev = ptensors[0].device
+    main = torch.cuda.current_stream(dev)
+    side = _SIDE_STREAMS.get(dev.index)
+    if side is None:
+        side = _SIDE_STREAMS[dev.index] = torch.cuda.Stream(dev)
+    with torch.cuda.stream(side):
+        bufs = [_grad_like(lib, p, cfg, i) if need else None for i, (p, need) in enumerate(zip(ptensors, needs))]
+        done = torch.cuda.Event()
+        done.record(side)
+    for b in bufs:
+        if b is not None:
+            b.record_stream(main)      # allocated on the side stream's pool, consumed on the caller's
+    return bufs, done
+
+
 def _ptr(t: Optional[torch.Tensor], off: int = 0) -> Optional[int]:
     if t is None:
         return None
@@ -281,6 +306,9 @@ class HbvPath(torch.autograd.Function):
         out.flux, out.state_out = _ptr(flux), _ptr(state_out)
         out.traj, out.aux = _ptr(traj), _ptr(aux)
         out.n_flux, out.traj_layout = cfg.n_flux, cfg.traj_layout
+        ctx.early_gp = None
+        if needs_grad and _EARLY_ZERO and lib.is_device and any(ctx.needs_input_grad[6:]):
+            ctx.early_gp = _early_grad_buffers(lib, cfg, ptensors, ctx.needs_input_grad[6:])
         _call(lib, 'hbvx_forward', lib.forward, desc, out, stream)
 
         routed = uh = None
@@ -314,8 +342,13 @@ class HbvPath(torch.autograd.Function):
         T, B, M = cfg.T, cfg.B, cfg.M
         stream = _stream_of(lib, x)
 
-        gp = [_grad_like(lib, p, cfg, i) if ctx.needs_input_grad[6 + i] else None
-              for i, p in enumerate(ptensors)]
+        early, ctx.early_gp = ctx.early_gp, None
+        if early is not None:
+            gp, done = early
+            torch.cuda.current_stream(dev).wait_event(done)
+        else:
+            gp = [_grad_like(lib, p, cfg, i) if ctx.needs_input_grad[6 + i] else None
+                  for i, p in enumerate(ptensors)]
 
         gq = None
         if g_routed is not None and cfg.route is not None:

@@ -15,11 +15,9 @@ from tests import seam  # noqa: E402
 from tools.bench_configs import gen  # noqa: E402
 
 PROBE_LIB = os.path.join(ROOT, "hydrodl2_amd", "csrc", "libhbvx_probe.so")
-SRC = os.path.join(ROOT, "hydrodl2_amd", "csrc", "hbvx.hip")
 if not os.path.exists(PROBE_LIB) or os.path.getmtime(PROBE_LIB) < os.path.getmtime(os.path.join(ROOT, "hydrodl2_amd", "csrc", "libhbvx.so")):
     import subprocess
-    import __graft_entry__ as ge
-    subprocess.check_call(["/opt/rocm/bin/hipcc"] + ge.HIPCC_FLAGS + ["-DPIPE_PROBE", "-o", PROBE_LIB, SRC])
+    subprocess.check_call(["bash", os.path.join(ROOT, "tools", "build_variant.sh"), "probe", "launch_pipe", "-DPIPE_PROBE"])
 seam.use_library(PROBE_LIB)
 lib = _lib.get_library()
 dev = torch.device("cuda:0")
