@@ -54,6 +54,11 @@ class HbvModule(torch.nn.Module):
         # (keep K-day checkpoints and recompute: 20/K instead of 28 bytes per lane-day); config key
         # 'adjoint_checkpoint' or, when unset, the environment variable HBVX_CKPT_DAYS
         self.adjoint_checkpoint = int(os.environ.get('HBVX_CKPT_DAYS', '0') or 0)
+        # not in the reference: the step's clamps (fmaxf / fminf) drop a NaN operand where torch.clamp /
+        # torch.minimum propagate it, so a missing forcing value gives finite output here and a NaN basin
+        # upstream.  With this key (or HBVX_CHECK_FINITE=1) non-finite forcings or
+        # parameters raise instead of being absorbed; off by default (it costs two reductions per call).
+        self.check_finite = os.environ.get('HBVX_CHECK_FINITE', '0') not in ('', '0')
 
         self.states, self._states_cache = None, None
 
@@ -86,7 +91,7 @@ class HbvModule(torch.nn.Module):
     # -- configuration --------------------------------------------------
     # config key -> attribute of the same name; absent keys keep the constructor default
     _CONFIG_KEYS = ('warm_up', 'warm_up_states', 'dy_drop', 'variables', 'routing', 'comprout',
-                    'nearzero', 'nmul', 'cache_states', 'adjoint_checkpoint')
+                    'nearzero', 'nmul', 'cache_states', 'adjoint_checkpoint', 'check_finite')
 
     def _read_config(self, config: dict) -> None:
         """Same keys and defaults as hbv.py:110-125; `dynamic_params` is REQUIRED once a config is
@@ -213,6 +218,10 @@ class HbvModule(torch.nn.Module):
 
         if self.adjoint_checkpoint not in (0, 4, 8, 16):
             raise ValueError("adjoint_checkpoint must be 0, 4, 8 or 16 days")
+        if self.check_finite:
+            for name, t in (('x_phy', x), ('parameters', parameters)):
+                if not bool(torch.isfinite(t).all()):
+                    raise ValueError(f"{name} holds non-finite values (check_finite is set)")
         base = dict(model=self._model_id, n_param=n, n_flux=self._n_flux(), B=ngrid, M=M,
                     raw_sigmoid=True, channels=self._channels(), nearzero=float(self.nearzero),
                     ckpt_days=int(self.adjoint_checkpoint))

@@ -105,6 +105,10 @@ class Hbv_2(HbvModule):
         ck = int(self.adjoint_checkpoint) if not self.initialize else 0
         if ck not in (0, 4, 8, 16):
             raise ValueError("adjoint_checkpoint must be 0, 4, 8 or 16 days")
+        if self.check_finite:
+            for name, t in (('x_phy', x), ('dynamic parameters', parameters[0]), ('static parameters', parameters[1])):
+                if not bool(torch.isfinite(t).all()):
+                    raise ValueError(f"{name} hold non-finite values (check_finite is set)")
         cfg = StepConfig(model=self._model_id, n_param=n, n_flux=12, T=T, t0=0, B=ngrid, M=M,
                          raw_sigmoid=False, channels=self._channels(),
                          nearzero=float(self.nearzero), params=srcs,

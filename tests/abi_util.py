@@ -51,7 +51,7 @@ def make_problem(model="Hbv", T=40, B=5, M=4, dyn=(), betaet=False, drop_frac=0.
     return prob
 
 
-def run_problem(prob, lib_path, device="cpu", x_grad=False, backward=True, t0=0):
+def run_problem(prob, lib_path, device="cpu", x_grad=False, backward=True, t0=0, keep_traj=True):
     """Run forward (+backward with fixed output gradients) under `lib_path` (None = product)."""
     seam.use_library(lib_path)
     try:
@@ -89,7 +89,7 @@ def run_problem(prob, lib_path, device="cpu", x_grad=False, backward=True, t0=0)
         res = {"flux": flux.detach().cpu().numpy(), "state_out": state_out.cpu().numpy()}
         if routed is not None:
             res["routed"] = routed.detach().cpu().numpy()
-        if traj is not None:    # always compared in the row layout [5, T+1, N]
+        if traj is not None and keep_traj:    # always compared in the row layout [5, T+1, N]
             res["traj"] = torch.stack([v.reshape(Tc + 1, B * M) for v in
                                        state_series(traj, cfg.traj_layout, Tc, B, M)]).cpu().numpy()
         if backward:

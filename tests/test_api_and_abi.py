@@ -119,3 +119,39 @@ def test_product_fails_loudly_without_gpu_tensors():
     m = load_model("hbv", "Hbv")(None, torch.device("cpu"))
     with pytest.raises(RuntimeError, match="GPU|HIP"):
         m({"x_phy": torch.rand(6, 2, 3)}, torch.randn(6, 2, 14))
+
+
+def _nan_forcing_case(device):
+    import torch
+    import hydrodl2_amd
+    T, B, M = 40, 3, 4
+    g = torch.Generator().manual_seed(3)
+    x = torch.stack([torch.rand((T, B), generator=g) * 10, torch.randn((T, B), generator=g) * 5 + 3,
+                     torch.rand((T, B), generator=g) * 4], -1)
+    x[7, 1, 1] = float("nan")            # one missing temperature
+    model = hydrodl2_amd.load_model("hbv", "Hbv")({"nmul": M, "dynamic_params": {"Hbv": []}}, device)
+    p = torch.randn((T, B, model.learnable_param_count), generator=g)
+    return model, x.to(device), p.to(device)
+
+
+def _check_nan_policy(model, x, p):
+    """Pins the documented divergence: the step's clamps are fmaxf / fminf, which drop a NaN
+    operand, so a missing forcing value is absorbed (finite output; the reference turns that basin NaN
+    from that day on) -- unless `check_finite` is set, which raises instead."""
+    import torch
+    out = model({"x_phy": x}, p)
+    assert torch.isfinite(out["streamflow"]).all()
+    model.check_finite = True
+    with pytest.raises(ValueError, match="non-finite"):
+        model({"x_phy": x}, p)
+    x2 = torch.nan_to_num(x, nan=1.0)
+    assert torch.isfinite(model({"x_phy": x2}, p)["streamflow"]).all()
+
+
+def test_nan_forcing_policy_on_oracle(oracle_backend):
+    _check_nan_policy(*_nan_forcing_case("cpu"))
+
+
+@pytest.mark.gpu
+def test_nan_forcing_policy_on_gpu(hip_backend):
+    _check_nan_policy(*_nan_forcing_case("cuda:0"))
