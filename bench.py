@@ -21,7 +21,7 @@ LOCAL_RANK / WORLD_SIZE set) or `python bench.py --gpus N` does it itself: the p
 children BEFORE touching the GPU and relays rank 0's JSON line.
 
 Rank 0 prints ONE JSON line.  `value` = whole-job basin-ensemble-timesteps/s.  At N = 1 the line also
-carries `secondary` (configs 2-dyn, 3, 4 and one GPU's share of 5, driver-timed in the same run) and
+carries `secondary` (configs 2-dyn, 3, 4, one GPU's share of 5 and the deltaMG minibatch shape, driver-timed in the same run) and
 `cpu_baseline` (the C/OpenMP oracle port and the pure-torch eager restatement on the host cores).
 """
 from __future__ import annotations
@@ -87,6 +87,8 @@ WORKLOADS = {
     "cfg4": ("hbv_adj", "HbvAdj", 7300, 671, 16, ["parBETAET"]),
     "cfg5": ("hbv_2", "Hbv_2", 730, 100000, 16, ["parBETA", "parK0", "parBETAET"]),
     "cfg5share": ("hbv_2", "Hbv_2", 730, 12500, 16, ["parBETA", "parK0", "parBETAET"]),
+    # the deltaMG minibatch shape of SURVEY §8d: 100 basins, 365 warm-up + 365 days
+    "dmg": ("hbv", "Hbv", 730, 100, 16, ["parBETA", "parBETAET"], {"warm_up": 365}),
 }
 
 
@@ -96,13 +98,15 @@ class Workload:
     def __init__(self, name, dev, seed, B=None, T=None, M=None):
         import torch
         import hydrodl2_amd
-        fam, cls, T0, B0, M0, dyn = WORKLOADS[name]
+        fam, cls, T0, B0, M0, dyn = WORKLOADS[name][:6]
+        extra = WORKLOADS[name][6] if len(WORKLOADS[name]) > 6 else {}
         self.name, self.T, self.B, self.M = name, T or T0, B or B0, M or M0
         T, B, M = self.T, self.B, self.M
         C = hydrodl2_amd.load_model(fam, cls)
         if dyn == "all":
             dyn = list(C(None, dev).parameter_bounds)
-        self.model = C({"nmul": M, "dynamic_params": {cls: list(dyn)}}, dev)
+        self.model = C({"nmul": M, "dynamic_params": {cls: list(dyn)}, **extra}, dev)
+        self.T_out = T - int(extra.get("warm_up", 0))     # warm_up_states (default): outputs start after the warm-up
         self.n_dyn = len(dyn)
         self.routed = bool(self.model.routing)
         self.n_flux = {"Hbv": 11, "HbvAdj": 1}.get(cls, 12)
@@ -120,7 +124,7 @@ class Workload:
             p = torch.randn((T, B, self.model.learnable_param_count), generator=g, device=dev).requires_grad_(True)
             self.params, self.leaves, self.shared = p, [p], p
         self.key = "flow_sim" if cls == "HbvAdj" else "streamflow"
-        self.w = torch.randn((T, B, 1), generator=g, device=dev)
+        self.w = torch.randn((self.T_out, B, 1), generator=g, device=dev)
         self.cls = cls
 
     @property
@@ -409,7 +413,7 @@ def main():
 
     from hydrodl2_amd import sharding
     strong = args.config == "cfg5"
-    _, _, T0, B0, M0, _ = WORKLOADS[args.config]
+    _, _, T0, B0, M0 = WORKLOADS[args.config][:5]
     B_total = args.basins or B0
     if strong:
         b0, b1 = sharding.basin_range(B_total, world, rank)
@@ -508,7 +512,7 @@ def main():
         # the other BASELINE configs under the same clock: 5 timed steps each, same event timing
         sec = []
         print(f"[bench] headline done: {ms_per_step:.3f} ms/step; secondary configs ...", file=sys.stderr, flush=True)
-        for name in ("cfg2dyn", "cfg3", "cfg4", "cfg5share"):
+        for name in ("cfg2dyn", "cfg3", "cfg4", "cfg5share", "dmg"):
             if name == args.config:
                 continue
             try:

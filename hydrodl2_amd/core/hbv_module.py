@@ -262,35 +262,32 @@ class HbvModule(torch.nn.Module):
     def _assemble(self, flux, routed, x, t0) -> dict[str, torch.Tensor]:
         """hbv.py:555-596: flux dictionary, BFI and the optional prediction cut-off."""
         F = _abi
-
-        def col(t):
-            return t.unsqueeze(-1)
-
+        # the kernels' series arrive as [T,B,1] views already (ops.HbvPath)
         if routed is not None:
-            Qs, Q0r, Q1r, Q2r = (col(routed[k]) for k in range(4))
+            Qs, Q0r, Q1r, Q2r = routed
         else:
             # The reference's Hbv crashes here (hbv.py:550-567); follow Hbv_2's
             # handling of routing=False instead (hbv_2.py:620-626).
-            Qs, Q0r, Q1r, Q2r = (col(flux[k]) for k in (F.F_QSIM, F.F_Q0, F.F_Q1, F.F_Q2))
-        BFI = Bfi.apply(Qs[:, :, 0], Q2r[:, :, 0], float(self.nearzero))
+            Qs, Q0r, Q1r, Q2r = (flux[k] for k in (F.F_QSIM, F.F_Q0, F.F_Q1, F.F_Q2))
+        BFI = Bfi.apply(Qs, Q2r, float(self.nearzero))
         pet = x[t0:, :, self.variables.index('pet')]
         out = {
             'streamflow': Qs, 'srflow': Q0r, 'ssflow': Q1r, 'gwflow': Q2r,
-            'AET_hydro': col(flux[F.F_AET]),
-            'PET_hydro': col(pet),
-            'SWE': col(flux[F.F_SWE]),
-            'streamflow_no_rout': col(flux[F.F_QSIM]),
-            'srflow_no_rout': col(flux[F.F_Q0]),
-            'ssflow_no_rout': col(flux[F.F_Q1]),
-            'gwflow_no_rout': col(flux[F.F_Q2]),
-            'recharge': col(flux[F.F_RECHARGE]),
-            'excs': col(flux[F.F_EXCS]),
-            'evapfactor': col(flux[F.F_EVAPFACTOR]),
-            'tosoil': col(flux[F.F_TOSOIL]),
-            'percolation': col(flux[F.F_PERC]),
+            'AET_hydro': flux[F.F_AET],
+            'PET_hydro': pet.unsqueeze(-1),
+            'SWE': flux[F.F_SWE],
+            'streamflow_no_rout': flux[F.F_QSIM],
+            'srflow_no_rout': flux[F.F_Q0],
+            'ssflow_no_rout': flux[F.F_Q1],
+            'gwflow_no_rout': flux[F.F_Q2],
+            'recharge': flux[F.F_RECHARGE],
+            'excs': flux[F.F_EXCS],
+            'evapfactor': flux[F.F_EVAPFACTOR],
+            'tosoil': flux[F.F_TOSOIL],
+            'percolation': flux[F.F_PERC],
         }
         if self._has_capillary:
-            out['capillary'] = col(flux[F.F_CAPILLARY])
+            out['capillary'] = flux[F.F_CAPILLARY]
         out['BFI'] = BFI
         if not self.warm_up_states:
             for key in out.keys():

@@ -132,7 +132,7 @@ class Hbv_2_hourly(HbvModule):
         if self.initialize:
             return {}, series
 
-        Qs = flux[_abi.F_QSIM]                                            # [T,B] rate per day
+        Qs = flux[_abi.F_QSIM][:, :, 0]                                   # [T,B] rate per day
         if self.routing:                                                  # :684-700
             rb_ = self.routing_parameter_bounds
             topo = GageTopology.from_outlet_topo(

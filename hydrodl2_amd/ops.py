@@ -162,6 +162,7 @@ def _grad_like(lib, p: torch.Tensor, cfg: "StepConfig", tensor_idx: int) -> torc
 # handed to backward through the autograd context (first backward only; a second one over a retained
 # graph fills its own).  HBVX_EARLY_ZERO=0 restores the fill at backward time.
 _EARLY_ZERO = os.environ.get("HBVX_EARLY_ZERO", "1") not in ("", "0")
+_EARLY_ZERO_MIN = 1 << 26     # elements: below 256 MB the stream switch costs the host more than the fill costs the GPU
 _SIDE_STREAMS: dict = {}
 
 
@@ -254,14 +255,14 @@ def _route_desc(cfg: StepConfig, ptensors, S: int = 4) -> _abi.RouteDesc:
 
 
 class HbvPath(torch.autograd.Function):
-    """routed, state_out, traj, *flux_rows = HbvPath.apply(cfg, x, state_in, muwts, ac, elev, *ptensors)
+    """state_out, traj, *routed_rows, *flux_rows = HbvPath.apply(cfg, x, state_in, muwts, ac, elev, *ptensors)
     (use `hbv_path`, which regroups the outputs).
 
-    flux_rows  n_flux tensors [T, B]: the ensemble-mean series (enum hbvx_flux order), views of one
+    flux_rows  n_flux tensors [T, B, 1]: the ensemble-mean series (enum hbvx_flux order), views of one
                [n_flux, T, B] buffer.  Separate autograd outputs, so that the adjoint learns WHICH
                series carry gradient (a loss on streamflow touches 1-4 of 12) instead of receiving a
                dense, mostly zero [n_flux, T, B] gradient.
-    routed     [4, T, B] UH-routed Qsim, Q0, Q1, Q2 (None when cfg.route is None)
+    routed_rows  four [T, B, 1] views: UH-routed Qsim, Q0, Q1, Q2 (none when cfg.route is None)
     state_out  [5, B, M]
     traj       saved trajectory or None; layout `cfg.traj_layout` (see `state_series`).
     """
@@ -307,7 +308,8 @@ class HbvPath(torch.autograd.Function):
         out.traj, out.aux = _ptr(traj), _ptr(aux)
         out.n_flux, out.traj_layout = cfg.n_flux, cfg.traj_layout
         ctx.early_gp = None
-        if needs_grad and _EARLY_ZERO and lib.is_device and any(ctx.needs_input_grad[6:]):
+        if (needs_grad and _EARLY_ZERO and lib.is_device and any(ctx.needs_input_grad[6:])
+                and sum(p.numel() for p in ptensors) >= _EARLY_ZERO_MIN):
             ctx.early_gp = _early_grad_buffers(lib, cfg, ptensors, ctx.needs_input_grad[6:])
         _call(lib, 'hbvx_forward', lib.forward, desc, out, stream)
 
@@ -327,12 +329,26 @@ class HbvPath(torch.autograd.Function):
         if traj is not None:
             nondiff.append(traj)
         ctx.mark_non_differentiable(*nondiff)
-        rows = tuple(flux.unbind(0)) if flux is not None else ()
-        return (routed, state_out, traj) + rows
+        # every series leaves as its own [T,B,1] view (the shape the flux dictionary holds): one autograd
+        # output each, no select / unsqueeze nodes on the caller's side (16 of them cost the host 0.1 ms
+        # per call, a fifth of a deltaMG-sized step)
+        rrows = tuple(routed.unsqueeze(-1).unbind(0)) if routed is not None else ()
+        rows = tuple(flux.unsqueeze(-1).unbind(0)) if flux is not None else ()
+        ctx.n_routed = len(rrows)
+        return (state_out, traj) + rrows + rows
 
     @staticmethod
     @_device_guard
-    def backward(ctx, g_routed, _g_state, _g_traj, *g_rows):
+    def backward(ctx, _g_state, _g_traj, *g_all):
+        g_rr, g_rows = g_all[:ctx.n_routed], g_all[ctx.n_routed:]
+        g_routed = None
+        first = next((g for g in g_rr if g is not None), None)
+        if first is not None:
+            g_routed = torch.zeros((4,) + tuple(first.shape[:2]), dtype=torch.float32, device=first.device)
+            for k, g in enumerate(g_rr):
+                if g is not None:
+                    g_routed[k] = g[..., 0]
+        g_rows = tuple(None if g is None else g[..., 0] for g in g_rows)
         lib = get_library()
         cfg: StepConfig = ctx.cfg
         saved = ctx.saved_tensors
@@ -419,11 +435,13 @@ class HbvPath(torch.autograd.Function):
 
 
 def hbv_path(cfg: StepConfig, x, state_in, muwts, ac, elev, *ptensors):
-    """flux, routed, state_out, traj = hbv_path(...): `flux` is the tuple of n_flux series [T,B]
-    (index it with the hbvx_flux enum) or None when cfg.want_flux is False."""
+    """flux, routed, state_out, traj = hbv_path(...): `flux` is the tuple of n_flux series [T,B,1]
+    (index it with the hbvx_flux enum) or None when cfg.want_flux is False; `routed` the tuple of the four
+    UH-routed runoff series [T,B,1] or None."""
     outs = HbvPath.apply(cfg, x, state_in, muwts, ac, elev, *ptensors)
-    routed, state_out, traj = outs[:3]
-    return (outs[3:] or None), routed, state_out, traj
+    state_out, traj = outs[:2]
+    nr = 4 if (cfg.route is not None and cfg.want_flux) else 0
+    return (outs[2 + nr:] or None), (outs[2:2 + nr] or None), state_out, traj
 
 
 def state_series(traj: torch.Tensor, layout: int, T: int, B: int, M: int):
@@ -540,7 +558,7 @@ class HbvAdjPath(torch.autograd.Function):
 
 
 class Bfi(torch.autograd.Function):
-    """BFI = 100 * sum_t q2 / (sum_t qs + nearzero)  (hbv.py:562-567), qs/q2 [T,B] views.
+    """BFI = 100 * sum_t q2 / (sum_t qs + nearzero)  (hbv.py:562-567), qs/q2 [T,B] or [T,B,1] views.
 
     Forward in the library (one deterministic pass); the gradient, which a streamflow loss never
     asks for, is two broadcasts in torch."""
@@ -549,8 +567,9 @@ class Bfi(torch.autograd.Function):
     @_device_guard
     def forward(ctx, qs, q2, nearzero: float):
         lib = get_library()
-        qs_c, q2_c = qs.contiguous(), q2.contiguous()
-        T, B = qs_c.shape
+        ctx.cols = qs.dim() == 3
+        T, B = qs.shape[:2]
+        qs_c, q2_c = qs.contiguous().view(T, B), q2.contiguous().view(T, B)
         out = _out((B,), qs.device)
         _call(lib, 'hbvx_bfi', lib.bfi, T, B, _ptr(qs_c), _ptr(q2_c), float(nearzero), _ptr(out),
               _stream_of(lib, qs_c))
@@ -566,6 +585,8 @@ class Bfi(torch.autograd.Function):
         num = q2.sum(0)
         g_q2 = (100.0 * g / den).unsqueeze(0).expand_as(q2)
         g_qs = (-100.0 * g * num / (den * den)).unsqueeze(0).expand_as(qs)
+        if ctx.cols:
+            g_qs, g_q2 = g_qs.unsqueeze(-1), g_q2.unsqueeze(-1)
         return g_qs, g_q2, None
 
 

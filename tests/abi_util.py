@@ -85,7 +85,9 @@ def run_problem(prob, lib_path, device="cpu", x_grad=False, backward=True, t0=0,
             off = (T - 1) * B * ny + n * M
             cfg.route = RouteSource(0, off, off + 1, ny, [0, 2.9], [0, 6.5])
         rows, routed, state_out, traj = hbv_path(cfg, x, None, mu, ac, elev, p)
-        flux = torch.stack(rows)
+        flux = torch.stack([r[..., 0] for r in rows])
+        if routed is not None:
+            routed = torch.stack([r[..., 0] for r in routed])
         res = {"flux": flux.detach().cpu().numpy(), "state_out": state_out.cpu().numpy()}
         if routed is not None:
             res["routed"] = routed.detach().cpu().numpy()
