@@ -181,10 +181,6 @@ def _slice_problem(prob, pick):
     ("Hbv_2_hourly", 4, 32800, 256, ("parBETA", "parK0", "parBETAET")),
     ("Hbv", 16, 8200, 260, ("parBETA", "parBETAET")),
     ("Hbv_1_1p", 16, 8200, 256, ()),
-    # beyond a buffer descriptor's 4 GiB: the packed trajectory (4.4 GB of records) and the raw
-    # [T, B, ny] parameter tensor (4.4 GB) -- the kernels rebase their descriptors on the day's rows
-    ("Hbv_2", 16, 24600, 700, ()),
-    ("Hbv", 16, 8200, 640, ("parBETA", "parBETAET")),
 ])
 def test_streaming_kernels_oracle_spot_check(model, M, B, T, dyn, hip_backend, oracle_path):
     """>= 2048 wavefronts of state, so BOTH directions take the streaming kernels (packed trajectory,
@@ -200,3 +196,64 @@ def test_streaming_kernels_oracle_spot_check(model, M, B, T, dyn, hip_backend, o
     assert_close("state_out", got["state_out"][:, pick], want["state_out"], 1e-4, 1e-5)
     assert_close("g_params", got["g_params"][:, pick], want["g_params"], 1e-3, 1e-5)
     assert_close("g_x", got["g_x"][:, pick], want["g_x"], 1e-3, 1e-5)
+
+
+@pytest.mark.parametrize("fam,cls,B,T,dyn", [
+    ("hbv", "Hbv", 8200, 640, ["parBETA", "parBETAET"]),             # raw [T,B,ny] parameters: 4.4 GB
+    ("hbv_2", "Hbv_2", 24600, 700, ["parBETA", "parK0", "parBETAET"]),  # packed trajectory records: 4.4 GB
+])
+def test_tensors_beyond_4gib(fam, cls, B, T, dyn, hip_backend, oracle_path):
+    """Beyond a buffer descriptor's 4 GiB: the streaming kernels rebase their descriptors on the day's
+    rows.  The module on the GPU at full size against the same module on the CPU oracle for three basins
+    (first, middle, last) -- inputs generated on the device, so the test costs seconds, not minutes."""
+    import hydrodl2_amd
+    from tests import seam
+    dev = torch.device("cuda:0")
+    M = 16
+    C = hydrodl2_amd.load_model(fam, cls)
+    conf = {"nmul": M, "dynamic_params": {cls: dyn}}
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    x, _, w = _gen(T, B, 1, 11, dev)
+    xd = {"x_phy": x}
+    if cls == "Hbv_2":
+        params = (torch.rand((T, B, len(dyn) * M), generator=g, device=dev).requires_grad_(True),
+                  torch.rand((B, (16 - len(dyn)) * M), generator=g, device=dev).requires_grad_(True))
+        xd["ac_all"] = torch.rand(B, generator=g, device=dev) * 5000
+        xd["elev_all"] = torch.rand(B, generator=g, device=dev) * 3000
+        leaves = list(params)
+        assert (T + 1) * B * M * 16 > 1 << 32
+    else:
+        model0 = C(conf, dev)
+        params = torch.randn((T, B, model0.learnable_param_count), generator=g, device=dev).requires_grad_(True)
+        leaves = [params]
+        assert params.numel() * 4 > 1 << 32
+    model = C(conf, dev)
+    out = model(xd, params)
+    (out["streamflow"] * w).sum().backward()
+    assert torch.isfinite(out["streamflow"]).all()
+
+    pick = [0, B // 2 + 1, B - 1]
+    sel = torch.tensor(pick, device=dev)
+
+    def cut(t, axis):
+        return t.detach().index_select(axis, sel).cpu().contiguous()
+    xd_c = {k: cut(v, 1 if k == "x_phy" else 0) for k, v in xd.items()}
+    if cls == "Hbv_2":
+        params_c = (cut(params[0], 1).requires_grad_(True), cut(params[1], 0).requires_grad_(True))
+        leaves_c = list(params_c)
+    else:
+        params_c = cut(params, 1).requires_grad_(True)
+        leaves_c = [params_c]
+    seam.use_library(oracle_path)
+    try:
+        ref = C(conf, torch.device("cpu"))
+        out_c = ref(xd_c, params_c)
+        (out_c["streamflow"] * cut(w, 1)).sum().backward()
+    finally:
+        seam.use_library(None)
+    assert_close("streamflow", out["streamflow"][:, sel].detach().cpu().numpy(), out_c["streamflow"].detach().numpy(),
+                 1e-4, 1e-5)
+    for a, b in zip(leaves, leaves_c):
+        axis = 1 if a.dim() == 3 else 0
+        assert_close("grad", a.grad.index_select(axis, sel).cpu().numpy(), b.grad.numpy(), 1e-3, 1e-5)
