@@ -156,12 +156,15 @@ def _grad_like(lib, p: torch.Tensor, cfg: "StepConfig", tensor_idx: int) -> torc
     return out
 
 
-# Parameter-gradient buffers are prepared while the forward kernel runs: the zero fill of a [T,B,ny]
-# gradient (3.8 GB, 0.55 ms at HBM speed for config 2) needs bandwidth, the pipelined forward needs
-# latency on 168 of 256 CUs -- on a second HIP stream the fill disappears behind it.  The buffers are
-# handed to backward through the autograd context (first backward only; a second one over a retained
-# graph fills its own).  HBVX_EARLY_ZERO=0 restores the fill at backward time.
-_EARLY_ZERO = os.environ.get("HBVX_EARLY_ZERO", "1") not in ("", "0")
+# Optional (HBVX_EARLY_ZERO=1): prepare the parameter-gradient buffers while the forward kernel runs.  The
+# zero fill of a [T,B,ny] gradient (3.8 GB, 0.57 ms at HBM speed for config 2) needs bandwidth, the pipelined
+# forward needs latency on 168 of 256 CUs; on a second HIP stream the fill hides behind it.  Measured at
+# config 2: step 3.47 -> 3.32 ms, but the forward kernel itself slows from 1.12 to 1.27 ms (its row drains
+# wait longer for memory) with a much wider spread (1.15-2.2 ms under the profiler).  Off by default: the gain
+# is small and the forward's time stops being a property of the forward.  The buffers are handed to
+# backward through the autograd context (first backward only; a second one over a retained graph fills
+# its own).
+_EARLY_ZERO = os.environ.get("HBVX_EARLY_ZERO", "0") not in ("", "0")
 _EARLY_ZERO_MIN = 1 << 26     # elements: below 256 MB the stream switch costs the host more than the fill costs the GPU
 _SIDE_STREAMS: dict = {}
 

@@ -9,6 +9,7 @@
     profiles/<tag>_bench.json            the bench line of the profiled run
     profiles/<tag>_lstm_kernel_stats.csv, <tag>_lstm.json   tools/bench_lstm.py (sequence LSTM beside torch's)
     profiles/<tag>_dpl_kernel_stats.csv, <tag>_dpl.json     examples/train_dpl.py --lstm fused
+    profiles/<tag>_sq_counters_cfg{2,3,5}.txt   per-kernel SQ counter means (tools/diag_pmc.sh) + derived VALU busy
     profiles/pmc_traffic.json            HBM bytes per ABI call (read by bench.py for roofline.traffic)
 """
 import csv
@@ -42,6 +43,43 @@ def counter_table(path):
         for row in csv.DictReader(f):
             acc[short(row["Kernel_Name"])].append(float(row["Counter_Value"]))
     return {k: (len(v), sum(v) / len(v)) for k, v in acc.items()}
+
+
+def sq_counters(tag, out):
+    """Per-kernel means of the SQ counter passes (tools/diag_pmc.sh <tag>_<cfg>) and the derived figures
+    DESIGN.md quotes: VALU instructions per wave-day and VALU busy = SQ_ACTIVE_INST_VALU x 4 cycles /
+    (SIMDs the kernel can use) / (GRBM_GUI_ACTIVE / 8 XCDs)."""
+    for cfg in ("cfg2", "cfg3", "cfg5"):
+        acc = defaultdict(lambda: defaultdict(list))
+        dur = defaultdict(list)
+        grids = {}
+        for f in glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_{tag}_{cfg}", "p*", "**", "*counter_collection.csv"),
+                           recursive=True):
+            for r in csv.DictReader(open(f)):
+                k = short(r["Kernel_Name"]).replace("hbvx::", "")
+                if not k.startswith("k_"):
+                    continue
+                acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+                grids[k] = (int(r.get("Grid_Size", 0) or 0), int(r.get("Workgroup_Size", 0) or 0))
+        if not acc:
+            continue
+        with open(os.path.join(out, f"{tag}_sq_counters_{cfg}.txt"), "w") as f:
+            f.write(f"# rocprofv3 --pmc passes of tools/bench_configs.py {cfg} (tools/diag_pmc.sh), per-launch means\n")
+            for k, v in sorted(acc.items()):
+                d = sorted(dur[k])[len(dur[k]) // 2]
+                if d < 0.2:
+                    continue
+                m = {c: sum(x) / len(x) for c, x in v.items()}
+                f.write(f"{k}  (median {d:.3f} ms under the profiler)\n")
+                for c in sorted(m):
+                    f.write(f"     {c:32s} {m[c] / 1e6:12.3f} M\n")
+                if "GRBM_GUI_ACTIVE" in m and "SQ_ACTIVE_INST_VALU" in m:
+                    gs, ws = grids.get(k, (0, 0))
+                    wgs = gs // ws if ws else 0
+                    cus = min(256, wgs) if wgs else 256          # one workgroup per CU at most when the grid is small
+                    busy = m["SQ_ACTIVE_INST_VALU"] * 4 / (cus * 4) / (m["GRBM_GUI_ACTIVE"] / 8)
+                    f.write(f"     -> VALU busy {100 * busy:.0f} % of the cycles of the {cus} CUs the grid covers\n")
 
 
 def main(tag):
@@ -94,6 +132,7 @@ def main(tag):
                     "WRITE_SIZE is exact for row and 16-byte streams and counts 16-byte pieces of a line twice"}
     with open(os.path.join(out, "pmc_traffic.json"), "w") as f:
         json.dump(traffic, f, indent=1)
+    sq_counters(tag, out)
     print(json.dumps({k: (round(v["fetch_bytes_raw"] / 1e9, 3), round(v["write_bytes"] / 1e9, 3))
                       for k, v in traffic.items()}))
 

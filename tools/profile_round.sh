@@ -18,5 +18,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG/
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG/lstm -o lstm -- python3 $R/tools/bench_lstm.py > $R/gpurun_out/prof_$TAG.lstm.json 2> $R/gpurun_out/prof_$TAG.lstm.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG/dpl -o dpl -- python3 $R/examples/train_dpl.py --lstm fused --steps 10 > $R/gpurun_out/prof_$TAG.dpl.json 2> $R/gpurun_out/prof_$TAG.dpl.log
 cd $R
+# SQ counters (VALU busy, instruction mix) of the cfg3 and cfg5-share kernels: four passes each
+bash tools/diag_pmc.sh ${TAG}_cfg3 cfg3 > gpurun_out/prof_$TAG.sq_cfg3.txt 2>&1 || true
+bash tools/diag_pmc.sh ${TAG}_cfg5 cfg5 > gpurun_out/prof_$TAG.sq_cfg5.txt 2>&1 || true
+bash tools/diag_pmc.sh ${TAG}_cfg2 cfg2 > gpurun_out/prof_$TAG.sq_cfg2.txt 2>&1 || true
 find gpurun_out/prof_$TAG -name "*.csv" | head -20
 tail -1 gpurun_out/prof_$TAG.bench.json
