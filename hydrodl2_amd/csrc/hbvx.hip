@@ -593,7 +593,7 @@ int hbvx_host::check_desc(const hbvx_desc *d)
     else if (d->model == HBVX_MODEL_HOURLY) ok = (d->n_param == 19);
     else return fail(HBVX_E_UNSUPPORTED, "unknown model");
     if (!ok) return fail(HBVX_E_SHAPE, "n_param does not match model");
-    if (!d->x) return fail(HBVX_E_NULL, "forcing pointer is NULL");
+    if (!d->x && d->T > 0) return fail(HBVX_E_NULL, "forcing pointer is NULL");   /* an empty record has no forcings */
     if (d->ch_prcp < 0 || d->ch_tmean < 0 || d->ch_pet < 0)
         return fail(HBVX_E_SHAPE, "negative forcing channel");
     if ((d->model == HBVX_MODEL_HBV20 || d->model == HBVX_MODEL_HOURLY) && (!d->ac || !d->elev))

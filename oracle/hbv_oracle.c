@@ -724,7 +724,7 @@ static int check_desc(const hbvx_desc *d)
     else if (d->model == HBVX_MODEL_HBVADJ) return fail(HBVX_E_UNSUPPORTED, "the implicit scheme's oracle is oracle/hbv_adj_oracle.py");
     else return fail(HBVX_E_UNSUPPORTED, "unknown model");
     if (!ok) return fail(HBVX_E_SHAPE, "n_param does not match model");
-    if (!d->x) return fail(HBVX_E_NULL, "forcing pointer is NULL");
+    if (!d->x && d->T > 0) return fail(HBVX_E_NULL, "forcing pointer is NULL");   /* an empty record has no forcings */
     if ((d->model == HBVX_MODEL_HBV20 || d->model == HBVX_MODEL_HOURLY) && (!d->ac || !d->elev))
         return fail(HBVX_E_NULL, "HBV 2.0 needs ac and elev");
     for (int i = 0; i < d->n_param; i++)

@@ -155,3 +155,31 @@ def test_nan_forcing_policy_on_oracle(oracle_backend):
 @pytest.mark.gpu
 def test_nan_forcing_policy_on_gpu(hip_backend):
     _check_nan_policy(*_nan_forcing_case("cuda:0"))
+
+
+def _zero_length_record(device):
+    """T = 0: nothing to step; the final storages are the initial ones and nothing else is touched."""
+    import torch
+    from hydrodl2_amd import _abi
+    from hydrodl2_amd.ops import ParamSource, StepConfig, hbv_path
+    dev = torch.device(device)
+    B, M, n = 3, 4, 12
+    ny = n * M + 2
+    p = torch.randn((1, B, ny), device=dev)
+    x = torch.zeros((0, B, 3), device=dev)
+    srcs = [ParamSource(slot=i, lo=0.0, hi=1.0, tensor_idx=0, sta_off=i * M, sta_bs=ny) for i in range(n)]
+    cfg = StepConfig(model=_abi.MODEL_HBV10, n_param=n, n_flux=11, T=0, t0=0, B=B, M=M, raw_sigmoid=True,
+                     channels=(0, 1, 2), nearzero=1e-5, params=srcs)
+    state_in = torch.rand((5, B, M), device=dev)
+    flux, routed, state_out, traj = hbv_path(cfg, x, state_in, None, None, None, p)
+    assert torch.equal(state_out, state_in)
+    assert all(f.shape[0] == 0 for f in flux)
+
+
+def test_zero_length_record_on_oracle(oracle_backend):
+    _zero_length_record("cpu")
+
+
+@pytest.mark.gpu
+def test_zero_length_record_on_gpu(hip_backend):
+    _zero_length_record("cuda:0")

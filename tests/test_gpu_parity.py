@@ -273,3 +273,20 @@ def test_checkpointed_adjoint_on_gpu(name, K, how, hip_backend, monkeypatch):
     if "states" in res and res["states"].shape != ref["states"].shape:
         res["states"] = ref["states"]
     compare(name, res, ref)
+
+
+@pytest.mark.parametrize("model", ["Hbv", "Hbv_1_1p", "Hbv_2", "Hbv_2_hourly"])
+@pytest.mark.parametrize("T,B,M", [(1, 1, 1), (1, 3, 16), (2, 1, 64), (3, 2, 5), (15, 1, 2), (16, 5, 1), (31, 2, 16), (33, 70, 3)])
+def test_degenerate_shapes_match_oracle(model, T, B, M, hip_backend, oracle_path):
+    """One day, one basin, one member, records shorter than a tile / the routing window / the chunk
+    length: every dispatch fallback (one-wave kernels, serial tiled adjoint) against the oracle."""
+    dyn = {"Hbv": ("parBETA", "parBETAET"), "Hbv_1_1p": ("parK0",), "Hbv_2": ("parBETA", "parK0", "parBETAET"),
+           "Hbv_2_hourly": ()}[model]
+    prob = make_problem(model=model, T=T, B=B, M=M, dyn=dyn, drop_frac=0.3 if dyn else 0.0, seed=T * 100 + B)
+    got = run_problem(prob, None, device="cuda:0", x_grad=True)
+    want = run_problem(prob, oracle_path, device="cpu", x_grad=True)
+    for k in ("flux", "routed", "state_out", "traj"):
+        if k in want:
+            assert_close(k, got[k], want[k], 1e-4, 1e-5)
+    for k in ("g_params", "g_x"):
+        assert_close(k, got[k], want[k], 1e-3, 1e-5)
