@@ -85,16 +85,20 @@ def main():
                     help="let torch's TunableOp pick the hipBLASLt/rocBLAS solution of every GEMM shape during "
                          "the warm-up steps (the LSTM's weight-gradient GEMMs have K = T*B: the default "
                          "heuristic is 2x off there)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default=None,
+                    help="process-group backend (default: nccl = RCCL on the GPU, gloo on the CPU)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="every rank uses cuda:0 (rehearsal of the multi-rank schedule on a one-GPU box; needs --backend gloo)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     on_gpu = args.device.startswith("cuda")
     if on_gpu:
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0")))
     dev = torch.device(args.device if not on_gpu else f"cuda:{torch.cuda.current_device()}")
     if world > 1:
-        dist.init_process_group("nccl" if on_gpu else "gloo")
+        dist.init_process_group(args.backend or ("nccl" if on_gpu else "gloo"))
 
     if args.tune_gemm and on_gpu:
         import torch.cuda.tunable as tunable
