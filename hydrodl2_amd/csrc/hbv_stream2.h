@@ -181,6 +181,28 @@ __device__ __forceinline__ S2Lane s2_lane(const hbvx_desc &d, int lgMp, int per_
     return L;
 }
 
+// The same for workgroups of MW waves (k_fwd_stream2, MW > 1): the workgroup owns MW consecutive basin
+// groups, the XCD map deals workgroups.
+__device__ __forceinline__ S2Lane s2_lane_mw(const hbvx_desc &d, int lgMp, int per_xcd, int mw)
+{
+    S2Lane L;
+    const int i = blockIdx.x;
+    const int group = ((i & 7) * per_xcd + (i >> 3)) * mw + (int)(threadIdx.x >> 6);
+    L.lane = threadIdx.x & 63;
+    const int Mp = 1 << lgMp;
+    L.jm = L.lane & (Mp - 1);
+    L.bl = L.lane >> lgMp;
+    const int b = group * (64 >> lgMp) + L.bl;
+    L.b0 = group * (64 >> lgMp);
+    L.valid = L.b0 < d.B;
+    L.bvalid = b < d.B;
+    L.active = (b < d.B) && (L.jm < d.M);
+    L.b = b < d.B ? b : d.B - 1;
+    L.j = L.jm < d.M ? L.jm : d.M - 1;
+    L.n = (int64_t)L.b * d.M + L.j;
+    return L;
+}
+
 // fp32 add into an LDS word this lane owns: plain read-modify-write (STREAM2_LDS_ACC 1) or the LDS
 // atomic ds_add_f32 (2).  Measured at config 5: the atomic form took the adjoint from 2.9 to 13 ms.
 __device__ __forceinline__ void s2_lds_add(float *w, float v)
@@ -244,8 +266,16 @@ __device__ __forceinline__ float s2_ens_sum16(const float *f, bool b0, bool b1)
 // checkpoints [ceil(T/K),5,N] (HBVX_TRAJ_CKPT; K a power of two).
 // XVEC: forcing channels are {0,1,2} and a basin's three values are adjacent (one 12-byte load).
 // ---------------------------------------------------------------------------------------------
-template <int MODEL, bool BETAET, int TRJ, int SC, bool XVEC>
-__global__ void __launch_bounds__(64) FWPE k_fwd_stream2(const StreamArgs A)
+// MW: waves per workgroup, 1 or 8.  With one wave per workgroup a wave's share of a flux row is 16 bytes
+// (4 basins) and the 11-12 such pieces per day were the most expensive stores of the kernel: 0.44 GB of
+// them cost 0.3 of 1.45 ms at the config-5 share, the 4.1 GB of trajectory 0.45 (builds without either).
+// Eight waves (Mp = 16: 32 basins) collect STREAM2_FD days of flux in LDS and the workgroup stores whole
+// 128-byte row segments, one barrier per STREAM2_FD days, double-buffered.
+#ifndef STREAM2_FD
+#define STREAM2_FD 8
+#endif
+template <int MODEL, bool BETAET, int TRJ, int SC, bool XVEC, int MW = 1>
+__global__ void __launch_bounds__(MW * 64) FWPE k_fwd_stream2(const StreamArgs A)
 {
     constexpr int NP = NParamT<MODEL, BETAET>::value;
     constexpr int NF = MODEL == MODEL_HBV10 ? 11 : 12;
@@ -254,8 +284,13 @@ __global__ void __launch_bounds__(64) FWPE k_fwd_stream2(const StreamArgs A)
     const hbvx_desc &d = A.d;
     const hbvx_fwd_out &o = A.o;
     const int lgMp = A.lgMp;
-    const S2Lane L = s2_lane(d, lgMp, A.per_xcd);
-    if (!L.valid) return;
+    const S2Lane L = MW > 1 ? s2_lane_mw(d, lgMp, A.per_xcd, MW) : s2_lane(d, lgMp, A.per_xcd);
+    if (MW == 1 && !L.valid) return;            // (with a barrier in the loop every wave of the workgroup stays)
+    const bool live = L.valid;
+    constexpr int FD = STREAM2_FD;
+    constexpr int FROW = 4 * MW + 4;             // padded row: the 12 series of a basin land in different banks
+    __shared__ float s_flux[MW > 1 ? 2 * FD * 12 * FROW : 1];      // [2][FD][12 series][4 MW basins (+ pad)]
+    const int wv = MW > 1 ? (int)(threadIdx.x >> 6) : 0;
     const int T = d.T, B = d.B;
     const int64_t N = (int64_t)B * d.M;
     const bool raw = d.raw_sigmoid != 0;
@@ -405,6 +440,11 @@ __global__ void __launch_bounds__(64) FWPE k_fwd_stream2(const StreamArgs A)
 #pragma unroll
             for (int k = 0; k < NF; k++) acc += f[k];
             if (acc == 123.456f) S2Buf::st(rflux, fvo_role, fso, acc);
+        } else if (MW > 1) {
+            // member lane jm holds series jm of its basin row: one LDS word per (day, series, basin)
+            const float v = s2_ens_sum16<NF>(f, jb0, jb1) * invM;
+            const int slot = t % (2 * FD);             // [buffer][day of the tile] in one index
+            if (L.jm < NF) s_flux[(slot * 12 + L.jm) * FROW + wv * 4 + (L.lane >> 4)] = v;
         } else if (roles) {
             float v = s2_ens_sum16<NF>(f, jb0, jb1);
             v = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane * 4, __builtin_bit_cast(int, v * invM)));
@@ -419,19 +459,55 @@ __global__ void __launch_bounds__(64) FWPE k_fwd_stream2(const StreamArgs A)
         }
     };
 
+    if (MW == 1) {
 #pragma unroll
-    for (int j = 0; j < D; j++) issue(j, j);
-    int t0 = 0;
-    for (; t0 + D <= T; t0 += D) {
+        for (int j = 0; j < D; j++) issue(j, j);
+        int t0 = 0;
+        for (; t0 + D <= T; t0 += D) {
 #pragma unroll
-        for (int j = 0; j < D; j++) {
-            day(t0 + j, j);
-            issue(t0 + j + D, j);
+            for (int j = 0; j < D; j++) {
+                day(t0 + j, j);
+                issue(t0 + j + D, j);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < D; j++)
+            if (t0 + j < T) day(t0 + j, j);
+    } else {
+        static_assert(STREAM2_FD % STREAM2_D == 0, "a flux tile holds whole rounds of the input ring");
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < D; j++) issue(j, j);
+        }
+        const int wb0 = ((int)(blockIdx.x & 7) * A.per_xcd + (int)(blockIdx.x >> 3)) * (4 * MW);   // first basin of the workgroup
+        for (int ta = 0; ta < T; ta += FD) {
+            const int tb = min(T, ta + FD);
+            if (live) {
+                int t = ta;
+                for (; t + D <= tb; t += D) {
+#pragma unroll
+                    for (int j = 0; j < D; j++) {
+                        day(t + j, j);
+                        issue(t + j + D, j);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < D; j++)
+                    if (t + j < tb) day(t + j, j);
+            }
+            __syncthreads();
+            // the tile's rows: (day, series) pairs dealt over half-waves, 4 MW consecutive basins each
+            const int col = threadIdx.x & (4 * MW - 1);
+            const bool cok = wb0 + col < B;
+            const unsigned cvo = (unsigned)((wb0 + col) * 4);
+            const int nrow = (tb - ta) * NF, rstep = (MW * 64) / (4 * MW);
+            for (int r = threadIdx.x / (4 * MW); r < nrow; r += rstep) {
+                const int dd = r / NF, k = r - dd * NF;
+                const float v = s_flux[(((ta + dd) % (2 * FD)) * 12 + k) * FROW + col];
+                S2Buf::sts(rflux, cok ? cvo + (unsigned)(ta + dd) * fB + (unsigned)k * fT : OOB, 0u, v);
+            }
         }
     }
-#pragma unroll
-    for (int j = 0; j < D; j++)
-        if (t0 + j < T) day(t0 + j, j);
     if (L.active) {
 #pragma unroll
         for (int k = 0; k < 5; k++) o.state_out[k * N + L.n] = st[k];

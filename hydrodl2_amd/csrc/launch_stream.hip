@@ -81,6 +81,18 @@ bool adjoint_pinned_elsewhere()
 template <int MODEL, bool BE, int SC>
 void go_fwd2(int trj, const StreamArgs &sa, dim3 grid, hipStream_t st)
 {
+    // 16-member ensembles: workgroups of eight waves that stage the flux rows in LDS (hbv_stream2.h, MW);
+    // the row trajectory (not what hbvx_preferred_traj_layout asks for) keeps the one-wave form
+    if (sa.lgMp == 4 && trj != 1 && env_int("HBVX_STREAM_MW", 1) != 0) {
+        StreamArgs sm = sa;
+        const int64_t waves = (int64_t)sa.per_xcd * 8;
+        sm.per_xcd = (int)(((waves + 7) / 8 + 7) / 8);
+        const dim3 gm((unsigned)(8 * sm.per_xcd));
+        if (trj == 3) hipLaunchKernelGGL((k_fwd_stream2<MODEL, BE, 3, SC, true, 8>), gm, dim3(512), 0, st, sm);
+        else if (trj == 2) hipLaunchKernelGGL((k_fwd_stream2<MODEL, BE, 2, SC, true, 8>), gm, dim3(512), 0, st, sm);
+        else hipLaunchKernelGGL((k_fwd_stream2<MODEL, BE, 0, SC, true, 8>), gm, dim3(512), 0, st, sm);
+        return;
+    }
     if (trj == 3) hipLaunchKernelGGL((k_fwd_stream2<MODEL, BE, 3, SC, true>), grid, dim3(64), 0, st, sa);
     else if (trj == 2) hipLaunchKernelGGL((k_fwd_stream2<MODEL, BE, 2, SC, true>), grid, dim3(64), 0, st, sa);
     else if (trj == 1) hipLaunchKernelGGL((k_fwd_stream2<MODEL, BE, 1, SC, true>), grid, dim3(64), 0, st, sa);
