@@ -172,9 +172,7 @@ _SIDE_STREAMS: dict = {}
 def _early_grad_buffers(lib, cfg: "StepConfig", ptensors, needs) -> Optional[tuple]:
     dev = ptensors[0].device
     main = torch.cuda.current_stream(dev)
-    side = _SIDE_STREAMS.get(dev.index)
-    if side is None:
-        side = _SIDE_STREAMS[dev.index] = torch.cuda.Stream(dev)
+    side = _side_stream(dev)
     with torch.cuda.stream(side):
         bufs = [_grad_like(lib, p, cfg, i) if need else None for i, (p, need) in enumerate(zip(ptensors, needs))]
         done = torch.cuda.Event()
@@ -183,6 +181,68 @@ def _early_grad_buffers(lib, cfg: "StepConfig", ptensors, needs) -> Optional[tup
         if b is not None:
             b.record_stream(main)      # allocated on the side stream's pool, consumed on the caller's
     return bufs, done
+
+
+# Default: the fill runs BESIDE the adjoint.  The adjoint kernels are bound by VALU issue, the
+# fill by HBM bandwidth, and the only thing that ties them is the static row: static-parameter and routing
+# gradients accumulate into the LAST row of the [T,B,ny] gradient.  So those go to a separate [B,ny] row
+# (the C ABI takes any pointer + stride for them), the big buffer is filled on a second HIP stream while
+# the adjoint runs on the caller's, and one small add joins them at the end.  Dynamic rows are written
+# (not accumulated) by the adjoint and skipped by hbvx_zero_except: disjoint bytes, no ordering needed.
+# HBVX_FILL_OVERLAP=0 restores the fill in front of the adjoint.
+_FILL_OVERLAP = os.environ.get("HBVX_FILL_OVERLAP", "1") not in ("", "0")
+
+
+def _side_stream(dev) -> "torch.cuda.Stream":
+    side = _SIDE_STREAMS.get(dev.index)
+    if side is None:
+        side = _SIDE_STREAMS[dev.index] = torch.cuda.Stream(dev)
+    return side
+
+
+def _overlapped_grad_buffers(lib, cfg: "StepConfig", ptensors, needs):
+    """(gp, rows, bases, start): gradient buffers, the separate last rows (None where a tensor keeps the
+    plain path), their element offsets inside the big tensors, and `start()` -> event: begins the fills
+    of the qualifying tensors on the side stream (call it when the caller's stream has nothing
+    bandwidth-bound left in front of the adjoint) and returns the event that marks them complete.
+    A tensor qualifies when it is large, [T,B,W]-shaped, holds no dynamic parameter of this call (the
+    adjoint then writes nothing into it but the static row) and every static / routing source of it lies
+    in its last row."""
+    dev = ptensors[0].device
+    gp, rows, bases, todo = [], [], [], []
+    for i, (p, need) in enumerate(zip(ptensors, needs)):
+        if not need:
+            gp.append(None); rows.append(None); bases.append(0)
+            continue
+        base = (p.shape[0] - 1) * p[0].numel() if p.dim() == 3 else -1
+        offs = [ps.sta_off for ps in cfg.params if ps.tensor_idx == i]
+        if cfg.route is not None and cfg.route.tensor_idx == i:
+            offs += [cfg.route.a_off, cfg.route.b_off]
+        ok = (p.dim() == 3 and p.is_contiguous() and p.numel() >= _EARLY_ZERO_MIN and p.shape[0] > 1
+              and all(o >= base for o in offs)
+              and not any(ps.dyn_off >= 0 and ps.dyn_tensor_idx == i for ps in cfg.params))
+        if not ok:
+            gp.append(_grad_like(lib, p, cfg, i)); rows.append(None); bases.append(0)
+            continue
+        big = torch.empty_like(p)            # on the caller's stream and pool: it is also where it dies
+        gp.append(big)
+        rows.append(torch.zeros_like(p[0]))
+        bases.append(base)
+        todo.append(big)
+
+    def start():
+        if not todo:
+            return None
+        main = torch.cuda.current_stream(dev)
+        side = _side_stream(dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            for big in todo:
+                _call(lib, 'hbvx_zero', lib.zero, big.data_ptr(), big.numel() * big.element_size(), _stream_of(lib, big))
+            done = torch.cuda.Event()
+            done.record(side)
+        return done
+    return gp, rows, bases, start
 
 
 def _ptr(t: Optional[torch.Tensor], off: int = 0) -> Optional[int]:
@@ -362,12 +422,31 @@ class HbvPath(torch.autograd.Function):
         stream = _stream_of(lib, x)
 
         early, ctx.early_gp = ctx.early_gp, None
+        rows = [None] * len(ptensors)
+        bases = [0] * len(ptensors)
+        fill_done, start_fill = None, None
         if early is not None:
             gp, done = early
             torch.cuda.current_stream(dev).wait_event(done)
+        elif _FILL_OVERLAP and lib.is_device:
+            gp, rows, bases, start_fill = _overlapped_grad_buffers(lib, cfg, ptensors, ctx.needs_input_grad[6:])
         else:
             gp = [_grad_like(lib, p, cfg, i) if ctx.needs_input_grad[6 + i] else None
                   for i, p in enumerate(ptensors)]
+
+        def sta_ptr(idx, off):
+            """static / routing gradient address: in the separate last row when the tensor has one"""
+            return _ptr(rows[idx], off - bases[idx]) if rows[idx] is not None else _ptr(gp[idx], off)
+
+        def join():
+            nonlocal fill_done
+            if start_fill is not None and fill_done is None:
+                fill_done = start_fill()       # (nothing ran in between: the fill simply starts now)
+            if fill_done is not None:
+                torch.cuda.current_stream(dev).wait_event(fill_done)
+                for big, row in zip(gp, rows):
+                    if row is not None:
+                        big[-1] += row
 
         gq = None
         if g_routed is not None and cfg.route is not None:
@@ -379,7 +458,8 @@ class HbvPath(torch.autograd.Function):
             ws = torch.empty((max(ws_bytes, 4) + 3) // 4, dtype=torch.float32, device=dev)
             g_routed = g_routed.contiguous()
             _call(lib, 'hbvx_route_backward', lib.route_backward, r, _ptr(flux), _ptr(uh),
-                  _ptr(g_routed), _ptr(gq), _ptr(gt, rs.a_off), _ptr(gt, rs.b_off),
+                  _ptr(g_routed), _ptr(gq), sta_ptr(rs.tensor_idx, rs.a_off) if gt is not None else None,
+                  sta_ptr(rs.tensor_idx, rs.b_off) if gt is not None else None,
                   _ptr(ws), ws_bytes, stream)
         # Which series carry gradient?  Only the four runoff series (the usual losses: streamflow,
         # with or without routing) -> a [4,T,B] buffer and the adjoint's 4-series kernels; anything
@@ -413,7 +493,7 @@ class HbvPath(torch.autograd.Function):
             g = io.g[ps.slot]
             gs = gp[ps.tensor_idx]
             if gs is not None:
-                g.sta = _ptr(gs, ps.sta_off)
+                g.sta = sta_ptr(ps.tensor_idx, ps.sta_off)
                 g.sta_b_stride = ps.sta_bs
             if ps.dyn_off >= 0 and gp[ps.dyn_tensor_idx] is not None:
                 g.dyn = _ptr(gp[ps.dyn_tensor_idx], ps.dyn_off)
@@ -421,6 +501,7 @@ class HbvPath(torch.autograd.Function):
         desc = _fill_desc(cfg, x, state_in, muwts, ac, elev, ptensors)
         if g_flux is None and gq is None:
             # nothing flows back through the series (a loss on nothing): gradients are zero
+            join()
             for ps in cfg.params:
                 if ps.dyn_off >= 0 and gp[ps.dyn_tensor_idx] is not None:
                     gp[ps.dyn_tensor_idx].zero_()
@@ -432,7 +513,10 @@ class HbvPath(torch.autograd.Function):
         if ws_bytes:
             ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
             io.workspace, io.workspace_bytes = _ptr(ws), ws_bytes
+        if start_fill is not None:
+            fill_done = start_fill()           # beside the adjoint kernels, behind the routing adjoint
         _call(lib, 'hbvx_backward', lib.backward, desc, io, stream)
+        join()
 
         return (None, gx, None, gmu, None, None, *gp)
 
