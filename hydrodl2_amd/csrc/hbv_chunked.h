@@ -368,12 +368,18 @@ __global__ void __launch_bounds__(64) k_bwd_chunk_phi(const ChunkArgs A)
         } else if constexpr (MODEL == MODEL_HBV11P || MODEL == MODEL_HBV20) {
             // capillary rise couples soil and groundwater, but the snow block still stands alone:
             // the SNOWPACK / MELTWATER unit adjoints never leave it
+            // the other three rows couple through the capillary exchange but stay sparse (Step::jt_cap):
+            // coefficients once per day, three applications instead of three full adjoint steps
             typedef Step<MODEL, BETAET> S;
-            const typename S::JT c = D.s.jt_coef_snow(D.p);
+            const typename S::JTC c = D.s.jt_coef_cap(D.p, nz);
             S::template jt_unit<0>(c, Phi[0]);
             S::template jt_unit<0>(c, Phi[1]);
 #pragma unroll
-            for (int k = 2; k < 5; k++) D.s.bwd(D.p, nz, g0, Phi[k], gp, gx);
+            for (int k = 2; k < 5; k++) S::jt_cap(c, Phi[k], 0.0f, 0.0f, 0.0f);
+            if constexpr (!GFULL) {
+                S::jt_cap(c, phi, D.g.gQ0 + D.g.gQ, D.g.gQ1 + D.g.gQ, D.g.gQ2 + D.g.gQ);
+                continue;
+            }
         } else {
 #pragma unroll
             for (int k = 0; k < 5; k++) D.s.bwd(D.p, nz, g0, Phi[k], gp, gx);

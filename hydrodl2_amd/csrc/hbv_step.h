@@ -641,6 +641,87 @@ struct Step {
         return c;
     }
 
+    // ---- the same for the capillary models (HBV 1.1p / 2.0) ---------------------------------
+    // Capillary rise feeds the lower zone back into the soil, so J^T couples the SM row with the
+    // groundwater block: out[SLZ] takes a share of a[SM], out[SM] a share of a[SLZ].  The snow block
+    // still stands alone (jt_unit<0> with jt_coef_snow / these coefficients).  From bwd() with zero
+    // flux adjoints, line for line:
+    //   sl = msl (1-K2) a4                       (HBV 2.0: msl = [SLZ + LF >= 0], else 1)
+    //   U  = cU a3 + wP sl                       = out[SUZ]
+    //   az = mz sl, ay = my a2                   (the two lower clamps after the capillary exchange)
+    //   out[SLZ] = az + kc (ay - az)             kc = w_SLZ + w_cap (1 - min(SM/FC, 1)) C
+    //   sm3      = ay - ks (ay - az)             ks = [SM/FC <= 1] w_cap C SLZ / FC
+    //   then the soil and snow rows of jt_unit<2> with sm3 in place of a2.
+    struct JTC : JT {
+        float msl, mz, my, kc, ks;
+    };
+
+    HBVX_HDM JTC jt_coef_cap(const float *p, float nz) const
+    {
+        static_assert(MODEL == MODEL_HBV11P || MODEL == MODEL_HBV20, "jt_coef_cap: HBV 1.1p / 2.0");
+        const float BETA = p[P_BETA], FC = p[P_FC], K0 = p[P_K0], K1 = p[P_K1], K2 = p[P_K2], C = p[P_C];
+        JTC c;
+        float wa, wb;
+        c.cS = 1.0f - K2;
+        c.msl = 1.0f;
+        if (MODEL == MODEL_HBV20) c.msl = (sl >= 0.0f) ? 1.0f : 0.0f;
+        minw_(SUZ1, p[P_PERC], wa, wb);
+        const float m0k0 = (u0 >= 0.0f) ? K0 : 0.0f;
+        c.cU = ((1.0f - K1) * (1.0f - m0k0)) * (1.0f - wa);
+        c.wP = wa;
+        c.K1 = K1; c.K2 = K2; c.k1c = 1.0f - K1; c.k0c = 1.0f - m0k0; c.k0m = m0k0; c.wac = 1.0f - wa;
+        // capillary exchange
+        c.mz = (slc >= nz) ? 1.0f : 0.0f;
+        c.my = (smc >= nz) ? 1.0f : 0.0f;
+        minw_(SLZ, capp, wa, wb);
+        c.kc = wa + (wb * om) * C;
+        c.ks = (x1 <= 1.0f) ? div_approx_(wb * cs, FC) : 0.0f;
+        // soil (BETAET always on in these models)
+        minw_(SM2, pe, wa, wb);
+        const float mef = (ef0 >= 0.0f && ef0 <= 1.0f) ? 1.0f : 0.0f;
+        const float dq = (q > 0.0f) ? mef * (p[P_BETAET] * div_approx_(ef0, q)) : 0.0f;
+        const float md = (dd >= nz) ? 1.0f : 0.0f;
+        c.kap = md * ((1.0f - wa) - (wb * PET) * div_approx_(dq, lpfc));
+        c.me = (e0 >= 0.0f) ? 1.0f : 0.0f;
+        const float msw = (sw0 >= 0.0f && sw0 <= 1.0f) ? 1.0f : 0.0f;
+        const float dr = (r > 0.0f) ? BETA * div_approx_(sw0, r) : 0.0f;
+        c.rho = div_approx_((rt * msw) * dr, FC);
+        c.sw = sw;
+        // snow
+        c.mts = (ts0 >= 0.0f) ? 1.0f : 0.0f;
+        c.cwh = p[P_CWH];
+        minw_(rpc, MW1, wa, wb);
+        c.wr = wb;
+        minw_(mpc, SP1, wa, wb);
+        c.wm = wb;
+        return c;
+    }
+
+    // a <- J^T a (+ the runoff-series sources s0 = gQ0 + gQ, s1 = gQ1 + gQ, s2 = gQ2 + gQ; zeros for a unit)
+    static HBVX_HDM void jt_cap(const JTC &c, float *a, float s0, float s1, float s2)
+    {
+        const float sl = c.msl * (c.cS * a[4] + c.K2 * s2);
+        const float z3 = c.k1c * a[3] + c.K1 * s1;
+        const float z2 = z3 * c.k0c + c.k0m * s0;
+        const float U = z2 * c.wac + c.wP * sl;
+        const float az = c.mz * sl, ay = c.my * a[2];
+        const float dc = ay - az;
+        a[3] = U;
+        a[4] = az + c.kc * dc;
+        const float sm3 = ay - c.ks * dc;
+        const float s2_ = c.kap * sm3;
+        const float s1_ = s2_ + c.me * (U - s2_);
+        const float w = U - s1_;
+        a[2] = s1_ + c.rho * w;
+        const float ats = s1_ + c.sw * w;
+        const float t = c.mts * (ats - a[1]);
+        const float mw2 = a[1] + t;
+        const float sp2 = a[0] - t * c.cwh;
+        const float mw1 = mw2 + (sp2 - mw2) * c.wr;
+        a[1] = mw1;
+        a[0] = sp2 + (mw1 - sp2) * c.wm;
+    }
+
     // a <- J^T a + c(g) when only the runoff series carry gradient (loss on streamflow):
     // s0 = gQ0 + gQ, s1 = gQ1 + gQ, s2 = gQ2 + gQ enter through the groundwater block, the rest
     // is jt_unit<2>.  Replaces a full bwd() for the offset vector of the chunk maps.

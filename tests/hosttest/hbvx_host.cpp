@@ -456,6 +456,55 @@ extern "C" float hbvx_test_jt_snow(const float *st, const float *f, const float 
     }
     return worst;
 }
+// capillary models: jt_coef_cap + jt_cap against bwd for the three coupled rows and for the affine form
+// with gradients on the runoff series; worst difference relative to the largest entry of the day's J^T
+template <int MODEL>
+static float jt_cap_check(const float *st, const float *f, const float *p, int n, float nz)
+{
+    float worst = 0.0f;
+    for (int i = 0; i < n; i++) {
+        Step<MODEL, true> s;
+        s.SP = st[i * 5]; s.MW = st[i * 5 + 1]; s.SM = st[i * 5 + 2]; s.SUZ = st[i * 5 + 3]; s.SLZ = st[i * 5 + 4];
+        s.P = f[i * 3]; s.Tf = f[i * 3 + 1]; s.PET = f[i * 3 + 2];
+        const float *pp = p + i * NPARAM_MAX;
+        // drainage areas on both sides of parAC / 2500 km2 and elevations on both sides of 2000 m
+        s.template fwd<false>(pp, nz, 40.0f + 3000.0f * (float)((i * 37) % 100) / 100.0f, (i & 1) ? 2500.0f : 500.0f, 0.0f, 0.0f);
+        FluxGrad g0;
+        memset(&g0, 0, sizeof g0);
+        const auto c = s.jt_coef_cap(pp, nz);
+        float scale = 1e-30f, err = 0.0f;
+        for (int k = 0; k < 5; k++) {
+            float a[5] = {0, 0, 0, 0, 0}, b[5] = {0, 0, 0, 0, 0}, gp[NPARAM_MAX] = {0}, gx[3];
+            a[k] = b[k] = 1.0f;
+            s.bwd(pp, nz, g0, a, gp, gx);
+            if (k < 2) Step<MODEL, true>::template jt_unit<0>(c, b);
+            else Step<MODEL, true>::jt_cap(c, b, 0.0f, 0.0f, 0.0f);
+            for (int j = 0; j < 5; j++) {
+                scale = fmaxf(scale, fabsf(a[j]));
+                err = fmaxf(err, fabsf(a[j] - b[j]));
+            }
+        }
+        {
+            float a[5], b[5], gp[NPARAM_MAX] = {0}, gx[3];
+            for (int j = 0; j < 5; j++) a[j] = b[j] = 0.3f * (float)(((i * 7 + j * 13) % 11) - 5);
+            FluxGrad g = g0;
+            g.gQ = 0.01f * (float)((i % 7) - 3); g.gQ0 = 0.02f * (float)((i % 5) - 2);
+            g.gQ1 = -0.015f * (float)((i % 3) - 1); g.gQ2 = 0.005f * (float)((i % 9) - 4);
+            s.bwd(pp, nz, g, a, gp, gx);
+            Step<MODEL, true>::jt_cap(c, b, g.gQ0 + g.gQ, g.gQ1 + g.gQ, g.gQ2 + g.gQ);
+            for (int j = 0; j < 5; j++) {
+                scale = fmaxf(scale, fabsf(a[j]));
+                err = fmaxf(err, fabsf(a[j] - b[j]));
+            }
+        }
+        worst = fmaxf(worst, err / scale);
+    }
+    return worst;
+}
+extern "C" float hbvx_test_jt_cap(const float *st, const float *f, const float *p, int n, float nz, int model)
+{
+    return model == 2 ? jt_cap_check<MODEL_HBV20>(st, f, p, n, nz) : jt_cap_check<MODEL_HBV11P>(st, f, p, n, nz);
+}
 extern "C" float hbvx_test_jt(const float *st, const float *f, const float *p, int n, float nz, int betaet)
 {
     return betaet ? jt_check<true>(st, f, p, n, nz) : jt_check<false>(st, f, p, n, nz);

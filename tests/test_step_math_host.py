@@ -128,3 +128,17 @@ def test_sparse_transposed_jacobian_matches_bwd(steptest_lib):
     worst = lib.hbvx_test_jt_snow(st.ctypes.data_as(C.c_void_p), f.ctypes.data_as(C.c_void_p),
                                   p2.ctypes.data_as(C.c_void_p), C.c_int(n), C.c_float(1e-5))
     assert worst < 2e-6, f"snow rows: worst difference {worst:.3g}"
+    # ... and the three rows the capillary exchange couples (Step::jt_coef_cap / jt_cap), HBV 1.1p and 2.0,
+    # with lower zones on both sides of the capillary demand (SLZ = 0 .. 200) and SM at FC
+    lib.hbvx_test_jt_cap.restype = C.c_float
+    for model, fam in ((1, "Hbv_1_1p"), (2, "Hbv_2")):
+        pc = np.zeros((n, 19), np.float32)
+        for i, nm in enumerate(PHY_NAMES[fam]):
+            lo, hi = BOUNDS[nm]
+            pc[:, i] = (lo + (hi - lo) * u(80 + 20 * model + i)).astype(np.float32)
+        stc = st.copy()
+        stc[: n // 10, 2] = pc[: n // 10, 1]
+        stc[n // 10: n // 5, 4] = 1e-5          # lower zone at its floor: capillary rise limited by SLZ
+        worst = lib.hbvx_test_jt_cap(stc.ctypes.data_as(C.c_void_p), f.ctypes.data_as(C.c_void_p),
+                                     pc.ctypes.data_as(C.c_void_p), C.c_int(n), C.c_float(1e-5), C.c_int(model))
+        assert worst < 4e-6, f"{fam}: worst relative difference {worst:.3g}"
