@@ -82,8 +82,12 @@ template <int MODEL, bool BE, int SC>
 void go_fwd2(int trj, const StreamArgs &sa, dim3 grid, hipStream_t st)
 {
     // 16-member ensembles: workgroups of eight waves that stage the flux rows in LDS (hbv_stream2.h, MW);
-    // the row trajectory (not what hbvx_preferred_traj_layout asks for) keeps the one-wave form
-    if (sa.lgMp == 4 && trj != 1 && env_int("HBVX_STREAM_MW", 1) != 0) {
+    // the row trajectory (not what hbvx_preferred_traj_layout asks for) keeps the one-wave form.  Eight-wave
+    // workgroups leave CUs empty on small grids: measured cross-over between 1024 and 1536 wavefronts
+    // (profiles/r02_grid_sweep.jsonl: hbv forward 0.70 / 0.90 / 1.15 / 2.18 ms with one wave per workgroup
+    // against 0.81 / 0.86 / 0.95 / 1.87 ms at 1024 / 1536 / 2048 / 4096 wavefronts)
+    const int mw_min = env_int("HBVX_STREAM_MW_MIN", 1280);
+    if (sa.lgMp == 4 && trj != 1 && env_int("HBVX_STREAM_MW", 1) != 0 && (int64_t)sa.per_xcd * 8 >= mw_min) {
         StreamArgs sm = sa;
         const int64_t waves = (int64_t)sa.per_xcd * 8;
         sm.per_xcd = (int)(((waves + 7) / 8 + 7) / 8);

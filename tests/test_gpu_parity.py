@@ -209,13 +209,16 @@ STREAM2_CASES = [
 ]
 
 
-@pytest.mark.parametrize("layout_env", [{"HBVX_STREAM_MIN": "1", "HBVX_STREAM_MIN_BWD": "1"},
-                                        {"HBVX_STREAM_MIN": "1", "HBVX_STREAM_MIN_BWD": "100000", "HBVX_BWD": "tiled"}],
-                         ids=["packed", "rows"])
+@pytest.mark.parametrize("layout_env", [{"HBVX_STREAM_MIN": "1"},
+                                        {"HBVX_STREAM_MIN": "1", "HBVX_STREAM_MW_MIN": "1"},
+                                        {"HBVX_STREAM_MIN": "1", "HBVX_BWD": "tiled"}],
+                         ids=["packed", "packed-8wave", "rows"])
 @pytest.mark.parametrize("kw", STREAM2_CASES, ids=lambda k: f"{k['model']}-B{k['B']}-M{k['M']}-{len(k['dyn'])}dyn")
 def test_stream2_matches_oracle(kw, layout_env, hip_backend, oracle_path, monkeypatch):
     """Second-generation streaming kernels (hbv_stream2.h) forced onto small problems: packed
-    trajectory + streaming adjoint, and row trajectory + the tiled adjoint reading it."""
+    trajectory + streaming adjoint (one wave per workgroup, and the eight-wave workgroups that stage
+    the flux rows in LDS: partly filled workgroups, records shorter and longer than a flux tile), and
+    row trajectory + the tiled adjoint reading it."""
     for k, v in layout_env.items():
         monkeypatch.setenv(k, v)
     prob = make_problem(seed=21, **kw)
