@@ -404,13 +404,19 @@ class HbvPath(torch.autograd.Function):
     @_device_guard
     def backward(ctx, _g_state, _g_traj, *g_all):
         g_rr, g_rows = g_all[:ctx.n_routed], g_all[ctx.n_routed:]
-        g_routed = None
-        first = next((g for g in g_rr if g is not None), None)
-        if first is not None:
-            g_routed = torch.zeros((4,) + tuple(first.shape[:2]), dtype=torch.float32, device=first.device)
-            for k, g in enumerate(g_rr):
-                if g is not None:
-                    g_routed[k] = g[..., 0]
+        # routed series with gradient: the routing adjoint runs over the leading n_live of the four (a
+        # streamflow loss: one), the rows behind them stay zero
+        g_routed, n_live = None, 0
+        live = [k for k, g in enumerate(g_rr) if g is not None]
+        if live:
+            n_live = max(live) + 1
+            first = g_rr[live[0]]
+            if n_live == 1:
+                g_routed = first[..., 0].unsqueeze(0)
+            else:
+                g_routed = torch.zeros((n_live,) + tuple(first.shape[:2]), dtype=torch.float32, device=first.device)
+                for k in live:
+                    g_routed[k] = g_rr[k][..., 0]
         g_rows = tuple(None if g is None else g[..., 0] for g in g_rows)
         lib = get_library()
         cfg: StepConfig = ctx.cfg
@@ -450,8 +456,10 @@ class HbvPath(torch.autograd.Function):
 
         gq = None
         if g_routed is not None and cfg.route is not None:
-            r = _route_desc(cfg, ptensors)
+            r = _route_desc(cfg, ptensors, S=n_live)
             gq = _out((4, T, B), dev)
+            if n_live < 4:
+                gq[n_live:].zero_()
             rs = cfg.route
             gt = gp[rs.tensor_idx]
             ws_bytes = lib.route_workspace_bytes(r)
