@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(MW * 64) FWPE k_fwd_stream2(const StreamArgs A
     // bytes (12 requests per day where one lane per series and basin would make 48 four-byte ones: the
     // address FIFO of the memory pipeline was full a fifth of the time).  Other Mp: the basin leader
     // stores the NF series one by one.
-    const bool roles = lgMp == 4;
+    const bool roles = MW > 1 ? true : lgMp == 4;   // (the eight-wave form is launched for Mp = 16 only)
     const int tl = L.lane;                          // as a target: series tl / 4 of basin tl % 4
     const int src_lane = (tl & 3) * 16 + (tl >> 2);  // who holds it: lane jm = series in basin row tl % 4
     const bool jb0 = (L.jm & 1) != 0, jb1 = (L.jm & 2) != 0;
