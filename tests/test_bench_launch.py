@@ -49,3 +49,35 @@ def test_world_size_mismatch_is_refused():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--device", "cpu"], env=env,
                          capture_output=True, text=True, timeout=120)
     assert out.returncode != 0 and "WORLD_SIZE" in (out.stderr + out.stdout)
+
+
+@pytest.mark.gpu
+def test_bench_line_contract_on_gpu():
+    """`python bench.py` on one GPU (child process): ONE JSON line with every field the driver reads, the
+    roofline object priced on live HIP-event kernel times, the CPU baselines with their core count, and
+    throughput consistent with the step time.  Small shape, the full code path."""
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-secondary",
+           "--basins", "64", "--days", "730", "--cpu-sample-days", "64"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in r, key
+    assert r["n_gpus"] == 1 and r["steps"] == 3 and r["warmup"] == 1 and r["higher_is_better"] is True
+    assert r["dtype"] == "f32" and r["data"] == "synthetic" and r["vs_baseline"] is None and "workload" in r["config"]
+    assert r["value"] == pytest.approx(64 * 16 * 730 / (r["ms_per_step"] * 1e-3), rel=1e-6)
+    rf = r["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in rf, key
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"], rel=1e-3) and 0.0 < rf["avg_ms"] < r["ms_per_step"]
+    cb = r["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in cb, key
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0
