@@ -104,6 +104,7 @@ __device__ __forceinline__ void pipe_reduce_pass(const hbvx_desc &d, const hbvx_
 
 #ifdef PIPE_PROBE
 __device__ unsigned long long g_pipe_probe[32];
+__device__ unsigned long long g_pipe_blocks[4096];   // busy + wait of the soil wave, per workgroup
 #define PIPE_BARRIER()                                                                             \
     do {                                                                                           \
         unsigned long long t_a = __builtin_readcyclecounter();                                     \
@@ -150,6 +151,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
         unsigned long long &b, &w;
         __device__ ~ProbeFlush()
         {
+            if ((threadIdx.x >> 6) == 1 && (threadIdx.x & 63) == 0 && blockIdx.x < 4096) g_pipe_blocks[blockIdx.x] = b + w;
             if (blockIdx.x == 5 && (threadIdx.x & 63) == 0) {
                 g_pipe_probe[(threadIdx.x >> 6) * 2] = b;
                 g_pipe_probe[(threadIdx.x >> 6) * 2 + 1] = w;

@@ -94,6 +94,11 @@ bool hbvx_host::try_fwd_pipe(const hbvx_desc *d, const hbvx_fwd_out *out, void *
 }
 
 #ifdef PIPE_PROBE
+extern "C" int hbvx_debug_pipe_blocks(unsigned long long *out, int n)
+{
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(hbvx::g_pipe_blocks), (size_t)(n > 4096 ? 4096 : n) * sizeof(unsigned long long));
+    return e == hipSuccess ? 0 : -1;
+}
 extern "C" int hbvx_debug_pipe_probe(unsigned long long *out32)
 {
     hipError_t e = hipMemcpyFromSymbol(out32, HIP_SYMBOL(hbvx::g_pipe_probe), 32 * sizeof(unsigned long long));

@@ -40,6 +40,12 @@ for grad in (True, False):
     buf = (C.c_ulonglong * 32)()
     assert lib.dll.hbvx_debug_pipe_probe(buf) == 0
     print("traj" if grad else "no traj")
+    nb = (B + 3) // 4
+    blk = (C.c_ulonglong * nb)()
+    if hasattr(lib.dll, "hbvx_debug_pipe_blocks") and lib.dll.hbvx_debug_pipe_blocks(blk, nb) == 0:
+        v = sorted(x / T for x in blk)
+        print(f"  per-workgroup cycles/day (soil wave, {nb} workgroups): min {v[0]:.1f}  median {v[nb // 2]:.1f}  "
+              f"p90 {v[int(nb * 0.9)]:.1f}  max {v[-1]:.1f}")
     roles = ["snow", "soil", "gw", "fill", "fill"] + ["drain"] * 11
     for w in range(16):
         print(f"  wave {w:2d} {roles[w]:6s} busy {buf[2*w]/T:8.1f}  wait {buf[2*w+1]/T:8.1f} counter ticks/step")
