@@ -51,6 +51,26 @@ def test_world_size_mismatch_is_refused():
     assert out.returncode != 0 and "WORLD_SIZE" in (out.stderr + out.stdout)
 
 
+def test_a_rank_that_dies_before_the_rendezvous_ends_the_job_quickly(oracle_path):
+    """Rank 1 raises before init_process_group: the parent must stop rank 0 (which is waiting in the
+    rendezvous) and exit non-zero within seconds, not after the collective's time-out."""
+    import time
+    env = dict(os.environ, HBVX_TEST_ABI_LIBRARY=oracle_path, HBVX_TEST_ROOT=ROOT, OMP_NUM_THREADS="1",
+               HBVX_BENCH_FAIL_RANK="1",
+               PYTHONPATH=os.path.join(ROOT, "tests", "cpu_seam") + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--device", "cpu", "--steps", "1",
+           "--warmup", "0", "--no-cpu-baseline", "--no-secondary", "--basins", "4", "--days", "20", "--nmul", "2"]
+    t0 = time.time()
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=120)
+    dt = time.time() - t0
+    assert out.returncode != 0
+    assert dt < 30.0, dt
+    assert "[rank 1]" in out.stderr and "injected failure" in out.stderr
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+
+
 @pytest.mark.gpu
 def test_bench_line_contract_on_gpu():
     """`python bench.py` on one GPU (child process): ONE JSON line with every field the driver reads, the
