@@ -104,7 +104,9 @@ __global__ void __launch_bounds__(64) k_adj_fwd(const AdjFwdArgs A)
 #pragma unroll
             for (int k = 0; k < 5; k++) o.traj[((int64_t)k * (T + 1) + t) * N + L.n] = x[k];
         }
-        adj_newton<BETAET>(s, p, x, 1.0f, d.adj_gtol, d.adj_max_iter, xn, d.adj_stop != 0);
+        float Qs = 0.0f;
+        if (d.adj_stop == 2) AdjStaged<BETAET>::day(p, s.P, s.Tf, s.PET, x, d.adj_gtol, d.adj_max_iter, xn, Qs);
+        else adj_newton<BETAET>(s, p, x, 1.0f, d.adj_gtol, d.adj_max_iter, xn, d.adj_stop != 0);
 #pragma unroll
         for (int k = 0; k < 5; k++) x[k] = xn[k];
         if (o.flux) {

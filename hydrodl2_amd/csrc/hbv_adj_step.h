@@ -209,6 +209,170 @@ HBVX_HD int adj_newton(AdjStep<BETAET> &s, const float *p, const float *xt, floa
     return it;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Staged solve (hbvx_desc.adj_stop = 2): the same equations G(x) = 0, solved block by block.
+//
+// dG/dx is block lower-triangular because f is (hbv_adj.py:425-429: dS0, dS1 read SNOWPACK and MELTWATER
+// only; dS2 adds SM; dS3 reads SM and SUZ; dS4 reads SUZ and SLZ).  The NONLINEAR system therefore
+// decouples the same way: (y0, y1) -> y2 -> y3 -> y4, each block an equation in its own unknowns with
+// the upstream blocks already solved.  Three of the four blocks are piecewise linear and monotone, so
+// they have closed forms (the branch is chosen by the sign of the block residual at the kinks, the
+// solution is then one linear solve); only the soil-moisture equation carries the two powers and keeps
+// the reference's Newton policy (stop at |G2| <= gtol, at most max_iter + 1 updates, hbv_adj.py:518-
+// 519,544 -- with the Jacobian always fresh: it is one scalar that the residual evaluation already
+// produced).  What the reference's joint iteration returns is ANY iterate with |G|_inf <= gtol (or the
+// fourth update); this solve returns a state with G0 = G1 = G3 = G4 = 0 up to rounding and |G2| <= gtol:
+// the same acceptance test, reached along a different path, and the three waves of a workgroup can run
+// the blocks of consecutive days as a pipeline (hbv_pipe.h) instead of one wave iterating on all five
+// unknowns.  The joint modified Newton above stays as adj_stop = 0 / 1 (policy cross-check).
+//
+// Invariant: storages entering a day are >= 0 (zeros at the start, hbv_adj.py:254, and every closed
+// form below returns >= 0 for inputs >= 0).  The flux expressions are those of AdjStep::eval, in the
+// same association order, so the adjoint's re-evaluation at the solved state sees the same branches.
+template <bool BETAET>
+struct AdjStaged {
+    // ---- block 1: snow.  (y0 - y0t)/dt = sf + refr - melt,  (y1 - y1t)/dt = melt - refr - Isnow
+    //      hbv_adj.py:425-426,444-468.  melt > 0 needs T > TT and refr > 0 needs T < TT: never both.
+    static HBVX_HDM void snow(const float *p, float P, float Tf, float dt, float y0t, float y1t,
+                              float &y0, float &y1, float &rf, float &Isnow)
+    {
+        const float TT = p[P_TT], CFMAX = p[P_CFMAX], CFR = p[P_CFR], CWH = p[P_CWH];
+        const float sf = P * ((Tf < TT) ? 1.0f : 0.0f);
+        rf = P * ((Tf >= TT) ? 1.0f : 0.0f);
+        const float cc = CFR * CFMAX;
+        const float rpc = fmax_(cc * (TT - Tf), 0.0f);
+        const float mpc = fmax_(CFMAX * (Tf - TT), 0.0f);
+        const float r1d = div_approx_(1.0f, 1.0f + dt);
+        const float a0 = y0t + dt * sf;
+        // warm day (refr = 0):  y0 + dt min(mpc, max(y0, 0)) = a0, increasing in y0: root <= k <=> value at k >= 0
+        const float y0w = (a0 <= 0.0f) ? a0 : ((a0 <= mpc * (1.0f + dt)) ? a0 * r1d : a0 - dt * mpc);
+        const float SPw = fmax_(y0w, 0.0f);
+        const float meltw = fmin_(mpc, SPw);
+        //   y1 + dt max(max(y1, 0) - CWH SP, 0) = b1
+        const float b1 = y1t + dt * meltw, cw = CWH * SPw;
+        const float y1w = (b1 <= cw) ? b1 : (b1 + dt * cw) * r1d;
+        // cold day (melt = 0):  y0 = a0 + dt refr,  y1 + dt min(rpc, y1+) + dt max(y1+ - CWH max(y0, 0), 0) = y1t
+        //   (increasing in y1 while dt CWH < 1).  Kinks: y1 = 0, y1 = rpc, and where meltwater starts to drain
+        const float ap = fmax_(a0, 0.0f);
+        const float S2 = fmax_(a0 + dt * rpc, 0.0f);                  // SNOWPACK once refr = rpc
+        const bool rmode = ((rpc + dt * rpc) + dt * fmax_(rpc - CWH * S2, 0.0f)) - y1t >= 0.0f;   // root <= rpc: refr = y1
+        const float k1 = div_approx_(CWH * ap, 1.0f - dt * CWH);        // y1 = CWH (a0 + dt y1)
+        const bool act = rmode ? (k1 * (1.0f + dt) < y1t) : (CWH * S2 + dt * rpc < y1t);          // Isnow > 0 at the root
+        const float y1ra = div_approx_(y1t + dt * (CWH * ap), (1.0f + 2.0f * dt) - (dt * dt) * CWH);
+        const float y1r = act ? y1ra : y1t * r1d;
+        const float y1f = act ? ((y1t - dt * rpc) + dt * (CWH * S2)) * r1d : y1t - dt * rpc;
+        const float y1c = (y1t <= 0.0f) ? y1t : (rmode ? y1r : y1f);
+        const float y0c = a0 + dt * fmin_(rpc, fmax_(y1c, 0.0f));
+        const bool warm = mpc > 0.0f;
+        y0 = warm ? y0w : y0c;
+        y1 = warm ? y1w : y1c;
+        Isnow = fmax_(fmax_(y1, 0.0f) - CWH * fmax_(y0, 0.0f), 0.0f);   // as AdjStep::eval (:464-468)
+    }
+
+    // ---- block 2: soil moisture.  (y2 - y2t)/dt = Isnow + rf - Peff - ex - et   (hbv_adj.py:427,470-486)
+    //      G2 is increasing in y2 (Peff, ex and et all grow with SM), so the root is bracketed: it lies in
+    //      [y2t - dt (ex + et)(y2t), y2t + dt (Isnow + rf)], and on the FC side that G2(FC) = (FC - y2t)/dt +
+    //      min(FC, PET) names (at SM = FC the wetness is 1 and, LP <= 1, so is the evaporation factor: no power
+    //      needed).  Newton from y2t, every update kept inside the bracket (a step that leaves it is replaced by
+    //      the midpoint; the bracket shrinks with the sign of each residual).  Plain Newton cycles across the
+    //      kink at FC when a large melt pulse meets a small store (slope 1 + In BETA / FC below, 2 above);
+    //      this cannot.  Returns the update count; Peff, ex: at the accepted state.
+    static HBVX_HDM int soil(const float *p, float rf, float Isnow, float PET, float idt, float y2t,
+                             float gtol, int max_iter, float &y2, float &Peff, float &ex)
+    {
+        const float BETA = p[P_BETA], FC = p[P_FC], LP = p[P_LP];
+        const float lpfc = LP * FC;
+        const float rt = rf + Isnow;
+        const float dt = (idt == 1.0f) ? 1.0f : div_approx_(1.0f, idt);
+        float x = y2t, lo = 0.0f, hi = 0.0f;
+        bool hi_new = false;   // hi is a bound that has not been an iterate yet
+        int it = 0;
+        for (;;) {
+            const float SM = fmax_(x, 1e-8f);
+            const float r = div_(SM, FC);
+            const float sw0 = pow_step_(r, BETA);
+            const float sw = fmin_(fmax_(sw0, 0.0f), 1.0f);
+            Peff = rt * sw;
+            const float e0 = SM - FC;
+            ex = fmax_(e0, 0.0f);
+            const float qe = div_(SM, lpfc);
+            const float ef0 = BETAET ? pow_step_(qe, p[P_BETAET]) : qe;
+            const float ef = fmin_(fmax_(ef0, 0.0f), 1.0f);
+            const float pe = PET * ef;
+            const float et = fmin_(SM, pe);
+            const float f2 = (((Isnow + rf) - Peff) - ex) - et;
+            const float g = (x - y2t) * idt - f2;
+            if (it == 0) {   // bracket from the first evaluation (x = y2t)
+                const bool below = (FC - y2t) * idt + fmin_(FC, PET) > 0.0f;   // G2(FC) > 0: root < FC
+                lo = y2t - dt * (ex + et);
+                hi = y2t + dt * rt;
+                hi_new = below && FC < hi;
+                hi = below ? fmin_(hi, FC) : hi;
+                lo = below ? lo : fmax_(lo, FC);
+            }
+            const bool more = fabsf(g) > gtol;
+            if (!(adj_any_(more, true) && it <= max_iter)) break;
+            it++;
+            lo = (g < 0.0f) ? fmax_(lo, x) : lo;
+            hi = (g < 0.0f) ? hi : fmin_(hi, x);
+            const float c2 = (x >= 1e-8f) ? 1.0f : 0.0f;
+            const float msw = (sw0 >= 0.0f && sw0 <= 1.0f) ? 1.0f : 0.0f;
+            const float dP = rt * (msw * (BETA * div_approx_(sw0, SM)));
+            const float mex = (e0 >= 0.0f) ? 1.0f : 0.0f;
+            const float mef = (ef0 >= 0.0f && ef0 <= 1.0f) ? 1.0f : 0.0f;
+            float wae, wbe;
+            minw_(SM, pe, wae, wbe);
+            const float def = BETAET ? mef * (p[P_BETAET] * div_approx_(ef0, SM)) : mef * div_approx_(1.0f, lpfc);
+            const float dE = wae + wbe * (PET * def);
+            const float J = idt + ((dP + mex) + dE) * c2;
+            // a step past FC lands ON FC first: below FC the residual is convex in SM (BETA >= 1), so Newton from the
+            // right end converges monotonically; any other step that leaves the bracket becomes its midpoint
+            float xn = x - div_approx_(g, J);
+            const bool past = xn > hi && hi_new;
+            xn = (xn >= lo && xn <= hi) ? xn : (past ? hi : 0.5f * (lo + hi));
+            hi_new = hi_new && !past && more;
+            x = more ? xn : x;      // a lane that has converged keeps its state
+        }
+        y2 = x;
+        return it;
+    }
+
+    // ---- blocks 3, 4: upper and lower zone.  (y3 - y3t)/dt = Peff + ex - perc - q0 - q1,
+    //      (y4 - y4t)/dt = perc - q2   (hbv_adj.py:428-429,488-498).  Q = q0 + q1 + q2 (:431)
+    static HBVX_HDM void gw(const float *p, float Peff, float ex, float dt, float y3t, float y4t,
+                            float &y3, float &y4, float &Q)
+    {
+        const float K0 = p[P_K0], K1 = p[P_K1], K2 = p[P_K2], PERCp = p[P_PERC], UZL = p[P_UZL];
+        const float b3 = y3t + dt * (Peff + ex);
+        // n(y) = y + dt (min(y+, PERC) + K0 max(y+ - UZL, 0) + K1 y+) - b3, increasing: root <= k <=> n(k) >= 0
+        const float nP = ((PERCp + dt * PERCp) + dt * (K0 * fmax_(PERCp - UZL, 0.0f))) + (dt * K1) * PERCp - b3;
+        const float nU = (UZL + dt * fmin_(UZL, PERCp)) + (dt * K1) * UZL - b3;
+        const bool lin = nP >= 0.0f;     // SUZ <= PERC: perc = SUZ
+        const bool q0a = nU < 0.0f;      // SUZ > UZL: interflow active
+        const float den = ((1.0f + dt * K1) + (lin ? dt : 0.0f)) + (q0a ? dt * K0 : 0.0f);
+        const float num = (b3 - (lin ? 0.0f : dt * PERCp)) + (q0a ? (dt * K0) * UZL : 0.0f);
+        y3 = (b3 <= 0.0f) ? b3 : div_approx_(num, den);
+        const float SUZ = fmax_(y3, 0.0f);
+        const float perc = fmin_(SUZ, PERCp);
+        const float b4 = y4t + dt * perc;
+        y4 = (b4 <= 0.0f) ? b4 : div_approx_(b4, 1.0f + dt * K2);
+        const float SLZ = fmax_(y4, 0.0f);
+        const float q0 = K0 * fmax_(SUZ - UZL, 0.0f);
+        Q = (q0 + K1 * SUZ) + K2 * SLZ;
+    }
+
+    // one day, all blocks (single-wave kernels, host build)
+    static HBVX_HDM int day(const float *p, float P, float Tf, float PET, const float *xt, float gtol,
+                            int max_iter, float *x, float &Q)
+    {
+        float rf, Isnow, Peff, ex;
+        snow(p, P, Tf, 1.0f, xt[0], xt[1], x[0], x[1], rf, Isnow);
+        const int it = soil(p, rf, Isnow, PET, 1.0f, xt[2], gtol, max_iter, x[2], Peff, ex);
+        gw(p, Peff, ex, 1.0f, xt[3], xt[4], x[3], x[4], Q);
+        return it;
+    }
+};
+
 // Implicit-function adjoint of one day at the solved state x (= y_{t+1}).
 //   a[5]  in : dL/dx from the future (lam_{t+1}/dt);  out: dL/dx_t = lam/dt
 //   gQ       : dL/dQ_t for this lane (Q = q0+q1+q2 evaluated at x, hbv_adj.py:309-313,431)

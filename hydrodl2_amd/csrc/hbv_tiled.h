@@ -277,7 +277,9 @@ __global__ void __launch_bounds__(512) k_fwd_tiled(const FwdTArgs A)
                         for (int k = 0; k < 5; k++) to[k * 64] = st[k];
                     }
                     float xn[5];
-                    adj_newton<BETAET>(s, p, st, 1.0f, d.adj_gtol, d.adj_max_iter, xn, d.adj_stop != 0);
+                    float Qs = 0.0f;
+                    if (d.adj_stop == 2) AdjStaged<BETAET>::day(p, fP, fT, fE, st, d.adj_gtol, d.adj_max_iter, xn, Qs);
+                    else adj_newton<BETAET>(s, p, st, 1.0f, d.adj_gtol, d.adj_max_iter, xn, d.adj_stop != 0);
 #pragma unroll
                     for (int k = 0; k < 5; k++) st[k] = xn[k];
                     if (has_flux) { // hbv_adj.py:309-313,431: Q at the solved storages

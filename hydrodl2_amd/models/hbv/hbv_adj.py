@@ -52,6 +52,11 @@ class HbvAdj(torch.nn.Module):
         # 'lane': every (basin, member) stops for itself; 'global': the reference's rule (hbv_adj.py:544,546:
         # one torch.max over the batch) applied to the 64 lanes of a wavefront (include/hbvx.h, adj_stop)
         self.newton_stop = 'lane'
+        # 'staged' (default): the block lower-triangular system is solved block by block -- snow, upper and lower
+        # zone in closed form, soil moisture by scalar Newton under newton_gtol / newton_max_iter (csrc/hbv_adj_step.h
+        # AdjStaged; the three blocks run as a wave pipeline).  'joint': the reference's modified Newton on all five
+        # unknowns (hbv_adj.py:507-581), kept as the policy cross-check; newton_stop applies to it only.
+        self.newton_solver = 'staged'
         self.parameter_bounds = {
             'parBETA': [1.0, 6.0], 'parFC': [50, 1000], 'parK0': [0.05, 0.9],
             'parK1': [0.01, 0.5], 'parK2': [0.001, 0.2], 'parLP': [0.2, 1],
@@ -77,6 +82,11 @@ class HbvAdj(torch.nn.Module):
             self.newton_stop = config.get('newton_stop', self.newton_stop)
             if self.newton_stop not in ('lane', 'global'):
                 raise ValueError("newton_stop must be 'lane' or 'global'")
+            self.newton_solver = config.get('newton_solver', 'joint' if 'newton_stop' in config else self.newton_solver)
+            if self.newton_solver not in ('staged', 'joint'):
+                raise ValueError("newton_solver must be 'staged' or 'joint'")
+            if self.newton_solver == 'staged' and self.newton_stop == 'global':
+                raise ValueError("newton_stop='global' is a rule of the joint iteration: use newton_solver='joint'")
             if 'parBETAET' in self.dynamic_params:
                 self.parameter_bounds['parBETAET'] = [0.3, 5]
         self.set_parameters()
@@ -125,7 +135,7 @@ class HbvAdj(torch.nn.Module):
         base = dict(model=_abi.MODEL_HBVADJ, n_param=n, n_flux=1, B=B, M=M, raw_sigmoid=True,
                     channels=ch, nearzero=float(self.nearzero),
                     adj_gtol=float(self.newton_gtol), adj_max_iter=int(self.newton_max_iter),
-                    adj_stop=1 if self.newton_stop == 'global' else 0)
+                    adj_stop=2 if self.newton_solver == 'staged' else (1 if self.newton_stop == 'global' else 0))
         state = None  # zeros (hbv_adj.py:254)
         wu = self.warm_up
         if wu > 0:  # hbv_adj.py:257-274: static parameters from row warm_up-1, differentiable

@@ -118,11 +118,19 @@ typedef struct hbvx_desc {
                              (hbv.py:201); 0: inputs already in [0,1] (hbv_2.py:211) */
     int32_t ch_prcp, ch_tmean, ch_pet; /* channel of each forcing (hbv.py:388-390) */
     float nearzero;       /* hbv.py:54 */
-    int32_t adj_stop;     /* hbvx_adj_* only: who decides that a day's Newton iteration stops.  0: every
-                             lane for itself.  1: the slowest lane of the WAVEFRONT (64 lanes = 64/Mp
-                             basins x Mp members) -- the reference's rule, one torch.max over the batch
-                             (hbv_adj.py:544,546), restricted to the lanes that share a wavefront: a
-                             batch-wide maximum would need a grid barrier per Newton update */
+    int32_t adj_stop;     /* hbvx_adj_* only: how a day's system G(x) = 0 is solved and who decides that the
+                             iteration stops.
+                             0: joint modified Newton on the five storages (hbv_adj.py:507-581), every lane
+                                stops for itself.
+                             1: the same, the slowest lane of the WAVEFRONT (64 lanes = 64/Mp basins x Mp
+                                members) decides -- the reference's rule, one torch.max over the batch
+                                (hbv_adj.py:544,546), restricted to the lanes that share a wavefront: a
+                                batch-wide maximum would need a grid barrier per Newton update.
+                             2: staged solve along the block lower-triangular structure of dG/dx
+                                (hbv_adj.py:425-429): snow, upper zone and lower zone in closed form
+                                (piecewise linear, monotone), soil moisture by scalar Newton under
+                                adj_gtol / adj_max_iter, per lane.  Same acceptance test |G|_inf <= gtol;
+                                the blocks of consecutive days run as a wave pipeline. */
     const float *x;       /* forcings: (t,b,c) at x[t*x_t_stride + b*x_b_stride + c] */
     int64_t x_t_stride, x_b_stride;
     const float *ac;      /* [B] HBV 2.0 `ac_all`  (hbv_2.py:345), else NULL */

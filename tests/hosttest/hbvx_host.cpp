@@ -251,6 +251,13 @@ static void run_adj_fwd(const hbvx_desc &d, const hbvx_fwd_out &o)
                 const float *xr = d.x + (int64_t)t * d.x_t_stride + (int64_t)b * d.x_b_stride;
                 s.P = xr[d.ch_prcp]; s.Tf = xr[d.ch_tmean]; s.PET = xr[d.ch_pet];
                 if (o.traj) for (int k = 0; k < 5; k++) o.traj[((int64_t)k * (T + 1) + t) * N + n] = x[k];
+                if (d.adj_stop == 2) {
+                    float Q;
+                    AdjStaged<BETAET>::day(p, s.P, s.Tf, s.PET, x, d.adj_gtol, d.adj_max_iter, xn, Q);
+                    for (int k = 0; k < 5; k++) x[k] = xn[k];
+                    acc[t] += Q;
+                    continue;
+                }
                 adj_newton<BETAET>(s, p, x, 1.0f, d.adj_gtol, d.adj_max_iter, xn);
                 for (int k = 0; k < 5; k++) x[k] = xn[k];
                 const float SUZ = fmaxf(x[3], 0.f), SLZ = fmaxf(x[4], 0.f);
@@ -432,6 +439,31 @@ static float jt_check(const float *st, const float *f, const float *p, int n, fl
         worst = fmaxf(worst, err / scale);
     }
     return worst;
+}
+// AdjStaged::day against the residual it claims to zero: G(x) = (x - xt)/dt - f(x) with f from AdjStep::eval
+// (the restatement of hbv_adj.py:385-431 the joint iteration uses).  out[k] = worst |G_k| over the n days,
+// relative to max(1, |xt_k|, |x_k|); out[5] = the largest soil-moisture update count.
+extern "C" void hbvx_test_staged_residual(const float *st, const float *f, const float *p, int n, float gtol,
+                                          int max_iter, float *out, float *g2_each)
+{
+    for (int k = 0; k < 6; k++) out[k] = 0.0f;
+    for (int i = 0; i < n; i++) {
+        const float *xt = st + i * 5, *pp = p + i * NPARAM_MAX;
+        float x[5], Q;
+        const int it = AdjStaged<true>::day(pp, f[i * 3], f[i * 3 + 1], f[i * 3 + 2], xt, gtol, max_iter, x, Q);
+        AdjStep<true> s;
+        s.P = f[i * 3]; s.Tf = f[i * 3 + 1]; s.PET = f[i * 3 + 2];
+        s.template eval<false>(x, pp);
+        for (int k = 0; k < 5; k++) {
+            const float g = (x[k] - xt[k]) - s.f[k];
+            const float sc = fmaxf(1.0f, fmaxf(fabsf(xt[k]), fabsf(x[k])));
+            out[k] = fmaxf(out[k], fabsf(g) / sc);
+        }
+        out[5] = fmaxf(out[5], (float)it);
+        if (g2_each) { g2_each[2 * i] = (x[2] - xt[2]) - s.f[2]; g2_each[2 * i + 1] = x[2]; }
+        const float Qe = (s.q0 + s.q1) + s.q2;
+        if (fabsf(Q - Qe) > 1e-6f * fmaxf(1.0f, fabsf(Qe))) out[5] = 1e9f;   // Q must be the flux at the solved state
+    }
 }
 // snow rows of the capillary models: jt_coef_snow + jt_unit<0> against bwd (HBV 2.0 instantiation)
 extern "C" float hbvx_test_jt_snow(const float *st, const float *f, const float *p, int n, float nz)

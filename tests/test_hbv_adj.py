@@ -66,8 +66,11 @@ CASES = [
 ]
 
 
-def _run_case(device, case, tight):
-    cfg = dict(case["cfg"])
+SOLVERS = ["staged", "joint"]   # csrc/hbv_adj_step.h: AdjStaged (the default) and the reference's joint iteration
+
+
+def _run_case(device, case, tight, solver="staged"):
+    cfg = dict(case["cfg"], newton_solver=solver)
     if tight:
         cfg.update(newton_gtol=1e-6, newton_max_iter=12)
     betaet = "parBETAET" in cfg["dynamic_params"]["HbvAdj"]
@@ -76,7 +79,7 @@ def _run_case(device, case, tight):
     torch.manual_seed(5)
     got, ggot = _product(device, x, p, w, cfg)
     torch.manual_seed(5)
-    want, gwant, its = _oracle(x, p, w, cfg)
+    want, gwant, its = _oracle(x, p, w, cfg)     # always the reference's joint iteration, float64
     return got, ggot, want, gwant, its
 
 
@@ -117,18 +120,22 @@ def test_oracle_gradient_is_the_implicit_function_derivative():
     assert worst < 2e-3, worst
 
 
+@pytest.mark.parametrize("solver", SOLVERS)
 @pytest.mark.parametrize("case", CASES, ids=lambda c: f"M{c['M']}-T{c['T']}")
-def test_host_math_matches_oracle_converged(case, host_math_backend):
-    """Tightly converged Newton: the scheme itself (values and implicit-function gradients)."""
-    got, ggot, want, gwant, _ = _run_case("cpu", case, tight=True)
+def test_host_math_matches_oracle_converged(case, solver, host_math_backend):
+    """Tightly converged Newton: the scheme itself (values and implicit-function gradients).  The staged
+    solve (closed-form snow / upper / lower zone blocks + scalar Newton on soil moisture) must land on the
+    same root as the float64 joint iteration."""
+    got, ggot, want, gwant, _ = _run_case("cpu", case, tight=True, solver=solver)
     _close("flow_sim", got, want, 2e-4, 2e-5)
     _close("grad", ggot, gwant, 2e-3, 2e-4)
 
 
+@pytest.mark.parametrize("solver", SOLVERS)
 @pytest.mark.parametrize("case", CASES[:2], ids=lambda c: f"M{c['M']}-T{c['T']}")
-def test_host_math_matches_oracle_reference_policy(case, host_math_backend):
+def test_host_math_matches_oracle_reference_policy(case, solver, host_math_backend):
     """The reference's Newton policy (gtol 1e-3, <= 4 updates), per-lane stopping."""
-    got, ggot, want, gwant, its = _run_case("cpu", case, tight=False)
+    got, ggot, want, gwant, its = _run_case("cpu", case, tight=False, solver=solver)
     assert float(its.max()) <= 4
     _close("flow_sim", got, want, 5e-3, 5e-4)
     _close("grad", ggot, gwant, 5e-2, 5e-3)
@@ -144,9 +151,10 @@ def test_global_stopping_rule_differs_only_within_gtol():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("solver", SOLVERS)
 @pytest.mark.parametrize("case", CASES, ids=lambda c: f"M{c['M']}-T{c['T']}")
-def test_hip_matches_oracle_converged(case, hip_backend):
-    got, ggot, want, gwant, _ = _run_case("cuda:0", case, tight=True)
+def test_hip_matches_oracle_converged(case, solver, hip_backend):
+    got, ggot, want, gwant, _ = _run_case("cuda:0", case, tight=True, solver=solver)
     _close("flow_sim", got, want, 2e-4, 2e-5)
     _close("grad", ggot, gwant, 2e-3, 2e-4)
 
