@@ -40,6 +40,7 @@
 #include "../../include/hbvx.h"
 #include "hbv_step.h"
 #include "hbv_tiled.h"
+#include "hbv_adj_step.h"
 
 namespace hbvx {
 
@@ -142,7 +143,11 @@ __device__ __forceinline__ constexpr int pipe_sc_flag(int X)
 template <int MODEL, bool BETAET, bool TRAJ, bool DYN, bool MANY = false, int SC = 0>
 __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
 {
-    constexpr bool CAP = MODEL != MODEL_HBV10;   // two-stage pipeline (see the header comment)
+    // ADJ: the implicit scheme (hbv_adj.py) with the staged solve of hbv_adj_step.h -- its blocks snow -> soil
+    // moisture -> upper / lower zone feed forward exactly like the explicit HBV 1.0 stages, so the same three
+    // waves run them one tile apart; flux = Q only, no saved powers
+    constexpr bool ADJ = MODEL == MODEL_HBVADJ;
+    constexpr bool CAP = MODEL != MODEL_HBV10 && !ADJ;   // two-stage pipeline (see the header comment)
     constexpr int KT = MANY ? PIPE_KT_MANY : PIPE_KT;
     constexpr int OBR = CAP ? 8 : 7, NFB = CAP ? 5 : 4;
 #ifdef PIPE_PROBE
@@ -200,8 +205,9 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
     if (wave == 0) {
         // ------------------------------ snow ------------------------------
         __builtin_amdgcn_s_setprio(3);
-        float SP = d.state_in ? d.state_in[0 * N + L.n] : 0.001f;
-        float MW = d.state_in ? d.state_in[1 * N + L.n] : 0.001f;
+        constexpr float S0 = ADJ ? 0.0f : 0.001f;   // hbv.py:128-136 / hbv_adj.py:254
+        float SP = d.state_in ? d.state_in[0 * N + L.n] : S0;
+        float MW = d.state_in ? d.state_in[1 * N + L.n] : S0;
         PIPE_BARRIER();
         for (int it = 0; it < nIt; it++) {
             const int tile = it;
@@ -215,7 +221,6 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                 DY_DECL(P_TT); DY_DECL(P_CFMAX); DY_DECL(P_CFR); DY_DECL(P_CWH);
                 if (DYN) { DY_LOAD(P_TT, pin); DY_LOAD(P_CFMAX, pin); DY_LOAD(P_CFR, pin); DY_LOAD(P_CWH, pin); }
                 auto day = [&](int tt, bool more) __attribute__((always_inline)) {
-                    Step<MODEL, BETAET> s;
                     const float4 f = fn;
                     if (DYN) { DY_USE(P_TT); DY_USE(P_CFMAX); DY_USE(P_CFR); DY_USE(P_CWH); }
                     if (more) {
@@ -225,15 +230,25 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                             DY_LOAD(P_TT, pt); DY_LOAD(P_CFMAX, pt); DY_LOAD(P_CFR, pt); DY_LOAD(P_CWH, pt);
                         }
                     }
-                    s.P = f.x; s.Tf = f.y;
-                    s.SP = SP; s.MW = MW;
-                    s.fwd_snow(p, elev);
-                    ab[tt * 128] = s.RAIN;
-                    ab[tt * 128 + 64] = s.tosoil;
                     float *q = oa + tt * 256;
-                    q[0] = s.SP3; q[64] = s.tosoil;
-                    if (TRAJ) { q[128] = SP; q[192] = MW; }
-                    SP = s.SP3; MW = s.MW3;
+                    if constexpr (ADJ) {
+                        float y0, y1, rfv, isn;
+                        AdjStaged<BETAET>::snow(p, f.x, f.y, 1.0f, SP, MW, y0, y1, rfv, isn);
+                        ab[tt * 128] = rfv;
+                        ab[tt * 128 + 64] = isn;
+                        if (TRAJ) { q[128] = SP; q[192] = MW; }
+                        SP = y0; MW = y1;
+                    } else {
+                        Step<MODEL, BETAET> s;
+                        s.P = f.x; s.Tf = f.y;
+                        s.SP = SP; s.MW = MW;
+                        s.fwd_snow(p, elev);
+                        ab[tt * 128] = s.RAIN;
+                        ab[tt * 128 + 64] = s.tosoil;
+                        q[0] = s.SP3; q[64] = s.tosoil;
+                        if (TRAJ) { q[128] = SP; q[192] = MW; }
+                        SP = s.SP3; MW = s.MW3;
+                    }
                 };
                 PIPE_DAYS(nt, day);
             }
@@ -337,7 +352,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
       } else {
         // ------------------------------ soil ------------------------------
         __builtin_amdgcn_s_setprio(3);
-        float SM = d.state_in ? d.state_in[2 * N + L.n] : 0.001f;
+        float SM = d.state_in ? d.state_in[2 * N + L.n] : (ADJ ? 0.0f : 0.001f);
         PIPE_BARRIER();
         for (int it = 0; it < nIt; it++) {
             const int tile = it - 1;
@@ -352,8 +367,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                 DY_DECL(P_BETA); DY_DECL(P_FC); DY_DECL(P_LP); DY_DECL(P_BETAET);
                 if (DYN) { DY_LOAD(P_BETA, pin); DY_LOAD(P_FC, pin); DY_LOAD(P_LP, pin); DY_LOAD(P_BETAET, pin); }
                 auto day = [&](int tt, bool more) __attribute__((always_inline)) {
-                    Step<MODEL, BETAET> s;
-                    s.PET = npet; s.RAIN = nrain; s.tosoil = nts;
+                    const float dPET = npet, dRAIN = nrain, dTS = nts;
                     if (DYN) { DY_USE(P_BETA); DY_USE(P_FC); DY_USE(P_LP); DY_USE(P_BETAET); }
                     if (more) {
                         npet = in4[(tt + 1) * 64 + lane].z;
@@ -364,14 +378,25 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                             DY_LOAD(P_BETA, pt); DY_LOAD(P_FC, pt); DY_LOAD(P_LP, pt); DY_LOAD(P_BETAET, pt);
                         }
                     }
-                    s.SM = SM;
-                    s.template fwd_soil<false>(p, nz, 0.0f, 0.0f);
-                    bc[tt * 128] = s.rech;
-                    bc[tt * 128 + 64] = s.exc;
                     float *q = ob + tt * OBR * 64;
-                    q[0] = s.ET; q[64] = s.rech; q[128] = s.exc; q[192] = s.ef;
-                    if (TRAJ) { q[256] = SM; q[320] = s.sw0; q[384] = s.ef0; }
-                    SM = s.SM3;
+                    if constexpr (ADJ) {
+                        float y2, Peff, exs;
+                        AdjStaged<BETAET>::soil(p, dRAIN, dTS, dPET, 1.0f, SM, d.adj_gtol, d.adj_max_iter, y2, Peff, exs);
+                        bc[tt * 128] = Peff;
+                        bc[tt * 128 + 64] = exs;
+                        if (TRAJ) q[256] = SM;
+                        SM = y2;
+                    } else {
+                        Step<MODEL, BETAET> s;
+                        s.PET = dPET; s.RAIN = dRAIN; s.tosoil = dTS;
+                        s.SM = SM;
+                        s.template fwd_soil<false>(p, nz, 0.0f, 0.0f);
+                        bc[tt * 128] = s.rech;
+                        bc[tt * 128 + 64] = s.exc;
+                        q[0] = s.ET; q[64] = s.rech; q[128] = s.exc; q[192] = s.ef;
+                        if (TRAJ) { q[256] = SM; q[320] = s.sw0; q[384] = s.ef0; }
+                        SM = s.SM3;
+                    }
                 };
                 PIPE_DAYS(nt, day);
             }
@@ -389,8 +414,8 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
       } else {
         // --------------------------- groundwater ---------------------------
         __builtin_amdgcn_s_setprio(3);
-        float SUZ = d.state_in ? d.state_in[3 * N + L.n] : 0.001f;
-        float SLZ = d.state_in ? d.state_in[4 * N + L.n] : 0.001f;
+        float SUZ = d.state_in ? d.state_in[3 * N + L.n] : (ADJ ? 0.0f : 0.001f);
+        float SLZ = d.state_in ? d.state_in[4 * N + L.n] : (ADJ ? 0.0f : 0.001f);
         PIPE_BARRIER();
         for (int it = 0; it < nIt; it++) {
             const int tile = it - 2;
@@ -403,8 +428,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                 DY_DECL(P_K0); DY_DECL(P_K1); DY_DECL(P_K2); DY_DECL(P_PERC); DY_DECL(P_UZL);
                 if (DYN) { DY_LOAD(P_K0, pin); DY_LOAD(P_K1, pin); DY_LOAD(P_K2, pin); DY_LOAD(P_PERC, pin); DY_LOAD(P_UZL, pin); }
                 auto day = [&](int tt, bool more) __attribute__((always_inline)) {
-                    Step<MODEL, BETAET> s;
-                    s.rech = nrech; s.exc = nexc;
+                    const float dRECH = nrech, dEXC = nexc;
                     if (DYN) { DY_USE(P_K0); DY_USE(P_K1); DY_USE(P_K2); DY_USE(P_PERC); DY_USE(P_UZL); }
                     if (more) {
                         nrech = bc[(tt + 1) * 128];
@@ -414,12 +438,22 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                             DY_LOAD(P_K0, pt); DY_LOAD(P_K1, pt); DY_LOAD(P_K2, pt); DY_LOAD(P_PERC, pt); DY_LOAD(P_UZL, pt);
                         }
                     }
-                    s.SUZ = SUZ; s.SLZ0 = SLZ;
-                    s.fwd_gw(p, 0.0f);
                     float *q = oc + tt * 448;
-                    q[0] = s.Q; q[64] = s.Q0; q[128] = s.Q1; q[192] = s.Q2; q[256] = s.PERC;
-                    if (TRAJ) { q[320] = SUZ; q[384] = SLZ; }
-                    SUZ = s.SUZ4; SLZ = s.SLZ2;
+                    if constexpr (ADJ) {
+                        float y3, y4, Q;
+                        AdjStaged<BETAET>::gw(p, dRECH, dEXC, 1.0f, SUZ, SLZ, y3, y4, Q);
+                        q[0] = Q;
+                        if (TRAJ) { q[320] = SUZ; q[384] = SLZ; }
+                        SUZ = y3; SLZ = y4;
+                    } else {
+                        Step<MODEL, BETAET> s;
+                        s.rech = dRECH; s.exc = dEXC;
+                        s.SUZ = SUZ; s.SLZ0 = SLZ;
+                        s.fwd_gw(p, 0.0f);
+                        q[0] = s.Q; q[64] = s.Q0; q[128] = s.Q1; q[192] = s.Q2; q[256] = s.PERC;
+                        if (TRAJ) { q[320] = SUZ; q[384] = SLZ; }
+                        SUZ = s.SUZ4; SLZ = s.SLZ2;
+                    }
                 };
                 PIPE_DAYS(nt, day);
             }
@@ -500,7 +534,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                     float v = ps.sta[(int64_t)L.b * ps.sta_b_stride + L.j];
                     v = raw ? sigmoid_(v) : v;
                     dsta[r] = descale_(v, ps.lo, ps.hi);
-                    duse[r] = ps.drop ? (ps.drop[L.b] == 0) : true;
+                    duse[r] = ps.drop ? (ps.drop[ADJ ? L.n : (int64_t)L.b] == 0) : true;   // hbv_adj.py:182-189: per lane
                 }
             }
             auto issue = [&](int tile) {
@@ -616,7 +650,10 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                     }
                     if (tt < ntC) { c0 = bufC[tt * 448 + 320]; c1 = bufC[tt * 448 + 384]; }
                     if (tt < ntA) { put(rSP, soff, a0); put(rMW, soff, a1); }
-                    if (tt < ntB) { put(rSM, soff, b0v); put(rSW, soff, b1); put(rEF, soff, b2); }
+                    if (tt < ntB) {
+                        put(rSM, soff, b0v);
+                        if (!ADJ) { put(rSW, soff, b1); put(rEF, soff, b2); }   // the implicit scheme keeps no powers
+                    }
                     if (tt < ntC) { put(rSUZ, soff, c0); put(rSLZ, soff, c1); }
                 }
                 PIPE_BARRIER();
@@ -635,13 +672,15 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                 const float *bufA = lds + P.oa + (tA & 1) * Kt * 256;
                 const float *bufB = lds + P.ob + (tB & 1) * Kt * OBR * 64;
                 const float *bufC = lds + P.oc + (tC & 1) * Kt * 448;
-                const int iA = ntA * 2 * bpw, iB = ntB * NFB * bpw, iC = ntC * 5 * bpw;
+                constexpr int NFC = ADJ ? 1 : 5;   // implicit scheme: Q only (hbv_adj.py:309-317)
+                const int iA = ADJ ? 0 : ntA * 2 * bpw, iB = ADJ ? 0 : ntB * NFB * bpw,
+                          iC = (ADJ && !o.flux) ? 0 : ntC * NFC * bpw;
                 const int pA = (iA + 63) >> 6, pB = (iB + 63) >> 6, pC = (iC + 63) >> 6;
                 const int nR = pA + pB + pC;
                 // heaviest passes first (C: 5 series), so the tail of the round-robin is light
                 for (int u = w; u < nR; u += NDR) {
                     if (u < pC)
-                        pipe_reduce_pass<7, 5, fmapC>(d, o, bufC, tC * Kt, iC, u, lane, lgMp, b0);
+                        pipe_reduce_pass<7, NFC, fmapC>(d, o, bufC, tC * Kt, iC, u, lane, lgMp, b0);
                     else if (u < pC + pB)
                         pipe_reduce_pass<OBR, NFB, fmapB>(d, o, bufB, tB * Kt, iB, u - pC, lane, lgMp, b0);
                     else

@@ -24,8 +24,9 @@ bool hbvx_host::try_fwd_pipe(const hbvx_desc *d, const hbvx_fwd_out *out, void *
         const int nd = count_dyn(d);
         const bool many = nd > PIPE_FEWDYN;          // 4-day tiles, several staged rows per filler wave
         const int Kt = many ? PIPE_KT_MANY : PIPE_KT;
-        const bool cap = d->model != HBVX_MODEL_HBV10;
-        const int nfl = cap ? 12 : 11;
+        const bool adj = d->model == HBVX_MODEL_HBVADJ;   // implicit scheme, staged solve (hbvx_adj_forward only)
+        const bool cap = d->model != HBVX_MODEL_HBV10 && !adj;
+        const int nfl = adj ? 1 : (cap ? 12 : 11);
         // per-lane and per-tile byte offsets are 32-bit in the pipelined kernel
         bool off32 = ((int64_t)d->B * d->x_b_stride + (int64_t)Kt * d->x_t_stride) * 4 < (int64_t)1 << 31;
         for (int i = 0; i < d->n_param; i++)
@@ -34,15 +35,17 @@ bool hbvx_host::try_fwd_pipe(const hbvx_desc *d, const hbvx_fwd_out *out, void *
                                      (int64_t)1 << 31;
         const int64_t wgs_p = ((int64_t)d->B + (64 >> lg_members(d->M)) - 1) / (64 >> lg_members(d->M));
         const bool pmodel = d->model == HBVX_MODEL_HBV10 || d->model == HBVX_MODEL_HBV11P ||
-                            d->model == HBVX_MODEL_HBV20 || d->model == HBVX_MODEL_HOURLY;
+                            d->model == HBVX_MODEL_HBV20 || d->model == HBVX_MODEL_HOURLY ||
+                            (adj && d->adj_stop == 2 && !many);
         const size_t lds = (size_t)PipeLds(Kt, nd > 0 ? (many ? nd : PIPE_FEWDYN) : 0, cap).total * 4;
         // HBVX_TRAJ_CKPT: the row drainers keep every K-th day only (no powers)
         const int ckpt_k = (out->traj && HBVX_TRAJ_KIND(out->traj_layout) == HBVX_TRAJ_CKPT)
                                ? HBVX_TRAJ_CKPT_DAYS(out->traj_layout) : 0;
         const bool ckpt_fits = !ckpt_k || ((int64_t)((d->T + ckpt_k - 1) / ckpt_k) * 5 * d->B * d->M * 4 < (int64_t)1 << 32);
         if (ckpt_fits && use_tiled(d) && !(fv && !strcmp(fv, "tiled")) && pmodel && off32 &&
-            nd <= PIPE_MAXDYN && (int)lds <= LDS_BUDGET && wgs_p < 4096 && !d->muwts && out->flux && d->T >= 4 * Kt &&
-            (ckpt_k ? out->aux == nullptr : (out->traj != nullptr) == (out->aux != nullptr)) &&
+            nd <= PIPE_MAXDYN && (int)lds <= LDS_BUDGET && wgs_p < 4096 && !d->muwts && (out->flux || adj) && d->T >= 4 * Kt &&
+            (adj ? (!ckpt_k && out->aux == nullptr)
+                 : (ckpt_k ? out->aux == nullptr : (out->traj != nullptr) == (out->aux != nullptr))) &&
             (int64_t)d->B * d->M * 4 * Kt < (int64_t)1 << 31 &&
             (int64_t)nfl * d->T * d->B * 4 < (int64_t)1 << 31) {
             PipeArgs pa;
@@ -79,7 +82,16 @@ bool hbvx_host::try_fwd_pipe(const hbvx_desc *d, const hbvx_fwd_out *out, void *
         if (tr) PIPE_GO3(MODEL, BE, true, S1, S2);                                                 \
         else PIPE_GO3(MODEL, BE, false, S1, S2);                                                   \
     } while (0)
-            if (d->model == HBVX_MODEL_HBV11P) PIPE_GO4(MODEL_HBV11P, true, true, false);
+            if (adj) {   // at most PIPE_FEWDYN dynamic parameters (pmodel), descriptor flags
+#define PIPE_GO_ADJ(BE)                                                                            \
+    do {                                                                                           \
+        if (tr) { if (dy) PIPE_GO(MODEL_HBVADJ, BE, true, true, false, 0); else PIPE_GO(MODEL_HBVADJ, BE, true, false, false, 0); } \
+        else { if (dy) PIPE_GO(MODEL_HBVADJ, BE, false, true, false, 0); else PIPE_GO(MODEL_HBVADJ, BE, false, false, false, 0); } \
+    } while (0)
+                if (be) PIPE_GO_ADJ(true);
+                else PIPE_GO_ADJ(false);
+#undef PIPE_GO_ADJ
+            } else if (d->model == HBVX_MODEL_HBV11P) PIPE_GO4(MODEL_HBV11P, true, true, false);
             else if (d->model == HBVX_MODEL_HBV20) PIPE_GO4(MODEL_HBV20, true, false, true);
             else if (d->model == HBVX_MODEL_HOURLY) PIPE_GO4(MODEL_HOURLY, true, false, true);
             else if (be) PIPE_GO4(MODEL_HBV10, true, true, true);

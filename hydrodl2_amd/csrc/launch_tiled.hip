@@ -158,6 +158,8 @@ extern "C" int hbvx_adj_forward(const hbvx_desc *d, const hbvx_fwd_out *out, voi
     if (rc) return rc;
     if (!out || !out->state_out) return fail(HBVX_E_NULL, "state_out is NULL");
     if (out->flux && out->n_flux != 1) return fail(HBVX_E_SHAPE, "hbvx_adj_forward writes n_flux = 1");
+    if (d->adj_stop < 0 || d->adj_stop > 2) return fail(HBVX_E_SHAPE, "adj_stop must be 0, 1 or 2");
+    if (d->adj_stop == 2 && try_fwd_pipe(d, out, stream, &rc)) return rc;   // staged solve: three-wave pipeline
     {
         FwdTArgs ta;
         if (use_tiled(d) && geom_fwd(d, out, ta.g)) {

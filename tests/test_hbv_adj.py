@@ -160,6 +160,18 @@ def test_hip_matches_oracle_converged(case, solver, hip_backend):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"M{c['M']}-T{c['T']}")
+def test_hip_pipelined_staged_forward_equals_the_one_wave_stepper(case, hip_backend, monkeypatch):
+    """The staged solve runs as a three-wave pipeline (hbv_pipe.h, blocks of consecutive days on different
+    waves); HBVX_FWD=tiled pins the single stepper wave that solves the three blocks in sequence.  Same
+    block code, same ensemble add order: bit-identical values and gradients."""
+    a, ga, _, _, _ = _run_case("cuda:0", case, tight=False)
+    monkeypatch.setenv("HBVX_FWD", "tiled")
+    b, gb, _, _, _ = _run_case("cuda:0", case, tight=False)
+    assert np.array_equal(a, b) and np.array_equal(ga, gb)
+
+
+@pytest.mark.gpu
 def test_hip_reference_policy_and_size(hip_backend):
     got, ggot, want, gwant, its = _run_case("cuda:0", CASES[1], tight=False)
     _close("flow_sim", got, want, 5e-3, 5e-4)
