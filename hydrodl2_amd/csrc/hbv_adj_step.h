@@ -229,6 +229,15 @@ HBVX_HD int adj_newton(AdjStep<BETAET> &s, const float *p, const float *xt, floa
 // Invariant: storages entering a day are >= 0 (zeros at the start, hbv_adj.py:254, and every closed
 // form below returns >= 0 for inputs >= 0).  The flux expressions are those of AdjStep::eval, in the
 // same association order, so the adjoint's re-evaluation at the solved state sees the same branches.
+#ifndef ADJ_SOIL_POW
+#define ADJ_SOIL_POW pow_fast_   // -DADJ_SOIL_POW=pow_step_: the 2-ulp power of the explicit models (A/B runs)
+#endif
+#ifndef ADJ_SOIL_HALLEY
+#define ADJ_SOIL_HALLEY 1
+#endif
+#ifndef ADJ_SOIL_PEEL
+#define ADJ_SOIL_PEEL 1
+#endif
 template <bool BETAET>
 struct AdjStaged {
     // ---- block 1: snow.  (y0 - y0t)/dt = sf + refr - melt,  (y1 - y1t)/dt = melt - refr - Isnow
@@ -281,58 +290,82 @@ struct AdjStaged {
                              float gtol, int max_iter, float &y2, float &Peff, float &ex)
     {
         const float BETA = p[P_BETA], FC = p[P_FC], LP = p[P_LP];
+        const float BE = BETAET ? p[P_BETAET] : 1.0f;
         const float lpfc = LP * FC;
         const float rt = rf + Isnow;
         const float dt = (idt == 1.0f) ? 1.0f : div_approx_(1.0f, idt);
-        float x = y2t, lo = 0.0f, hi = 0.0f;
-        bool hi_new = false;   // hi is a bound that has not been an iterate yet
-        int it = 0;
-        for (;;) {
+        // day constants (off the iteration's dependency chain)
+        const float rFC = div_approx_(1.0f, FC), rLF = div_approx_(1.0f, lpfc);
+        const float rtB = rt * BETA, B1 = BETA - 1.0f, PB = BETAET ? PET * BE : PET * rLF, E1 = BE - 1.0f;
+        float x = y2t, g, J, H, et;
+        // Residual, slope and curvature at x in ONE straight block: the iteration is a chain of dependent
+        // instructions on a wave that owns its SIMD, so everything that does not have to wait for the powers
+        // (1/SM, the masks) or for the residual (slope, curvature) is issued beside them.  Values as in
+        // AdjStep::eval up to the rounding of the quotients (SM/FC by reciprocal: the iteration's acceptance
+        // test is 1e-3, and SM <= FC decides the wetness clamp instead of the power's side of 1).
+        auto eval = [&]() __attribute__((always_inline)) {
             const float SM = fmax_(x, 1e-8f);
-            const float r = div_(SM, FC);
-            const float sw0 = pow_step_(r, BETA);
-            const float sw = fmin_(fmax_(sw0, 0.0f), 1.0f);
-            Peff = rt * sw;
+            const float rSM = div_approx_(1.0f, SM);
+            const float sw0 = ADJ_SOIL_POW(SM * rFC, BETA);
+            const float qe = SM * rLF;
+            const float ef0 = BETAET ? ADJ_SOIL_POW(qe, BE) : qe;
             const float e0 = SM - FC;
+            Peff = rt * fmin_(sw0, 1.0f);
             ex = fmax_(e0, 0.0f);
-            const float qe = div_(SM, lpfc);
-            const float ef0 = BETAET ? pow_step_(qe, p[P_BETAET]) : qe;
-            const float ef = fmin_(fmax_(ef0, 0.0f), 1.0f);
-            const float pe = PET * ef;
-            const float et = fmin_(SM, pe);
+            const float pe = PET * fmin_(ef0, 1.0f);
+            et = fmin_(SM, pe);
             const float f2 = (((Isnow + rf) - Peff) - ex) - et;
-            const float g = (x - y2t) * idt - f2;
-            if (it == 0) {   // bracket from the first evaluation (x = y2t)
-                const bool below = (FC - y2t) * idt + fmin_(FC, PET) > 0.0f;   // G2(FC) > 0: root < FC
-                lo = y2t - dt * (ex + et);
-                hi = y2t + dt * rt;
-                hi_new = below && FC < hi;
-                hi = below ? fmin_(hi, FC) : hi;
-                lo = below ? lo : fmax_(lo, FC);
-            }
-            const bool more = fabsf(g) > gtol;
-            if (!(adj_any_(more, true) && it <= max_iter)) break;
+            g = (x - y2t) * idt - f2;
+            // G2' and G2'' between the kinks (the iteration needs a slope, not autograd's tie conventions)
+            const float dP = (e0 <= 0.0f) ? rtB * (sw0 * rSM) : 0.0f;                  // d Peff / d SM
+            const float dEp = (qe <= 1.0f) ? (BETAET ? PB * (ef0 * rSM) : PB) : 0.0f;  // d (PET ef) / d SM
+            const bool epow = pe < SM;                                                 // et = PET ef
+            const bool live = x >= 1e-8f;        // below the clamp of hbv_adj.py:389 the fluxes do not move
+            const float Jf = (dP + ((e0 >= 0.0f) ? 1.0f : 0.0f)) + (epow ? dEp : 1.0f);
+            J = idt + (live ? Jf : 0.0f);
+            // sw'' = (BETA - 1) sw' / SM, ef'' likewise: four multiplications
+            H = (ADJ_SOIL_HALLEY && live) ? rSM * (B1 * dP + ((BETAET && epow) ? E1 * dEp : 0.0f)) : 0.0f;
+        };
+        eval();
+        // bracket from the first evaluation (x = y2t)
+        const bool below = (FC - y2t) * idt + fmin_(FC, PET) > 0.0f;   // G2(FC) > 0: root < FC
+        float lo = y2t - dt * (ex + et);
+        float hi = y2t + dt * rt;
+        bool hi_new = below && FC < hi;   // hi is a bound that has not been an iterate yet
+        hi = below ? fmin_(hi, FC) : hi;
+        lo = below ? lo : fmax_(lo, FC);
+        int it = 0;
+        bool more = fabsf(g) > gtol;
+        auto update = [&]() __attribute__((always_inline)) {
             it++;
+            // Newton's step g / J with Halley's correction g / (J - g H / 2J) -- the powers make G2 smooth between
+            // its kinks, and the correction saves the second update (a whole residual evaluation, two powers) on
+            // most days -- as ONE reciprocal: g J / (J^2 - g H / 2); Newton's step is kept where the correction
+            // is large (denominator below J^2 / 2)
+            const float JJ = J * J, den = JJ - 0.5f * (g * H);
+            const bool hal = den > 0.5f * JJ;
+            const float dx = (hal ? g * J : g) * div_approx_(1.0f, hal ? den : J);
             lo = (g < 0.0f) ? fmax_(lo, x) : lo;
             hi = (g < 0.0f) ? hi : fmin_(hi, x);
-            const float c2 = (x >= 1e-8f) ? 1.0f : 0.0f;
-            const float msw = (sw0 >= 0.0f && sw0 <= 1.0f) ? 1.0f : 0.0f;
-            const float dP = rt * (msw * (BETA * div_approx_(sw0, SM)));
-            const float mex = (e0 >= 0.0f) ? 1.0f : 0.0f;
-            const float mef = (ef0 >= 0.0f && ef0 <= 1.0f) ? 1.0f : 0.0f;
-            float wae, wbe;
-            minw_(SM, pe, wae, wbe);
-            const float def = BETAET ? mef * (p[P_BETAET] * div_approx_(ef0, SM)) : mef * div_approx_(1.0f, lpfc);
-            const float dE = wae + wbe * (PET * def);
-            const float J = idt + ((dP + mex) + dE) * c2;
             // a step past FC lands ON FC first: below FC the residual is convex in SM (BETA >= 1), so Newton from the
             // right end converges monotonically; any other step that leaves the bracket becomes its midpoint
-            float xn = x - div_approx_(g, J);
+            float xn = x - dx;
             const bool past = xn > hi && hi_new;
             xn = (xn >= lo && xn <= hi) ? xn : (past ? hi : 0.5f * (lo + hi));
             hi_new = hi_new && !past && more;
             x = more ? xn : x;      // a lane that has converged keeps its state
-        }
+            eval();
+            more = fabsf(g) > gtol;
+        };
+#if ADJ_SOIL_PEEL
+        // The first ADJ_SOIL_PEEL updates run without asking the wave whether any lane still needs them: lanes that
+        // have converged keep their state (the update is masked), so the result is that of the loop below, and a
+        // day that is already solved (no input, no evaporation) is rare enough to pay for the missing vote.
+#pragma unroll
+        for (int k = 0; k < ADJ_SOIL_PEEL; k++)
+            if (k <= max_iter) update();
+#endif
+        while (adj_any_(more, true) && it <= max_iter) update();
         y2 = x;
         return it;
     }

@@ -53,7 +53,7 @@ namespace hbvx {
 // address is base + immediate and the loop-carried registers need no rotation moves.
 #define PIPE_DAYS(nt, body)                                                                        \
     do {                                                                                           \
-        if ((nt) == KT) {                                                                          \
+        if ((nt) == KT && !PIPE_NO_UNROLL) {                                                       \
             _Pragma("unroll") for (int tt_ = 0; tt_ < KT; tt_++) body(tt_, tt_ + 1 < KT);          \
         } else {                                                                                   \
             for (int tt_ = 0; tt_ < (nt); tt_++) body(tt_, tt_ + 1 < (nt));                        \
@@ -147,6 +147,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
     // moisture -> upper / lower zone feed forward exactly like the explicit HBV 1.0 stages, so the same three
     // waves run them one tile apart; flux = Q only, no saved powers
     constexpr bool ADJ = MODEL == MODEL_HBVADJ;
+    constexpr bool PIPE_NO_UNROLL = ADJ;   // a day of the implicit scheme is an iteration, not 70 straight-line instructions
     constexpr bool CAP = MODEL != MODEL_HBV10 && !ADJ;   // two-stage pipeline (see the header comment)
     constexpr int KT = MANY ? PIPE_KT_MANY : PIPE_KT;
     constexpr int OBR = CAP ? 8 : 7, NFB = CAP ? 5 : 4;

@@ -254,6 +254,20 @@ HBVX_HD float pow_step_(float x, float y)
 #endif
 }
 
+// x**y as 2^(y log2 x) straight on the hardware transcendentals: three dependent instructions instead of the
+// ~16 of pow_core_.  The error of v_log_f32 (1 ulp of log2 x) is multiplied by |y log2 x|, so the RELATIVE error
+// grows with the exponent -- but every power of the implicit scheme is clamped to [0, 1] (hbv_adj.py:472-473,
+// 484-485), where 2^z |z| 2^-23 <= 7e-8 ABSOLUTE whatever z <= 0, and results above 1 only need their side of 1
+// (exact at x == 1).  Used inside the Newton iteration of AdjStaged::soil, whose acceptance test is 1e-3.
+HBVX_HD float pow_fast_(float x, float y)   // x a normal positive number (the caller's clamp guarantees it)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
+#else
+    return exp2f(y * log2f(x));
+#endif
+}
+
 // natural log for the adjoint's d(x**y)/dy = x**y ln x: gradients are compared at rtol 1e-3,
 // the hardware v_log_f32 (1 ulp on log2) is ample.
 HBVX_HD float log_fast_(float v)

@@ -465,6 +465,29 @@ extern "C" void hbvx_test_staged_residual(const float *st, const float *f, const
         if (fabsf(Q - Qe) > 1e-6f * fmaxf(1.0f, fabsf(Qe))) out[5] = 1e9f;   // Q must be the flux at the solved state
     }
 }
+// Diagnostics: how many soil-moisture updates the staged solve takes on a synthetic record.  N lanes (static
+// parameters p [N][NPARAM_MAX], forcing f [T][N/M][3]), T days from zero storages; hist[k] counts WAVE-days
+// (64 consecutive lanes) whose slowest lane took k updates, hist[16 + k] counts lane-days.
+extern "C" void hbvx_test_staged_iters(const float *f, const float *p, int T, int N, int M, float gtol,
+                                       int max_iter, long long *hist)
+{
+    for (int k = 0; k < 32; k++) hist[k] = 0;
+    std::vector<float> x((size_t)N * 5, 0.0f);
+    std::vector<int> wmax((size_t)(N + 63) / 64);
+    for (int t = 0; t < T; t++) {
+        std::fill(wmax.begin(), wmax.end(), 0);
+        for (int n = 0; n < N; n++) {
+            const float *ff = f + ((size_t)t * (N / M) + n / M) * 3;
+            float xn[5], Q;
+            const int it = AdjStaged<true>::day(p + (size_t)n * NPARAM_MAX, ff[0], ff[1], ff[2], &x[(size_t)n * 5],
+                                                gtol, max_iter, xn, Q);
+            for (int k = 0; k < 5; k++) x[(size_t)n * 5 + k] = xn[k];
+            hist[16 + (it < 15 ? it : 15)]++;
+            wmax[n / 64] = it > wmax[n / 64] ? it : wmax[n / 64];
+        }
+        for (int w : wmax) hist[w < 15 ? w : 15]++;
+    }
+}
 // snow rows of the capillary models: jt_coef_snow + jt_unit<0> against bwd (HBV 2.0 instantiation)
 extern "C" float hbvx_test_jt_snow(const float *st, const float *f, const float *p, int n, float nz)
 {

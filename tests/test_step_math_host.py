@@ -179,14 +179,16 @@ def test_staged_implicit_solve_zeroes_the_residual(steptest_lib):
     lib.hbvx_test_staged_residual(*args, C.c_float(1e-3), C.c_int(3), out.ctypes.data_as(C.c_void_p),
                                   g2.ctypes.data_as(C.c_void_p))
     assert out[5] <= 4, f"soil-moisture updates (or Q mismatch): {out[5]}"
-    for kk in (0, 1, 3, 4):
-        assert out[kk] < 2e-6, f"block residual G{kk}: {out[kk]:.3g} (relative)"
-    # a melt pulse of hundreds of mm into an empty 50 mm store is not solved to 1e-3 in four updates (measured:
-    # ~100 of these 200 000 days, worst |G2| 0.15; unbracketed Newton left as many with |G2| up to 76) -- the cap
-    # is the reference's, the bracket keeps what is left small
+    # (G3 sees Peff from the soil block's reciprocal-based quotients against the checker's divisions: a few 1e-7
+    # of a flux of hundreds of mm)
+    for kk, bound in ((0, 2e-6), (1, 2e-6), (3, 6e-6), (4, 2e-6)):
+        assert out[kk] < bound, f"block residual G{kk}: {out[kk]:.3g} (relative)"
+    # even a melt pulse of hundreds of mm into an empty 50 mm store is solved to 1e-3 within the four updates: the
+    # bracket (root below / above FC known from G2(FC), which needs no power) plus Halley's correction.  (Plain
+    # Newton left ~100 of these 200 000 days unsolved, cycling across the kink at FC with |G2| up to 76.)
     late = np.abs(g2[:, 0]) > 1e-3
-    assert late.sum() <= 200 and np.abs(g2[:, 0]).max() < 0.5, (int(late.sum()), float(np.abs(g2[:, 0]).max()))
+    assert late.sum() == 0, (int(late.sum()), float(np.abs(g2[:, 0]).max()))
     # given the updates, every day converges
     lib.hbvx_test_staged_residual(*args, C.c_float(1e-3), C.c_int(12), out.ctypes.data_as(C.c_void_p),
                                   g2.ctypes.data_as(C.c_void_p))
-    assert out[5] <= 8 and np.abs(g2[:, 0]).max() <= 1e-3, (out[5], float(np.abs(g2[:, 0]).max()))
+    assert out[5] <= 4 and np.abs(g2[:, 0]).max() <= 1e-3, (out[5], float(np.abs(g2[:, 0]).max()))
