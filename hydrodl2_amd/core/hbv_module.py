@@ -12,6 +12,7 @@ from __future__ import annotations
 
 from typing import Any, Optional, Union
 
+import copy
 import os
 
 import torch
@@ -61,6 +62,7 @@ class HbvModule(torch.nn.Module):
         self.check_finite = os.environ.get('HBVX_CHECK_FINITE', '0') not in ('', '0')
 
         self.states, self._states_cache = None, None
+        self._cfg_cache, self._pmat_cache = {}, {}     # per input shape: step configs / Bernoulli probabilities
 
         self.state_names = ['SNOWPACK', 'MELTWATER', 'SM', 'SUZ', 'SLZ']  # hbv.py:61-67
         self.flux_names = [  # hbv.py:68-86
@@ -146,6 +148,23 @@ class HbvModule(torch.nn.Module):
             return None                     # nothing dropped: the kernels take their mask-free paths
         return drmask.reshape(ngrid).to(torch.uint8).to(device)
 
+    def _draw_drop_masks(self, n_dyn: int, ngrid: int, device):
+        """The n_dyn draws of `_draw_drop_mask`, in the reference's order (one per dynamic parameter, hbv.py:236-
+        246), as ONE call: the CPU generator hands out its numbers element by element, so an [n_dyn, B] draw
+        consumes the stream exactly like n_dyn successive [1, B, 1] draws (tests: golden case hbv_dyn2_drop).
+        Returns None per parameter when nothing can be dropped."""
+        if n_dyn == 0:
+            return []
+        key = (n_dyn, ngrid, float(self.dy_drop))
+        pm = self._pmat_cache.get(key)
+        if pm is None:
+            pm = self._pmat_cache[key] = torch.full((n_dyn, ngrid), float(self.dy_drop))
+        drmask = torch.bernoulli(pm)
+        if self.dy_drop <= 0:
+            return [None] * n_dyn
+        dm = drmask.to(torch.uint8).to(device)
+        return [dm[k] for k in range(n_dyn)]
+
     def _stack_states(self, states, ngrid: int, device):
         if states is None:
             return None
@@ -166,7 +185,7 @@ class HbvModule(torch.nn.Module):
         return mu.expand(T, B, self.nmul).contiguous()
 
     def _param_sources(self, T_total: int, B: int, ny: int, t_first: int, sta_row: int,
-                       dy_list, device):
+                       dy_list, device, draw: bool = True):
         """Addressing of every physical parameter inside raw `parameters[T,B,ny]`:
         column i*nmul + j (hbv.py:201-208); static value = row `sta_row` (hbv.py:242)."""
         M = self.nmul
@@ -180,16 +199,53 @@ class HbvModule(torch.nn.Module):
                 ps.dyn_tensor_idx = 0
                 ps.dyn_off = t_first * B * ny + i * M
                 ps.dyn_ts, ps.dyn_bs = B * ny, ny
-                ps.drop = self._draw_drop_mask(B, device)
+                if draw:
+                    ps.drop = self._draw_drop_mask(B, device)
             srcs.append(ps)
         return srcs
+
+    def _step_configs(self, T_total: int, ngrid: int, ny: int, warm_up: int, device):
+        """(warm-up config or None, main config) for this input shape.  Everything in them -- shapes, bounds,
+        element offsets of every parameter inside `parameters[T,B,ny]`, the routing columns -- is a function of
+        the shape and of the module's settings, so they are built once and reused (their descriptor plans with
+        them, ops._desc_plan): a deltaMG minibatch step spent more host time rebuilding them than the GPU spent on
+        the kernels.  dy_drop masks are per call; a config that carries them is a copy."""
+        M, n = self.nmul, len(self.parameter_bounds)
+        key = (T_total, ngrid, ny, warm_up, M, n, tuple(self.dynamic_params), bool(self.routing), self._model_id,
+               tuple(self.variables), float(self.nearzero), int(self.adjoint_checkpoint),
+               tuple(map(tuple, self.parameter_bounds.values())),
+               tuple(map(tuple, self.routing_parameter_bounds.values())), str(device))
+        hit = self._cfg_cache.get(key)
+        if hit is not None:
+            return hit
+        base = dict(model=self._model_id, n_param=n, n_flux=self._n_flux(), B=ngrid, M=M,
+                    raw_sigmoid=True, channels=self._channels(), nearzero=float(self.nearzero),
+                    ckpt_days=int(self.adjoint_checkpoint))
+        cfg_w = None
+        if warm_up > 0:     # hbv.py:327-346: all parameters static from row warm_up-1, states only
+            cfg_w = StepConfig(T=warm_up, t0=0, want_flux=False, **base)
+            cfg_w.params = self._param_sources(T_total, ngrid, ny, 0, warm_up - 1, [], device, draw=False)
+        T = T_total - warm_up
+        cfg = StepConfig(T=T, t0=warm_up, want_bfi=True, **base)
+        cfg.params = self._param_sources(T_total, ngrid, ny, warm_up, T_total - 1, self.dynamic_params, device,
+                                         draw=False)
+        if self.routing:
+            off = (T_total - 1) * ngrid * ny + n * M  # hbv.py:212-214: last row only
+            cfg.route = RouteSource(0, off, off + 1, ny,
+                                    self.routing_parameter_bounds['route_a'],
+                                    self.routing_parameter_bounds['route_b'])
+        cfg.mu_t0 = 0                      # muwts rows are post-warm-up days already
+        if len(self._cfg_cache) > 16:
+            self._cfg_cache.clear()
+        self._cfg_cache[key] = (cfg_w, cfg)
+        return cfg_w, cfg
 
     # -- forward ---------------------------------------------------------
     def forward(self, x_dict: dict[str, torch.Tensor], parameters: torch.Tensor
                 ) -> Union[tuple, dict[str, torch.Tensor]]:
         """Reference: hbv.py:284-361 (orchestration) + :363-596 (`_PBM`)."""
         x = x_dict['x_phy']
-        self.muwts = x_dict.get('muwts', None)
+        self.__dict__['muwts'] = x_dict.get('muwts', None)     # (plain attribute: nn.Module.__setattr__ costs 5 us)
         T_total, ngrid = x.shape[0], x.shape[1]
         M = self.nmul
         n = len(self.parameter_bounds)
@@ -222,44 +278,36 @@ class HbvModule(torch.nn.Module):
             for name, t in (('x_phy', x), ('parameters', parameters)):
                 if not bool(torch.isfinite(t).all()):
                     raise ValueError(f"{name} holds non-finite values (check_finite is set)")
-        base = dict(model=self._model_id, n_param=n, n_flux=self._n_flux(), B=ngrid, M=M,
-                    raw_sigmoid=True, channels=self._channels(), nearzero=float(self.nearzero),
-                    ckpt_days=int(self.adjoint_checkpoint))
+        cfg_w, cfg = self._step_configs(T_total, ngrid, ny, warm_up, x.device)
 
         # hbv.py:327-346: state warm-up, all parameters static from row warm_up-1, no grad
-        if warm_up > 0:
+        if cfg_w is not None:
             with torch.no_grad():
-                cfg_w = StepConfig(T=warm_up, t0=0, want_flux=False, **base)
-                cfg_w.params = self._param_sources(T_total, ngrid, ny, 0, warm_up - 1, [],
-                                                   x.device)
-                _, _, state_in, _ = hbv_path(cfg_w, x, state_in, None, None, None,
-                                                  parameters.detach())
+                state_in = hbv_path(cfg_w, x, state_in, None, None, None, parameters.detach()).state_out
 
-        # hbv.py:349-353
+        # hbv.py:349-353.  The dy_drop masks are drawn per call (hbv.py:240-246), also when nothing can drop
         T = T_total - warm_up
-        cfg = StepConfig(T=T, t0=warm_up, **base)
-        cfg.params = self._param_sources(T_total, ngrid, ny, warm_up, T_total - 1,
-                                         self.dynamic_params, x.device)
-        if self.routing:
-            off = (T_total - 1) * ngrid * ny + n * M  # hbv.py:212-214: last row only
-            cfg.route = RouteSource(0, off, off + 1, ny,
-                                    self.routing_parameter_bounds['route_a'],
-                                    self.routing_parameter_bounds['route_b'])
+        dyn_idx = [i for i, ps in enumerate(cfg.params) if ps.dyn_off >= 0]
+        masks = self._draw_drop_masks(len(dyn_idx), ngrid, x.device)
+        if any(m is not None for m in masks):
+            cfg = copy.copy(cfg)               # a config with masks belongs to this call (and its backward) alone
+            cfg.params = [copy.copy(ps) for ps in cfg.params]
+            for i, m in zip(dyn_idx, masks):
+                cfg.params[i].drop = m
         muwts = self._expand_muwts(self.muwts, T, T_total, ngrid)
-        cfg.mu_t0 = 0                      # muwts rows are post-warm-up days already
-        flux, routed, state_out, _ = hbv_path(cfg, x, state_in, muwts, None, None,
-                                                   parameters)
+        res = hbv_path(cfg, x, state_in, muwts, None, None, parameters)
+        flux, routed, state_out = res.flux, res.routed, res.state_out
 
         # hbv.py:356-359
-        self._states_cache = [s for s in state_out.detach().unbind(0)]
+        self.__dict__['_states_cache'] = list(state_out.detach().unbind(0))
         if self.cache_states:
             self.states = self._states_cache
 
         if self.initialize:
             return tuple(self._states_cache)
-        return self._assemble(flux, routed, x, warm_up)
+        return self._assemble(flux, routed, x, warm_up, res.bfi)
 
-    def _assemble(self, flux, routed, x, t0) -> dict[str, torch.Tensor]:
+    def _assemble(self, flux, routed, x, t0, bfi=None) -> dict[str, torch.Tensor]:
         """hbv.py:555-596: flux dictionary, BFI and the optional prediction cut-off."""
         F = _abi
         # the kernels' series arrive as [T,B,1] views already (ops.HbvPath)
@@ -269,7 +317,7 @@ class HbvModule(torch.nn.Module):
             # The reference's Hbv crashes here (hbv.py:550-567); follow Hbv_2's
             # handling of routing=False instead (hbv_2.py:620-626).
             Qs, Q0r, Q1r, Q2r = (flux[k] for k in (F.F_QSIM, F.F_Q0, F.F_Q1, F.F_Q2))
-        BFI = Bfi.apply(Qs, Q2r, float(self.nearzero))
+        BFI = bfi if bfi is not None else Bfi.apply(Qs, Q2r, float(self.nearzero))
         pet = x[t0:, :, self.variables.index('pet')]
         out = {
             'streamflow': Qs, 'srflow': Q0r, 'ssflow': Q1r, 'gwflow': Q2r,

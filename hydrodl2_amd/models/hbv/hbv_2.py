@@ -119,12 +119,13 @@ class Hbv_2(HbvModule):
                                     self.routing_parameter_bounds['route_a'],
                                     self.routing_parameter_bounds['route_b'])
         muwts = self._expand_muwts(self.muwts, T, T, ngrid)
-        flux, routed, state_out, traj = hbv_path(cfg, x, state_in, muwts, ac, elev, p_dyn, p_sta)
+        res = hbv_path(cfg, x, state_in, muwts, ac, elev, p_dyn, p_sta)
+        flux, routed, state_out, traj = res.flux, res.routed, res.state_out, res.traj
 
         # hbv_2.py:385-388,628: the state cache is the full series [T,B,nmul] x 5 (views of the
         # saved trajectory: storages after day t = storages entering day t + 1)
         if ck == 0:
-            self._state_cache = tuple(s[1:] for s in state_series(traj.detach(), cfg.traj_layout, T, ngrid, M))
+            self._state_cache = tuple(s[1:] for s in state_series(traj.detach(), res.traj_layout, T, ngrid, M))
         else:
             self._state_cache = tuple(s.unsqueeze(0) for s in state_out.detach().unbind(0))
         if self.cache_states:

@@ -127,8 +127,9 @@ class Hbv_2_hourly(HbvModule):
                          nearzero=float(self.nearzero), params=srcs,
                          want_flux=not self.initialize, want_traj=True)
         muwts = self._expand_muwts(self.muwts, T, T, ngrid)
-        flux, _, _, traj = hbv_path(cfg, x, state_in, muwts, ac, elev, *ptensors)
-        series = tuple(s[1:] for s in state_series(traj.detach(), cfg.traj_layout, T, ngrid, M))   # :725
+        res = hbv_path(cfg, x, state_in, muwts, ac, elev, *ptensors)
+        flux, traj = res.flux, res.traj
+        series = tuple(s[1:] for s in state_series(traj.detach(), res.traj_layout, T, ngrid, M))   # :725
         if self.initialize:
             return {}, series
 

@@ -12,10 +12,12 @@ only; every arithmetic step of the path runs in the HIP library.
 """
 from __future__ import annotations
 
+import ctypes as _C
 from dataclasses import dataclass, field
 import functools
 import os
-from typing import List, Optional, Sequence
+import struct
+from typing import List, NamedTuple, Optional, Sequence
 
 import torch
 
@@ -73,7 +75,7 @@ class StepConfig:
     adj_max_iter: int = 3      # implicit scheme only (hbv_adj.py:518)
     adj_stop: int = 0          # implicit scheme only: 0 per-lane stopping rule, 1 per wavefront (hbv_adj.py:544)
     mu_t0: Optional[int] = None  # first row of muwts used by this call (None: same as t0)
-    traj_layout: int = 0       # set by HbvPath.forward: enum hbvx_traj_layout of the saved trajectory
+    want_bfi: bool = False     # also return BFI (hbv.py:562-567) from the same autograd node (no second Function)
     ckpt_days: int = 0         # 4 / 8 / 16: keep K-day checkpoints instead of the trajectory (memory-lean adjoint)
 
 
@@ -85,7 +87,7 @@ def _device_guard(fn):
     @functools.wraps(fn)
     def wrapped(ctx, *args):
         dev = next((a.device for a in args if torch.is_tensor(a) and a.is_cuda), None)
-        if dev is None:
+        if dev is None or torch.cuda.current_device() == dev.index:   # the common case: nothing to switch
             return fn(ctx, *args)
         with torch.cuda.device(dev):
             return fn(ctx, *args)
@@ -271,7 +273,27 @@ def _mu_t0(cfg: StepConfig) -> int:
     return cfg.t0 if cfg.mu_t0 is None else cfg.mu_t0
 
 
-def _fill_desc(cfg: StepConfig, x, state_in, muwts, ac, elev, ptensors) -> _abi.Desc:
+# ---------------------------------------------------------------------------------------------
+# Descriptors.  A StepConfig that a module keeps across calls (same shapes, same dynamic set) carries a
+# plan: the hbvx_desc bytes with every shape / bound / stride field filled in once, and the byte offsets of
+# the pointer fields.  A call copies the template (1.3 KB) and packs the pointers in place -- the step of the
+# deltaMG minibatch shape spent more host time marshalling descriptors than the GPU spent on its kernels.
+_PTR = struct.Struct("<Q")
+_D = _abi.Desc
+_PS_SIZE = _C.sizeof(_abi.ParamSrc)
+_OFF_P = _D.p.offset
+_OFF_DYN, _OFF_STA, _OFF_DROP = _abi.ParamSrc.dyn.offset, _abi.ParamSrc.sta.offset, _abi.ParamSrc.drop.offset
+
+
+class _DescPlan:
+    __slots__ = ("key", "template", "sta", "dyn", "drop")
+
+
+def _desc_plan(cfg: StepConfig, x, has_mu: bool) -> _DescPlan:
+    key = (x.stride(0), x.stride(1), has_mu, len(cfg.params), cfg.T, cfg.t0, cfg.B, cfg.M)
+    plan = getattr(cfg, "_plan", None)
+    if plan is not None and plan.key == key:
+        return plan
     d = _abi.Desc()
     d.abi_version = _abi.ABI_VERSION
     d.model = cfg.model
@@ -280,26 +302,51 @@ def _fill_desc(cfg: StepConfig, x, state_in, muwts, ac, elev, ptensors) -> _abi.
     d.raw_sigmoid = 1 if cfg.raw_sigmoid else 0
     d.ch_prcp, d.ch_tmean, d.ch_pet = cfg.channels
     d.nearzero = cfg.nearzero
-    d.x = _ptr(x, cfg.t0 * x.stride(0))
     d.x_t_stride, d.x_b_stride = x.stride(0), x.stride(1)
-    d.ac = _ptr(ac)
-    d.elev = _ptr(elev)
-    if muwts is not None:  # full [Tx,B,M] contiguous (the module expands broadcasts)
-        d.muwts = _ptr(muwts, _mu_t0(cfg) * cfg.B * cfg.M)
+    if has_mu:  # full [Tx,B,M] contiguous (the module expands broadcasts)
         d.mu_t_stride, d.mu_b_stride = cfg.B * cfg.M, cfg.M
-    d.state_in = _ptr(state_in)
-    for ps in cfg.params:
+    plan = _DescPlan()
+    plan.key, plan.sta, plan.dyn, plan.drop = key, [], [], []
+    for i, ps in enumerate(cfg.params):
         s = d.p[ps.slot]
-        s.sta = _ptr(ptensors[ps.tensor_idx], ps.sta_off)
+        base = _OFF_P + ps.slot * _PS_SIZE
         s.sta_b_stride = ps.sta_bs
+        plan.sta.append((base + _OFF_STA, ps.tensor_idx, 4 * ps.sta_off))
         if ps.dyn_off >= 0:
-            s.dyn = _ptr(ptensors[ps.dyn_tensor_idx], ps.dyn_off)
             s.dyn_t_stride, s.dyn_b_stride = ps.dyn_ts, ps.dyn_bs
-            if ps.drop is not None:
-                s.drop = ps.drop.data_ptr()
+            plan.dyn.append((base + _OFF_DYN, ps.dyn_tensor_idx, 4 * ps.dyn_off))
+            plan.drop.append((base + _OFF_DROP, i))
         s.lo, s.hi = ps.lo, ps.hi
     d.adj_gtol, d.adj_max_iter, d.adj_stop = cfg.adj_gtol, cfg.adj_max_iter, cfg.adj_stop
-    return d
+    plan.template = bytes(d)
+    cfg._plan = plan
+    return plan
+
+
+def _fill_desc(cfg: StepConfig, x, state_in, muwts, ac, elev, ptensors) -> _abi.Desc:
+    plan = _desc_plan(cfg, x, muwts is not None)
+    buf = bytearray(plan.template)
+    pk = _PTR.pack_into
+    pk(buf, _D.x.offset, x.data_ptr() + 4 * cfg.t0 * x.stride(0))
+    if ac is not None:
+        pk(buf, _D.ac.offset, ac.data_ptr())
+    if elev is not None:
+        pk(buf, _D.elev.offset, elev.data_ptr())
+    if muwts is not None:
+        pk(buf, _D.muwts.offset, muwts.data_ptr() + 4 * _mu_t0(cfg) * cfg.B * cfg.M)
+    if state_in is not None:
+        pk(buf, _D.state_in.offset, state_in.data_ptr())
+    bases = [t.data_ptr() for t in ptensors]
+    for off, ti, boff in plan.sta:
+        pk(buf, off, bases[ti] + boff)
+    for off, ti, boff in plan.dyn:
+        pk(buf, off, bases[ti] + boff)
+    params = cfg.params
+    for off, i in plan.drop:
+        m = params[i].drop
+        if m is not None:
+            pk(buf, off, m.data_ptr())
+    return _abi.Desc.from_buffer(buf)      # the struct keeps `buf` alive
 
 
 def _route_desc(cfg: StepConfig, ptensors, S: int = 4) -> _abi.RouteDesc:
@@ -315,6 +362,101 @@ def _route_desc(cfg: StepConfig, ptensors, S: int = 4) -> _abi.RouteDesc:
     r.a_lo, r.a_hi = rs.a_bounds
     r.b_lo, r.b_hi = rs.b_bounds
     return r
+
+
+class _NoCtx:
+    """Stands in for the autograd context when a call needs no gradient (warm-up under no_grad, inference):
+    the forward then runs as a plain function, without the ~20 us of autograd.Function.apply."""
+    needs_input_grad = ()
+
+    def save_for_backward(self, *a):
+        pass
+
+    def mark_non_differentiable(self, *a):
+        pass
+
+    def set_materialize_grads(self, v):
+        pass
+
+
+def _hbv_forward(ctx, cfg: StepConfig, x, state_in, muwts, ac, elev, ptensors):
+    lib = get_library()
+    _check_tensor(lib, x, "x_phy")
+    for i, p in enumerate(ptensors):
+        _check_tensor(lib, p, f"parameters[{i}]")
+        if not p.is_contiguous():
+            raise ValueError("parameter tensors must be contiguous")
+    if x.stride(2) != 1:
+        raise ValueError("x_phy must have unit stride on the forcing axis")
+    if muwts is not None:
+        _check_tensor(lib, muwts, "muwts")
+        if not muwts.is_contiguous() or tuple(muwts.shape[1:]) != (cfg.B, cfg.M):
+            raise ValueError("muwts must be a contiguous [T,B,nmul] tensor")
+    dev = x.device
+    T, B, M = cfg.T, cfg.B, cfg.M
+    needs_grad = any(ctx.needs_input_grad)
+    keep = needs_grad or cfg.want_traj
+    stream = _stream_of(lib, x)
+
+    desc = _fill_desc(cfg, x, state_in, muwts, ac, elev, ptensors)
+    out = _abi.FwdOut()
+    flux = _out((cfg.n_flux, T, B), dev) \
+        if cfg.want_flux else None
+    state_out = _out((5, B, M), dev)
+    # same two buffers whatever the layout the library asks for (include/hbvx.h, hbvx_traj_layout)
+    ckpt = cfg.ckpt_days if (needs_grad and cfg.want_flux and not cfg.want_traj) else 0
+    if ckpt:
+        # K-day checkpoints [ceil(T/K), 5, N] instead of the trajectory; the adjoint recomputes
+        traj = _out(((T + ckpt - 1) // ckpt * 5, B * M), dev)
+        aux = None
+        layout = _abi.TRAJ_CKPT | (ckpt << 8)
+    else:
+        traj = _out((5, T + 1, B * M), dev) if keep else None
+        aux = _out((2, T, B * M), dev) if needs_grad else None
+        layout = lib.preferred_traj_layout(desc) if (keep and cfg.want_flux) else _abi.TRAJ_ROWS
+    out.flux, out.state_out = _ptr(flux), _ptr(state_out)
+    out.traj, out.aux = _ptr(traj), _ptr(aux)
+    out.n_flux, out.traj_layout = cfg.n_flux, layout
+    ctx.early_gp = None
+    if (needs_grad and _EARLY_ZERO and lib.is_device and any(ctx.needs_input_grad[6:])
+            and sum(p.numel() for p in ptensors) >= _EARLY_ZERO_MIN):
+        ctx.early_gp = _early_grad_buffers(lib, cfg, ptensors, ctx.needs_input_grad[6:])
+    _call(lib, 'hbvx_forward', lib.forward, desc, out, stream)
+
+    routed = uh = None
+    if cfg.route is not None and cfg.want_flux:
+        r = _route_desc(cfg, ptensors)
+        routed = _out((4, T, B), dev)
+        uh = _out((B, r.L), dev)
+        _call(lib, 'hbvx_route_forward', lib.route_forward, r, _ptr(flux), _ptr(uh), _ptr(routed), stream)
+
+    # BFI (hbv.py:562-567) of the routed (or, without routing, the raw) streamflow and groundwater series: one
+    # more output of this node instead of a second autograd.Function on the caller's side
+    bfi = None
+    if cfg.want_bfi and cfg.want_flux:
+        src = routed if routed is not None else flux
+        k2 = 3 if routed is not None else _abi.F_Q2
+        bfi = _out((B,), dev)
+        _call(lib, 'hbvx_bfi', lib.bfi, T, B, _ptr(src), _ptr(src, k2 * T * B), float(cfg.nearzero), _ptr(bfi), stream)
+
+    ctx.cfg = cfg
+    ctx.traj_layout = layout
+    ctx.desc = desc if needs_grad else None        # its pointers stay valid: every tensor it names is saved below
+    ctx.has_bfi = bfi is not None
+    ctx.set_materialize_grads(False)
+    if needs_grad:
+        ctx.save_for_backward(x, state_in, muwts, ac, elev, traj, aux, flux, uh, routed, *ptensors)
+    nondiff = [state_out]
+    if traj is not None:
+        nondiff.append(traj)
+    ctx.mark_non_differentiable(*nondiff)
+    # every series leaves as its own [T,B,1] view (the shape the flux dictionary holds): one autograd
+    # output each, no select / unsqueeze nodes on the caller's side (16 of them cost the host 0.1 ms
+    # per call, a fifth of a deltaMG-sized step)
+    rrows = tuple(routed.unsqueeze(-1).unbind(0)) if routed is not None else ()
+    rows = tuple(flux.unsqueeze(-1).unbind(0)) if flux is not None else ()
+    ctx.n_routed = len(rrows)
+    return (state_out, traj, layout, bfi) + rrows + rows
 
 
 class HbvPath(torch.autograd.Function):
@@ -333,77 +475,24 @@ class HbvPath(torch.autograd.Function):
     @staticmethod
     @_device_guard
     def forward(ctx, cfg: StepConfig, x, state_in, muwts, ac, elev, *ptensors):
-        lib = get_library()
-        _check_tensor(lib, x, "x_phy")
-        for i, p in enumerate(ptensors):
-            _check_tensor(lib, p, f"parameters[{i}]")
-            if not p.is_contiguous():
-                raise ValueError("parameter tensors must be contiguous")
-        if x.stride(2) != 1:
-            raise ValueError("x_phy must have unit stride on the forcing axis")
-        if muwts is not None:
-            _check_tensor(lib, muwts, "muwts")
-            if not muwts.is_contiguous() or tuple(muwts.shape[1:]) != (cfg.B, cfg.M):
-                raise ValueError("muwts must be a contiguous [T,B,nmul] tensor")
-        dev = x.device
-        T, B, M = cfg.T, cfg.B, cfg.M
-        needs_grad = any(ctx.needs_input_grad)
-        keep = needs_grad or cfg.want_traj
-        stream = _stream_of(lib, x)
-
-        desc = _fill_desc(cfg, x, state_in, muwts, ac, elev, ptensors)
-        out = _abi.FwdOut()
-        flux = _out((cfg.n_flux, T, B), dev) \
-            if cfg.want_flux else None
-        state_out = _out((5, B, M), dev)
-        # same two buffers whatever the layout the library asks for (include/hbvx.h, hbvx_traj_layout)
-        ckpt = cfg.ckpt_days if (needs_grad and cfg.want_flux and not cfg.want_traj) else 0
-        if ckpt:
-            # K-day checkpoints [ceil(T/K), 5, N] instead of the trajectory; the adjoint recomputes
-            traj = _out(((T + ckpt - 1) // ckpt * 5, B * M), dev)
-            aux = None
-            cfg.traj_layout = _abi.TRAJ_CKPT | (ckpt << 8)
-        else:
-            traj = _out((5, T + 1, B * M), dev) if keep else None
-            aux = _out((2, T, B * M), dev) if needs_grad else None
-            cfg.traj_layout = lib.preferred_traj_layout(desc) if (keep and cfg.want_flux) else _abi.TRAJ_ROWS
-        out.flux, out.state_out = _ptr(flux), _ptr(state_out)
-        out.traj, out.aux = _ptr(traj), _ptr(aux)
-        out.n_flux, out.traj_layout = cfg.n_flux, cfg.traj_layout
-        ctx.early_gp = None
-        if (needs_grad and _EARLY_ZERO and lib.is_device and any(ctx.needs_input_grad[6:])
-                and sum(p.numel() for p in ptensors) >= _EARLY_ZERO_MIN):
-            ctx.early_gp = _early_grad_buffers(lib, cfg, ptensors, ctx.needs_input_grad[6:])
-        _call(lib, 'hbvx_forward', lib.forward, desc, out, stream)
-
-        routed = uh = None
-        if cfg.route is not None and cfg.want_flux:
-            r = _route_desc(cfg, ptensors)
-            routed = _out((4, T, B), dev)
-            uh = _out((B, r.L), dev)
-            _call(lib, 'hbvx_route_forward', lib.route_forward, r, _ptr(flux), _ptr(uh), _ptr(routed), stream)
-
-        ctx.cfg = cfg
-        ctx.traj_layout = cfg.traj_layout
-        ctx.set_materialize_grads(False)
-        if needs_grad:
-            ctx.save_for_backward(x, state_in, muwts, ac, elev, traj, aux, flux, uh, *ptensors)
-        nondiff = [state_out]
-        if traj is not None:
-            nondiff.append(traj)
-        ctx.mark_non_differentiable(*nondiff)
-        # every series leaves as its own [T,B,1] view (the shape the flux dictionary holds): one autograd
-        # output each, no select / unsqueeze nodes on the caller's side (16 of them cost the host 0.1 ms
-        # per call, a fifth of a deltaMG-sized step)
-        rrows = tuple(routed.unsqueeze(-1).unbind(0)) if routed is not None else ()
-        rows = tuple(flux.unsqueeze(-1).unbind(0)) if flux is not None else ()
-        ctx.n_routed = len(rrows)
-        return (state_out, traj) + rrows + rows
+        return _hbv_forward(ctx, cfg, x, state_in, muwts, ac, elev, ptensors)
 
     @staticmethod
     @_device_guard
-    def backward(ctx, _g_state, _g_traj, *g_all):
-        g_rr, g_rows = g_all[:ctx.n_routed], g_all[ctx.n_routed:]
+    def backward(ctx, _g_state, _g_traj, _g_layout, g_bfi, *g_all):
+        g_rr, g_rows = list(g_all[:ctx.n_routed]), list(g_all[ctx.n_routed:])
+        if g_bfi is not None:
+            # the gradient a streamflow loss never asks for: two broadcasts in torch, added to the series' own
+            saved_ = ctx.saved_tensors
+            flux_, routed_ = saved_[7], saved_[9]
+            src = routed_ if routed_ is not None else flux_
+            qs, q2 = src[0], src[3 if routed_ is not None else _abi.F_Q2]
+            den = qs.sum(0) + ctx.cfg.nearzero
+            g_q2 = (100.0 * g_bfi / den).unsqueeze(0).expand_as(q2).unsqueeze(-1)
+            g_qs = (-100.0 * g_bfi * q2.sum(0) / (den * den)).unsqueeze(0).expand_as(qs).unsqueeze(-1)
+            tgt = g_rr if routed_ is not None else g_rows
+            for k, g in ((0, g_qs), (3 if routed_ is not None else _abi.F_Q2, g_q2)):
+                tgt[k] = g if tgt[k] is None else tgt[k] + g
         # routed series with gradient: the routing adjoint runs over the leading n_live of the four (a
         # streamflow loss: one), the rows behind them stay zero
         g_routed, n_live = None, 0
@@ -422,7 +511,7 @@ class HbvPath(torch.autograd.Function):
         cfg: StepConfig = ctx.cfg
         saved = ctx.saved_tensors
         x, state_in, muwts, ac, elev, traj, aux, flux, uh = saved[:9]
-        ptensors = saved[9:]
+        ptensors = saved[10:]
         dev = x.device
         T, B, M = cfg.T, cfg.B, cfg.M
         stream = _stream_of(lib, x)
@@ -506,7 +595,7 @@ class HbvPath(torch.autograd.Function):
             if ps.dyn_off >= 0 and gp[ps.dyn_tensor_idx] is not None:
                 g.dyn = _ptr(gp[ps.dyn_tensor_idx], ps.dyn_off)
                 g.dyn_t_stride, g.dyn_b_stride = ps.dyn_ts, ps.dyn_bs
-        desc = _fill_desc(cfg, x, state_in, muwts, ac, elev, ptensors)
+        desc = ctx.desc if ctx.desc is not None else _fill_desc(cfg, x, state_in, muwts, ac, elev, ptensors)
         if g_flux is None and gq is None:
             # nothing flows back through the series (a loss on nothing): gradients are zero
             join()
@@ -529,14 +618,33 @@ class HbvPath(torch.autograd.Function):
         return (None, gx, None, gmu, None, None, *gp)
 
 
-def hbv_path(cfg: StepConfig, x, state_in, muwts, ac, elev, *ptensors):
-    """flux, routed, state_out, traj = hbv_path(...): `flux` is the tuple of n_flux series [T,B,1]
-    (index it with the hbvx_flux enum) or None when cfg.want_flux is False; `routed` the tuple of the four
-    UH-routed runoff series [T,B,1] or None."""
-    outs = HbvPath.apply(cfg, x, state_in, muwts, ac, elev, *ptensors)
-    state_out, traj = outs[:2]
+class PathOut(NamedTuple):
+    """What one call of the path returns.  `flux`: tuple of the n_flux series [T,B,1] (index it with the hbvx_flux
+    enum) or None when cfg.want_flux is False; `routed`: tuple of the four UH-routed runoff series [T,B,1] or
+    None; `traj` + `traj_layout`: the saved trajectory (see `state_series`); `bfi` [B] when cfg.want_bfi."""
+    flux: Optional[tuple]
+    routed: Optional[tuple]
+    state_out: torch.Tensor
+    traj: Optional[torch.Tensor]
+    traj_layout: int
+    bfi: Optional[torch.Tensor]
+
+
+def hbv_path(cfg: StepConfig, x, state_in, muwts, ac, elev, *ptensors) -> PathOut:
+    """Run the path.  A call that cannot need a gradient (grad mode off, or no input requires one) runs the
+    forward as a plain function; otherwise through the autograd node `HbvPath`."""
+    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in ptensors)
+                                    or (muwts is not None and muwts.requires_grad)
+                                    or (state_in is not None and state_in.requires_grad)):
+        outs = HbvPath.apply(cfg, x, state_in, muwts, ac, elev, *ptensors)
+    elif x.is_cuda and torch.cuda.current_device() != x.device.index:
+        with torch.cuda.device(x.device):
+            outs = _hbv_forward(_NoCtx(), cfg, x, state_in, muwts, ac, elev, ptensors)
+    else:
+        outs = _hbv_forward(_NoCtx(), cfg, x, state_in, muwts, ac, elev, ptensors)
+    state_out, traj, layout, bfi = outs[:4]
     nr = 4 if (cfg.route is not None and cfg.want_flux) else 0
-    return (outs[2 + nr:] or None), (outs[2:2 + nr] or None), state_out, traj
+    return PathOut((outs[4 + nr:] or None), (outs[4:4 + nr] or None), state_out, traj, layout, bfi)
 
 
 def state_series(traj: torch.Tensor, layout: int, T: int, B: int, M: int):

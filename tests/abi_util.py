@@ -84,7 +84,8 @@ def run_problem(prob, lib_path, device="cpu", x_grad=False, backward=True, t0=0,
         if prob["routing"]:
             off = (T - 1) * B * ny + n * M
             cfg.route = RouteSource(0, off, off + 1, ny, [0, 2.9], [0, 6.5])
-        rows, routed, state_out, traj = hbv_path(cfg, x, None, mu, ac, elev, p)
+        po = hbv_path(cfg, x, None, mu, ac, elev, p)
+        rows, routed, state_out, traj = po.flux, po.routed, po.state_out, po.traj
         flux = torch.stack([r[..., 0] for r in rows])
         if routed is not None:
             routed = torch.stack([r[..., 0] for r in routed])
@@ -93,7 +94,7 @@ def run_problem(prob, lib_path, device="cpu", x_grad=False, backward=True, t0=0,
             res["routed"] = routed.detach().cpu().numpy()
         if traj is not None and keep_traj:    # always compared in the row layout [5, T+1, N]
             res["traj"] = torch.stack([v.reshape(Tc + 1, B * M) for v in
-                                       state_series(traj, cfg.traj_layout, Tc, B, M)]).cpu().numpy()
+                                       state_series(traj, po.traj_layout, Tc, B, M)]).cpu().numpy()
         if backward:
             gf = torch.from_numpy(prob["gflux"][:, t0:]).to(dev)
             loss = (flux * gf).sum()

@@ -171,7 +171,7 @@ def _zero_length_record(device):
     cfg = StepConfig(model=_abi.MODEL_HBV10, n_param=n, n_flux=11, T=0, t0=0, B=B, M=M, raw_sigmoid=True,
                      channels=(0, 1, 2), nearzero=1e-5, params=srcs)
     state_in = torch.rand((5, B, M), device=dev)
-    flux, routed, state_out, traj = hbv_path(cfg, x, state_in, None, None, None, p)
+    flux, routed, state_out, traj = hbv_path(cfg, x, state_in, None, None, None, p)[:4]
     assert torch.equal(state_out, state_in)
     assert all(f.shape[0] == 0 for f in flux)
 
