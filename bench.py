@@ -215,6 +215,7 @@ class Workload:
 
 
 def timed_steps(wl, steps, warmup, dev, world, after_step=None):
+    timed_steps.device_mallocs = 0
     """W untimed + K timed steps with per-launch HIP events; returns (seconds, per-call avg ms)."""
     import torch
     import torch.distributed as dist
@@ -226,8 +227,10 @@ def timed_steps(wl, steps, warmup, dev, world, after_step=None):
     ops.KERNEL_EVENTS = []          # per-launch HIP events on the launch stream
     if world > 1:
         dist.barrier()
+    mallocs0 = 0
     if dev.type == "cuda":
         torch.cuda.synchronize()
+        mallocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
     t0 = time.perf_counter()
     for _ in range(steps):
         wl.step()
@@ -238,6 +241,10 @@ def timed_steps(wl, steps, warmup, dev, world, after_step=None):
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    if dev.type == "cuda":
+        # a hipMalloc inside the timed region (the caching allocator still growing: tens of GB at cfg5) is a
+        # host stall of tens to hundreds of ms that no kernel time shows; reported so that a step time can be trusted
+        timed_steps.device_mallocs = torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - mallocs0
     events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
     per = {}
     for name, e0, e1 in events:
@@ -600,6 +607,7 @@ def main():
                        "parallelism": f"basin-shard x{world}"},
             "rccl_ranks": dist.get_world_size() if world > 1 else 1,
             "rank_ms_per_step": rank_ms, "allreduce_ms": ar_ms,
+            "device_mallocs_in_timed_steps": timed_steps.device_mallocs,
         }
         if dev.type == "cuda" and "hbvx_forward" in kavg:
             # Dominant kernel = the one kernel behind hbvx_forward (rocprofv3 --stats: the largest single
@@ -643,10 +651,11 @@ def main():
                 continue
             try:
                 w2 = Workload(name, dev, seed=7)
-                dt2, k2 = timed_steps(w2, 5, 2, dev, 1)
+                dt2, k2 = timed_steps(w2, 5, 3, dev, 1)
                 ms2 = 1e3 * dt2 / 5
                 e = {"config": name, "T": w2.T, "B": w2.B, "M": w2.M, "n_dyn": w2.n_dyn, "steps": 5,
-                     "ms_per_step": round(ms2, 4), "lane_steps_per_s": w2.lane_steps / (ms2 * 1e-3)}
+                     "ms_per_step": round(ms2, 4), "lane_steps_per_s": w2.lane_steps / (ms2 * 1e-3),
+                     "device_mallocs_in_timed_steps": timed_steps.device_mallocs}
                 e.update(roofline_entry(w2, k2, ms2))
                 sec.append(e)
                 print(f"[bench] {name}: {ms2:.3f} ms/step", file=sys.stderr, flush=True)
