@@ -15,12 +15,42 @@ using namespace hbvx_host;
 
 namespace {
 
+// Days per block.  The block's scratch is (5 (Tb + 1) + 2 Tb) N floats of re-materialised trajectory plus the
+// inner adjoint's own workspace: 28 bytes per lane-day, i.e. 23 GB for 512 days of 1.6 M lanes -- not "lean".
+// So the block is sized by BYTES: at most HBVX_CKPT_SCRATCH_MB (default 2048) of trajectory scratch, at most
+// HBVX_CKPT_BLOCK (default 512) days, at least 8 K days (shorter blocks cost launches: 4 kernels per block),
+// a multiple of K.
 int block_days(const hbvx_desc *d, int K)
 {
     int tb = env_int("HBVX_CKPT_BLOCK", 512);
-    tb = tb < K ? K : (tb / K) * K;
+    const uint64_t N = (uint64_t)d->B * d->M;
+    const uint64_t budget = (uint64_t)env_int("HBVX_CKPT_SCRATCH_MB", 2048) << 20;
+    const uint64_t by_bytes = budget / (28 * (N ? N : 1));
+    if ((uint64_t)tb > by_bytes) tb = (int)by_bytes;
+    if (tb < 8 * K) tb = 8 * K;
+    tb = (tb / K) * K;
     const int tfull = ((d->T + K - 1) / K) * K;
     return tb > tfull ? tfull : tb;
+}
+
+// out[s][t][b] = in[s][t0 + t][b] for t < tb: the block's window of S gradient series [S,T,B] -> [S,tb,B].
+// (A strided device copy: hipMemcpy2DAsync would do, but its pitch here is T*B*4 bytes -- 2.9 GB for 100 000
+// basins x 7 300 days, beyond 2^31 -- and its width 200 MB: outside what 2-D copies are exercised at.)
+__global__ void __launch_bounds__(256) k_ckpt_window(const float *__restrict__ in, float *__restrict__ out, int64_t row,
+                                                     int64_t T_B, int64_t t0_B)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= row) return;
+    const int s = blockIdx.y;
+    out[(int64_t)s * row + i] = in[(int64_t)s * T_B + t0_B + i];
+}
+
+hipError_t copy_window(const float *in, float *out, int S, int tb, int T, int B, int t0, hipStream_t st)
+{
+    const int64_t row = (int64_t)tb * B;
+    hipLaunchKernelGGL(k_ckpt_window, dim3((unsigned)((row + 255) / 256), (unsigned)S), dim3(256), 0, st, in, out, row,
+                       (int64_t)T * B, (int64_t)t0 * B);
+    return hipGetLastError();
 }
 
 struct Plan {
@@ -100,12 +130,8 @@ bool hbvx_host::try_bwd_ckpt(const hbvx_desc *d, const hbvx_bwd_io *io, void *st
             else launch_remat(k_ckpt_remat<MODEL_HBV20, true>, ra, grid, st);
             hipError_t e = hipGetLastError();
             // the block's window of the gradient series, compacted to [series, tb, B]
-            if (e == hipSuccess && io->grad_flux)
-                e = hipMemcpy2DAsync(s_gf, (size_t)tb * B * 4, io->grad_flux + (int64_t)t0 * B, (size_t)T * B * 4,
-                                     (size_t)tb * B * 4, nf, hipMemcpyDeviceToDevice, st);
-            if (e == hipSuccess && io->grad_flux4)
-                e = hipMemcpy2DAsync(s_g4, (size_t)tb * B * 4, io->grad_flux4 + (int64_t)t0 * B, (size_t)T * B * 4,
-                                     (size_t)tb * B * 4, 4, hipMemcpyDeviceToDevice, st);
+            if (e == hipSuccess && io->grad_flux) e = copy_window(io->grad_flux, s_gf, nf, tb, T, B, t0, st);
+            if (e == hipSuccess && io->grad_flux4) e = copy_window(io->grad_flux4, s_g4, 4, tb, T, B, t0, st);
             if (e != hipSuccess) {
                 *rc = hip_fail(e, "hbvx_backward (checkpoints) block setup");
                 return true;

@@ -45,14 +45,40 @@ def shard_inputs(x_dict: dict, parameters, world: int, rank: int):
     return xs, ps
 
 
+_BUCKETS: dict = {}     # (device, dtype, numel) -> persistent flat buffer of the step's one collective
+
+
+def _bucket(tensors: Sequence[torch.Tensor]) -> torch.Tensor:
+    """Flat staging buffer for `tensors`, kept between steps: the bucket sits on the tail of every training step,
+    and a fresh torch.cat there is an allocation plus a kernel per step for a buffer whose size never changes."""
+    t0 = tensors[0]
+    n = sum(t.numel() for t in tensors)
+    key = (t0.device, t0.dtype, n)
+    flat = _BUCKETS.get(key)
+    if flat is None:
+        if len(_BUCKETS) > 8:
+            _BUCKETS.clear()
+        flat = _BUCKETS[key] = torch.empty(n, dtype=t0.dtype, device=t0.device)
+    off = 0
+    for t in tensors:
+        k = t.numel()
+        flat[off:off + k].copy_(t.reshape(-1))
+        off += k
+    return flat
+
+
 def all_reduce_sum_(tensors: Sequence[torch.Tensor], group=None) -> None:
     """Sum `tensors` over ranks in ONE bucketed all-reduce (flatten -> all_reduce -> scatter back).
 
     xGMI is point-to-point and a ring all-reduce of a small bucket is latency-bound, so the
-    loss scalar(s) and the shared-network gradient travel together in a single collective."""
+    loss scalar(s) and the shared-network gradient travel together in a single collective.  A single tensor is
+    reduced in place (no staging at all)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
-    flat = torch.cat([t.reshape(-1) for t in tensors])
+    if len(tensors) == 1 and tensors[0].is_contiguous():
+        dist.all_reduce(tensors[0], op=dist.ReduceOp.SUM, group=group)
+        return
+    flat = _bucket(tensors)
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     off = 0
     for t in tensors:

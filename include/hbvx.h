@@ -157,7 +157,8 @@ enum hbvx_traj_layout { HBVX_TRAJ_ROWS = 0, HBVX_TRAJ_PACKED = 1, HBVX_TRAJ_CKPT
  * storages entering days 0, K, 2K, ... as [ceil(T/K), 5, N] and `aux` is NULL (20/K bytes per lane-day
  * instead of 28); hbvx_backward re-materialises each K-day segment from its checkpoint (one extra
  * forward step per day).  The caller chooses it when the full trajectory does not fit
- * (100 000 basins x 16 x 7 300 days: 327 GB against 16 GB at K = 8). */
+ * (100 000 basins x 16 x 7 300 days: 327 GB of trajectory against 29 GB of checkpoints at K = 8, 15 GB at
+ * K = 16; the block-wise adjoint adds at most 2 GB of scratch, hbvx_ckpt_workspace_bytes). */
 #define HBVX_TRAJ_KIND(layout) ((layout) & 0xFF)
 #define HBVX_TRAJ_CKPT_DAYS(layout) ((layout) >> 8)
 

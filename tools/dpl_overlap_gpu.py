@@ -15,6 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def run(extra):
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -22,14 +23,19 @@ def run(extra):
     for rank in range(2):
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE="2",
                    LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "examples", "train_dpl.py"), "--backend", "gloo",
-                                       "--share-gpu", "--basins", "200", "--steps", "20", *extra],
-                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
-    outs = [p.communicate(timeout=600) for p in procs]
-    for p, (o, e) in zip(procs, outs):
+        # stderr goes to a file per rank and only rank 0's stdout is piped: two PIPEs drained one after the other
+        # dead-lock when the rank that is not being read fills its 64 KB pipe while the other waits for it in a collective
+        err = open(os.path.join(ROOT, "gpurun_out", f"dpl_overlap_rank{rank}.err"), "w")
+        procs.append((subprocess.Popen([sys.executable, os.path.join(ROOT, "examples", "train_dpl.py"), "--backend", "gloo",
+                                        "--share-gpu", "--basins", "200", "--steps", "20", *extra], env=env,
+                                       stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, stderr=err, text=True), err))
+    out0, _ = procs[0][0].communicate(timeout=600)
+    for rank, (p, err) in enumerate(procs):
+        p.wait(timeout=600)
+        err.close()
         if p.returncode:
-            raise SystemExit(f"rank failed ({p.returncode}):\n{e[-2000:]}")
-    return json.loads(outs[0][0].strip().splitlines()[-1])
+            raise SystemExit(f"rank {rank} failed ({p.returncode}):\n" + open(err.name).read()[-2000:])
+    return json.loads(out0.strip().splitlines()[-1])
 
 
 if __name__ == "__main__":
