@@ -131,17 +131,18 @@ def _zeros_like(lib, t: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def _grad_like(lib, p: torch.Tensor, cfg: "StepConfig", tensor_idx: int) -> torch.Tensor:
-    """Gradient buffer for parameter tensor `p`: zero wherever the adjoint accumulates (static rows,
-    routing columns) or never writes, left alone where it STORES -- the nmul columns of every dynamic
-    parameter on the days of this call (hbvx_backward writes each of those elements exactly once,
-    0 for a dy_drop-masked basin).  Falls back to the dense fill when the layout is not the plain
-    [T,B,width] one.  Under HBVX_DEBUG_POISON the left-alone part is NaN: an element a kernel skipped
-    cannot pass."""
+def _dyn_columns(p: torch.Tensor, cfg: "StepConfig", tensor_idx: int):
+    """Which elements of the gradient of parameter tensor `p` the adjoint STORES (never accumulates): the nmul
+    columns of every dynamic parameter on the days of this call (hbvx_backward writes each of those elements
+    exactly once, 0 for a dy_drop-masked basin).  Returns (keep bit mask over column groups of width nmul,
+    first day) for hbvx_zero_except, (0, 0) when the tensor holds no dynamic parameter, or None when its layout
+    is not the plain [T,B,width] one (then only a dense fill is safe)."""
     dyn = [ps for ps in cfg.params if ps.dyn_off >= 0 and ps.dyn_tensor_idx == tensor_idx]
+    if not dyn:
+        return 0, 0
     M, B, T = cfg.M, cfg.B, cfg.T
-    if not dyn or p.dim() != 3 or not p.is_contiguous() or p.shape[1] != B:
-        return _zeros_like(lib, p)
+    if p.dim() != 3 or not p.is_contiguous() or p.shape[1] != B:
+        return None
     W = p.shape[2]
     keep, t_first = 0, None
     for ps in dyn:
@@ -149,12 +150,30 @@ def _grad_like(lib, p: torch.Tensor, cfg: "StepConfig", tensor_idx: int) -> torc
         k, j0 = divmod(rem, M)
         if (ps.dyn_ts != B * W or ps.dyn_bs != W or rem >= W or j0 != 0 or (k + 1) * M > W or k >= 32
                 or (t_first is not None and tf != t_first) or tf + T > p.shape[0]):
-            return _zeros_like(lib, p)
+            return None
         t_first = tf
         keep |= 1 << k
+    return keep, t_first
+
+
+def _fill_grad(lib, out: torch.Tensor, cfg: "StepConfig", cols) -> None:
+    """Zero `out` (a [T,B,W] gradient buffer) except the columns the adjoint stores (`cols` from _dyn_columns)."""
+    keep, t_first = cols
+    B, W = out.shape[1], out.shape[2]
+    _call(lib, 'hbvx_zero', lib.zero_except, out.data_ptr(), out.shape[0] * B, W, t_first * B, (t_first + cfg.T) * B,
+          cfg.M, keep, _stream_of(lib, out))
+
+
+def _grad_like(lib, p: torch.Tensor, cfg: "StepConfig", tensor_idx: int) -> torch.Tensor:
+    """Gradient buffer for parameter tensor `p`: zero wherever the adjoint accumulates (static rows,
+    routing columns) or never writes, left alone where it STORES (_dyn_columns).  Falls back to the dense fill
+    when the layout is not the plain [T,B,width] one.  Under HBVX_DEBUG_POISON the left-alone part is NaN: an
+    element a kernel skipped cannot pass."""
+    cols = _dyn_columns(p, cfg, tensor_idx)
+    if cols is None or cols[0] == 0:
+        return _zeros_like(lib, p)
     out = torch.full_like(p, float("nan")) if _POISON else torch.empty_like(p)
-    _call(lib, 'hbvx_zero', lib.zero_except, out.data_ptr(), p.shape[0] * B, W, t_first * B, (t_first + T) * B,
-          M, keep, _stream_of(lib, out))
+    _fill_grad(lib, out, cfg, cols)
     return out
 
 
@@ -220,17 +239,22 @@ def _overlapped_grad_buffers(lib, cfg: "StepConfig", ptensors, needs):
         offs = [ps.sta_off for ps in cfg.params if ps.tensor_idx == i]
         if cfg.route is not None and cfg.route.tensor_idx == i:
             offs += [cfg.route.a_off, cfg.route.b_off]
+        cols = _dyn_columns(p, cfg, i)
+        # (a tensor with dynamic columns stays on the plain path: hbvx_zero_except may fall back to the dense fill
+        # when few columns are kept, which is only correct IN FRONT of the adjoint's stores, not beside them --
+        # measured as wrong gradients when tried; a gate between the fill and the sweep kernel would be needed)
         ok = (p.dim() == 3 and p.is_contiguous() and p.numel() >= _EARLY_ZERO_MIN and p.shape[0] > 1
-              and all(o >= base for o in offs)
-              and not any(ps.dyn_off >= 0 and ps.dyn_tensor_idx == i for ps in cfg.params))
+              and all(o >= base for o in offs) and cols == (0, 0))
         if not ok:
             gp.append(_grad_like(lib, p, cfg, i)); rows.append(None); bases.append(0)
             continue
-        big = torch.empty_like(p)            # on the caller's stream and pool: it is also where it dies
+        # on the caller's stream and pool: it is also where it dies.  (Poisoned in the test tiers, so that a
+        # dynamic column the adjoint skipped cannot pass; the fill below leaves those columns alone.)
+        big = torch.full_like(p, float("nan")) if (_POISON and cols[0]) else torch.empty_like(p)
         gp.append(big)
         rows.append(torch.zeros_like(p[0]))
         bases.append(base)
-        todo.append(big)
+        todo.append((big, cols))
 
     def start():
         if not todo:
@@ -239,8 +263,11 @@ def _overlapped_grad_buffers(lib, cfg: "StepConfig", ptensors, needs):
         side = _side_stream(dev)
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            for big in todo:
-                _call(lib, 'hbvx_zero', lib.zero, big.data_ptr(), big.numel() * big.element_size(), _stream_of(lib, big))
+            for big, cols in todo:
+                if cols[0]:
+                    _fill_grad(lib, big, cfg, cols)      # dynamic columns of the call's days: stored by the adjoint
+                else:
+                    _call(lib, 'hbvx_zero', lib.zero, big.data_ptr(), big.numel() * big.element_size(), _stream_of(lib, big))
             done = torch.cuda.Event()
             done.record(side)
         return done
@@ -714,8 +741,20 @@ class HbvAdjPath(torch.autograd.Function):
         dev = x.device
         T, B, M = cfg.T, cfg.B, cfg.M
         stream = _stream_of(lib, x)
-        gp = [_zeros_like(lib, p) if ctx.needs_input_grad[3 + i] else None
-              for i, p in enumerate(ptensors)]
+        # gradient buffers: the [T,B,ny] fill beside the adjoint kernels on a second stream, static rows apart
+        # (as HbvPath.backward; _overlapped_grad_buffers)
+        rows = [None] * len(ptensors)
+        bases = [0] * len(ptensors)
+        start_fill = None
+        if _FILL_OVERLAP and lib.is_device:
+            gp, rows, bases, start_fill = _overlapped_grad_buffers(lib, cfg, ptensors, ctx.needs_input_grad[3:])
+        else:
+            gp = [_grad_like(lib, p, cfg, i) if ctx.needs_input_grad[3 + i] else None
+                  for i, p in enumerate(ptensors)]
+
+        def sta_ptr(idx, off):
+            return _ptr(rows[idx], off - bases[idx]) if rows[idx] is not None else _ptr(gp[idx], off)
+
         gq = None
         if g_routed is not None and cfg.route is not None:
             r = _route_desc(cfg, ptensors, S=1)
@@ -726,7 +765,8 @@ class HbvAdjPath(torch.autograd.Function):
             ws = torch.empty((max(ws_bytes, 4) + 3) // 4, dtype=torch.float32, device=dev)
             g_routed_c = g_routed.contiguous()     # named: must outlive the launch that reads its pointer
             _call(lib, 'hbvx_route_backward', lib.route_backward, r, _ptr(flux), _ptr(uh),
-                  _ptr(g_routed_c), _ptr(gq), _ptr(gt, rs.a_off), _ptr(gt, rs.b_off),
+                  _ptr(g_routed_c), _ptr(gq), sta_ptr(rs.tensor_idx, rs.a_off) if gt is not None else None,
+                  sta_ptr(rs.tensor_idx, rs.b_off) if gt is not None else None,
                   _ptr(ws), ws_bytes, stream)
         # contiguous copies of incoming gradients are bound to locals that live until after the launch:
         # a temporary would be freed at once and the caching allocator could hand its block to gs_in / ws
@@ -746,7 +786,7 @@ class HbvAdjPath(torch.autograd.Function):
             g = io.g[ps.slot]
             gs = gp[ps.tensor_idx]
             if gs is not None:
-                g.sta = _ptr(gs, ps.sta_off)
+                g.sta = sta_ptr(ps.tensor_idx, ps.sta_off)
                 g.sta_b_stride = ps.sta_bs
             if ps.dyn_off >= 0 and gp[ps.dyn_tensor_idx] is not None:
                 g.dyn = _ptr(gp[ps.dyn_tensor_idx], ps.dyn_off)
@@ -756,7 +796,13 @@ class HbvAdjPath(torch.autograd.Function):
         if ws_bytes:
             ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
             io.workspace, io.workspace_bytes = _ptr(ws), ws_bytes
+        fill_done = start_fill() if start_fill is not None else None     # beside the adjoint kernels
         _call(lib, 'hbvx_adj_backward', lib.adj_backward, desc, io, stream)
+        if fill_done is not None:
+            torch.cuda.current_stream(dev).wait_event(fill_done)
+            for big, row in zip(gp, rows):
+                if row is not None:
+                    big[-1] += row
         return (None, None, gs_in, *gp)
 
 
