@@ -75,7 +75,7 @@ static hipError_t launch_chunked_t(const ChunkArgs &a, hipStream_t st)
         // whole-row gradient stores when every parameter's gradient sits in one [T,B,ny] tensor in the
         // reference's column order, rows 8-byte aligned (hbv_chunked.h, ROWST)
         const hbvx_param_grad &g0 = a.io.g[0];
-        bool rows = env_int("HBVX_CHUNK_ROWST", 1) != 0 && g0.dyn && ((uintptr_t)g0.dyn & 7) == 0 &&
+        bool rows = g0.dyn && ((uintptr_t)g0.dyn & 7) == 0 &&
                     (g0.dyn_b_stride & 1) == 0 && (g0.dyn_t_stride & 1) == 0 && ((d.n_param * d.M) & 1) == 0;
         for (int i = 1; i < d.n_param && rows; i++)
             rows = a.io.g[i].dyn == g0.dyn + (int64_t)i * d.M && a.io.g[i].dyn_b_stride == g0.dyn_b_stride &&

@@ -65,8 +65,7 @@ bool hbvx_host::try_fwd_pipe(const hbvx_desc *d, const hbvx_fwd_out *out, void *
             // compile-time dynamic sets (hbv_pipe.h, SC): {BETA, BETAET} and {BETA, K0, BETAET}
             unsigned dmask = 0;
             for (int i = 0; i < d->n_param; i++) dmask |= d->p[i].dyn ? (1u << i) : 0u;
-            const int sc = env_int("HBVX_PIPE_SC", 1) == 0 ? 0
-                         : dmask == ((1u << P_BETA) | (1u << P_BETAET)) ? 1
+            const int sc = dmask == ((1u << P_BETA) | (1u << P_BETAET)) ? 1
                          : dmask == ((1u << P_BETA) | (1u << P_K0) | (1u << P_BETAET)) ? 2 : 0;
 #define PIPE_GO(MODEL, BE, TR, DY, MANY, SC) e = launch_tiled_one(k_fwd_pipe<MODEL, BE, TR, DY, MANY, SC>, pa, grid_p, pthreads, lds, st)
 #define PIPE_GO3(MODEL, BE, TR, S1, S2)                                                            \

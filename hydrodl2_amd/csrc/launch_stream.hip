@@ -54,7 +54,7 @@ StreamPlan plan_stream(const hbvx_desc *d)
     const int c0 = d->ch_prcp, c1 = d->ch_tmean, c2 = d->ch_pet;
     // second generation: the forcing channels in (prcp, tmean, pet) order, a basin's three values adjacent
     P.xvec = c0 == 0 && c1 == 1 && c2 == 2 && d->x_b_stride >= 3;
-    if (env_int("HBVX_STREAM2", 1) == 0 || !P.xvec) P.sc = -1;
+    if (!P.xvec) P.sc = -1;
     P.rows_ok = 5 * (int64_t)(d->T + 1) * N * 4 < lim;
     P.packed_ok = N * 20 < lim;
     if (P.sc < 0) P.ok = P.ok && P.gen1_ok && P.rows_ok;
@@ -87,7 +87,7 @@ void go_fwd2(int trj, const StreamArgs &sa, dim3 grid, hipStream_t st)
     // (profiles/r02_grid_sweep.jsonl: hbv forward 0.70 / 0.90 / 1.15 / 2.18 ms with one wave per workgroup
     // against 0.81 / 0.86 / 0.95 / 1.87 ms at 1024 / 1536 / 2048 / 4096 wavefronts)
     const int mw_min = env_int("HBVX_STREAM_MW_MIN", 1280);
-    if (sa.lgMp == 4 && trj != 1 && env_int("HBVX_STREAM_MW", 1) != 0 && (int64_t)sa.per_xcd * 8 >= mw_min) {
+    if (sa.lgMp == 4 && trj != 1 && (int64_t)sa.per_xcd * 8 >= mw_min) {
         StreamArgs sm = sa;
         const int64_t waves = (int64_t)sa.per_xcd * 8;
         sm.per_xcd = (int)(((waves + 7) / 8 + 7) / 8);
@@ -117,8 +117,6 @@ bool four_waves_pay(int64_t wgs)
         n_cu = n_cu_of[dev];
     }
     const int64_t s3 = (int64_t)n_cu * 4 * 3, s4 = (int64_t)n_cu * 4 * 4;
-    const int force = env_int("HBVX_STREAM_W4", -1);
-    if (force >= 0) return force != 0;
     return (wgs + s4 - 1) / s4 < (wgs + s3 - 1) / s3;
 }
 

@@ -18,7 +18,7 @@ import torch  # noqa: E402
 import hydrodl2_amd  # noqa: E402
 from hydrodl2_amd import ops  # noqa: E402
 
-MODES = {"auto": {}, "stream": {"HBVX_STREAM_MIN": "1", "HBVX_STREAM_MIN_BWD": "1"}, "nostream": {"HBVX_STREAM": "0"}}
+MODES = {"auto": {}, "stream": {"HBVX_STREAM_MIN": "1"}, "nostream": {"HBVX_STREAM": "0"}}
 
 
 def one(fam, B, T=730, M=16, steps=4):
@@ -45,7 +45,7 @@ def one(fam, B, T=730, M=16, steps=4):
     w = torch.randn((T, B, 1), generator=g, device=dev)
     res = {"model": fam, "B": B, "W": (B + 3) // 4, "T": T}
     for mode, env in MODES.items():
-        for k in ("HBVX_STREAM_MIN", "HBVX_STREAM_MIN_BWD", "HBVX_STREAM"):
+        for k in ("HBVX_STREAM_MIN", "HBVX_STREAM"):
             os.environ.pop(k, None)
         os.environ.update(env)
 
