@@ -8,6 +8,8 @@ caches the full state series.
 """
 from typing import Any, Optional
 
+import copy
+
 import torch
 
 from hydrodl2_amd import _abi
@@ -75,23 +77,52 @@ class Hbv_2(HbvModule):
 
         # hbv_2.py:258: dynamic parameters are indexed in the ORDER OF THE CONFIG LIST,
         # with a Bernoulli drop mask per entry; static ones in table order (hbv_2.py:363-367).
-        srcs = []
-        drops = {name: self._draw_drop_mask(ngrid, x.device) for name in dy}
-        stat_list = [name for name in self.parameter_bounds if name not in dy]
-        for name in self.parameter_bounds:
-            lo, hi = self.parameter_bounds[name]
-            slot = _abi.PARAM_SLOTS.index(name)
-            if name in dy:
-                i = dy.index(name)
-                srcs.append(ParamSource(
-                    slot=slot, lo=float(lo), hi=float(hi),
-                    tensor_idx=0, sta_off=(T - 1) * ngrid * wd + i * M, sta_bs=wd,  # :259
-                    dyn_tensor_idx=0, dyn_off=i * M, dyn_ts=ngrid * wd, dyn_bs=wd,
-                    drop=drops[name]))
-            else:
-                i = stat_list.index(name)
-                srcs.append(ParamSource(slot=slot, lo=float(lo), hi=float(hi), tensor_idx=1,
-                                        sta_off=i * M, sta_bs=ws))
+        # The addressing is a function of the shapes and settings: built once per shape (see HbvModule._step_configs)
+        ck = int(self.adjoint_checkpoint) if not self.initialize else 0
+        if ck not in (0, 4, 8, 16):
+            raise ValueError("adjoint_checkpoint must be 0, 4, 8 or 16 days")
+        key = (T, ngrid, wd, ws, M, tuple(dy), bool(self.routing), bool(self.initialize), ck, float(self.nearzero),
+               tuple(self.variables), tuple(map(tuple, self.parameter_bounds.values())),
+               tuple(map(tuple, self.routing_parameter_bounds.values())))
+        cfg = self._cfg_cache.get(key)
+        if cfg is None:
+            srcs = []
+            stat_list = [name for name in self.parameter_bounds if name not in dy]
+            for name in self.parameter_bounds:
+                lo, hi = self.parameter_bounds[name]
+                slot = _abi.PARAM_SLOTS.index(name)
+                if name in dy:
+                    i = dy.index(name)
+                    srcs.append(ParamSource(
+                        slot=slot, lo=float(lo), hi=float(hi),
+                        tensor_idx=0, sta_off=(T - 1) * ngrid * wd + i * M, sta_bs=wd,  # :259
+                        dyn_tensor_idx=0, dyn_off=i * M, dyn_ts=ngrid * wd, dyn_bs=wd))
+                else:
+                    i = stat_list.index(name)
+                    srcs.append(ParamSource(slot=slot, lo=float(lo), hi=float(hi), tensor_idx=1,
+                                            sta_off=i * M, sta_bs=ws))
+            cfg = StepConfig(model=self._model_id, n_param=n, n_flux=12, T=T, t0=0, B=ngrid, M=M,
+                             raw_sigmoid=False, channels=self._channels(),
+                             nearzero=float(self.nearzero), params=srcs,
+                             want_flux=not self.initialize, want_traj=ck == 0, ckpt_days=ck,
+                             want_bfi=not self.initialize)
+            if self.routing:
+                off = (n - n_dy) * M  # hbv_2.py:228
+                cfg.route = RouteSource(1, off, off + 1, ws,
+                                        self.routing_parameter_bounds['route_a'],
+                                        self.routing_parameter_bounds['route_b'])
+            if len(self._cfg_cache) > 16:
+                self._cfg_cache.clear()
+            self._cfg_cache[key] = cfg
+        # one Bernoulli draw per dynamic parameter, in the order of the config list (hbv_2.py:254-258)
+        masks = self._draw_drop_masks(n_dy, ngrid, x.device)
+        if any(m is not None for m in masks):
+            cfg = copy.copy(cfg)
+            cfg.params = [copy.copy(ps) for ps in cfg.params]
+            by_name = dict(zip(dy, masks))
+            for ps, name in zip(cfg.params, self.parameter_bounds):
+                if name in by_name:
+                    ps.drop = by_name[name]
 
         # hbv_2.py:370-373
         if (not self.states) or (not self.cache_states):
@@ -102,22 +133,10 @@ class Hbv_2(HbvModule):
         # adjoint_checkpoint (not in the reference): keep K-day checkpoints instead of the state
         # trajectory -- 100 000 basins x 16 x 7 300 days do not fit otherwise.  The price on this class:
         # the state cache then holds the final storages only (a one-step series), not the full series.
-        ck = int(self.adjoint_checkpoint) if not self.initialize else 0
-        if ck not in (0, 4, 8, 16):
-            raise ValueError("adjoint_checkpoint must be 0, 4, 8 or 16 days")
         if self.check_finite:
             for name, t in (('x_phy', x), ('dynamic parameters', parameters[0]), ('static parameters', parameters[1])):
                 if not bool(torch.isfinite(t).all()):
                     raise ValueError(f"{name} hold non-finite values (check_finite is set)")
-        cfg = StepConfig(model=self._model_id, n_param=n, n_flux=12, T=T, t0=0, B=ngrid, M=M,
-                         raw_sigmoid=False, channels=self._channels(),
-                         nearzero=float(self.nearzero), params=srcs,
-                         want_flux=not self.initialize, want_traj=ck == 0, ckpt_days=ck)
-        if self.routing:
-            off = (n - n_dy) * M  # hbv_2.py:228
-            cfg.route = RouteSource(1, off, off + 1, ws,
-                                    self.routing_parameter_bounds['route_a'],
-                                    self.routing_parameter_bounds['route_b'])
         muwts = self._expand_muwts(self.muwts, T, T, ngrid)
         res = hbv_path(cfg, x, state_in, muwts, ac, elev, p_dyn, p_sta)
         flux, routed, state_out, traj = res.flux, res.routed, res.state_out, res.traj
@@ -133,4 +152,4 @@ class Hbv_2(HbvModule):
 
         if self.initialize:
             return {}
-        return self._assemble(flux, routed, x, 0)
+        return self._assemble(flux, routed, x, 0, res.bfi)

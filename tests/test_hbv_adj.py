@@ -241,10 +241,11 @@ def test_hip_global_newton_rule_is_the_oracles_global_rule(hip_backend):
 
 
 @pytest.mark.gpu
-def test_hip_cfg4_full_length_and_oracle_spot_check(hip_backend):
-    """BASELINE config 4 at its full size -- 671 basins x 16 members x 7300 days, tiled forward +
-    time-parallel adjoint: finite and basin-independent; and a float64-oracle spot check (values and
-    gradients) of three basins over 1460 days with the reference's Newton policy."""
+def test_hip_cfg4_full_length_and_oracle_spot_check(hip_backend, monkeypatch):
+    """BASELINE config 4 at its full size -- 671 basins x 16 members x 7300 days, pipelined staged forward +
+    time-parallel adjoint: finite, basin-independent, bit-identical to the one-wave stepper over the whole
+    record; and a float64-oracle spot check (values and gradients) of three basins over 1460 days with the
+    reference's Newton policy."""
     import hydrodl2_amd
     dev = torch.device("cuda:0")
     H = hydrodl2_amd.load_model("hbv_adj", "HbvAdj")
@@ -263,6 +264,13 @@ def test_hip_cfg4_full_length_and_oracle_spot_check(hip_backend):
     p2 = p.detach()[:, pick].contiguous().requires_grad_(True)
     out2 = m({"x_phy": x[:, pick].contiguous()}, p2)["flow_sim"]
     assert torch.equal(out[:, pick], out2)
+    # the three-wave pipeline against the single stepper wave solving the three blocks in sequence: 913 tiles of
+    # 8 days, dynamic parBETAET staged by the filler waves, 168 workgroups -- same numbers to the last bit
+    monkeypatch.setenv("HBVX_FWD", "tiled")
+    with torch.no_grad():
+        out_t = m({"x_phy": x}, p.detach())["flow_sim"]
+    monkeypatch.delenv("HBVX_FWD")
+    assert torch.equal(out, out_t)
     # oracle: the first 1460 days of those three basins (a day-by-day float64 autograd loop)
     Ts = 1460
     xs, ps = x[:Ts, pick].cpu(), p.detach()[:Ts, pick].cpu()

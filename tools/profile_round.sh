@@ -13,7 +13,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG/
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_$TAG/fetch -o fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-secondary --no-cpu-baseline > /dev/null 2> $R/gpurun_out/prof_$TAG.fetch.log
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_$TAG/write -o write -- python3 $R/bench.py --steps 3 --warmup 1 --no-secondary --no-cpu-baseline > /dev/null 2> $R/gpurun_out/prof_$TAG.write.log
 # the kernels of the secondary configurations, one stats pass
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG/cfgs -o cfgs -- python3 $R/tools/bench_configs.py cfg2dyn cfg3 cfg5 > $R/gpurun_out/prof_$TAG.cfgs.jsonl 2> $R/gpurun_out/prof_$TAG.cfgs.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG/cfgs -o cfgs -- python3 $R/tools/bench_configs.py cfg2dyn cfg3 cfg4 cfg5 dmg > $R/gpurun_out/prof_$TAG.cfgs.jsonl 2> $R/gpurun_out/prof_$TAG.cfgs.log
 # the caller side: sequence LSTM beside torch's, and the end-to-end training step
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG/lstm -o lstm -- python3 $R/tools/bench_lstm.py > $R/gpurun_out/prof_$TAG.lstm.json 2> $R/gpurun_out/prof_$TAG.lstm.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG/dpl -o dpl -- python3 $R/examples/train_dpl.py --lstm fused --steps 10 > $R/gpurun_out/prof_$TAG.dpl.json 2> $R/gpurun_out/prof_$TAG.dpl.log
