@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_PARAM = 20
 GAGE_MAXLEN = 72
 NSTATE = 5
@@ -68,7 +68,7 @@ class BwdIO(C.Structure):
                 ("grad_muwts", _fp), ("grad_state_in", _fp),
                 ("n_flux", C.c_int32), ("traj_layout", C.c_int32),
                 ("g", ParamGrad * MAX_PARAM),
-                ("workspace", _fp), ("workspace_bytes", C.c_uint64)]
+                ("workspace", _fp), ("workspace_bytes", C.c_uint64), ("store_gate", _fp)]
 
 
 class RouteDesc(C.Structure):

@@ -728,6 +728,7 @@ extern "C" int hbvx_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *st
     a.lgMp = lg_members(d->M);
     const int bpw = 64 >> a.lgMp;
     dim3 grid((d->B + bpw - 1) / bpw);
+    store_gate(io, (hipStream_t)stream);
     hipError_t e = launch_variant(d, a, grid, (hipStream_t)stream,
                                   k_bwd<MODEL_HBV10, false>, k_bwd<MODEL_HBV10, true>,
                                   k_bwd<MODEL_HBV11P, true>, k_bwd<MODEL_HBV20, true>, k_bwd<MODEL_HOURLY, true>);

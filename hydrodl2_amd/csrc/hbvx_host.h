@@ -32,6 +32,11 @@ static const int LDS_BUDGET = 160 * 1024 - 512; // gfx950: 160 KiB per CU, one w
 bool try_fwd_pipe(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream, int *rc);
 // launch_stream.hip
 bool try_fwd_stream(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream, int *rc, bool any_size = false);
+// hbvx_bwd_io.store_gate: make `st` wait for the caller's event before a kernel that stores gradients is launched
+inline void store_gate(const hbvx_bwd_io *io, hipStream_t st)
+{
+    if (io->store_gate) (void)hipStreamWaitEvent(st, (hipEvent_t)io->store_gate, 0);
+}
 bool try_bwd_stream(const hbvx_desc *d, const hbvx_bwd_io *io, void *stream, int *rc);
 // launch_tiled.hip
 bool try_fwd_tiled(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream, int *rc);

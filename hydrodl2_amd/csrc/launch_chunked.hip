@@ -54,6 +54,7 @@ static hipError_t launch_chunked_t(const ChunkArgs &a, hipStream_t st)
         if (sc == 1) {
             hipLaunchKernelGGL((k_bwd_chunk_phi<MODEL, BETAET, DYN, GFULL, 1>), g2, dim3(64), 0, st, a);
             hipLaunchKernelGGL(k_bwd_chunk_scan, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, st, a);
+            store_gate(&a.io, st);
             hipLaunchKernelGGL((k_bwd_chunk_sweep<MODEL, BETAET, DYN, GFULL, 1>), g2, dim3(64), 0, st, a);
         }
     }
@@ -61,6 +62,7 @@ static hipError_t launch_chunked_t(const ChunkArgs &a, hipStream_t st)
         if (sc == 2) {
             hipLaunchKernelGGL((k_bwd_chunk_phi<MODEL, BETAET, DYN, GFULL, 2>), g2, dim3(64), 0, st, a);
             hipLaunchKernelGGL(k_bwd_chunk_scan, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, st, a);
+            store_gate(&a.io, st);
             hipLaunchKernelGGL((k_bwd_chunk_sweep<MODEL, BETAET, DYN, GFULL, 2>), g2, dim3(64), 0, st, a);
         }
     }
@@ -71,6 +73,7 @@ static hipError_t launch_chunked_t(const ChunkArgs &a, hipStream_t st)
     }
     hipLaunchKernelGGL((k_bwd_chunk_phi<MODEL, BETAET, DYN, GFULL>), g2, dim3(64), 0, st, a);
     hipLaunchKernelGGL(k_bwd_chunk_scan, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, st, a);
+    store_gate(&a.io, st);       // phi and scan only read; the sweep stores
     if constexpr (DYN == 3) {
         // whole-row gradient stores when every parameter's gradient sits in one [T,B,ny] tensor in the
         // reference's column order, rows 8-byte aligned (hbv_chunked.h, ROWST)

@@ -250,6 +250,7 @@ bool hbvx_host::try_bwd_stream(const hbvx_desc *d, const hbvx_bwd_io *io, void *
     const bool few = P.nd > 0, gfull = io->grad_flux != nullptr;
     dim3 grid_s((unsigned)P.wgs);
     hipStream_t st = (hipStream_t)stream;
+    store_gate(io, st);          // single pass: the one kernel stores
     if (P.sc >= 0) {
         sa.per_xcd = (int)((P.wgs + 7) / 8);
         const dim3 grid2((unsigned)(8 * sa.per_xcd));

@@ -122,6 +122,7 @@ bool hbvx_host::try_bwd_tiled(const hbvx_desc *d, const hbvx_bwd_io *io, void *s
             const size_t lds = (size_t)2 * (ta.g.in_sz + ta.g.out_sz) * 4;
             const bool dyn = ta.g.NDm > 0, gfull = io->grad_flux != nullptr;
             hipStream_t st_ = (hipStream_t)stream;
+            store_gate(io, st_);
             hipError_t e =
                 [&]() -> hipError_t {
                     if (dyn) {
@@ -220,6 +221,7 @@ extern "C" int hbvx_adj_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void
         if (d->n_param == 13) hipLaunchKernelGGL(k_adj_chunk_phi<true>, g2, dim3(64), 0, st, *d, *io, ca.lgMp, ca.C, ca.phi);
         else hipLaunchKernelGGL(k_adj_chunk_phi<false>, g2, dim3(64), 0, st, *d, *io, ca.lgMp, ca.C, ca.phi);
         launch_chunk_scan(ca, st);
+        store_gate(io, st);      // phi and scan only read; the sweep stores the dynamic gradients
         if (d->n_param == 13) hipLaunchKernelGGL(k_adj_chunk_sweep<true>, g2, dim3(64), 0, st, *d, *io, ca.lgMp, ca.C, ca.abnd, ca.gpart);
         else hipLaunchKernelGGL(k_adj_chunk_sweep<false>, g2, dim3(64), 0, st, *d, *io, ca.lgMp, ca.C, ca.abnd, ca.gpart);
         launch_chunk_reduce(ca, d->n_param, st);
@@ -233,6 +235,7 @@ extern "C" int hbvx_adj_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void
     a.lgMp = lg_members(d->M);
     const int bpw = 64 >> a.lgMp;
     dim3 grid((d->B + bpw - 1) / bpw);
+    store_gate(io, (hipStream_t)stream);
     if (d->n_param == 13) hipLaunchKernelGGL(k_adj_bwd<true>, grid, dim3(64), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(k_adj_bwd<false>, grid, dim3(64), 0, (hipStream_t)stream, a);
     hipError_t e = hipGetLastError();

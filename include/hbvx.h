@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define HBVX_ABI_VERSION 7
+#define HBVX_ABI_VERSION 8
 #define HBVX_MAX_PARAM 20
 #define HBVX_NSTATE 5   /* SNOWPACK, MELTWATER, SM, SUZ, SLZ  (hbv.py:61-67) */
 #define HBVX_MAX_FLUX 12
@@ -191,6 +191,12 @@ typedef struct hbvx_bwd_io {
     void *workspace;          /* optional caller-owned scratch of hbvx_backward_workspace_bytes();
                                  enables the time-parallel (chunked) adjoint */
     uint64_t workspace_bytes;
+    void *store_gate;         /* optional hipEvent_t: `stream` waits for it before the first kernel that STORES
+                                 dynamic-parameter / forcing / muwts gradients is launched (kernels that only read
+                                 -- the transfer-map and scan passes of the time-parallel adjoint -- run ahead of
+                                 it).  Lets the caller fill the gradient tensor ([T,B,ny]: 3.8 GB at config 2) on
+                                 another stream BESIDE the first half of the adjoint instead of in front of it.
+                                 NULL: no wait.  The CPU oracle ignores it. */
 } hbvx_bwd_io;
 
 /* Unit-hydrograph routing of S series that share one UH per basin. */
