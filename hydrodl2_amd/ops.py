@@ -225,12 +225,13 @@ def _overlapped_grad_buffers(lib, cfg: "StepConfig", ptensors, needs):
     """(gp, rows, bases, start): gradient buffers, the separate last rows (None where a tensor keeps the
     plain path), their element offsets inside the big tensors, and `start()` -> event: begins the fills
     of the qualifying tensors on the side stream (call it when the caller's stream has nothing
-    bandwidth-bound left in front of the adjoint) and returns the event that marks them complete.
-    A tensor qualifies when it is large, [T,B,W]-shaped, holds no dynamic parameter of this call (the
-    adjoint then writes nothing into it but the static row) and every static / routing source of it lies
-    in its last row."""
+    bandwidth-bound left in front of the adjoint) and returns the event that marks them complete;
+    `start.gated`: that event must reach the library as `store_gate`.
+    A tensor qualifies when it is large, [T,B,W]-shaped, every static / routing source of it lies in its last
+    row, and at most half of its columns belong to dynamic parameters of this call."""
     dev = ptensors[0].device
     gp, rows, bases, todo = [], [], [], []
+    gated = False
     for i, (p, need) in enumerate(zip(ptensors, needs)):
         if not need:
             gp.append(None); rows.append(None); bases.append(0)
@@ -240,21 +241,25 @@ def _overlapped_grad_buffers(lib, cfg: "StepConfig", ptensors, needs):
         if cfg.route is not None and cfg.route.tensor_idx == i:
             offs += [cfg.route.a_off, cfg.route.b_off]
         cols = _dyn_columns(p, cfg, i)
-        # (a tensor with dynamic columns stays on the plain path: hbvx_zero_except may fall back to the dense fill
-        # when few columns are kept, which is only correct IN FRONT of the adjoint's stores, not beside them --
-        # measured as wrong gradients when tried; a gate between the fill and the sweep kernel would be needed)
+        # A tensor with dynamic columns is filled DENSELY (the fastest fill) and the adjoint's stores into those
+        # columns must land after it: the fill's event goes to the library as hbvx_bwd_io.store_gate, which holds
+        # back the storing kernel only (the transfer-map and scan passes of the time-parallel adjoint run beside
+        # the fill).  Without the gate the two race (measured: wrong gradients).  Worth it while few columns are
+        # dynamic -- with most of them dynamic (config 3) hbvx_zero_except in front of the adjoint writes a
+        # fraction of the bytes and stays.
+        few_dyn = cols is not None and bin(cols[0]).count("1") * cfg.M * 2 <= p.shape[-1]
         ok = (p.dim() == 3 and p.is_contiguous() and p.numel() >= _EARLY_ZERO_MIN and p.shape[0] > 1
-              and all(o >= base for o in offs) and cols == (0, 0))
+              and all(o >= base for o in offs) and cols is not None and (cols[0] == 0 or few_dyn))
         if not ok:
             gp.append(_grad_like(lib, p, cfg, i)); rows.append(None); bases.append(0)
             continue
-        # on the caller's stream and pool: it is also where it dies.  (Poisoned in the test tiers, so that a
-        # dynamic column the adjoint skipped cannot pass; the fill below leaves those columns alone.)
-        big = torch.full_like(p, float("nan")) if (_POISON and cols[0]) else torch.empty_like(p)
+        # on the caller's stream and pool: it is also where it dies
+        big = torch.empty_like(p)
         gp.append(big)
         rows.append(torch.zeros_like(p[0]))
         bases.append(base)
-        todo.append((big, cols))
+        todo.append(big)
+        gated = gated or cols[0] != 0
 
     def start():
         if not todo:
@@ -263,14 +268,12 @@ def _overlapped_grad_buffers(lib, cfg: "StepConfig", ptensors, needs):
         side = _side_stream(dev)
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            for big, cols in todo:
-                if cols[0]:
-                    _fill_grad(lib, big, cfg, cols)      # dynamic columns of the call's days: stored by the adjoint
-                else:
-                    _call(lib, 'hbvx_zero', lib.zero, big.data_ptr(), big.numel() * big.element_size(), _stream_of(lib, big))
+            for big in todo:
+                _call(lib, 'hbvx_zero', lib.zero, big.data_ptr(), big.numel() * big.element_size(), _stream_of(lib, big))
             done = torch.cuda.Event()
             done.record(side)
         return done
+    start.gated = gated      # the fill covers columns the adjoint stores: pass the event as store_gate
     return gp, rows, bases, start
 
 
@@ -639,6 +642,8 @@ class HbvPath(torch.autograd.Function):
             io.workspace, io.workspace_bytes = _ptr(ws), ws_bytes
         if start_fill is not None:
             fill_done = start_fill()           # beside the adjoint kernels, behind the routing adjoint
+            if fill_done is not None and start_fill.gated:
+                io.store_gate = fill_done.cuda_event      # the storing kernel waits for the fill; the others do not
         _call(lib, 'hbvx_backward', lib.backward, desc, io, stream)
         join()
 
@@ -797,6 +802,8 @@ class HbvAdjPath(torch.autograd.Function):
             ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
             io.workspace, io.workspace_bytes = _ptr(ws), ws_bytes
         fill_done = start_fill() if start_fill is not None else None     # beside the adjoint kernels
+        if fill_done is not None and start_fill.gated:
+            io.store_gate = fill_done.cuda_event
         _call(lib, 'hbvx_adj_backward', lib.adj_backward, desc, io, stream)
         if fill_done is not None:
             torch.cuda.current_stream(dev).wait_event(fill_done)

@@ -17,7 +17,9 @@ ADJ_H = os.path.join(os.path.dirname(HERE), "hydrodl2_amd", "csrc", "hbv_adj_ste
 
 @pytest.fixture(scope="module")
 def steptest_lib():
-    newest = max(os.path.getmtime(SRC), os.path.getmtime(STEP_H), os.path.getmtime(ADJ_H))
+    deps = [SRC, STEP_H, ADJ_H, os.path.join(os.path.dirname(HERE), "include", "hbvx.h"),
+            os.path.join(os.path.dirname(HERE), "hydrodl2_amd", "csrc", "hbv_step_hourly.h")]
+    newest = max(os.path.getmtime(f) for f in deps)
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < newest:
         subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-std=c++17",
                                "-ffp-contract=off", "-o", LIB, SRC, "-ldl"])
