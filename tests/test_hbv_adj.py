@@ -63,6 +63,9 @@ CASES = [
          cfg=dict(nmul=16, warm_up=10, dynamic_params={"HbvAdj": ["parBETA", "parBETAET"]})),
     dict(T=36, B=6, M=3, seed=83, cold=True, scale=2.0,
          cfg=dict(nmul=3, dy_drop=0.5, dynamic_params={"HbvAdj": ["parK0", "parFC", "parBETAET"]})),
+    # a 40-day warm-up: long enough for the pipelined kernel, which then runs WITHOUT a flux output and is
+    # differentiated through (hbv_adj.py:257-274), followed by 50 main days with a dynamic snow parameter
+    dict(T=90, B=5, M=16, seed=84, cfg=dict(nmul=16, warm_up=40, dynamic_params={"HbvAdj": ["parCFMAX"]})),
 ]
 
 
