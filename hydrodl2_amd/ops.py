@@ -379,6 +379,15 @@ def _fill_desc(cfg: StepConfig, x, state_in, muwts, ac, elev, ptensors) -> _abi.
     return _abi.Desc.from_buffer(buf)      # the struct keeps `buf` alive
 
 
+def _cached(cfg: StepConfig, key, fn):
+    """Per-config memo for the library's size / layout queries (functions of the shape, not of the pointers)."""
+    memo = cfg.__dict__.setdefault("_memo", {})
+    v = memo.get(key)
+    if v is None:
+        v = memo[key] = fn()
+    return v
+
+
 def _route_desc(cfg: StepConfig, ptensors, S: int = 4) -> _abi.RouteDesc:
     r = _abi.RouteDesc()
     rs = cfg.route
@@ -443,7 +452,8 @@ def _hbv_forward(ctx, cfg: StepConfig, x, state_in, muwts, ac, elev, ptensors):
     else:
         traj = _out((5, T + 1, B * M), dev) if keep else None
         aux = _out((2, T, B * M), dev) if needs_grad else None
-        layout = lib.preferred_traj_layout(desc) if (keep and cfg.want_flux) else _abi.TRAJ_ROWS
+        layout = (_cached(cfg, ("layout", x.stride(0), x.stride(1)), lambda: lib.preferred_traj_layout(desc))
+                  if (keep and cfg.want_flux) else _abi.TRAJ_ROWS)
     out.flux, out.state_out = _ptr(flux), _ptr(state_out)
     out.traj, out.aux = _ptr(traj), _ptr(aux)
     out.n_flux, out.traj_layout = cfg.n_flux, layout
@@ -581,7 +591,7 @@ class HbvPath(torch.autograd.Function):
                 gq[n_live:].zero_()
             rs = cfg.route
             gt = gp[rs.tensor_idx]
-            ws_bytes = lib.route_workspace_bytes(r)
+            ws_bytes = _cached(cfg, ("route_ws", n_live), lambda: lib.route_workspace_bytes(r))
             ws = torch.empty((max(ws_bytes, 4) + 3) // 4, dtype=torch.float32, device=dev)
             g_routed = g_routed.contiguous()
             _call(lib, 'hbvx_route_backward', lib.route_backward, r, _ptr(flux), _ptr(uh),
@@ -633,10 +643,12 @@ class HbvPath(torch.autograd.Function):
                 if ps.dyn_off >= 0 and gp[ps.dyn_tensor_idx] is not None:
                     gp[ps.dyn_tensor_idx].zero_()
             return (None, gx, None, gmu, None, None, *gp)
-        if (ctx.traj_layout & 0xFF) == _abi.TRAJ_CKPT:
-            ws_bytes = lib.ckpt_workspace_bytes(desc, ctx.traj_layout >> 8)     # block-wise re-materialisation
+        if (ctx.traj_layout & 0xFF) == _abi.TRAJ_CKPT:    # block-wise re-materialisation
+            ws_bytes = _cached(cfg, ("ckpt_ws", ctx.traj_layout), lambda: lib.ckpt_workspace_bytes(desc, ctx.traj_layout >> 8))
+        elif ctx.traj_layout == _abi.TRAJ_ROWS:
+            ws_bytes = _cached(cfg, "bwd_ws", lambda: lib.backward_workspace_bytes(desc))
         else:
-            ws_bytes = lib.backward_workspace_bytes(desc) if ctx.traj_layout == _abi.TRAJ_ROWS else 0   # packed: single pass
+            ws_bytes = 0                                     # packed: single pass
         if ws_bytes:
             ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
             io.workspace, io.workspace_bytes = _ptr(ws), ws_bytes
