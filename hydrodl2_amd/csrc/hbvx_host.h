@@ -32,6 +32,23 @@ static const int LDS_BUDGET = 160 * 1024 - 512; // gfx950: 160 KiB per CU, one w
 bool try_fwd_pipe(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream, int *rc);
 // launch_stream.hip
 bool try_fwd_stream(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream, int *rc, bool any_size = false);
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device, size) and thread instead of once per
+// launch: the attribute sticks, and the call is a driver round trip on the enqueue path of every step.
+inline hipError_t set_dynamic_lds(const void *kern, int lds)
+{
+    struct Entry { const void *k; int dev, lds; };
+    static thread_local Entry seen[16];
+    static thread_local int n_seen = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    for (int i = 0; i < n_seen; i++)
+        if (seen[i].k == kern && seen[i].dev == dev && seen[i].lds == lds) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) {
+        seen[n_seen < 16 ? n_seen++ : (n_seen = 1, 0)] = Entry{kern, dev, lds};
+    }
+    return e;
+}
 // hbvx_bwd_io.store_gate: make `st` wait for the caller's event before a kernel that stores gradients is launched
 inline void store_gate(const hbvx_bwd_io *io, hipStream_t st)
 {

@@ -69,8 +69,7 @@ template <typename Args, typename K>
 static hipError_t launch_tiled_one(K kern, const Args &a, dim3 grid, int threads, size_t lds,
                                    hipStream_t st)
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = set_dynamic_lds(reinterpret_cast<const void *>(kern), (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, grid, dim3(threads), lds, st, a);
     return hipGetLastError();
