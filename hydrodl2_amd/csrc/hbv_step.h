@@ -268,6 +268,24 @@ HBVX_HD float pow_fast_(float x, float y)   // x a normal positive number (the c
 #endif
 }
 
+// The powers of the time step whose RESULT is clamped to [0, 1] right away -- soil wetness (SM/FC)**BETA and the
+// evaporation factor (hbv.py:462-465,474-477) -- or lies there by construction (the hourly infiltration decay).
+// HBVX_POW_UNIT_FAST: 2^(y log2 x) straight on the hardware transcendentals (pow_fast_).  What the 2-ulp
+// arrangement of pow_core_ buys is RELATIVE accuracy for results far from 1; on [0, 1] the plain form is as good in
+// ABSOLUTE terms (|error| <= 2^z |z| 2^-23 <= 7e-8 for every z <= 0, and ~1 ulp near the clamp at 1 where |z| is
+// small; exact at x == 1), and an absolute error is what the fluxes see: rech = (RAIN + tosoil) sw.
+#ifndef HBVX_POW_UNIT_FAST
+#define HBVX_POW_UNIT_FAST 1
+#endif
+HBVX_HD float pow_unit_(float x, float y)
+{
+#if HBVX_POW_UNIT_FAST && !defined(HBVX_POW_F64)
+    return pow_fast_(fmax_(x, 1.17549435e-38f), y);
+#else
+    return pow_step_(x, y);
+#endif
+}
+
 // natural log for the adjoint's d(x**y)/dy = x**y ln x: gradients are compared at rtol 1e-3,
 // the hardware v_log_f32 (1 ulp on log2) is ample.
 HBVX_HD float log_fast_(float v)
@@ -356,7 +374,7 @@ struct Step {
     {
         const float BETA = p[P_BETA], FC = p[P_FC], LP = p[P_LP];
         r = div_(SM, FC);
-        sw0 = USE_AUX ? aux_sw0 : pow_step_(r, BETA);
+        sw0 = USE_AUX ? aux_sw0 : pow_unit_(r, BETA);
         sw = fmin_(fmax_(sw0, 0.0f), 1.0f);
         rt = RAIN + tosoil;
         rech = rt * sw;
@@ -366,7 +384,7 @@ struct Step {
         SM2 = SM1 - exc;
         lpfc = LP * FC;
         q = div_(SM2, lpfc);
-        if (BETAET) ef0 = USE_AUX ? aux_ef0 : pow_step_(q, p[P_BETAET]);
+        if (BETAET) ef0 = USE_AUX ? aux_ef0 : pow_unit_(q, p[P_BETAET]);
         else ef0 = q;
         ef = fmin_(fmax_(ef0, 0.0f), 1.0f);
         pe = PET * ef;

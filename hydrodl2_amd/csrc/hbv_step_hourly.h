@@ -104,12 +104,12 @@ struct Step<MODEL_HOURLY, BETAET_UNUSED> {
         sc = fmin_(fmax_(r, 0.0f), (float)(1.0 - 0.01));
         fminF = FMIN * F0;
         oms = 1.0f - sc;
-        pw = pow_step_(oms, ALPHA);
+        pw = pow_unit_(oms, ALPHA);
         fcap = fminF + (F0 - fminF) * pw;
         infil = fmin_(W, fcap);
         ie0 = W - fcap;
         IE = fmax_(ie0, 0.0f);
-        sw0 = USE_AUX ? aux_sw0 : pow_step_(r, BETA);
+        sw0 = USE_AUX ? aux_sw0 : pow_unit_(r, BETA);
         sw = fmin_(fmax_(sw0, 0.0f), 1.0f);
         rech = infil * sw;
         SM1 = SMc + (infil - rech) * dt;
@@ -119,7 +119,7 @@ struct Step<MODEL_HOURLY, BETAET_UNUSED> {
         SM2 = SM1 - exc * dt;
         lpfc = LP * FC;
         q = div_(SM2, lpfc);
-        ef0 = USE_AUX ? aux_ef0 : pow_step_(q, BE);
+        ef0 = USE_AUX ? aux_ef0 : pow_unit_(q, BE);
         ef = fmin_(fmax_(ef0, 0.0f), 1.0f);
         pe = PETr * ef;
         pedt = pe * dt;
