@@ -512,7 +512,13 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
             // this wave stages the dynamic rows frow, frow + NF, ... (row k = k-th set bit of dmask);
             // wave 3 also stages the forcings, so with many rows it comes last in the rotation and gets the
             // short share (with at most three rows the order 3, 4, 6 keeps them off the stage waves' SIMDs)
-            const int frow = MANY ? (fidx + NF - 1) % NF : fidx;
+#ifndef PIPE_REBALANCE
+#define PIPE_REBALANCE 1
+#endif
+            // (with at most three rows too, the forcing wave comes last in the rotation: with the delta-MG default of
+            // two dynamic parameters it stages no row at all -- it was the busiest wave of the workgroup, 453 of 489
+            // cycles per day, with forcings AND a row)
+            const int frow = (MANY || PIPE_REBALANCE) ? (fidx + NF - 1) % NF : fidx;
             const float *dsrc[NRW];
             unsigned dvo[NRW];
             int64_t dts[NRW];
@@ -585,7 +591,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                 if (it + 3 < nT) issue(it + 3);
                 PIPE_BARRIER();
             }
-        } else if (quad == 1 || !(quad == 3 ? TRAJ : true)) {
+        } else if ((quad == 1 && !(PIPE_REBALANCE && DYN && !MANY)) || !(quad == 3 ? TRAJ : true)) {
             // the soil wave's SIMD stays free; without a trajectory the row drainers have no work
             PIPE_BARRIER();
             for (int it = 0; it < nIt; it++) PIPE_BARRIER();
@@ -662,8 +668,13 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
         } else {
             // reducers: waves 4, 8, 12 (next to the snow wave) and 6, 10, 14 (next to groundwater);
             // with dynamic parameters 4 and 6 are fillers and the reducers start at wave 8
-            const int w = ((wave - rbase) >> 2) * 2 + (quad == 2 ? 1 : 0);
-            const int NDR = ((nw - rbase + 3) >> 2) + ((nw - rbase - 2 + 3) >> 2);
+            // with few dynamic parameters waves 4 and 6 are fillers and only four reducers are left for the six passes
+            // of a tile (two of them ran 385-439 of 489 cycles per day): the three waves on the soil wave's SIMD
+            // (5, 9, 13), idle otherwise, take the last -- lightest -- passes; the soil wave has the slack (309 of 489)
+            const bool r1 = PIPE_REBALANCE && DYN && !MANY;
+            const int n02 = ((nw - rbase + 3) >> 2) + ((nw - rbase - 2 + 3) >> 2);
+            const int w = quad == 1 ? n02 + ((wave - 5) >> 2) : ((wave - rbase) >> 2) * 2 + (quad == 2 ? 1 : 0);
+            const int NDR = n02 + (r1 ? (nw - 5 + 3) >> 2 : 0);
             PIPE_BARRIER();
             for (int it = 0; it < nIt; it++) {
                 const int tA = it - 1, tB = it - 2, tC = CAP ? it - 2 : it - 3;
