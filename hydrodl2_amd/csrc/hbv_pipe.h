@@ -591,16 +591,24 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                 if (it + 3 < nT) issue(it + 3);
                 PIPE_BARRIER();
             }
-        } else if ((quad == 1 && !(PIPE_REBALANCE && DYN && !MANY)) || !(quad == 3 ? TRAJ : true)) {
+#ifndef PIPE_Q1
+#define PIPE_Q1 2     // what the three waves on the soil wave's SIMD (5, 9, 13) do: 0 idle, 1 reducers (few dynamic
+#endif                // parameters only), 2 row drainers (whenever a trajectory is kept, not with MANY)
+        } else if ((quad == 1 && !(PIPE_Q1 == 1 && DYN && !MANY) && !(PIPE_Q1 == 2 && TRAJ && !MANY)) ||
+                   !(quad == 3 ? TRAJ : true)) {
             // the soil wave's SIMD stays free; without a trajectory the row drainers have no work
             PIPE_BARRIER();
             for (int it = 0; it < nIt; it++) PIPE_BARRIER();
-        } else if (quad == 3) {
+        } else if (quad == 3 || (PIPE_Q1 == 2 && quad == 1 && TRAJ && !MANY)) {
             // row drainers (waves 7, 11, 15): day tt of every stage tile -> 7 rows.  One buffer
             // descriptor per storage series and tile (base = row of the tile's first day, range =
             // the tile's Kt rows: the range check includes the scalar offset), the day inside the
             // tile goes into the scalar offset operand.
-            const int w = (wave - 7) >> 2, NRD = (nw - 7 + 3) >> 2;
+            // (PIPE_Q1 == 2: six drainers -- waves 7, 11, 15 and 5, 9, 13 -- take one or two of a tile's eight days each)
+            constexpr bool SIX = PIPE_Q1 == 2 && !MANY;
+            const int n3 = (nw - 7 + 3) >> 2;
+            const int w = (SIX && quad == 1) ? n3 + ((wave - 5) >> 2) : (wave - 7) >> 2;
+            const int NRD = n3 + (SIX ? (nw - 5 + 3) >> 2 : 0);
             const int64_t SR = (int64_t)(T + 1) * N;   // storage row blocks in traj
             auto rsrc = [&](float *base) {
                 return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(row_bytes * KT), 0x00020000);
@@ -671,7 +679,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
             // with few dynamic parameters waves 4 and 6 are fillers and only four reducers are left for the six passes
             // of a tile (two of them ran 385-439 of 489 cycles per day): the three waves on the soil wave's SIMD
             // (5, 9, 13), idle otherwise, take the last -- lightest -- passes; the soil wave has the slack (309 of 489)
-            const bool r1 = PIPE_REBALANCE && DYN && !MANY;
+            const bool r1 = PIPE_Q1 == 1 && DYN && !MANY;
             const int n02 = ((nw - rbase + 3) >> 2) + ((nw - rbase - 2 + 3) >> 2);
             const int w = quad == 1 ? n02 + ((wave - 5) >> 2) : ((wave - rbase) >> 2) * 2 + (quad == 2 ? 1 : 0);
             const int NDR = n02 + (r1 ? (nw - 5 + 3) >> 2 : 0);

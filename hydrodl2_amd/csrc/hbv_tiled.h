@@ -136,6 +136,23 @@ __device__ __forceinline__ float ens_sum_lane(const float *src, int M, int lgMp,
     return q[0];
 }
 
+// The same sum for full 16-member ensembles (Mp = M = 16: every BASELINE configuration), as straight code: the four
+// 16-byte reads leave together and are waited for once.  ens_sum_lane's general form branches per quad on wave-uniform
+// flags, which makes the compiler wait for every read before it issues the next (4 x ~120 cycles of LDS latency per
+// item: the reducer waves of the pipelined forward were busy 270-315 of its 330-360 cycles per day with that).
+// Same quads, same order, same tree: bit-identical.
+__device__ __forceinline__ float ens_sum_lane16(const float *src, int rot)
+{
+    const float4 a = *reinterpret_cast<const float4 *>(src + 4 * (rot & 3));
+    const float4 b = *reinterpret_cast<const float4 *>(src + 4 * ((rot + 1) & 3));
+    const float4 c = *reinterpret_cast<const float4 *>(src + 4 * ((rot + 2) & 3));
+    const float4 e = *reinterpret_cast<const float4 *>(src + 4 * ((rot + 3) & 3));
+    const float t0 = (a.x + a.y) + (a.z + a.w), t1 = (b.x + b.y) + (b.z + b.w);
+    const float t2 = (c.x + c.y) + (c.z + c.w), t3 = (e.x + e.y) + (e.z + e.w);
+    const bool odd = rot & 1;
+    return (t0 + (odd ? t3 : t1)) + (t2 + (odd ? t1 : t3));
+}
+
 // Reduce `items` (= nt * NFS * bpw) basin-series of an output tile and hand each sum to `emit`.
 // Item e -> (bl = e % bpw, ks = (e / bpw) % NFS, tt = e / (bpw * NFS)); values of item e live at
 // buf[(tt * NSER + ks) * 64 + bl * Mp ...].  One lane per item, 64 items per wave and pass: per
@@ -152,7 +169,7 @@ __device__ __forceinline__ void ens_reduce_pass(const float *buf, int items, int
     const int r = ec >> (6 - lgMp);
     const int ks = r % NFS, tt = r / NFS;
     const float *src = buf + (tt * NSER + ks) * 64 + (bl << lgMp);
-    const float v = ens_sum_lane(src, M, lgMp, r);
+    const float v = (lgMp == 4 && M == 16) ? ens_sum_lane16(src, r) : ens_sum_lane(src, M, lgMp, r);
     if (valid) emit(tt, ks, bl, v);
 }
 
