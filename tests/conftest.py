@@ -48,6 +48,12 @@ def oracle_path():
 
 
 @pytest.fixture()
+def oracle_backend_path(oracle_path):
+    """Path of the oracle library for a test that switches the seam itself (GPU and CPU runs in one test)."""
+    return oracle_path
+
+
+@pytest.fixture()
 def oracle_backend(oracle_path):
     """Route the package's host logic to the CPU oracle (tests only)."""
     from tests import seam

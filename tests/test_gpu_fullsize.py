@@ -160,6 +160,58 @@ def test_hbv2_many_basins(hip_backend):
     torch.testing.assert_close(ps.grad[sel], ps2.grad, rtol=1e-4, atol=1e-6 * float(ps2.grad.abs().max()))
 
 
+def test_cfg5_full_size_on_one_gpu(hip_backend, oracle_backend_path):
+    """BASELINE config 5 at its stated size on ONE GPU: hbv_2, 100 000 basins x 16 members x 730 days, three
+    dynamic parameters (1.17e9 lane-days; ~70 GB of inputs, trajectory and gradients of the 288 GB), forward +
+    backward through the module.  Finite; basins at both ends and in the middle reproduce, bit for bit in the
+    outputs and to rounding in the gradients, what they give as a six-basin problem (which takes other kernels:
+    pipelined forward + time-parallel adjoint instead of the streaming pair); and three of them agree with the CPU
+    oracle."""
+    import hydrodl2_amd
+    from tests import seam
+    dev = torch.device("cuda:0")
+    T, B, M = 730, 100000, 16
+    H2 = hydrodl2_amd.load_model("hbv_2", "Hbv_2")
+    dyn = ["parBETA", "parK0", "parBETAET"]
+    cfgd = {"nmul": M, "dynamic_params": {"Hbv_2": dyn}}
+    model = H2(cfgd, dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(15)
+    x, _, w = _gen(T, B, 1, 15, dev)
+    pd = torch.rand((T, B, 3 * M), generator=g, device=dev).requires_grad_(True)
+    ps = torch.rand((B, 13 * M), generator=g, device=dev).requires_grad_(True)
+    xd = {"x_phy": x, "ac_all": torch.rand(B, generator=g, device=dev) * 5000,
+          "elev_all": torch.rand(B, generator=g, device=dev) * 3000}
+    out = model(xd, (pd, ps))
+    (out["streamflow"] * w).sum().backward()
+    assert out["streamflow"].shape == (T, B, 1)
+    assert torch.isfinite(out["streamflow"]).all() and torch.isfinite(pd.grad).all() and torch.isfinite(ps.grad).all()
+    sel = torch.tensor([0, 3, 49999, 50002, 99996, 99999], device=dev)
+
+    def small(device, lib):
+        seam.use_library(lib)
+        try:
+            pd2 = pd.detach()[:, sel].to(device).contiguous().requires_grad_(True)
+            ps2 = ps.detach()[sel].to(device).contiguous().requires_grad_(True)
+            xd2 = {"x_phy": x[:, sel].to(device).contiguous(), "ac_all": xd["ac_all"][sel].to(device),
+                   "elev_all": xd["elev_all"][sel].to(device)}
+            m2 = H2(cfgd, torch.device(device))
+            o2 = m2(xd2, (pd2, ps2))
+            (o2["streamflow"] * w[:, sel].to(device)).sum().backward()
+            return o2["streamflow"].detach(), pd2.grad, ps2.grad
+        finally:
+            seam.use_library(None)
+
+    q2, gd2, gs2 = small("cuda:0", None)
+    assert torch.equal(out["streamflow"][:, sel], q2)
+    torch.testing.assert_close(pd.grad[:, sel], gd2, rtol=1e-4, atol=1e-6 * float(gd2.abs().max()))
+    torch.testing.assert_close(ps.grad[sel], gs2, rtol=1e-4, atol=1e-6 * float(gs2.abs().max()))
+    qo, gdo, gso = small("cpu", oracle_backend_path)
+    assert_close("streamflow", q2.cpu().numpy(), qo.numpy(), 1e-4, 1e-5)
+    assert_close("g_dyn", gd2.cpu().numpy(), gdo.numpy(), 1e-3, 1e-5)
+    assert_close("g_sta", gs2.cpu().numpy(), gso.numpy(), 1e-3, 1e-5)
+
+
 def _slice_problem(prob, pick):
     """The sub-problem of basins `pick` (every per-basin array of tests/abi_util.make_problem)."""
     sub = dict(prob)
