@@ -21,7 +21,7 @@ LOCAL_RANK / WORLD_SIZE set) or `python bench.py --gpus N` does it itself: the p
 children BEFORE touching the GPU and relays rank 0's JSON line.
 
 Rank 0 prints ONE JSON line.  `value` = whole-job basin-ensemble-timesteps/s.  At N = 1 the line also
-carries `secondary` (configs 2-dyn, 3, 4, one GPU's share of 5 and the deltaMG minibatch shape, driver-timed in the same run) and
+carries `secondary` (configs 2-dyn, 3, 4, one GPU's share of 5, config 5 at full size and the deltaMG minibatch shape, driver-timed in the same run) and
 `cpu_baseline` (the C/OpenMP oracle port and the pure-torch eager restatement on the host cores).
 """
 from __future__ import annotations
@@ -134,6 +134,8 @@ WORKLOADS = {
     "cfg4": ("hbv_adj", "HbvAdj", 7300, 671, 16, ["parBETAET"]),
     "cfg5": ("hbv_2", "Hbv_2", 730, 100000, 16, ["parBETA", "parK0", "parBETAET"]),
     "cfg5share": ("hbv_2", "Hbv_2", 730, 12500, 16, ["parBETA", "parK0", "parBETAET"]),
+    # configs[4] at its stated size on ONE GPU (~70 GB of its 288): what `--config cfg5 --gpus 1` runs
+    "cfg5full": ("hbv_2", "Hbv_2", 730, 100000, 16, ["parBETA", "parK0", "parBETAET"]),
     # the deltaMG minibatch shape of SURVEY §8d: 100 basins, 365 warm-up + 365 days
     "dmg": ("hbv", "Hbv", 730, 100, 16, ["parBETA", "parBETAET"], {"warm_up": 365}),
 }
@@ -646,7 +648,7 @@ def main():
         # the other BASELINE configs under the same clock: 5 timed steps each, same event timing
         sec = []
         print(f"[bench] headline done: {ms_per_step:.3f} ms/step; secondary configs ...", file=sys.stderr, flush=True)
-        for name in ("cfg2dyn", "cfg3", "cfg4", "cfg5share", "dmg"):
+        for name in ("cfg2dyn", "cfg3", "cfg4", "cfg5share", "cfg5full", "dmg"):
             if name == args.config:
                 continue
             try:
