@@ -37,6 +37,14 @@ for grad in (True, False):
         for _ in range(3):
             out = model({"x_phy": x}, pp)
     torch.cuda.synchronize()
+    # kernel time of this (probe) build beside its cycle counts: ticks per microsecond of the counter
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.set_grad_enabled(grad):
+        e0.record()
+        out = model({"x_phy": x}, pp)
+        e1.record()
+    torch.cuda.synchronize()
+    ms_call = e0.elapsed_time(e1)
     buf = (C.c_ulonglong * 32)()
     assert lib.dll.hbvx_debug_pipe_probe(buf) == 0
     print("traj" if grad else "no traj")
@@ -46,6 +54,8 @@ for grad in (True, False):
         v = sorted(x / T for x in blk)
         print(f"  per-workgroup cycles/day (soil wave, {nb} workgroups): min {v[0]:.1f}  median {v[nb // 2]:.1f}  "
               f"p90 {v[int(nb * 0.9)]:.1f}  max {v[-1]:.1f}")
+        print(f"  model call {ms_call:.3f} ms (all its kernels) -> {v[-1] * T / (ms_call * 1e3):.0f} counter ticks per us "
+              f"if the slowest workgroup spanned the whole call")
     roles = ["snow", "soil", "gw", "fill", "fill"] + ["drain"] * 11
     for w in range(16):
         print(f"  wave {w:2d} {roles[w]:6s} busy {buf[2*w]/T:8.1f}  wait {buf[2*w+1]/T:8.1f} counter ticks/step")
