@@ -209,6 +209,25 @@ namespace hbvx {
 
 struct ChunkArgs; // hbv_chunked.h
 
+// What a day of the time-parallel kernels reads, loaded ONE DAY AHEAD of its use (the adjoint runs t1-1 .. t0): the
+// kernels are a wave per (64 lanes, chunk) walking 64 days, and with the loads at the top of the day that consumes
+// them every day paid a full HBM round trip; the dynamic-parameter rows (any subset) stay in the day itself.
+struct AdjRaw {
+    float f[3], x[5], gQ;
+};
+__device__ __forceinline__ void adj_issue(const hbvx_desc &d, const hbvx_bwd_io &io, const AdjLane &L, int t, int64_t N,
+                                          AdjRaw &R)
+{
+    const float *xr = d.x + (int64_t)t * d.x_t_stride + (int64_t)L.b * d.x_b_stride;
+    R.f[0] = xr[d.ch_prcp]; R.f[1] = xr[d.ch_tmean]; R.f[2] = xr[d.ch_pet];
+#pragma unroll
+    for (int k = 0; k < 5; k++) R.x[k] = io.traj[((int64_t)k * (d.T + 1) + (t + 1)) * N + L.n];
+    const int64_t gi = (int64_t)t * d.B + L.b;
+    float g = io.grad_flux ? io.grad_flux[gi] : 0.0f;
+    if (io.grad_flux4) g += io.grad_flux4[gi];
+    R.gQ = g;
+}
+
 template <bool BETAET>
 __global__ void __launch_bounds__(64) k_adj_chunk_phi(const hbvx_desc d, const hbvx_bwd_io io, int lgMp,
                                                       int C, float *phi_ws)
@@ -236,19 +255,18 @@ __global__ void __launch_bounds__(64) k_adj_chunk_phi(const hbvx_desc d, const h
 #pragma unroll
         for (int i = 0; i < 5; i++) Phi[k][i] = (i == k) ? 1.0f : 0.0f;
     }
-    const float *xb = d.x + (int64_t)L.b * d.x_b_stride;
+    AdjRaw Rn;
+    adj_issue(d, io, L, t1 - 1, N, Rn);
     for (int t = t1 - 1; t >= t0; t--) {
+        const AdjRaw Rc = Rn;
+        if (t > t0) adj_issue(d, io, L, t - 1, N, Rn);     // next day's loads in flight
         float u[NP], p[NPARAM_MAX], x[5];
         adj_params<NP>(d, L, t, raw, usta, use_dyn, u, p);
         AdjStep<BETAET> s;
-        const float *xr = xb + (int64_t)t * d.x_t_stride;
-        s.P = xr[d.ch_prcp]; s.Tf = xr[d.ch_tmean]; s.PET = xr[d.ch_pet];
+        s.P = Rc.f[0]; s.Tf = Rc.f[1]; s.PET = Rc.f[2];
 #pragma unroll
-        for (int k = 0; k < 5; k++) x[k] = io.traj[((int64_t)k * (T + 1) + (t + 1)) * N + L.n];
-        const int64_t gi = (int64_t)t * d.B + L.b;
-        float gQ = io.grad_flux ? io.grad_flux[gi] : 0.0f;
-        if (io.grad_flux4) gQ += io.grad_flux4[gi];
-        gQ *= invM;
+        for (int k = 0; k < 5; k++) x[k] = Rc.x[k];
+        const float gQ = Rc.gQ * invM;
         s.template eval<true>(x, p);
         float lam[5];
 #pragma unroll
@@ -298,19 +316,18 @@ __global__ void __launch_bounds__(64) k_adj_chunk_sweep(const hbvx_desc d, const
     float a[5];
 #pragma unroll
     for (int k = 0; k < 5; k++) a[k] = abnd[((int64_t)chunk * 5 + k) * N + L.n];
-    const float *xb = d.x + (int64_t)L.b * d.x_b_stride;
+    // (no one-day-ahead prefetch here: its nine registers take this kernel from 165 to 171 VGPRs, i.e. from three waves
+    // per SIMD to two -- measured 3.53 instead of 3.15 ms for the adjoint of config 4)
     for (int t = t1 - 1; t >= t0; t--) {
+        AdjRaw Rc;
+        adj_issue(d, io, L, t, N, Rc);
         float u[NP], p[NPARAM_MAX], x[5], gp[NPARAM_MAX];
         adj_params<NP>(d, L, t, raw, usta, use_dyn, u, p);
         AdjStep<BETAET> s;
-        const float *xr = xb + (int64_t)t * d.x_t_stride;
-        s.P = xr[d.ch_prcp]; s.Tf = xr[d.ch_tmean]; s.PET = xr[d.ch_pet];
+        s.P = Rc.f[0]; s.Tf = Rc.f[1]; s.PET = Rc.f[2];
 #pragma unroll
-        for (int k = 0; k < 5; k++) x[k] = io.traj[((int64_t)k * (T + 1) + (t + 1)) * N + L.n];
-        const int64_t gi = (int64_t)t * d.B + L.b;
-        float gQ = io.grad_flux ? io.grad_flux[gi] : 0.0f;
-        if (io.grad_flux4) gQ += io.grad_flux4[gi];
-        gQ *= invM;
+        for (int k = 0; k < 5; k++) x[k] = Rc.x[k];
+        const float gQ = Rc.gQ * invM;
 #pragma unroll
         for (int i = 0; i < NPARAM_MAX; i++) gp[i] = 0.0f;
         adj_backstep<BETAET>(s, p, x, 1.0f, gQ, a, gp);

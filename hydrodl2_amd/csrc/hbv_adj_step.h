@@ -71,7 +71,7 @@ struct AdjStep {
         Isnow = fmax_(ts0, 0.0f);
         // :470-474 effective precipitation
         r = div_(SM, FC);
-        sw0 = pow_step_(r, BETA);
+        sw0 = pow_unit_(r, BETA);
         sw = fmin_(fmax_(sw0, 0.0f), 1.0f);
         const float rt = rf + Isnow;
         Peff = rt * sw;
@@ -81,7 +81,7 @@ struct AdjStep {
         // :481-486 evapotranspiration
         const float lpfc = LP * FC;
         qe = div_(SM, lpfc);
-        ef0 = BETAET ? pow_step_(qe, p[P_BETAET]) : qe;
+        ef0 = BETAET ? pow_unit_(qe, p[P_BETAET]) : qe;
         ef = fmin_(fmax_(ef0, 0.0f), 1.0f);
         pe = PET * ef;
         et = fmin_(SM, pe);
