@@ -48,6 +48,13 @@ namespace hbvx {
 #define PIPE_KT_MANY 4  // ... with more: the staged parameter rows need the LDS
 #define PIPE_FEWDYN 3   // rows staged one per filler wave
 #define PIPE_MAXDYN 18  // rows staged at most (shared by the three or four filler waves)
+// Helper roles, switchable for A/B builds (tools/build_variant.sh; the defaults are what was measured best):
+#ifndef PIPE_REBALANCE
+#define PIPE_REBALANCE 1   // the forcing filler comes last in the row rotation also with <= 3 dynamic rows
+#endif
+#ifndef PIPE_Q1
+#define PIPE_Q1 2          // the three waves on the soil wave's SIMD (5, 9, 13): 0 idle, 1 reducers (few dynamic
+#endif                     // parameters only), 2 row drainers (whenever a trajectory is kept, not with MANY)
 
 // Run `body(tt, has_next)` for the nt days of a tile; full tiles are unrolled so that every LDS
 // address is base + immediate and the loop-carried registers need no rotation moves.
@@ -512,9 +519,6 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
             // this wave stages the dynamic rows frow, frow + NF, ... (row k = k-th set bit of dmask);
             // wave 3 also stages the forcings, so with many rows it comes last in the rotation and gets the
             // short share (with at most three rows the order 3, 4, 6 keeps them off the stage waves' SIMDs)
-#ifndef PIPE_REBALANCE
-#define PIPE_REBALANCE 1
-#endif
             // (with at most three rows too, the forcing wave comes last in the rotation: with the delta-MG default of
             // two dynamic parameters it stages no row at all -- it was the busiest wave of the workgroup, 453 of 489
             // cycles per day, with forcings AND a row)
@@ -591,9 +595,6 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                 if (it + 3 < nT) issue(it + 3);
                 PIPE_BARRIER();
             }
-#ifndef PIPE_Q1
-#define PIPE_Q1 2     // what the three waves on the soil wave's SIMD (5, 9, 13) do: 0 idle, 1 reducers (few dynamic
-#endif                // parameters only), 2 row drainers (whenever a trajectory is kept, not with MANY)
         } else if ((quad == 1 && !(PIPE_Q1 == 1 && DYN && !MANY) && !(PIPE_Q1 == 2 && TRAJ && !MANY)) ||
                    !(quad == 3 ? TRAJ : true)) {
             // the soil wave's SIMD stays free; without a trajectory the row drainers have no work
