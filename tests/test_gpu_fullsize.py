@@ -334,3 +334,35 @@ def test_gradient_fill_schedules_are_equivalent(mode, hip_backend, monkeypatch):
     assert torch.equal(s0, s1)
     assert torch.equal(g0, g1)
     assert float(g1[:-1].abs().max()) == 0.0 and float(g1[-1].abs().max()) > 0.0
+
+
+@pytest.mark.parametrize("dy_drop", [0.0, 0.4])
+def test_gated_fill_with_dynamic_columns_is_equivalent(dy_drop, hip_backend, monkeypatch):
+    """A gradient tensor with FEW dynamic columns (BETA + BETAET of 13 parameters: the delta-MG default) is filled
+    densely on the second stream beside the reading passes of the adjoint, and the adjoint's storing kernel waits for
+    the fill through hbvx_bwd_io.store_gate.  Bit-identical to the plain fill-then-adjoint order -- without the gate
+    the two race (that was measured: wrong gradients) -- also with dy_drop masks, whose dropped basins accumulate
+    into the separate static row."""
+    import hydrodl2_amd
+    from hydrodl2_amd import ops
+    dev = torch.device("cuda:0")
+    T, B, M = 400, 1000, 16
+    conf = {"nmul": M, "dy_drop": dy_drop, "dynamic_params": {"Hbv": ["parBETA", "parBETAET"]}}
+    model = hydrodl2_amd.load_model("hbv", "Hbv")(conf, dev)
+    x, p, w = _gen(T, B, model.learnable_param_count, 23, dev)
+    assert p.numel() >= ops._EARLY_ZERO_MIN
+
+    def run(overlap):
+        monkeypatch.setattr(ops, "_FILL_OVERLAP", overlap)
+        torch.manual_seed(3)        # the dy_drop masks come from the CPU generator
+        out, grad = _fwd_bwd(model, x, p, w, keys=("streamflow",))
+        return out["streamflow"].detach().clone(), grad.clone()
+    s0, g0 = run(False)
+    for _ in range(3):              # a race would not show every time
+        s1, g1 = run(True)
+        assert torch.equal(s0, s1)
+        assert torch.equal(g0, g1)
+    dyn_cols = torch.zeros(p.shape[-1], dtype=torch.bool, device=dev)
+    dyn_cols[0:M] = True
+    dyn_cols[12 * M:13 * M] = True
+    assert float(g1[:-1][:, :, ~dyn_cols].abs().max()) == 0.0 and float(g1[:-1][:, :, dyn_cols].abs().max()) > 0.0
