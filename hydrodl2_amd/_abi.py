@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 MAX_PARAM = 20
 GAGE_MAXLEN = 72
 NSTATE = 5
@@ -178,6 +178,8 @@ class Library:
                 raise HbvxError(f"{path}: layout mismatch for {st.__name__}: "
                                 f"{d.hbvx_sizeof(which)} != {C.sizeof(st)}")
         self.backend = d.hbvx_backend().decode()
+        # A/B builds with -DHBVX_SAVE_POW=1 (csrc/hbv_step.h) want the `aux` rows next to the trajectory
+        self.saves_pow = "+savepow" in self.backend
 
     @property
     def is_device(self) -> bool:

@@ -3,7 +3,7 @@
 // The forward recurrence is nonlinear and strictly serial in time, but its adjoint
 //     a_t = J_t^T a_{t+1} + c_t        (a_t = dL/d(storages entering day t); c_t from dL/d(flux_t))
 // is LINEAR in a, and J_t, c_t depend only on the saved trajectory.  With the trajectory in HBM
-// (hbvx_fwd_out.traj/aux) the 7300-day chain therefore splits into independent chunks:
+// (hbvx_fwd_out.traj) the 7300-day chain therefore splits into independent chunks:
 //
 //   B1 k_bwd_chunk_phi    per (64 lanes, chunk of C days), all chunks in parallel: sweep the chunk
 //                         backwards propagating the 5 unit adjoints and the offset, i.e. build
@@ -101,7 +101,7 @@ template <int NP>
 struct ChunkRaw {
     float f[3];      // P, T, PET
     float st[5];     // storages entering the day
-    float sw0, ef0;  // saved pow results
+    float sw0, ef0;  // saved pow results (HBVX_SAVE_POW builds only)
     float gf[HBVX_MAX_FLUX];
     float dv[NP];    // raw dynamic-parameter values
     float mu;
@@ -153,9 +153,13 @@ __device__ __forceinline__ void chunk_issue(const hbvx_desc &d, const hbvx_bwd_i
     const int64_t ks = (int64_t)(T + 1) * N;
 #pragma unroll
     for (int k = 0; k < 5; k++) R.st[k] = tp[k * ks];
-    const float *ap = io.aux + (int64_t)t * N + L.n;
-    R.sw0 = ap[0];
-    R.ef0 = ap[(int64_t)T * N];
+    if (SAVE_POW) {
+        const float *ap = io.aux + (int64_t)t * N + L.n;
+        R.sw0 = ap[0];
+        R.ef0 = ap[(int64_t)T * N];
+    } else {
+        R.sw0 = R.ef0 = 0.0f;   // recomputed by chunk_finish (HBVX_SAVE_POW, hbv_step.h)
+    }
     const int64_t fs = (int64_t)T * d.B, go = (int64_t)t * d.B + L.b;
 #pragma unroll
     for (int k = 0; k < HBVX_MAX_FLUX; k++) {
@@ -239,7 +243,7 @@ __device__ __forceinline__ void chunk_finish(const hbvx_desc &d, const ChunkRaw<
     }
 #pragma unroll
     for (int i = NP; i < NPARAM_MAX; i++) D.p[i] = 0.0f;
-    D.s.template fwd<true>(D.p, nz, ac, elev, R.sw0, R.ef0);
+    D.s.template fwd<SAVE_POW>(D.p, nz, ac, elev, R.sw0, R.ef0);
     D.gq = R.gf[HBVX_F_QSIM];
     const float wq = (DYN == 2 && d.muwts) ? R.mu : invM;
     D.g.gQ = D.gq * wq;

@@ -299,8 +299,10 @@ __global__ void __launch_bounds__(64) k_ckpt_remat(const RematArgs A)
         if (L.active) {
 #pragma unroll
             for (int k = 0; k < 5; k++) A.traj[((int64_t)k * (tb + 1) + l) * N + L.n] = st[k];
-            A.aux[(int64_t)l * N + L.n] = s.sw0;
-            A.aux[((int64_t)tb + l) * N + L.n] = s.ef0;
+            if (SAVE_POW) {
+                A.aux[(int64_t)l * N + L.n] = s.sw0;
+                A.aux[((int64_t)tb + l) * N + L.n] = s.ef0;
+            }
         }
         st[0] = s.SP3; st[1] = s.MW3; st[2] = s.SM4; st[3] = s.SUZ4; st[4] = s.SLZ2;
     }

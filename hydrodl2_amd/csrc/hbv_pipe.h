@@ -143,7 +143,7 @@ __device__ __forceinline__ constexpr int pipe_sc_flag(int X)
 #define DY_LOAD(X, ptr) do { pn_##X = (ptr)[ix_##X]; } while (0)
 #define DY_USE(X) do { p[X] = dy_##X ? pn_##X : p[X]; } while (0)
 
-// TRAJ: the forward also saves the storage trajectory and the pow results (traj and aux given).
+// TRAJ: the forward also saves the storage trajectory (and, in HBVX_SAVE_POW builds, the pow results: traj and aux given).
 // DYN: parameters vary per day: filler waves de-scale them (sigmoid, range, dy_drop blend) into LDS
 // tiles five deep (snow reads tile it, groundwater tile it-2, the fillers write it+2).
 // MANY: more than PIPE_FEWDYN of them: 4-day tiles, the filler waves share the rows round-robin.
@@ -334,7 +334,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                     }
                     float *q = ob + tt * OBR * 64;
                     q[0] = s.ET; q[64] = s.rech; q[128] = s.exc; q[192] = s.ef; q[256] = s.cap;
-                    if (TRAJ) { q[320] = SM; q[384] = s.sw0; q[448] = s.ef0; }
+                    if (TRAJ) { q[320] = SM; if (SAVE_POW) { q[384] = s.sw0; q[448] = s.ef0; } }
                     float *r = oc + tt * 448;
                     r[0] = s.Q; r[64] = s.Q0; r[128] = s.Q1; r[192] = s.Q2; r[256] = s.PERC;
                     if (TRAJ) { r[320] = SUZ; r[384] = SLZ; }
@@ -402,7 +402,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                         bc[tt * 128] = s.rech;
                         bc[tt * 128 + 64] = s.exc;
                         q[0] = s.ET; q[64] = s.rech; q[128] = s.exc; q[192] = s.ef;
-                        if (TRAJ) { q[256] = SM; q[320] = s.sw0; q[384] = s.ef0; }
+                        if (TRAJ) { q[256] = SM; if (SAVE_POW) { q[320] = s.sw0; q[384] = s.ef0; } }
                         SM = s.SM3;
                     }
                 };
@@ -630,8 +630,8 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                 const int64_t dA = (int64_t)max(tA, 0) * Kt * N, dB = (int64_t)max(tB, 0) * Kt * N,
                               dC = (int64_t)max(tC, 0) * Kt * N;
                 const auto rSP = rsrc(o.traj + dA), rMW = rsrc(o.traj + SR + dA);
-                const auto rSM = rsrc(o.traj + 2 * SR + dB), rSW = rsrc(o.aux + dB),
-                           rEF = rsrc(o.aux + (int64_t)T * N + dB);
+                const auto rSM = rsrc(o.traj + 2 * SR + dB), rSW = rsrc((SAVE_POW ? o.aux : o.traj) + dB),
+                           rEF = rsrc((SAVE_POW ? o.aux : o.traj) + (int64_t)T * N + dB);
                 const auto rSUZ = rsrc(o.traj + 3 * SR + dC), rSLZ = rsrc(o.traj + 4 * SR + dC);
                 if (A.ckptK) {
                     // checkpoints: of each stage tile only the days that are multiples of K, into
@@ -658,17 +658,18 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                 }
                 for (int tt = w; tt < Kt; tt += NRD) {
                     const unsigned soff = (unsigned)tt * row_bytes;
-                    float a0, a1, b0v, b1, b2, c0, c1;
+                    float a0, a1, b0v, b1 = 0.0f, b2 = 0.0f, c0, c1;
                     if (tt < ntA) { a0 = bufA[tt * 256 + 128]; a1 = bufA[tt * 256 + 192]; }
                     if (tt < ntB) {
                         const float *rb = bufB + (tt * OBR + NFB) * 64;
-                        b0v = rb[0]; b1 = rb[64]; b2 = rb[128];
+                        b0v = rb[0];
+                        if (SAVE_POW) { b1 = rb[64]; b2 = rb[128]; }
                     }
                     if (tt < ntC) { c0 = bufC[tt * 448 + 320]; c1 = bufC[tt * 448 + 384]; }
                     if (tt < ntA) { put(rSP, soff, a0); put(rMW, soff, a1); }
                     if (tt < ntB) {
                         put(rSM, soff, b0v);
-                        if (!ADJ) { put(rSW, soff, b1); put(rEF, soff, b2); }   // the implicit scheme keeps no powers
+                        if (SAVE_POW && !ADJ) { put(rSW, soff, b1); put(rEF, soff, b2); }   // the implicit scheme keeps no powers
                     }
                     if (tt < ntC) { put(rSUZ, soff, c0); put(rSLZ, soff, c1); }
                 }

@@ -286,6 +286,17 @@ HBVX_HD float pow_unit_(float x, float y)
 #endif
 }
 
+// HBVX_SAVE_POW: whether the forward keeps the two pre-clamp powers of a lane-day, (SM/FC)**BETA and the
+// evaporation factor, next to the trajectory (hbvx_fwd_out.aux, 8 of 28 bytes per lane-day) for the adjoint.
+// That paid while a power cost ~16 dependent instructions; with pow_unit_ it is log, multiply, exp, and the adjoint
+// passes run beside a 3.8 GB gradient fill that wants the same HBM.  Default 0: nothing is
+// written to or read from `aux`, the adjoint recomputes both powers with the forward's own instruction sequence
+// -- the same bits, so every clamp predicate matches.  1 restores the saved rows (A/B builds only).
+#ifndef HBVX_SAVE_POW
+#define HBVX_SAVE_POW 0
+#endif
+constexpr bool SAVE_POW = HBVX_SAVE_POW != 0;
+
 // natural log for the adjoint's d(x**y)/dy = x**y ln x: gradients are compared at rtol 1e-3,
 // the hardware v_log_f32 (1 ulp on log2) is ample.
 HBVX_HD float log_fast_(float v)

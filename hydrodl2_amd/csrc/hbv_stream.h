@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(64) k_fwd_stream(const StreamArgs A)
         }
     }
     // outputs
-    const auto rtraj = rsrc(o.traj), raux = rsrc(o.aux), rflux = rsrc(o.flux);
+    const auto rtraj = rsrc(o.traj), raux = rsrc(SAVE_POW ? o.aux : o.traj), rflux = rsrc(o.flux);
     unsigned tvo[5], avo[2];
 #pragma unroll
     for (int k = 0; k < 5; k++) tvo[k] = (TRAJ && L.active) ? (unsigned)((k * (int64_t)(T + 1) * N + L.n) * 4) : OOB;
@@ -181,8 +181,10 @@ __global__ void __launch_bounds__(64) k_fwd_stream(const StreamArgs A)
         if (TRAJ && !(STREAM_EXP & 4)) {
 #pragma unroll
             for (int k = 0; k < 5; k++) bstore(rtraj, tvo[k], so, st[k]);
-            bstore(raux, avo[0], so, s.sw0);
-            bstore(raux, avo[1], so, s.ef0);
+            if (SAVE_POW) {
+                bstore(raux, avo[0], so, s.sw0);
+                bstore(raux, avo[1], so, s.ef0);
+            }
         }
         st[0] = s.SP3; st[1] = s.MW3; st[2] = s.SM4; st[3] = s.SUZ4; st[4] = s.SLZ2;
         const float act = L.active ? 1.0f : 0.0f;
@@ -294,7 +296,7 @@ __global__ void __launch_bounds__(64) k_bwd_stream(const StreamBwdArgs A)
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, vo, so, 0);
     };
 
-    const auto rx = rsrc(d.x), rtraj = rsrc(io.traj), raux = rsrc(io.aux);
+    const auto rx = rsrc(d.x), rtraj = rsrc(io.traj), raux = rsrc(SAVE_POW ? io.aux : io.traj);
     const auto rgf = rsrc(io.grad_flux ? io.grad_flux : io.grad_flux4);
     const auto rg4 = rsrc(io.grad_flux4 ? io.grad_flux4 : io.grad_flux);
     const bool has_gf = io.grad_flux != nullptr, has_g4 = io.grad_flux4 != nullptr;
@@ -349,7 +351,8 @@ __global__ void __launch_bounds__(64) k_bwd_stream(const StreamBwdArgs A)
         fx[j][0] = bload(rx, xvo, so + xcp); fx[j][1] = bload(rx, xvo, so + xct); fx[j][2] = bload(rx, xvo, so + xce);
 #pragma unroll
         for (int k = 0; k < 5; k++) st[j][k] = bload(rtraj, tvo[k], sr);
-        ax[j][0] = bload(raux, avo[0], sr); ax[j][1] = bload(raux, avo[1], sr);
+        if (SAVE_POW) { ax[j][0] = bload(raux, avo[0], sr); ax[j][1] = bload(raux, avo[1], sr); }
+        else ax[j][0] = ax[j][1] = 0.0f;
 #pragma unroll
         for (int k = 0; k < NG; k++) {
             float v = 0.0f;
@@ -375,7 +378,7 @@ __global__ void __launch_bounds__(64) k_bwd_stream(const StreamBwdArgs A)
                     p[A.dslot[k]] = duse[k] ? descale_(ud[k], dlo[k], dhi[k]) : dsta[k];
                 }
         }
-        s.template fwd<true>(p, nz, ac, elev, ax[j][0], ax[j][1]);
+        s.template fwd<SAVE_POW>(p, nz, ac, elev, ax[j][0], ax[j][1]);
         FluxGrad g;
         auto GF = [&](int k) -> float { return k < NG ? gf[j][k] * invM : 0.0f; };
         g.gQ = GF(HBVX_F_QSIM); g.gQ0 = GF(HBVX_F_Q0); g.gQ1 = GF(HBVX_F_Q1); g.gQ2 = GF(HBVX_F_Q2);

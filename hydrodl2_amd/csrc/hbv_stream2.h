@@ -7,9 +7,9 @@
 // latency at low occupancy (one wave alone issues a dependent fp32 chain at ~10 cycles per
 // instruction, independent work at ~2.9; tools/micro/issue_rate.hip).  Hence:
 //
-//   * packed trajectory (HBVX_TRAJ_PACKED): per lane-day one 16-byte record (SP, MW, SM, SUZ), one
-//     4-byte SLZ row and one 8-byte record of the two saved powers -- 3 stores in the forward and 3
-//     loads in the adjoint instead of 7 + 7, inside the same two caller buffers;
+//   * packed trajectory (HBVX_TRAJ_PACKED): per lane-day one 16-byte record (SP, MW, SM, SUZ) and one
+//     4-byte SLZ row (HBVX_SAVE_POW builds: plus one 8-byte record of the two saved powers) -- 2 (3) stores
+//     in the forward and 2 (3) loads in the adjoint instead of 5 + 5 (7 + 7), inside the same caller buffer;
 //   * one flux store per day: after the ensemble butterflies every lane of a basin holds every mean;
 //     member lane j keeps series j and the wave writes 12 series x 4 basins with ONE store;
 //   * the three forcings of a basin in one 12-byte load when their channels are adjacent;
@@ -402,8 +402,10 @@ __global__ void __launch_bounds__(MW * 64) FWPE k_fwd_stream2(const StreamArgs A
             const unsigned so = (unsigned)t * row4;
 #pragma unroll
             for (int k = 0; k < 5; k++) S2Buf::st(rtraj, tvo[k], so, st[k]);
-            S2Buf::st(raux, avo[0], so, s.sw0);
-            S2Buf::st(raux, avo[1], so, s.ef0);
+            if (SAVE_POW) {
+                S2Buf::st(raux, avo[0], so, s.sw0);
+                S2Buf::st(raux, avo[1], so, s.ef0);
+            }
         }
         if (TRJ == 3) {
             if ((t & (ckK - 1)) == 0) {   // wave-uniform
@@ -420,7 +422,7 @@ __global__ void __launch_bounds__(MW * 64) FWPE k_fwd_stream2(const StreamArgs A
             const int64_t tN = (int64_t)t * N;
             if (!(STREAM2_EXP & 8)) S2Buf::st4(S2Buf::words(o.traj + tN * 4), pvo4, 0u, rec);
             if (!(STREAM2_EXP & 16)) S2Buf::sts(S2Buf::rsrc(slz0 + tN), pvo1, 0u, st[4]);
-            if (!(STREAM2_EXP & 32)) S2Buf::sts2(S2Buf::rsrc(o.aux + tN * 2), pvo2, 0u, pw);
+            if (SAVE_POW && !(STREAM2_EXP & 32)) S2Buf::sts2(S2Buf::rsrc(o.aux + tN * 2), pvo2, 0u, pw);
         }
         st[0] = s.SP3; st[1] = s.MW3; st[2] = s.SM4; st[3] = s.SUZ4; st[4] = s.SLZ2;
         const float act = L.active ? 1.0f : 0.0f;
@@ -601,7 +603,7 @@ k_bwd_stream2(const StreamBwdArgs A)
 #endif
     }
 
-    const auto rx = S2Buf::rsrc(d.x), rtraj = S2Buf::rsrc(io.traj), raux = S2Buf::rsrc(io.aux);
+    const auto rx = S2Buf::rsrc(d.x), rtraj = S2Buf::rsrc(io.traj), raux = S2Buf::rsrc(SAVE_POW ? io.aux : io.traj);
     const float *const slz0 = io.traj + 4 * (int64_t)(T + 1) * N;   // packed layout: the SLZ rows
     const auto rgf = S2Buf::rsrc(io.grad_flux ? io.grad_flux : io.grad_flux4);
     const auto rg4 = S2Buf::rsrc(io.grad_flux4 ? io.grad_flux4 : io.grad_flux);
@@ -669,13 +671,16 @@ k_bwd_stream2(const StreamBwdArgs A)
             const s2_f4 rec = S2Buf::ld4(S2Buf::rsrc(io.traj + tN * 4), pvo4, 0u);
             I.st[0] = rec.x; I.st[1] = rec.y; I.st[2] = rec.z; I.st[3] = rec.w;
             I.st[4] = S2Buf::ld(S2Buf::rsrc(slz0 + tN), pvo1, 0u);
-            const s2_f2 pw = S2Buf::ld2(S2Buf::rsrc(io.aux + tN * 2), pvo2, 0u);
-            I.ax[0] = pw.x; I.ax[1] = pw.y;
+            if (SAVE_POW) {
+                const s2_f2 pw = S2Buf::ld2(S2Buf::rsrc(io.aux + tN * 2), pvo2, 0u);
+                I.ax[0] = pw.x; I.ax[1] = pw.y;
+            }
         } else {
 #pragma unroll
             for (int k = 0; k < 5; k++) I.st[k] = S2Buf::ld(rtraj, tvo[k], sr);
-            I.ax[0] = S2Buf::ld(raux, avo[0], sr); I.ax[1] = S2Buf::ld(raux, avo[1], sr);
+            if (SAVE_POW) { I.ax[0] = S2Buf::ld(raux, avo[0], sr); I.ax[1] = S2Buf::ld(raux, avo[1], sr); }
         }
+        if (!SAVE_POW) I.ax[0] = I.ax[1] = 0.0f;
 #pragma unroll
         for (int k = 0; k < NG; k++) {
             float v = 0.0f;
@@ -701,7 +706,7 @@ k_bwd_stream2(const StreamBwdArgs A)
             ud[k] = raw ? sigmoid_dyn_(I.dv[k]) : I.dv[k];
             p[stream_slot<SC>(k)] = duse[k] ? ud[k] * dsc[k] + dlo[k] : dsta[k];
         }
-        s.template fwd<true>(p, nz, ac, elev, I.ax[0], I.ax[1]);
+        s.template fwd<SAVE_POW>(p, nz, ac, elev, I.ax[0], I.ax[1]);
         FluxGrad g;
         auto GF = [&](int k) -> float { return k < NG ? I.gf[k] * invM : 0.0f; };
         g.gQ = GF(HBVX_F_QSIM); g.gQ0 = GF(HBVX_F_Q0); g.gQ1 = GF(HBVX_F_Q1); g.gQ2 = GF(HBVX_F_Q2);
@@ -747,7 +752,7 @@ k_bwd_stream2(const StreamBwdArgs A)
         // before, compute.  Only ONE set of inputs occupies registers, and it dies as the step
         // consumes it.
         __shared__ s2_f4 l_rec[64];
-        __shared__ float l_x[64 * 4], l_st[5][64], l_ax[2 * 64], l_gf[NG][64], l_dv[ND > 0 ? ND : 1][64];
+        __shared__ float l_x[64 * 4], l_st[5][64], l_ax[SAVE_POW ? 2 * 64 : 1], l_gf[NG][64], l_dv[ND > 0 ? ND : 1][64];
         const int ln = threadIdx.x & 63;
         auto arm = [&](int t) {
             const unsigned tc = (unsigned)max(t, 0);
@@ -761,17 +766,21 @@ k_bwd_stream2(const StreamBwdArgs A)
             }
             if (TRJ == 2) {
                 const int64_t tN = (int64_t)tc * N;
-                const auto rpw = S2Buf::rsrc(io.aux + tN * 2);
                 S2Buf::ld_lds<16>(S2Buf::rsrc(io.traj + tN * 4), l_rec, pvo4, 0u);
                 S2Buf::ld_lds<4>(S2Buf::rsrc(slz0 + tN), l_st[4], pvo1, 0u);
-                // 8-byte LDS-DMA does not exist: the two saved powers travel as two 4-byte rows
-                S2Buf::ld_lds<4>(rpw, l_ax, pvo2, 0u);
-                S2Buf::ld_lds<4>(rpw, l_ax + 64, pvo2 + 4u, 0u);
+                if (SAVE_POW) {
+                    // 8-byte LDS-DMA does not exist: the two saved powers travel as two 4-byte rows
+                    const auto rpw = S2Buf::rsrc(io.aux + tN * 2);
+                    S2Buf::ld_lds<4>(rpw, l_ax, pvo2, 0u);
+                    S2Buf::ld_lds<4>(rpw, l_ax + 64, pvo2 + 4u, 0u);
+                }
             } else {
 #pragma unroll
                 for (int k = 0; k < 5; k++) S2Buf::ld_lds<4>(rtraj, l_st[k], tvo[k], sr);
-                S2Buf::ld_lds<4>(raux, l_ax, avo[0], sr);
-                S2Buf::ld_lds<4>(raux, l_ax + 64, avo[1], sr);
+                if (SAVE_POW) {
+                    S2Buf::ld_lds<4>(raux, l_ax, avo[0], sr);
+                    S2Buf::ld_lds<4>(raux, l_ax + 64, avo[1], sr);
+                }
             }
 #pragma unroll
             for (int k = 0; k < NG; k++) {
@@ -797,7 +806,7 @@ k_bwd_stream2(const StreamBwdArgs A)
 #pragma unroll
                 for (int k = 0; k < 5; k++) I.st[k] = l_st[k][ln];
             }
-            I.ax[0] = l_ax[ln]; I.ax[1] = l_ax[64 + ln];
+            if (SAVE_POW) { I.ax[0] = l_ax[ln]; I.ax[1] = l_ax[64 + ln]; } else { I.ax[0] = I.ax[1] = 0.0f; }
             const unsigned sg = (unsigned)t * fB;
 #pragma unroll
             for (int k = 0; k < NG; k++) {

@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(512) k_fwd_tiled(const FwdTArgs A)
     const int nT = (T + Kt - 1) / Kt;
     const int64_t N = (int64_t)d.B * d.M;
     const bool raw = d.raw_sigmoid != 0;
-    const bool has_flux = o.flux != nullptr, has_traj = o.traj != nullptr, has_aux = o.aux != nullptr;
+    const bool has_flux = o.flux != nullptr, has_traj = o.traj != nullptr, has_aux = SAVE_POW && o.aux != nullptr;
     const bool has_mu = DYN && d.muwts != nullptr;
 
     unsigned dmask = 0;
@@ -527,7 +527,7 @@ __global__ void __launch_bounds__((bwd_tiled_threads<MODEL, DYN>())) k_bwd_tiled
                     if ((dmask >> i) & 1) p[i] = pr[dyn_index(dmask, i) * 64];
                 const float *tr = tin + tt * 7 * 64 + lane;
                 s.SP = tr[0]; s.MW = tr[64]; s.SM = tr[128]; s.SUZ = tr[192]; s.SLZ = tr[256];
-                const float sw0 = tr[320], ef0 = tr[384];
+                const float sw0 = SAVE_POW ? tr[320] : 0.0f, ef0 = SAVE_POW ? tr[384] : 0.0f;
                 const float *gr = gin + tt * NG * bpw + L.bl;
                 FluxGrad g;
                 const float gq = gr[HBVX_F_QSIM * bpw];
@@ -544,7 +544,7 @@ __global__ void __launch_bounds__((bwd_tiled_threads<MODEL, DYN>())) k_bwd_tiled
                 g.gtosoil = GFULL ? gr[HBVX_F_TOSOIL * bpw] : 0.0f;
                 g.gPERC = GFULL ? gr[HBVX_F_PERC * bpw] : 0.0f;
                 g.gcap = (GFULL && NF > HBVX_F_CAPILLARY) ? gr[(NF - 1) * bpw] : 0.0f;
-                s.template fwd<true>(p, nz, ac, elev, sw0, ef0);
+                s.template fwd<SAVE_POW>(p, nz, ac, elev, sw0, ef0);
                 float gp[NPARAM_MAX], gx[3];
 #pragma unroll
                 for (int i = 0; i < NPARAM_MAX; i++) gp[i] = 0.0f;
@@ -617,8 +617,12 @@ __global__ void __launch_bounds__((bwd_tiled_threads<MODEL, DYN>())) k_bwd_tiled
                 float tv[7];
 #pragma unroll
                 for (int k = 0; k < 5; k++) tv[k] = io.traj[((int64_t)k * (T + 1) + t) * N + L.n];
-                tv[5] = io.aux[((int64_t)0 * T + t) * N + L.n];
-                tv[6] = io.aux[((int64_t)1 * T + t) * N + L.n];
+                if (SAVE_POW) {
+                    tv[5] = io.aux[((int64_t)0 * T + t) * N + L.n];
+                    tv[6] = io.aux[((int64_t)1 * T + t) * N + L.n];
+                } else {
+                    tv[5] = tv[6] = 0.0f;
+                }
                 float rv[NP];
 #pragma unroll
                 for (int i = 0; i < NP; i++)
@@ -627,7 +631,7 @@ __global__ void __launch_bounds__((bwd_tiled_threads<MODEL, DYN>())) k_bwd_tiled
                 in4[tt * 64 + lane] = f;
                 float *tr = tin + tt * 7 * 64 + lane;
 #pragma unroll
-                for (int k = 0; k < 7; k++) tr[k * 64] = tv[k];
+                for (int k = 0; k < (SAVE_POW ? 7 : 5); k++) tr[k * 64] = tv[k];
                 float *pr = pin + tt * G.NDm * 64 + lane;
 #pragma unroll
                 for (int i = 0; i < NP; i++)

@@ -33,7 +33,7 @@ int hbvx_host::hip_fail(hipError_t e, const char *what)
 
 extern "C" int hbvx_version(void) { return HBVX_ABI_VERSION; }
 extern "C" const char *hbvx_last_error(void) { return g_err; }
-extern "C" const char *hbvx_backend(void) { return "hip:gfx950"; }
+extern "C" const char *hbvx_backend(void) { return hbvx::SAVE_POW ? "hip:gfx950+savepow" : "hip:gfx950"; }
 extern "C" uint64_t hbvx_sizeof(int which)
 {
     switch (which) {
@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(64) k_fwd(const FwdArgs A)
 #pragma unroll
             for (int k = 0; k < 5; k++) o.traj[((int64_t)k * (T + 1) + t) * N + L.n] = st[k];
         }
-        if (o.aux && L.active) {
+        if (SAVE_POW && o.aux && L.active) {
             o.aux[((int64_t)0 * T + t) * N + L.n] = s.sw0;
             o.aux[((int64_t)1 * T + t) * N + L.n] = s.ef0;
         }
@@ -284,8 +284,8 @@ __global__ void __launch_bounds__(64) k_bwd(const BwdArgs A)
         s.SM = io.traj[((int64_t)2 * (T + 1) + t) * N + L.n];
         s.SUZ = io.traj[((int64_t)3 * (T + 1) + t) * N + L.n];
         s.SLZ = io.traj[((int64_t)4 * (T + 1) + t) * N + L.n];
-        const float sw0 = io.aux[((int64_t)0 * T + t) * N + L.n];
-        const float ef0 = io.aux[((int64_t)1 * T + t) * N + L.n];
+        const float sw0 = SAVE_POW ? io.aux[((int64_t)0 * T + t) * N + L.n] : 0.0f;
+        const float ef0 = SAVE_POW ? io.aux[((int64_t)1 * T + t) * N + L.n] : 0.0f;
         float ud[NP];
 #pragma unroll
         for (int i = 0; i < NP; i++) {
@@ -299,7 +299,7 @@ __global__ void __launch_bounds__(64) k_bwd(const BwdArgs A)
                 }
             }
         }
-        s.template fwd<true>(p, nz, ac, elev, sw0, ef0);
+        s.template fwd<SAVE_POW>(p, nz, ac, elev, sw0, ef0);
 
         FluxGrad g;
         const int64_t fs = (int64_t)T * d.B;
@@ -641,6 +641,27 @@ bool hbvx_host::use_tiled(const hbvx_desc *d)
     return d->T > 0;
 }
 
+hipError_t hbvx_host::set_dynamic_lds(const void *kern, int lds)
+{
+    struct Entry { const void *k; int dev, lds; };
+    static std::mutex mu;
+    static Entry seen[256];
+    static int n_seen = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    Entry *e = nullptr;
+    for (int i = 0; i < n_seen && !e; i++)
+        if (seen[i].k == kern && seen[i].dev == dev) e = &seen[i];
+    if (e && lds <= e->lds) return hipSuccess;
+    const hipError_t rc = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (rc != hipSuccess) return rc;
+    if (e) e->lds = lds;
+    else if (n_seen < 256) seen[n_seen++] = Entry{kern, dev, lds};
+    // (a full table only costs the driver round trip again: the attribute is still raised before the launch)
+    return hipSuccess;
+}
+
 int hbvx_host::count_dyn(const hbvx_desc *d)
 {
     int nd = 0;
@@ -706,7 +727,7 @@ extern "C" int hbvx_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *st
     if (rc) return rc;
     if (d->model == HBVX_MODEL_HBVADJ) return fail(HBVX_E_UNSUPPORTED, "use hbvx_adj_backward for HBVADJ");
     if (!io || !io->traj) return fail(HBVX_E_NULL, "traj is NULL");
-    if (!io->aux && HBVX_TRAJ_KIND(io->traj_layout) != HBVX_TRAJ_CKPT) return fail(HBVX_E_NULL, "aux is NULL");
+    if (SAVE_POW && !io->aux && HBVX_TRAJ_KIND(io->traj_layout) != HBVX_TRAJ_CKPT) return fail(HBVX_E_NULL, "aux is NULL");
     const int want_nf = (d->model == HBVX_MODEL_HBV10) ? 11 : 12;
     if (io->n_flux != want_nf) return fail(HBVX_E_SHAPE, "n_flux does not match model");
     if (d->T == 0) return HBVX_OK;

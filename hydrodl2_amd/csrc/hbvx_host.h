@@ -13,8 +13,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "../../include/hbvx.h"
+#include "hbv_step.h"
 
 namespace hbvx_host {
 
@@ -25,6 +27,8 @@ int lg_members(int M);
 int count_dyn(const hbvx_desc *d);
 bool use_tiled(const hbvx_desc *d);      // false under HBVX_KERNEL=simple
 int check_desc(const hbvx_desc *d);
+// whether this call's aux pointers are consistent with its trajectory: only HBVX_SAVE_POW builds look at aux at all
+inline bool aux_matches_traj(const hbvx_fwd_out *out) { return !hbvx::SAVE_POW || ((out->traj != nullptr) == (out->aux != nullptr)); }
 
 static const int LDS_BUDGET = 160 * 1024 - 512; // gfx950: 160 KiB per CU, one workgroup may take it all
 
@@ -32,23 +36,12 @@ static const int LDS_BUDGET = 160 * 1024 - 512; // gfx950: 160 KiB per CU, one w
 bool try_fwd_pipe(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream, int *rc);
 // launch_stream.hip
 bool try_fwd_stream(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream, int *rc, bool any_size = false);
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device, size) and thread instead of once per
-// launch: the attribute sticks, and the call is a driver round trip on the enqueue path of every step.
-inline hipError_t set_dynamic_lds(const void *kern, int lds)
-{
-    struct Entry { const void *k; int dev, lds; };
-    static thread_local Entry seen[16];
-    static thread_local int n_seen = 0;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    for (int i = 0; i < n_seen; i++)
-        if (seen[i].k == kern && seen[i].dev == dev && seen[i].lds == lds) return hipSuccess;
-    const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e == hipSuccess) {
-        seen[n_seen < 16 ? n_seen++ : (n_seen = 1, 0)] = Entry{kern, dev, lds};
-    }
-    return e;
-}
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) only when a launch needs MORE than the kernel was ever granted on
+// this device: the attribute holds one value per kernel (the last one set) and is a ceiling for the launch, so it is
+// raised and never lowered -- a template instance whose LDS request varies with the problem (train and validation
+// models with different dynamic sets) would otherwise launch "big, small, big" with the attribute left at "small".
+// One process-wide table under a mutex (autograd's backward thread and the main thread share it); hbvx.hip defines it.
+hipError_t set_dynamic_lds(const void *kern, int lds);
 // hbvx_bwd_io.store_gate: make `st` wait for the caller's event before a kernel that stores gradients is launched
 inline void store_gate(const hbvx_bwd_io *io, hipStream_t st)
 {

@@ -15,19 +15,21 @@ using namespace hbvx_host;
 
 namespace {
 
-// Days per block.  The block's scratch is (5 (Tb + 1) + 2 Tb) N floats of re-materialised trajectory plus the
-// inner adjoint's own workspace: 28 bytes per lane-day, i.e. 23 GB for 512 days of 1.6 M lanes -- not "lean".
-// So the block is sized by BYTES: at most HBVX_CKPT_SCRATCH_MB (default 2048) of trajectory scratch, at most
-// HBVX_CKPT_BLOCK (default 512) days, at least 8 K days (shorter blocks cost launches: 4 kernels per block),
-// a multiple of K.
+// Days per block.  The block's scratch is 5 (Tb + 1) N floats of re-materialised trajectory (20 bytes per lane-day;
+// 28 in HBVX_SAVE_POW builds) plus the inner adjoint's own workspace: 16 GB for 512 days of 1.6 M lanes -- not
+// "lean".  So the block is sized by BYTES: at most HBVX_CKPT_SCRATCH_MB (default 2048) of trajectory scratch, at
+// most HBVX_CKPT_BLOCK (default 512) days, a multiple of K.  Short blocks cost launches (4 kernels per block), so
+// the block is at least 8 K days while the byte budget allows it; when it does not (1.6 M lanes at K = 16: 67
+// days) the budget wins down to a floor of 2 K days -- the bound include/hbvx.h states is kept.
 int block_days(const hbvx_desc *d, int K)
 {
     int tb = env_int("HBVX_CKPT_BLOCK", 512);
     const uint64_t N = (uint64_t)d->B * d->M;
     const uint64_t budget = (uint64_t)env_int("HBVX_CKPT_SCRATCH_MB", 2048) << 20;
-    const uint64_t by_bytes = budget / (28 * (N ? N : 1));
-    if ((uint64_t)tb > by_bytes) tb = (int)by_bytes;
+    const uint64_t by_bytes = budget / ((SAVE_POW ? 28 : 20) * (N ? N : 1));
     if (tb < 8 * K) tb = 8 * K;
+    if ((uint64_t)tb > by_bytes) tb = (int)by_bytes;
+    if (tb < 2 * K) tb = 2 * K;
     tb = (tb / K) * K;
     const int tfull = ((d->T + K - 1) / K) * K;
     return tb > tfull ? tfull : tb;
@@ -66,7 +68,7 @@ Plan plan(const hbvx_desc *d, int K)
     P.Tb = block_days(d, K);
     const uint64_t N = (uint64_t)d->B * d->M, nf = d->model == HBVX_MODEL_HBV10 ? 11 : 12;
     P.traj = al(5 * (uint64_t)(P.Tb + 1) * N * 4);
-    P.aux = al(2 * (uint64_t)P.Tb * N * 4);
+    P.aux = SAVE_POW ? al(2 * (uint64_t)P.Tb * N * 4) : 0;   // the block's saved powers (HBVX_SAVE_POW builds only)
     P.gf = al(nf * (uint64_t)P.Tb * d->B * 4);
     P.g4 = al(4 * (uint64_t)P.Tb * d->B * 4);
     P.carry = al(5 * N * 4);
@@ -179,6 +181,7 @@ bool hbvx_host::try_bwd_ckpt(const hbvx_desc *d, const hbvx_bwd_io *io, void *st
     a.K = K;
     const dim3 grid(W);
     const size_t lds = (size_t)K * 7 * 64 * sizeof(float);
+    store_gate(io, st);   // the one kernel of this path stores the dynamic-parameter / forcing gradients
     if (m == HBVX_MODEL_HBV10 && d->n_param == 12) hipLaunchKernelGGL((k_bwd_ckpt<MODEL_HBV10, false>), grid, dim3(64), lds, st, a);
     else if (m == HBVX_MODEL_HBV10) hipLaunchKernelGGL((k_bwd_ckpt<MODEL_HBV10, true>), grid, dim3(64), lds, st, a);
     else if (m == HBVX_MODEL_HBV11P) hipLaunchKernelGGL((k_bwd_ckpt<MODEL_HBV11P, true>), grid, dim3(64), lds, st, a);

@@ -43,8 +43,7 @@ bool hbvx_host::try_fwd_pipe(const hbvx_desc *d, const hbvx_fwd_out *out, void *
         const bool ckpt_fits = !ckpt_k || ((int64_t)((d->T + ckpt_k - 1) / ckpt_k) * 5 * d->B * d->M * 4 < (int64_t)1 << 32);
         if (ckpt_fits && use_tiled(d) && !(fv && !strcmp(fv, "tiled")) && pmodel && off32 &&
             nd <= PIPE_MAXDYN && (int)lds <= LDS_BUDGET && wgs_p < 4096 && !d->muwts && (out->flux || adj) && d->T >= 4 * Kt &&
-            (adj ? (!ckpt_k && out->aux == nullptr)
-                 : (ckpt_k ? out->aux == nullptr : (out->traj != nullptr) == (out->aux != nullptr))) &&
+            (adj ? !ckpt_k : (ckpt_k ? true : aux_matches_traj(out))) &&
             (int64_t)d->B * d->M * 4 * Kt < (int64_t)1 << 31 &&
             (int64_t)nfl * d->T * d->B * 4 < (int64_t)1 << 31) {
             PipeArgs pa;

@@ -176,7 +176,7 @@ bool hbvx_host::try_fwd_stream(const hbvx_desc *d, const hbvx_fwd_out *out, void
         if (!(P.ok && out->flux && P.sc >= 0 && P.packed_ok)) return false;
     }
     // the second generation also takes a trajectory without the saved powers (inference that keeps the state series)
-    bool ok = P.ok && out->flux && (P.sc >= 0 ? (out->traj || !out->aux) : (out->traj != nullptr) == (out->aux != nullptr));
+    bool ok = P.ok && out->flux && (P.sc >= 0 ? (!SAVE_POW || out->traj || !out->aux) : aux_matches_traj(out));
     if (out->traj && !packed && !ckpt) ok = ok && P.rows_ok;
     if (packed) {
         if (!(ok && P.sc >= 0 && P.packed_ok)) {

@@ -451,7 +451,9 @@ def _hbv_forward(ctx, cfg: StepConfig, x, state_in, muwts, ac, elev, ptensors):
         layout = _abi.TRAJ_CKPT | (ckpt << 8)
     else:
         traj = _out((5, T + 1, B * M), dev) if keep else None
-        aux = _out((2, T, B * M), dev) if needs_grad else None
+        # the two saved powers per lane-day: only for A/B builds of the library with -DHBVX_SAVE_POW=1
+        # (csrc/hbv_step.h); the default build recomputes them in the adjoint and never touches `aux`
+        aux = _out((2, T, B * M), dev) if (needs_grad and lib.saves_pow) else None
         layout = (_cached(cfg, ("layout", x.stride(0), x.stride(1)), lambda: lib.preferred_traj_layout(desc))
                   if (keep and cfg.want_flux) else _abi.TRAJ_ROWS)
     out.flux, out.state_out = _ptr(flux), _ptr(state_out)

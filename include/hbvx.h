@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define HBVX_ABI_VERSION 8
+#define HBVX_ABI_VERSION 9
 #define HBVX_MAX_PARAM 20
 #define HBVX_NSTATE 5   /* SNOWPACK, MELTWATER, SM, SUZ, SLZ  (hbv.py:61-67) */
 #define HBVX_MAX_FLUX 12
@@ -146,19 +146,27 @@ typedef struct hbvx_desc {
     int32_t adj_max_iter;  /* updates allowed = max_iter + 1; reference max_iter = 3 */
 } hbvx_desc;
 
-/* Layout of the saved trajectory (hbvx_fwd_out.traj / .aux, same two buffers and sizes either way):
- *   ROWS    traj [5,T+1,N] (storage k entering day t at traj[(k*(T+1)+t)*N + n]), aux [2,T,N]
- *   PACKED  traj = records [T+1,N,4] (SNOWPACK, MELTWATER, SM, SUZ) followed by SLZ rows [T+1,N];
- *           aux = records [T,N,2].  Three wide stores / loads per lane-day instead of seven: what the
- *           streaming kernels for large grids use (a vector-memory instruction costs the same issue
- *           time whatever its width).  N = B*M, lane n = b*M + j. */
+/* Layout of the saved trajectory (hbvx_fwd_out.traj, same buffer and size either way):
+ *   ROWS    traj [5,T+1,N] (storage k entering day t at traj[(k*(T+1)+t)*N + n])
+ *   PACKED  traj = records [T+1,N,4] (SNOWPACK, MELTWATER, SM, SUZ) followed by SLZ rows [T+1,N].
+ *           Two wide stores / loads per lane-day instead of five: what the streaming kernels for
+ *           large grids use (a vector-memory instruction costs the same issue time whatever its
+ *           width).  N = B*M, lane n = b*M + j.
+ * `aux` (ABI <= 8: the two pre-clamp powers of every lane-day, [2,T,N] / records [T,N,2]) is no longer
+ * part of the trajectory: since ABI 9 the adjoint recomputes both powers from the saved storages with
+ * the forward's own instruction sequence (20 instead of 28 bytes per lane-day), and the library neither
+ * writes nor reads the pointer -- pass NULL.  (Development builds with -DHBVX_SAVE_POW=1 restore the
+ * old behaviour for A/B measurements; hbvx_backend() then ends in "+savepow".) */
 enum hbvx_traj_layout { HBVX_TRAJ_ROWS = 0, HBVX_TRAJ_PACKED = 1, HBVX_TRAJ_CKPT = 2 };
 /* traj_layout = kind | (K << 8).  HBVX_TRAJ_CKPT with K in {4, 8, 16}: `traj` holds only the five
- * storages entering days 0, K, 2K, ... as [ceil(T/K), 5, N] and `aux` is NULL (20/K bytes per lane-day
- * instead of 28); hbvx_backward re-materialises each K-day segment from its checkpoint (one extra
+ * storages entering days 0, K, 2K, ... as [ceil(T/K), 5, N] (20/K bytes per lane-day instead of 20);
+ * hbvx_backward re-materialises each K-day segment from its checkpoint (one extra
  * forward step per day).  The caller chooses it when the full trajectory does not fit
  * (100 000 basins x 16 x 7 300 days: 327 GB of trajectory against 29 GB of checkpoints at K = 8, 15 GB at
- * K = 16; the block-wise adjoint adds at most 2 GB of scratch, hbvx_ckpt_workspace_bytes). */
+ * K = 16; the block-wise adjoint re-materialises one block of days at a time into caller scratch:
+ * at most HBVX_CKPT_SCRATCH_MB (default 2048 MB) of trajectory -- or 2 K days of it, 40 K N bytes, if that
+ * is more -- plus the block's gradient-series windows, two 20 N-byte carries and the inner adjoint's own
+ * workspace; hbvx_ckpt_workspace_bytes returns the exact sum). */
 #define HBVX_TRAJ_KIND(layout) ((layout) & 0xFF)
 #define HBVX_TRAJ_CKPT_DAYS(layout) ((layout) >> 8)
 
@@ -168,8 +176,7 @@ typedef struct hbvx_fwd_out {
     float *traj;      /* optional [5,T+1,B*M]: storages entering step t; row T = final.
                          Needed by hbvx_backward; rows 1..T are HBV 2.0's state series
                          (hbv_2.py:571-575) */
-    float *aux;       /* optional [2,T,B*M]: (SM/FC)^BETA and the evap factor before
-                         their clamps; saved for hbvx_backward */
+    float *aux;       /* unused since ABI 9 (see above): NULL */
     int32_t n_flux;   /* 11 (HBV 1.0) or 12 */
     int32_t traj_layout; /* enum hbvx_traj_layout: how traj / aux are laid out.  Must be what
                             hbvx_preferred_traj_layout() returns for this desc, or HBVX_TRAJ_ROWS */
@@ -177,7 +184,7 @@ typedef struct hbvx_fwd_out {
 
 typedef struct hbvx_bwd_io {
     const float *traj;       /* from hbvx_forward, required */
-    const float *aux;        /* from hbvx_forward, required */
+    const float *aux;        /* unused since ABI 9: NULL */
     const float *grad_flux;  /* [n_flux,T,B] dL/d(flux series) or NULL (= zeros) */
     const float *grad_flux4; /* optional [4,T,B]: extra gradient of series 0..3 (Qsim,Q0,Q1,Q2),
                                 i.e. grad_q of hbvx_route_backward; added to grad_flux */
@@ -291,7 +298,7 @@ int hbvx_gage_route_backward(const hbvx_gage_desc *r, const float *qs, const flo
  * (hbv_adj.py:669-687) by modified Newton (hbv_adj.py:507-581) with the analytic 5x5 Jacobian;
  * flux[0][t][b] = ensemble mean of q0+q1+q2 at the solved state (hbv_adj.py:309-317).
  * Uses hbvx_desc (model HBVX_MODEL_HBVADJ; `drop` is per LANE [B*M], hbv_adj.py:182-189),
- * hbvx_fwd_out with n_flux = 1 (traj rows 1..T = solved states; aux unused) and hbvx_bwd_io.
+ * hbvx_fwd_out with n_flux = 1 (traj rows 1..T = solved states) and hbvx_bwd_io.
  * The backward is the implicit-function adjoint the reference intends (hbv_adj.py:617-633):
  * (dG/dx)^T lambda = dL/dx, dL/dtheta = -lambda^T dG/dtheta, dL/dx_t = lambda/dt. */
 int hbvx_adj_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream);

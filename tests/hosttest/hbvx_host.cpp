@@ -130,9 +130,13 @@ static void run_bwd(const hbvx_desc &d, const hbvx_bwd_io &io)
                 s.SM = io.traj[((int64_t)2 * (T + 1) + t) * N + n];
                 s.SUZ = io.traj[((int64_t)3 * (T + 1) + t) * N + n];
                 s.SLZ = io.traj[((int64_t)4 * (T + 1) + t) * N + n];
-                s.template fwd<true>(p, d.nearzero, d.ac ? d.ac[b] : 0.f, d.elev ? d.elev[b] : 0.f,
-                                     io.aux[((int64_t)0 * T + t) * N + n],
-                                     io.aux[((int64_t)1 * T + t) * N + n]);
+                // like the device adjoints: the two powers are recomputed unless the caller kept them
+                if (io.aux)
+                    s.template fwd<true>(p, d.nearzero, d.ac ? d.ac[b] : 0.f, d.elev ? d.elev[b] : 0.f,
+                                         io.aux[((int64_t)0 * T + t) * N + n],
+                                         io.aux[((int64_t)1 * T + t) * N + n]);
+                else
+                    s.template fwd<false>(p, d.nearzero, d.ac ? d.ac[b] : 0.f, d.elev ? d.elev[b] : 0.f, 0.f, 0.f);
                 float gfv[HBVX_MAX_FLUX];
                 for (int k = 0; k < nf; k++) {
                     gfv[k] = io.grad_flux ? io.grad_flux[(int64_t)k * fs + (int64_t)t * B + b] : 0.f;
