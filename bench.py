@@ -497,6 +497,37 @@ def cpu_baseline_eager(B, M, budget_s=90.0):
             "passes": passes}
 
 
+def validate_collective(dev, world, rank):
+    """First use of the backend, self-validating: all-reduce a ones-vector and require `world` in every element, so
+    that a record of an N-rank run says "the collective summed N ranks", not "N processes ran".  Every rank reports
+    its device and the RCCL version on stderr (the launcher relays it with a rank prefix)."""
+    import torch
+    import torch.distributed as dist
+    info = {"backend": None, "ranks_summed": 1, "nccl_version": None}
+    name = torch.cuda.get_device_name(dev) if dev.type == "cuda" else "cpu"
+    if world > 1:
+        info["backend"] = dist.get_backend()
+        ones = torch.ones(64, device=dev)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        lo, hi = float(ones.min().item()), float(ones.max().item())
+        if lo != float(world) or hi != float(world):
+            raise SystemExit(f"rank {rank}: all-reduce of ones over {world} ranks returned [{lo}, {hi}]")
+        info["ranks_summed"] = int(lo)
+        # and a rank-dependent payload: sum_r (r + 1) = world (world + 1) / 2 catches a collective that talks to itself
+        v = torch.full((4,), float(rank + 1), device=dev)
+        dist.all_reduce(v, op=dist.ReduceOp.SUM)
+        if float(v[0].item()) != world * (world + 1) / 2:
+            raise SystemExit(f"rank {rank}: all-reduce of rank ids returned {float(v[0].item())}")
+    if dev.type == "cuda":
+        try:
+            info["nccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            info["nccl_version"] = None
+    print(f"[bench] rank {rank}/{world}: device {name}, backend {info['backend']}, rccl {info['nccl_version']}, "
+          f"ones summed over {info['ranks_summed']} rank(s)", file=sys.stderr, flush=True)
+    return info
+
+
 # --------------------------------------------------------------------------------------------
 def main():
     if len(sys.argv) >= 5 and sys.argv[1] == "--eager-child":
@@ -545,6 +576,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev, timeout=tmo)
         else:
             dist.init_process_group("gloo", timeout=tmo)
+    collective = validate_collective(dev, world, rank)
 
     from hydrodl2_amd import sharding
     strong = args.config == "cfg5"
@@ -607,7 +639,8 @@ def main():
             "config": {"workload": what, "name": args.config, "basins_total": B_total if strong else B_total * world,
                        "basins_per_gpu": B_rank, "nmul": wl.M, "days": wl.T,
                        "parallelism": f"basin-shard x{world}"},
-            "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+            # the number of ranks the collective itself summed over (validate_collective), not the launcher's word
+            "rccl_ranks": collective["ranks_summed"], "collective_check": collective,
             "rank_ms_per_step": rank_ms, "allreduce_ms": ar_ms,
             "device_mallocs_in_timed_steps": timed_steps.device_mallocs,
         }

@@ -67,6 +67,75 @@ def synth(T, B, n_attr, dev, seed):
     return x, attrs
 
 
+def make_trainer(dev, basins=100, rho=365, warm_up=365, nmul=16, hidden=256, lstm="fused", world=1, rank=0,
+                 overlap_wanted=True):
+    """The training step as a closure (bench.py times it as the `dpl` workload; main() below runs it):
+    returns (step, info) with step() -> mean loss of the step."""
+    T, B, M = warm_up + rho, basins, nmul
+    dyn = ["parBETA", "parBETAET"]
+    cfg = {"nmul": M, "warm_up": warm_up, "dynamic_params": {"Hbv": dyn}}
+    Hbv = hydrodl2_amd.load_model("hbv", "Hbv")
+    phy = Hbv(cfg, dev)
+    ny = phy.learnable_param_count
+    n_attr = 8
+
+    # global synthetic data set, identical on every rank; each rank keeps its block of basins
+    x_all, attrs_all = synth(T, B, n_attr, dev, seed=0)
+    torch.manual_seed(1)
+    truth = ParamNet(3 + n_attr, 32, ny).to(dev)
+    b0, b1 = sharding.basin_range(B, world, rank)
+    x, attrs = x_all[:, b0:b1].contiguous(), attrs_all[b0:b1]
+    mean, std = x_all.mean((0, 1)), x_all.std((0, 1)) + 1e-6
+    z = torch.cat([(x - mean) / std, attrs[None].expand(T, -1, -1)], -1)
+    with torch.no_grad():
+        obs = Hbv(cfg, dev)({"x_phy": x}, truth(z))["streamflow"][:, :, 0]
+
+    torch.manual_seed(2)                       # same initial network on every rank
+    net = ParamNet(3 + n_attr, hidden, ny, fused=lstm == "fused").to(dev)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    params = [p for p in net.parameters()]
+
+    # Backward produces gradients output-layer-first: net.out right after the HBV adjoint, then the
+    # LSTM (the expensive part), then net.inp.  With --overlap (default) the first bucket -- loss
+    # normalisers + net.out -- is all-reduced asynchronously from a gradient hook while the LSTM backward
+    # runs; the second bucket follows when backward returns.
+    overlap = world > 1 and overlap_wanted
+    early = list(net.out.parameters())
+    late = [p for p in params if all(p is not q for q in early)]
+    pending = {}
+
+    def on_grad(_p):
+        if "bucket" not in pending and all(q.grad is not None for q in early):
+            pending["bucket"] = sharding.AsyncBucket([pending["stats"]] + [q.grad for q in early]).start()
+
+    if overlap:
+        for q in early:
+            q.register_post_accumulate_grad_hook(on_grad)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        raw = net(z)
+        sim = phy({"x_phy": x}, raw)["streamflow"][:, :, 0]
+        loss_sum, count = nse_loss(sim, obs)
+        stats = torch.stack([loss_sum.detach(), torch.tensor(float(count), device=dev)])
+        pending.clear()
+        pending["stats"] = stats
+        loss_sum.backward()
+        if overlap:
+            second = sharding.AsyncBucket([p.grad for p in late]).start()
+            pending["bucket"].finish()
+            second.finish()
+        else:
+            # one bucketed all-reduce: [loss sum, basin count, every network gradient]
+            sharding.all_reduce_sum_([stats] + [p.grad for p in params])
+        for p in params:
+            p.grad /= stats[1]
+        opt.step()
+        return float(stats[0] / stats[1])
+
+    return step, {"T": T, "B": B, "M": M, "ny": ny, "overlap": overlap}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--basins", type=int, default=100)
@@ -106,68 +175,9 @@ def main():
         tunable.set_max_tuning_duration(1000)       # ms per GEMM shape
         tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), "tunableop_dpl.csv"))
 
-    T, B, M = args.warm_up + args.rho, args.basins, args.nmul
-    dyn = ["parBETA", "parBETAET"]
-    cfg = {"nmul": M, "warm_up": args.warm_up, "dynamic_params": {"Hbv": dyn}}
-    Hbv = hydrodl2_amd.load_model("hbv", "Hbv")
-    phy = Hbv(cfg, dev)
-    ny = phy.learnable_param_count
-    n_attr = 8
-
-    # global synthetic data set, identical on every rank; each rank keeps its block of basins
-    x_all, attrs_all = synth(T, B, n_attr, dev, seed=0)
-    torch.manual_seed(1)
-    truth = ParamNet(3 + n_attr, 32, ny).to(dev)
-    b0, b1 = sharding.basin_range(B, world, rank)
-    x, attrs = x_all[:, b0:b1].contiguous(), attrs_all[b0:b1]
-    mean, std = x_all.mean((0, 1)), x_all.std((0, 1)) + 1e-6
-    z = torch.cat([(x - mean) / std, attrs[None].expand(T, -1, -1)], -1)
-    with torch.no_grad():
-        obs = Hbv(cfg, dev)({"x_phy": x}, truth(z))["streamflow"][:, :, 0]
-
-    torch.manual_seed(2)                       # same initial network on every rank
-    net = ParamNet(3 + n_attr, args.hidden, ny, fused=args.lstm == "fused").to(dev)
-    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
-    params = [p for p in net.parameters()]
-
-    # Backward produces gradients output-layer-first: net.out right after the HBV adjoint, then the
-    # LSTM (the expensive part), then net.inp.  With --overlap (default) the first bucket -- loss
-    # normalisers + net.out -- is all-reduced asynchronously from a gradient hook while the LSTM backward
-    # runs; the second bucket follows when backward returns.
-    overlap = world > 1 and not args.no_overlap
-    early = list(net.out.parameters())
-    late = [p for p in params if all(p is not q for q in early)]
-    pending = {}
-
-    def on_grad(_p):
-        if "bucket" not in pending and all(q.grad is not None for q in early):
-            pending["bucket"] = sharding.AsyncBucket([pending["stats"]] + [q.grad for q in early]).start()
-
-    if overlap:
-        for q in early:
-            q.register_post_accumulate_grad_hook(on_grad)
-
-    def step():
-        opt.zero_grad(set_to_none=True)
-        raw = net(z)
-        sim = phy({"x_phy": x}, raw)["streamflow"][:, :, 0]
-        loss_sum, count = nse_loss(sim, obs)
-        stats = torch.stack([loss_sum.detach(), torch.tensor(float(count), device=dev)])
-        pending.clear()
-        pending["stats"] = stats
-        loss_sum.backward()
-        if overlap:
-            second = sharding.AsyncBucket([p.grad for p in late]).start()
-            pending["bucket"].finish()
-            second.finish()
-        else:
-            # one bucketed all-reduce: [loss sum, basin count, every network gradient]
-            sharding.all_reduce_sum_([stats] + [p.grad for p in params])
-        for p in params:
-            p.grad /= stats[1]
-        opt.step()
-        return float(stats[0] / stats[1])
-
+    step, info = make_trainer(dev, args.basins, args.rho, args.warm_up, args.nmul, args.hidden, args.lstm, world, rank,
+                              not args.no_overlap)
+    T, B, M, overlap = info["T"], info["B"], info["M"], info["overlap"]
     losses = [step() for _ in range(3)]        # warm-up
     ops.KERNEL_EVENTS = [] if on_gpu else None
     if on_gpu:

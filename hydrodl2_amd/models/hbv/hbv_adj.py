@@ -82,7 +82,10 @@ class HbvAdj(torch.nn.Module):
             self.newton_stop = config.get('newton_stop', self.newton_stop)
             if self.newton_stop not in ('lane', 'global'):
                 raise ValueError("newton_stop must be 'lane' or 'global'")
-            self.newton_solver = config.get('newton_solver', 'joint' if 'newton_stop' in config else self.newton_solver)
+            # The solver never follows from the mere PRESENCE of another key: 'staged' unless asked otherwise.  The one
+            # value that only the joint iteration implements -- the reference's batch-wide stopping rule -- selects it.
+            self.newton_solver = config.get('newton_solver',
+                                            'joint' if self.newton_stop == 'global' else self.newton_solver)
             if self.newton_solver not in ('staged', 'joint'):
                 raise ValueError("newton_solver must be 'staged' or 'joint'")
             if self.newton_solver == 'staged' and self.newton_stop == 'global':

@@ -379,9 +379,19 @@ def _fill_desc(cfg: StepConfig, x, state_in, muwts, ac, elev, ptensors) -> _abi.
     return _abi.Desc.from_buffer(buf)      # the struct keeps `buf` alive
 
 
+# The library's layout / workspace answers also depend on its (test and tool) environment knobs; their values are
+# part of the memo key, so a knob changed between two calls on the same module is seen (a stale TRAJ_PACKED under
+# HBVX_STREAM=0 made hbvx_forward refuse the call; a stale workspace size silently demoted the adjoint).
+_MEMO_ENV = ("HBVX_KERNEL", "HBVX_FWD", "HBVX_BWD", "HBVX_STREAM", "HBVX_STREAM_MIN", "HBVX_STREAM_MW_MIN", "HBVX_CHUNK",
+             "HBVX_CKPT_BLOCK", "HBVX_CKPT_SCRATCH_MB", "HBVX_CKPT_BLOCKWISE")
+
+
 def _cached(cfg: StepConfig, key, fn):
-    """Per-config memo for the library's size / layout queries (functions of the shape, not of the pointers)."""
+    """Per-config memo for the library's size / layout queries (functions of the shape and the knobs above, not of
+    the pointers)."""
     memo = cfg.__dict__.setdefault("_memo", {})
+    env = os.environ
+    key = (key, tuple(env.get(k) for k in _MEMO_ENV))
     v = memo.get(key)
     if v is None:
         v = memo[key] = fn()

@@ -45,20 +45,28 @@ def shard_inputs(x_dict: dict, parameters, world: int, rank: int):
     return xs, ps
 
 
-_BUCKETS: dict = {}     # (device, dtype, numel) -> persistent flat buffer of the step's one collective
+_BUCKETS: dict = {}     # (tag, device, dtype, numel) -> persistent flat buffer of a step's collective
 
 
-def _bucket(tensors: Sequence[torch.Tensor]) -> torch.Tensor:
-    """Flat staging buffer for `tensors`, kept between steps: the bucket sits on the tail of every training step,
-    and a fresh torch.cat there is an allocation plus a kernel per step for a buffer whose size never changes."""
+def _persistent(tag: str, device, dtype, numel: int) -> torch.Tensor:
+    """A flat buffer kept between steps.  The collectives sit on the tail of every training step; a fresh
+    allocation there is a caching-allocator call (and, while the pool still grows, a hipMalloc) per step for a
+    buffer whose size never changes.  `tag` keeps buffers that are alive at the same time apart (the blocking
+    bucket, an AsyncBucket in flight, the all-gather's send and receive sides)."""
+    key = (tag, device, dtype, numel)
+    buf = _BUCKETS.get(key)
+    if buf is None:
+        if len(_BUCKETS) > 32:
+            _BUCKETS.clear()
+        buf = _BUCKETS[key] = torch.empty(numel, dtype=dtype, device=device)
+    return buf
+
+
+def _bucket(tensors: Sequence[torch.Tensor], tag: str = "sync") -> torch.Tensor:
+    """Flat staging buffer for `tensors`, kept between steps (see _persistent), filled with their values."""
     t0 = tensors[0]
     n = sum(t.numel() for t in tensors)
-    key = (t0.device, t0.dtype, n)
-    flat = _BUCKETS.get(key)
-    if flat is None:
-        if len(_BUCKETS) > 8:
-            _BUCKETS.clear()
-        flat = _BUCKETS[key] = torch.empty(n, dtype=t0.dtype, device=t0.device)
+    flat = _persistent(tag, t0.device, t0.dtype, n)
     off = 0
     for t in tensors:
         k = t.numel()
@@ -97,13 +105,18 @@ class AsyncBucket:
     right after the HBV adjoint) while the part that is produced last (the LSTM) is still being
     computed -- the overlap SURVEY.md §8f rank 4 asks for."""
 
+    _live = 0    # buckets in flight: each gets its own persistent staging buffer
+
     def __init__(self, tensors: Sequence[torch.Tensor], group=None):
         self.tensors, self.group = list(tensors), group
         self.flat = self.work = None
 
     def start(self) -> "AsyncBucket":
         if dist.is_initialized() and dist.get_world_size(self.group) > 1:
-            self.flat = torch.cat([t.reshape(-1) for t in self.tensors])
+            # the staging buffer persists between steps like the blocking path's (one per bucket in flight: the
+            # step's early and late buckets overlap in time)
+            self.flat = _bucket(self.tensors, tag=f"async{AsyncBucket._live}")
+            AsyncBucket._live += 1
             self.work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         return self
 
@@ -116,6 +129,7 @@ class AsyncBucket:
             n = t.numel()
             t.copy_(self.flat[off:off + n].view_as(t))
             off += n
+        AsyncBucket._live -= 1
         self.flat = self.work = None
 
 
@@ -127,14 +141,23 @@ def gather_basins(local: torch.Tensor, n_basins: int, dim: int, group=None) -> t
     per = (n_basins + world - 1) // world
     pad_shape = list(local.shape)
     pad_shape[dim] = per
-    padded = local.new_zeros(pad_shape)
-    padded.narrow(dim, 0, local.shape[dim]).copy_(local)
-    parts = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(parts, padded.contiguous(), group=group)
+    n = 1
+    for v in pad_shape:
+        n *= v
+    # send and receive sides persist between calls (one flat receive buffer for all ranks, all_gather_into_tensor:
+    # no per-call list of `world` padded tensors); only the result is a fresh tensor
+    send = _persistent("gather_send", local.device, local.dtype, n).view(pad_shape)
+    have = local.shape[dim]
+    send.narrow(dim, 0, have).copy_(local)
+    if have < per:
+        send.narrow(dim, have, per - have).zero_()
+    recv = _persistent("gather_recv", local.device, local.dtype, n * world)
+    dist.all_gather_into_tensor(recv, send.reshape(-1), group=group)
+    parts = recv.view([world] + pad_shape)
     out = []
-    for r, p in enumerate(parts):
+    for r in range(world):
         b0, b1 = basin_range(n_basins, world, r)
-        out.append(p.narrow(dim, 0, b1 - b0))
+        out.append(parts[r].narrow(dim, 0, b1 - b0))
     return torch.cat(out, dim=dim)
 
 

@@ -31,6 +31,8 @@ def _run(oracle_path, *extra):
 def test_self_launch_weak_cfg2(oracle_path):
     r = _run(oracle_path, "--config", "cfg2", "--basins", "6", "--days", "40", "--nmul", "4")
     assert r["n_gpus"] == 2 and r["rccl_ranks"] == 2 and r["scaling"] == "weak"
+    # the rank count comes from the collective itself (a ones-vector summed over the ranks), not from the launcher
+    assert r["collective_check"] == {"backend": "gloo", "ranks_summed": 2, "nccl_version": None}
     assert r["config"]["basins_total"] == 12 and r["config"]["basins_per_gpu"] == 6
     assert len(r["rank_ms_per_step"]) == 2 and r["ms_per_step"] == pytest.approx(max(r["rank_ms_per_step"]), rel=1e-3)
     assert r["value"] == pytest.approx(12 * 4 * 40 / (r["ms_per_step"] * 1e-3), rel=1e-6)

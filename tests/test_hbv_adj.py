@@ -144,6 +144,20 @@ def test_host_math_matches_oracle_reference_policy(case, solver, host_math_backe
     _close("grad", ggot, gwant, 5e-2, 5e-3)
 
 
+def test_the_solver_is_never_inferred_from_the_presence_of_a_key():
+    """{'newton_stop': 'lane'} -- the default written out -- must select what omitting it selects."""
+    import hydrodl2_amd
+    C = hydrodl2_amd.load_model("hbv_adj", "HbvAdj")
+    base = {"nmul": 2, "dynamic_params": {"HbvAdj": ["parBETAET"]}}
+    dev = torch.device("cpu")
+    assert C(base, dev).newton_solver == "staged"
+    assert C(dict(base, newton_stop="lane"), dev).newton_solver == "staged"
+    assert C(dict(base, newton_stop="global"), dev).newton_solver == "joint"      # only the joint iteration has that rule
+    assert C(dict(base, newton_solver="joint"), dev).newton_solver == "joint"
+    with pytest.raises(ValueError):
+        C(dict(base, newton_solver="staged", newton_stop="global"), dev)
+
+
 def test_global_stopping_rule_differs_only_within_gtol():
     """What the per-lane rule changes w.r.t. the reference's batch-global maximum."""
     case = CASES[0]
@@ -227,8 +241,8 @@ def test_hip_global_newton_rule_is_the_oracles_global_rule(hip_backend):
     T, B, M = 60, 4, 16
     x, p, w = _inputs(T, B, M, 91, True)
     cfg = dict(nmul=M, dynamic_params={"HbvAdj": ["parBETA", "parBETAET"]})
-    got_g, gg_g = _product("cuda:0", x, p, w, dict(cfg, newton_stop="global"))
-    got_l, gg_l = _product("cuda:0", x, p, w, dict(cfg, newton_stop="lane"))
+    got_g, gg_g = _product("cuda:0", x, p, w, dict(cfg, newton_solver="joint", newton_stop="global"))
+    got_l, gg_l = _product("cuda:0", x, p, w, dict(cfg, newton_solver="joint", newton_stop="lane"))
     want_g, gw_g, its_g = _oracle(x, p, w, cfg, stop="global")
     want_l, _, its_l = _oracle(x, p, w, cfg, stop="lane")
     assert float(its_g.max()) <= 4
