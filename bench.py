@@ -21,7 +21,9 @@ LOCAL_RANK / WORLD_SIZE set) or `python bench.py --gpus N` does it itself: the p
 children BEFORE touching the GPU and relays rank 0's JSON line.
 
 Rank 0 prints ONE JSON line.  `value` = whole-job basin-ensemble-timesteps/s.  At N = 1 the line also
-carries `secondary` (configs 2-dyn, 3, 4, one GPU's share of 5, config 5 at full size and the deltaMG minibatch shape, driver-timed in the same run) and
+carries `secondary` (configs 2-dyn, 3, 4 -- staged and under the reference's joint Newton policy --, one GPU's share of 5,
+config 5 at full size, the deltaMG minibatch shape, Hbv_2_hourly with gage routing, the sequence LSTM and one
+examples/train_dpl.py step; driver-timed in the same run, each with what limits it: `limited_by`) and
 `cpu_baseline` (the C/OpenMP oracle port and the pure-torch eager restatement on the host cores).
 """
 from __future__ import annotations
@@ -138,7 +140,50 @@ WORKLOADS = {
     "cfg5full": ("hbv_2", "Hbv_2", 730, 100000, 16, ["parBETA", "parK0", "parBETAET"]),
     # the deltaMG minibatch shape of SURVEY §8d: 100 basins, 365 warm-up + 365 days
     "dmg": ("hbv", "Hbv", 730, 100, 16, ["parBETA", "parBETAET"], {"warm_up": 365}),
+    # configs[3] under the REFERENCE's Newton policy: joint modified Newton on the five storages, max_iter 3,
+    # gtol 1e-3 (hbv_adj.py:544-581); `cfg4` above times this package's default, the staged solve
+    "cfg4joint": ("hbv_adj", "HbvAdj", 7300, 671, 16, ["parBETAET"], {"newton_solver": "joint"}),
+    # Hbv_2_hourly + gage routing (hbv_2_hourly.py:527-675,800-897): 4 000 units x 4 members x
+    # 2 160 hours draining to 100 gages (~12 000 gage-unit pairs)
+    "hourly": ("hbv_2_hourly", "Hbv_2_hourly", 2160, 4000, 4, ["parBETA", "parK0", "parBETAET"], {"gages": 100}),
 }
+
+# What actually limits each configuration on this chip, with the evidence on file (DESIGN.md §4 "what binds").  The
+# `roofline` objects price every kernel against HBM (the contract's bounding roofline for an element-wise
+# recurrence: "bound": "hbm"); `limited_by` says what the counters / probes show instead of pretending the HBM
+# fraction is the lever: hbm | valu-issue | latency | host.
+LIMITED_BY = {
+    "cfg2": ("latency", "forward: 168 workgroups x 7 300 serial days, the soil wave's dependent chain and one barrier per "
+                        "8-day tile (tools/pipe_probe.py, DESIGN.md §0); adjoint kernels VALU-issue bound",
+             {"k_bwd_chunk_phi": 0.85, "k_bwd_chunk_sweep": 0.80}, "profiles/r03_sq_counters_cfg2.txt"),
+    "cfg2dyn": ("latency", "as cfg2; the soil wave carries two dynamic powers", {}, "profiles/r03_sq_counters_cfg2.txt"),
+    "cfg3": ("hbm", "14 dynamic rows streamed twice by the two-pass adjoint at 4.3 TB/s per kernel (69 % of the 6.3 TB/s "
+                    "this chip copies at); forward balanced between fillers / reducers / drainers",
+             {"k_bwd_chunk_phi": 0.78, "k_bwd_chunk_sweep": 0.72}, "profiles/r03_sq_counters_cfg3.txt"),
+    "cfg4": ("latency", "the soil-moisture wave's Newton iteration: 1 480 of 1 490 cycles per day busy, one wave per SIMD "
+                        "(tools/pipe_probe.py)", {}, "DESIGN.md §0"),
+    "cfg4joint": ("latency", "one wave per 64 lanes iterating the reference's joint 5-variable Newton", {}, "DESIGN.md §4"),
+    "cfg5share": ("valu-issue", "streaming adjoint 345-365 VALU per wave-day at 4 waves per SIMD",
+                  {"k_bwd_stream2": 0.75, "k_fwd_stream2": 0.56}, "profiles/r03_sq_counters_cfg5.txt"),
+    "cfg5full": ("valu-issue", "as cfg5share, 25 000 waves", {"k_bwd_stream2": 0.75, "k_fwd_stream2": 0.56},
+                 "profiles/r03_sq_counters_cfg5.txt"),
+    "cfg5": ("valu-issue", "as cfg5share", {"k_bwd_stream2": 0.75, "k_fwd_stream2": 0.56}, "profiles/r03_sq_counters_cfg5.txt"),
+    "dmg": ("host", "kernels sum to less than the enqueue time of the step's launches (tools/host_overhead.py)", {},
+            "profiles/r03_host_overhead.txt"),
+    "hourly": ("latency", "two-stage pipelined forward (1 000 workgroups), gage routing FIR pair-parallel", {}, "DESIGN.md §4"),
+    "lstm": ("latency", "per time step one L1-bypassing store -> load hand-off between the workgroups of a row tile "
+                        "(~1.2 us) + H/4 MFMAs; 4 % of HBM peak, 12 % of the fp32 MFMA peak", {}, "DESIGN.md §4"),
+    "dpl": ("latency", "LSTM recurrence (two persistent kernels) + four fp32 library GEMMs + the HBV calls", {},
+            "profiles/r03_dpl.json"),
+}
+
+
+def limited_by(name):
+    lb, why, busy, src = LIMITED_BY[name]
+    out = {"limited_by": lb, "evidence": why, "evidence_file": src}
+    if busy:
+        out["valu_busy"] = busy
+    return out
 
 
 class Workload:
@@ -148,7 +193,8 @@ class Workload:
         import torch
         import hydrodl2_amd
         fam, cls, T0, B0, M0, dyn = WORKLOADS[name][:6]
-        extra = WORKLOADS[name][6] if len(WORKLOADS[name]) > 6 else {}
+        extra = dict(WORKLOADS[name][6]) if len(WORKLOADS[name]) > 6 else {}
+        gages = int(extra.pop("gages", 0))       # (not a module key: the synthetic gage topology of `hourly`)
         self.name, self.T, self.B, self.M = name, T or T0, B or B0, M or M0
         T, B, M = self.T, self.B, self.M
         C = hydrodl2_amd.load_model(fam, cls)
@@ -157,13 +203,34 @@ class Workload:
         self.model = C({"nmul": M, "dynamic_params": {cls: list(dyn)}, **extra}, dev)
         self.T_out = T - int(extra.get("warm_up", 0))     # warm_up_states (default): outputs start after the warm-up
         self.n_dyn = len(dyn)
-        self.routed = bool(self.model.routing)
+        self.routed = bool(self.model.routing) and cls != "Hbv_2_hourly"    # (hourly: gage routing, priced in extra_bytes)
         self.n_flux = {"Hbv": 11, "HbvAdj": 1}.get(cls, 12)
         g = torch.Generator(device=dev)
         g.manual_seed(seed)
         x = synth_forcing(T, B, dev, g)
         self.xd = {"x_phy": x}
-        if cls == "Hbv_2":
+        self.extra_bytes = (0.0, 0.0)       # per launch, beyond the recurrence: (forward, backward)
+        out_cols = B
+        if cls == "Hbv_2_hourly":
+            # per-step depths at an hourly step; every gage drains ~2 % of the units + one unit of its own
+            x = x * torch.tensor([1 / 8.0, 1.0, 1 / 24.0], device=dev)
+            self.xd["x_phy"] = x
+            topo = (torch.rand((gages, B), generator=g, device=dev) < 0.02).float()
+            topo[torch.arange(B, device=dev) % gages, torch.arange(B, device=dev)] = 1.0
+            pd = torch.rand((T, B, self.n_dyn * M), generator=g, device=dev).requires_grad_(True)
+            ps = torch.rand((B, (19 - self.n_dyn) * M), generator=g, device=dev).requires_grad_(True)
+            pr = torch.rand((int(topo.sum()), 3), generator=g, device=dev).requires_grad_(True)
+            self.params, self.leaves, self.shared = (pd, ps, pr), [pd, ps, pr], ps
+            self.xd["ac_all"] = torch.rand(B, generator=g, device=dev) * 5000
+            self.xd["elev_all"] = torch.rand(B, generator=g, device=dev) * 3000
+            self.xd["outlet_topo"] = topo
+            self.xd["areas"] = torch.rand(B, generator=g, device=dev) * 90 + 5
+            self.n_pairs = int(topo.sum())
+            out_cols = gages
+            # gage routing (include/hbvx.h: hbvx_gage_route_*): 4 (T U + T G) bytes each way + the pair parameters
+            gb = 4.0 * (T * B + T * gages) + 12.0 * self.n_pairs
+            self.extra_bytes = (gb, gb)
+        elif cls == "Hbv_2":
             pd = torch.rand((T, B, self.n_dyn * M), generator=g, device=dev).requires_grad_(True)
             ps = torch.rand((B, (16 - self.n_dyn) * M), generator=g, device=dev).requires_grad_(True)
             self.params, self.leaves, self.shared = (pd, ps), [pd, ps], ps
@@ -173,7 +240,7 @@ class Workload:
             p = torch.randn((T, B, self.model.learnable_param_count), generator=g, device=dev).requires_grad_(True)
             self.params, self.leaves, self.shared = p, [p], p
         self.key = "flow_sim" if cls == "HbvAdj" else "streamflow"
-        self.w = torch.randn((self.T_out, B, 1), generator=g, device=dev)
+        self.w = torch.randn((self.T_out, out_cols, 1), generator=g, device=dev)
         self.cls = cls
 
     @property
@@ -207,13 +274,15 @@ class Workload:
 
     def design_bytes(self):
         """Bytes this build's kernels move per lane-step by construction: the forward
-        saves the whole trajectory + two pow results (28 B) instead of K-day checkpoints, the
-        time-parallel adjoint reads its inputs twice."""
+        saves the whole trajectory (20 B: the five storages; the two powers are recomputed since round 4)
+        instead of K-day checkpoints; the time-parallel adjoint (small grids) reads its inputs twice, the
+        streaming adjoint (large grids) once."""
         M, nd = self.M, self.n_dyn
         n_g = 4 if self.routed else 1
-        fwd = 12.0 / M + 4.0 * nd + 4.0 * self.n_flux / M + 28.0
-        one = 12.0 / M + 4.0 * nd + 28.0 + 4.0 * n_g / M
-        return fwd, one + 4.0 * nd
+        fwd = 12.0 / M + 4.0 * nd + 4.0 * self.n_flux / M + 20.0
+        one = 12.0 / M + 4.0 * nd + 20.0 + 4.0 * n_g / M
+        passes = 1 if self.B * self.M >= 768 * 64 else 2      # the cross-over of hbvx.hip's dispatch
+        return fwd, passes * one + 4.0 * nd
 
 
 def timed_steps(wl, steps, warmup, dev, world, after_step=None):
@@ -255,26 +324,121 @@ def timed_steps(wl, steps, warmup, dev, world, after_step=None):
     return dt, {k: sum(v) / steps for k, v in per.items()}
 
 
+_PMC = None
+
+
+def pmc_traffic(name):
+    """HBM bytes per ABI call from the committed counter passes (profiles/pmc_traffic.json: rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate passes, corrected as DESIGN.md §5 states) for configuration `name`, or None.
+    Not re-measured in the run: counters need the profiler."""
+    global _PMC
+    if _PMC is None:
+        try:
+            _PMC = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        except Exception:
+            _PMC = {}
+    tab = _PMC.get("configs", {}).get(name) or (_PMC if name == "cfg2" else None)
+    if not tab:
+        return None
+    out = {k: v.get("hbm_bytes") for k, v in tab.items() if isinstance(v, dict) and "hbm_bytes" in v}
+    return out or None
+
+
 def roofline_entry(wl, kms, ms_per_step):
     """HBM roofline figures of one workload from its per-call kernel times."""
     ls = wl.lane_steps
     f8, b8, rf8, rb8 = wl.alg_bytes()
     fd, bd = wl.design_bytes()
+    xf, xb = wl.extra_bytes
     fk = "hbvx_adj_forward" if wl.cls == "HbvAdj" else "hbvx_forward"
     bk = "hbvx_adj_backward" if wl.cls == "HbvAdj" else "hbvx_backward"
     out = {"bytes_per_lane_step_8d": {"fwd": round(f8, 3), "bwd": round(b8, 3), "route": round(rf8 + rb8, 3),
                                       "K": CKPT_K},
            "kernel_ms": {k: round(v, 4) for k, v in kms.items()}}
+    if xf or xb:
+        out["gage_routing_bytes_per_launch"] = {"fwd": xf, "bwd": xb}
     if fk in kms and bk in kms:
         gf = f8 * ls / (kms[fk] * 1e-3) / 1e9
         gb = b8 * ls / (kms[bk] * 1e-3) / 1e9
-        whole = (f8 + b8 + rf8 + rb8) * ls / (ms_per_step * 1e-3) / 1e9
+        whole = ((f8 + b8 + rf8 + rb8) * ls + xf + xb) / (ms_per_step * 1e-3) / 1e9
         out.update({"fwd_GBps_8d": round(gf, 1), "bwd_GBps_8d": round(gb, 1), "step_GBps_8d": round(whole, 1),
                     "frac_fwd": round(gf / HBM_PEAK_GBPS, 4), "frac_bwd": round(gb / HBM_PEAK_GBPS, 4),
                     "frac_step": round(whole / HBM_PEAK_GBPS, 4),
                     "fwd_GBps_design": round(fd * ls / (kms[fk] * 1e-3) / 1e9, 1),
                     "bwd_GBps_design": round(bd * ls / (kms[bk] * 1e-3) / 1e9, 1)})
+    if wl.name in LIMITED_BY:
+        out.update(limited_by(wl.name))
+    tr = pmc_traffic(wl.name)
+    if tr:
+        out["traffic"] = tr
+        out["traffic_source"] = "profiles/pmc_traffic.json (committed rocprofv3 --pmc passes; not re-measured in this run)"
     return out
+
+
+class LstmWorkload:
+    """SURVEY §8f rank 4, the caller side: the hand-written sequence LSTM (include/hbvx_lstm.h, csrc/lstm_seq.h),
+    forward + backward at the deltaMG shape (T = 730 days, B = 100 basins, H = 256), torch.nn.LSTM semantics."""
+    name, cls = "lstm", "SeqLSTM"
+
+    def __init__(self, dev, seed, T=730, B=100, H=256):
+        import torch
+        from hydrodl2_amd.lstm import SeqLSTM
+        torch.manual_seed(seed)
+        self.T, self.B, self.H = T, B, H
+        self.net = SeqLSTM(H, H).to(dev)
+        self.x = torch.randn(T, B, H, device=dev, requires_grad=True)
+        self.gh = torch.randn(T, B, H, device=dev)
+
+    def step(self):
+        for p in self.net.parameters():
+            p.grad = None
+        self.x.grad = None
+        (self.net(self.x)[0] * self.gh).sum().backward()
+
+    def entry(self, ms, kms):
+        T, B, H = self.T, self.B, self.H
+        # algorithmic HBM bytes of the two recurrence kernels (tools/bench_lstm.py): gate pre-activations in, gates /
+        # cell / hidden series out; backward: those back in, gate gradients out
+        bf, bb = T * B * H * 4.0 * (4 + 4 + 1 + 1), T * B * H * 4.0 * (4 + 4 + 2 + 1)
+        tiles = (B + 15) // 16
+        flops = 2.0 * T * tiles * 16 * H * 4 * H            # padded row tiles; the same for either direction
+        e = {"config": "lstm", "what": f"SeqLSTM fwd+bwd, T={T} B={B} I=H={H} (recurrence kernels + 4 fp32 library GEMMs)",
+             "T": T, "B": B, "H": H, "steps": 5, "ms_per_step": round(ms, 4),
+             "sequence_steps_per_s": T * B / (ms * 1e-3), "kernel_ms": {k: round(v, 4) for k, v in kms.items()}}
+        for d, by in (("forward", bf), ("backward", bb)):
+            k = f"hbvx_lstm_{d}"
+            if k in kms:
+                e[f"{d}_GBps_algorithmic"] = round(by / (kms[k] * 1e-3) / 1e9, 1)
+                e[f"{d}_frac_hbm"] = round(by / (kms[k] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+                e[f"{d}_mfma_tflops"] = round(flops / (kms[k] * 1e-3) / 1e12, 2)
+                e[f"{d}_us_per_time_step"] = round(kms[k] * 1e3 / T, 2)
+        e.update(limited_by("lstm"))
+        return e
+
+
+class DplWorkload:
+    """One step of examples/train_dpl.py: LSTM parameter network -> Hbv (2 dynamic parameters, 365 + 365 days, 100
+    basins x 16) -> 1 - NSE -> backward -> Adam, one rank (the bucketed all-reduce is a no-op at world 1)."""
+    name, cls = "dpl", "train_dpl"
+
+    def __init__(self, dev, seed):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("train_dpl", os.path.join(ROOT, "examples", "train_dpl.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        self.step, self.info = mod.make_trainer(dev)
+
+    def entry(self, ms, kms):
+        i = self.info
+        hbv = sum(v for k, v in kms.items() if "lstm" not in k)
+        lstm = sum(v for k, v in kms.items() if "lstm" in k)
+        e = {"config": "dpl", "what": "examples/train_dpl.py step: LSTM-256 -> Hbv -> 1-NSE -> Adam (fused LSTM kernels)",
+             "T": i["T"], "B": i["B"], "M": i["M"], "steps": 5, "ms_per_step": round(ms, 4),
+             "lane_steps_per_s": i["T"] * i["B"] * i["M"] / (ms * 1e-3),
+             "hbv_calls_ms": round(hbv, 4), "lstm_kernels_ms": round(lstm, 4),
+             "kernel_ms": {k: round(v, 4) for k, v in kms.items()}}
+        e.update(limited_by("dpl"))
+        return e
 
 
 # --------------------------------------------------------------------------------------------
@@ -655,14 +819,14 @@ def main():
             ls = wl.lane_steps
             ach = f8 * ls / (kavg["hbvx_forward"] * 1e-3) / 1e9
             ach_d = fd * ls / (kavg["hbvx_forward"] * 1e-3) / 1e9
-            pmc, src = {}, os.path.join("profiles", "pmc_traffic.json")
-            try:
-                pmc = json.load(open(os.path.join(ROOT, src)))
-            except Exception:
-                pmc = {}
-            traffic = pmc.get("hbvx_forward", {}).get("hbm_bytes") if args.config == "cfg2" else None
+            src = os.path.join("profiles", "pmc_traffic.json")
+            tr = pmc_traffic("cfg2" if args.config == "cfg2" else "cfg5share" if wl.B == 12500 else "none")
+            traffic = tr.get("hbvx_forward") if tr else None
             res["roofline"] = {
-                "bound": "hbm", "kernel": "the kernel of hbvx_forward (k_fwd_pipe at cfg2, k_fwd_stream at cfg5)",
+                # the roofline `achieved` / `peak` are priced against (contract: hbm | mfma; no contraction on this path);
+                # `limited_by` is what the counters and probes say actually binds this configuration
+                "bound": "hbm", "kernel": "the kernel of hbvx_forward (k_fwd_pipe at cfg2, k_fwd_stream2 at cfg5)",
+                **limited_by(args.config),
                 "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBPS, 5), "frac_8d": round(ach / HBM_PEAK_GBPS, 5),
                 "frac_design": round(ach_d / HBM_PEAK_GBPS, 5),
@@ -681,17 +845,21 @@ def main():
         # the other BASELINE configs under the same clock: 5 timed steps each, same event timing
         sec = []
         print(f"[bench] headline done: {ms_per_step:.3f} ms/step; secondary configs ...", file=sys.stderr, flush=True)
-        for name in ("cfg2dyn", "cfg3", "cfg4", "cfg5share", "cfg5full", "dmg"):
+        for name in ("cfg2dyn", "cfg3", "cfg4", "cfg4joint", "cfg5share", "cfg5full", "dmg", "hourly", "lstm", "dpl"):
             if name == args.config:
                 continue
             try:
-                w2 = Workload(name, dev, seed=7)
+                w2 = (LstmWorkload(dev, 7) if name == "lstm" else DplWorkload(dev, 7) if name == "dpl"
+                      else Workload(name, dev, seed=7))
                 dt2, k2 = timed_steps(w2, 5, 3, dev, 1)
                 ms2 = 1e3 * dt2 / 5
-                e = {"config": name, "T": w2.T, "B": w2.B, "M": w2.M, "n_dyn": w2.n_dyn, "steps": 5,
-                     "ms_per_step": round(ms2, 4), "lane_steps_per_s": w2.lane_steps / (ms2 * 1e-3),
-                     "device_mallocs_in_timed_steps": timed_steps.device_mallocs}
-                e.update(roofline_entry(w2, k2, ms2))
+                if name in ("lstm", "dpl"):
+                    e = w2.entry(ms2, k2)
+                else:
+                    e = {"config": name, "T": w2.T, "B": w2.B, "M": w2.M, "n_dyn": w2.n_dyn, "steps": 5,
+                         "ms_per_step": round(ms2, 4), "lane_steps_per_s": w2.lane_steps / (ms2 * 1e-3)}
+                    e.update(roofline_entry(w2, k2, ms2))
+                e["device_mallocs_in_timed_steps"] = timed_steps.device_mallocs
                 sec.append(e)
                 print(f"[bench] {name}: {ms2:.3f} ms/step", file=sys.stderr, flush=True)
                 del w2

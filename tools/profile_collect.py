@@ -24,7 +24,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CALLS = {
     "hbvx_forward": ["k_fwd_pipe", "k_fwd_tiled", "k_fwd_stream"],
     "hbvx_backward": ["k_bwd_chunk_phi", "k_bwd_chunk_scan", "k_bwd_chunk_sweep", "k_bwd_chunk_reduce",
-                      "k_bwd_tiled", "k_bwd_stream"],
+                      "k_bwd_tiled", "k_bwd_stream", "k_bwd_pipe"],
     "hbvx_route_forward": ["k_route_fwd", "k_uh_gamma"],
     "hbvx_route_backward": ["k_route_bwd"],
     "hbvx_bfi": ["k_bfi"],
@@ -107,34 +107,49 @@ def main(tag):
                 lines = [l for l in f if l.startswith("{")]
             with open(os.path.join(out, f"{tag}_{extra}.json"), "w") as f:
                 f.write(lines[-1])
-    tables = {}
-    for kind in ("fetch", "write"):
-        src = glob.glob(os.path.join(raw, kind, "**", "*counter_collection.csv"), recursive=True)[0]
-        tab = {k: v for k, v in counter_table(src).items() if "hbvx" in k or k.startswith("k_")}
-        tables[kind] = tab
-        with open(os.path.join(out, f"{tag}_pmc_{kind}_size.csv"), "w") as f:
-            f.write("kernel,dispatches,mean_%s_SIZE_KiB\n" % kind.upper())
-            for k, (n, v) in sorted(tab.items()):
-                f.write(f"\"{k}\",{n},{v:.3f}\n")
-    traffic = {}
-    for call, pats in CALLS.items():
-        ks = sorted({k for kind in tables.values() for k in kind if any(p in k for p in pats)})
-        if not ks:
-            continue
-        fb = sum(tables["fetch"].get(k, (0, 0.0))[1] for k in ks) * 1024
-        wb = sum(tables["write"].get(k, (0, 0.0))[1] for k in ks) * 1024
-        traffic[call] = {
-            "kernels": ks, "fetch_bytes_raw": fb, "write_bytes": wb, "hbm_bytes_raw": fb + wb,
-            "hbm_bytes": 2.0 * fb + wb,
-            "note": "per ABI call (sum over its kernels), rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "
-                    "separate passes, KiB x1024.  hbm_bytes = 2 x FETCH_SIZE + WRITE_SIZE: the guide's x2 for "
-                    "FETCH_SIZE also holds for 4 B/lane row loads (profiles/r02_pmc_calibration.csv); "
-                    "WRITE_SIZE is exact for row and 16-byte streams and counts 16-byte pieces of a line twice"}
+    NOTE = ("per ABI call (sum over its kernels), rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "
+            "separate passes, KiB x1024.  hbm_bytes = 2 x FETCH_SIZE + WRITE_SIZE: the guide's x2 for "
+            "FETCH_SIZE also holds for 4 B/lane row loads (profiles/r02_pmc_calibration.csv); "
+            "WRITE_SIZE is exact for row and 16-byte streams and counts 16-byte pieces of a line twice")
+
+    def traffic_of(suffix, csv_tag):
+        tables = {}
+        for kind in ("fetch", "write"):
+            found = glob.glob(os.path.join(raw, kind + suffix, "**", "*counter_collection.csv"), recursive=True)
+            if not found:
+                return None
+            tab = {k: v for k, v in counter_table(found[0]).items() if "hbvx" in k or k.startswith("k_")}
+            tables[kind] = tab
+            with open(os.path.join(out, f"{tag}_pmc_{kind}_size{csv_tag}.csv"), "w") as f:
+                f.write("kernel,dispatches,mean_%s_SIZE_KiB\n" % kind.upper())
+                for k, (n, v) in sorted(tab.items()):
+                    f.write(f"\"{k}\",{n},{v:.3f}\n")
+        traffic = {}
+        for call, pats in CALLS.items():
+            ks = sorted({k for kind in tables.values() for k in kind if any(p in k for p in pats)})
+            if not ks:
+                continue
+            fb = sum(tables["fetch"].get(k, (0, 0.0))[1] for k in ks) * 1024
+            wb = sum(tables["write"].get(k, (0, 0.0))[1] for k in ks) * 1024
+            traffic[call] = {"kernels": ks, "fetch_bytes_raw": fb, "write_bytes": wb, "hbm_bytes_raw": fb + wb,
+                             "hbm_bytes": 2.0 * fb + wb}
+        return traffic
+
+    # top level: the headline configuration (bench.py, cfg2); "configs": the others (tools/bench_configs.py)
+    traffic = traffic_of("", "") or {}
+    traffic["note"] = NOTE
+    traffic["configs"] = {}
+    for cfg, name in (("cfg3", "cfg3"), ("cfg5", "cfg5share")):
+        t = traffic_of("_" + cfg, "_" + cfg)
+        if t:
+            traffic["configs"][name] = t
     with open(os.path.join(out, "pmc_traffic.json"), "w") as f:
         json.dump(traffic, f, indent=1)
     sq_counters(tag, out)
     print(json.dumps({k: (round(v["fetch_bytes_raw"] / 1e9, 3), round(v["write_bytes"] / 1e9, 3))
-                      for k, v in traffic.items()}))
+                      for k, v in traffic.items() if isinstance(v, dict) and "write_bytes" in v}))
+    for name, t in traffic["configs"].items():
+        print(name, json.dumps({k: (round(v["fetch_bytes_raw"] / 1e9, 3), round(v["write_bytes"] / 1e9, 3)) for k, v in t.items()}))
 
 
 if __name__ == "__main__":
