@@ -140,6 +140,9 @@ WORKLOADS = {
     "cfg5full": ("hbv_2", "Hbv_2", 730, 100000, 16, ["parBETA", "parK0", "parBETAET"]),
     # the deltaMG minibatch shape of SURVEY §8d: 100 basins, 365 warm-up + 365 days
     "dmg": ("hbv", "Hbv", 730, 100, 16, ["parBETA", "parBETAET"], {"warm_up": 365}),
+    # the same step through captured HIP graphs (module key `graph`: hydrodl2_amd/graphed.py) -- opt-in, for steps whose
+    # kernels are shorter than their enqueue time
+    "dmggraph": ("hbv", "Hbv", 730, 100, 16, ["parBETA", "parBETAET"], {"warm_up": 365, "graph": True}),
     # configs[3] under the REFERENCE's Newton policy: joint modified Newton on the five storages, max_iter 3,
     # gtol 1e-3 (hbv_adj.py:544-581); `cfg4` above times this package's default, the staged solve
     "cfg4joint": ("hbv_adj", "HbvAdj", 7300, 671, 16, ["parBETAET"], {"newton_solver": "joint"}),
@@ -170,6 +173,8 @@ LIMITED_BY = {
     "cfg5": ("valu-issue", "as cfg5share", {"k_bwd_stream2": 0.75, "k_fwd_stream2": 0.56}, "profiles/r03_sq_counters_cfg5.txt"),
     "dmg": ("host", "kernels sum to less than the enqueue time of the step's launches (tools/host_overhead.py)", {},
             "profiles/r03_host_overhead.txt"),
+    "dmggraph": ("latency", "two graph launches per step; what is left is the kernels' own time and the gaps between "
+                            "the ~20 nodes of the two graphs", {}, "profiles/r04_host_overhead.txt"),
     "hourly": ("latency", "two-stage pipelined forward (1 000 workgroups), gage routing FIR pair-parallel", {}, "DESIGN.md §4"),
     "lstm": ("latency", "per time step one L1-bypassing store -> load hand-off between the workgroups of a row tile "
                         "(~1.2 us) + H/4 MFMAs; 4 % of HBM peak, 12 % of the fp32 MFMA peak", {}, "DESIGN.md §4"),
@@ -845,7 +850,7 @@ def main():
         # the other BASELINE configs under the same clock: 5 timed steps each, same event timing
         sec = []
         print(f"[bench] headline done: {ms_per_step:.3f} ms/step; secondary configs ...", file=sys.stderr, flush=True)
-        for name in ("cfg2dyn", "cfg3", "cfg4", "cfg4joint", "cfg5share", "cfg5full", "dmg", "hourly", "lstm", "dpl"):
+        for name in ("cfg2dyn", "cfg3", "cfg4", "cfg4joint", "cfg5share", "cfg5full", "dmg", "dmggraph", "hourly", "lstm", "dpl"):
             if name == args.config:
                 continue
             try:

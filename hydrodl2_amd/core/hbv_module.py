@@ -60,6 +60,9 @@ class HbvModule(torch.nn.Module):
         # upstream.  With this key (or HBVX_CHECK_FINITE=1) non-finite forcings or
         # parameters raise instead of being absorbed; off by default (it costs two reductions per call).
         self.check_finite = os.environ.get('HBVX_CHECK_FINITE', '0') not in ('', '0')
+        # not in the reference: replay the call's launch sequence (forward and backward) as HIP graphs captured per
+        # input shape -- for steps whose kernels are shorter than their enqueue time (hydrodl2_amd/graphed.py)
+        self.graph = False
 
         self.states, self._states_cache = None, None
         self._cfg_cache, self._pmat_cache = {}, {}     # per input shape: step configs / Bernoulli probabilities
@@ -93,7 +96,7 @@ class HbvModule(torch.nn.Module):
     # -- configuration --------------------------------------------------
     # config key -> attribute of the same name; absent keys keep the constructor default
     _CONFIG_KEYS = ('warm_up', 'warm_up_states', 'dy_drop', 'variables', 'routing', 'comprout',
-                    'nearzero', 'nmul', 'cache_states', 'adjoint_checkpoint', 'check_finite')
+                    'nearzero', 'nmul', 'cache_states', 'adjoint_checkpoint', 'check_finite', 'graph')
 
     def _read_config(self, config: dict) -> None:
         """Same keys and defaults as hbv.py:110-125; `dynamic_params` is REQUIRED once a config is
@@ -240,10 +243,30 @@ class HbvModule(torch.nn.Module):
         self._cfg_cache[key] = (cfg_w, cfg)
         return cfg_w, cfg
 
+    def _settings_key(self):
+        """Everything besides the input shapes that decides what a call launches (key of the step-config and graph
+        caches)."""
+        return (self.nmul, len(self.parameter_bounds), tuple(self.dynamic_params), bool(self.routing), self._model_id,
+                tuple(self.variables), float(self.nearzero), int(self.adjoint_checkpoint), int(self.warm_up),
+                bool(self.warm_up_states), float(self.dy_drop), bool(self.comprout),
+                tuple(map(tuple, self.parameter_bounds.values())),
+                tuple(map(tuple, self.routing_parameter_bounds.values())))
+
+    def _advance_rng(self, ngrid: int) -> None:
+        """Consume the CPU generator as one call of forward() does (the dy_drop draws, hbv.py:240-246)."""
+        self._draw_drop_masks(len(self.dynamic_params), ngrid, torch.device('cpu'))
+
     # -- forward ---------------------------------------------------------
     def forward(self, x_dict: dict[str, torch.Tensor], parameters: torch.Tensor
                 ) -> Union[tuple, dict[str, torch.Tensor]]:
         """Reference: hbv.py:284-361 (orchestration) + :363-596 (`_PBM`)."""
+        if self.graph and x_dict['x_phy'].is_cuda:
+            from hydrodl2_amd.graphed import graphed_forward
+            return graphed_forward(self, x_dict, parameters)
+        return self._forward_eager(x_dict, parameters)
+
+    def _forward_eager(self, x_dict: dict[str, torch.Tensor], parameters: torch.Tensor
+                       ) -> Union[tuple, dict[str, torch.Tensor]]:
         x = x_dict['x_phy']
         self.__dict__['muwts'] = x_dict.get('muwts', None)     # (plain attribute: nn.Module.__setattr__ costs 5 us)
         T_total, ngrid = x.shape[0], x.shape[1]

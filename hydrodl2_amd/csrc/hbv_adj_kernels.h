@@ -28,13 +28,13 @@ struct AdjLane {
     int64_t n;
 };
 
-__device__ __forceinline__ AdjLane adj_lane(const hbvx_desc &d, int lgMp)
+__device__ __forceinline__ AdjLane adj_lane(const hbvx_desc &d, int lgMp, int bx = -1)
 {
     AdjLane L;
     const int lane = threadIdx.x & 63;
     const int Mp = 1 << lgMp;
     L.jm = lane & (Mp - 1);
-    int b = blockIdx.x * (64 >> lgMp) + (lane >> lgMp);
+    int b = (bx < 0 ? (int)blockIdx.x : bx) * (64 >> lgMp) + (lane >> lgMp);
     L.active = (b < d.B) && (L.jm < d.M);
     L.leader = (b < d.B) && (L.jm == 0);
     L.b = b < d.B ? b : d.B - 1;
@@ -230,11 +230,13 @@ __device__ __forceinline__ void adj_issue(const hbvx_desc &d, const hbvx_bwd_io 
 
 template <bool BETAET>
 __global__ void __launch_bounds__(64) k_adj_chunk_phi(const hbvx_desc d, const hbvx_bwd_io io, int lgMp,
-                                                      int C, float *phi_ws)
+                                                      int C, float *phi_ws, int per_xcd)
 {
     constexpr int NP = BETAET ? 13 : 12;
-    const AdjLane L = adj_lane(d, lgMp);
-    const int chunk = blockIdx.y;
+    ChunkBlock blk;                          // XCD-aware block map (hbv_chunked.h)
+    if (!chunk_block(d, lgMp, per_xcd, blk)) return;
+    const AdjLane L = adj_lane(d, lgMp, blk.bx);
+    const int chunk = blk.chunk;
     const int T = d.T, t0 = chunk * C, t1 = min(T, t0 + C);
     const int64_t N = (int64_t)d.B * d.M;
     const bool raw = d.raw_sigmoid != 0;
@@ -294,11 +296,13 @@ __global__ void __launch_bounds__(64) k_adj_chunk_phi(const hbvx_desc d, const h
 
 template <bool BETAET>
 __global__ void __launch_bounds__(64) k_adj_chunk_sweep(const hbvx_desc d, const hbvx_bwd_io io, int lgMp,
-                                                        int C, const float *abnd, float *gpart)
+                                                        int C, const float *abnd, float *gpart, int per_xcd)
 {
     constexpr int NP = BETAET ? 13 : 12;
-    const AdjLane L = adj_lane(d, lgMp);
-    const int chunk = blockIdx.y;
+    ChunkBlock blk;
+    if (!chunk_block(d, lgMp, per_xcd, blk)) return;
+    const AdjLane L = adj_lane(d, lgMp, blk.bx);
+    const int chunk = blk.chunk;
     const int T = d.T, t0 = chunk * C, t1 = min(T, t0 + C);
     const int64_t N = (int64_t)d.B * d.M;
     const bool raw = d.raw_sigmoid != 0;

@@ -42,7 +42,39 @@ struct ChunkArgs {
     float *gpart; // [nchunk][NP][N]  per-chunk static-parameter gradient (unit space)
     int nd;       // DYN == 1: number of dynamic parameters (<= CHUNK_FEW) and their slots
     int dslot[3];
+    int per_xcd;  // basin groups per XCD of the block map below (host: chunk_per_xcd)
 };
+
+// XCD-aware block -> (basin group, chunk) map of the two chunk-parallel kernels.  Workgroups are dealt round-robin
+// over the 8 XCDs (block i runs on XCD i % 8: observed, not guaranteed -- it only matters for speed), each with its
+// own L2.  A wave reads 48 bytes of a day's forcing row and 16 of each gradient-series row (4 basins): with the
+// plain (basin group, chunk) grid the 168 waves that share a day's rows are spread over all eight L2s and every XCD
+// pulls every line -- counters at config 2 (profiles/r04_pmc_fetch_size.csv): 2.2 GB of the adjoint's 5.5 GB of HBM
+// reads were those 137 MB of basin-shared rows fetched 8 times per pass.  Here XCD c owns the contiguous run of basin
+// groups [c * per, (c + 1) * per) for every chunk, walking basin groups first, so the waves of an XCD that are in
+// flight together share days AND neighbouring basins.  Grid = 8 * per * nchunk blocks, 1-D; groups past the end
+// return at once.
+struct ChunkBlock {
+    int bx, chunk;
+};
+__host__ __device__ inline int chunk_per_xcd(int B, int lgMp)
+{
+    const int bpw = 64 >> lgMp;
+    return ((B + bpw - 1) / bpw + 7) / 8;
+}
+__device__ __forceinline__ bool chunk_block(const hbvx_desc &d, int lgMp, int per_xcd, ChunkBlock &b)
+{
+    const int i = blockIdx.x;
+#if defined(HBVX_CHUNK_XCD) && HBVX_CHUNK_XCD == 0      // A/B builds: the plain map (consecutive blocks = consecutive basin groups)
+    b.chunk = i / (8 * per_xcd);
+    b.bx = i - b.chunk * (8 * per_xcd);
+#else
+    const int c = i & 7, k = i >> 3;
+    b.chunk = k / per_xcd;
+    b.bx = c * per_xcd + (k - b.chunk * per_xcd);
+#endif
+    return b.bx * (64 >> lgMp) < d.B;
+}
 
 // DYN template values: 0 all static; 1 "few": at most CHUNK_FEW dynamic parameters, no muwts -- only
 // those rows are loaded / de-scaled / stored, addressed through the wave-uniform slot list (the
@@ -75,13 +107,13 @@ struct ChunkLane {
     int64_t n;
 };
 
-__device__ __forceinline__ ChunkLane chunk_lane(const hbvx_desc &d, int lgMp)
+__device__ __forceinline__ ChunkLane chunk_lane(const hbvx_desc &d, int lgMp, int bx)
 {
     ChunkLane L;
     const int lane = threadIdx.x & 63;
     const int Mp = 1 << lgMp;
     L.jm = lane & (Mp - 1);
-    int b = blockIdx.x * (64 >> lgMp) + (lane >> lgMp);
+    int b = bx * (64 >> lgMp) + (lane >> lgMp);
     L.active = (b < d.B) && (L.jm < d.M);
     L.leader = (b < d.B) && (L.jm == 0);
     L.b = b < d.B ? b : d.B - 1;
@@ -311,8 +343,10 @@ __global__ void __launch_bounds__(64) k_bwd_chunk_phi(const ChunkArgs A)
     constexpr int NP = ChunkNP<MODEL, BETAET>::value;
     const hbvx_desc &d = A.d;
     const hbvx_bwd_io &io = A.io;
-    const ChunkLane L = chunk_lane(d, A.lgMp);
-    const int chunk = blockIdx.y;
+    ChunkBlock blk;
+    if (!chunk_block(d, A.lgMp, A.per_xcd, blk)) return;
+    const ChunkLane L = chunk_lane(d, A.lgMp, blk.bx);
+    const int chunk = blk.chunk;
     const int t0 = chunk * A.C, t1 = min(d.T, t0 + A.C);
     const int64_t N = (int64_t)d.B * d.M;
     const bool raw = d.raw_sigmoid != 0;
@@ -469,8 +503,10 @@ __global__ void __launch_bounds__(64) k_bwd_chunk_sweep(const ChunkArgs A)
     __shared__ float rowbuf[ROWST ? 64 * NP : 1];
     const hbvx_desc &d = A.d;
     const hbvx_bwd_io &io = A.io;
-    const ChunkLane L = chunk_lane(d, A.lgMp);
-    const int chunk = blockIdx.y;
+    ChunkBlock blk;
+    if (!chunk_block(d, A.lgMp, A.per_xcd, blk)) return;
+    const ChunkLane L = chunk_lane(d, A.lgMp, blk.bx);
+    const int chunk = blk.chunk;
     const int t0 = chunk * A.C, t1 = min(d.T, t0 + A.C);
     const int64_t N = (int64_t)d.B * d.M;
     const bool raw = d.raw_sigmoid != 0;
@@ -545,7 +581,7 @@ __global__ void __launch_bounds__(64) k_bwd_chunk_sweep(const ChunkArgs A)
                 }
             }
             // (one wave per workgroup: LDS traffic is ordered by the hardware, no barrier)
-            const int b0 = blockIdx.x * (64 >> A.lgMp);
+            const int b0 = blk.bx * (64 >> A.lgMp);
             const int nb = min(64 >> A.lgMp, d.B - b0);
             const int half = rowf >> 1, total2 = nb * half;                 // rowf is even (host)
             float *gbase = io.g[0].dyn + (int64_t)t * io.g[0].dyn_t_stride + (int64_t)b0 * io.g[0].dyn_b_stride;

@@ -43,7 +43,8 @@ static hipError_t launch_chunked_t(const ChunkArgs &a, hipStream_t st)
     const hbvx_desc &d = a.d;
     const int bpw = 64 >> a.lgMp;
     const int64_t N = (int64_t)d.B * d.M;
-    dim3 g2((d.B + bpw - 1) / bpw, a.nchunk);
+    (void)bpw;
+    dim3 g2((unsigned)(8 * a.per_xcd * a.nchunk));      // XCD-aware 1-D block map (hbv_chunked.h::chunk_block)
     // the two slot lists users actually run get compile-time slots (hbv_chunked.h::SlotCombo)
     int sc = 0;
     if (DYN == 1 && MODEL == MODEL_HBV10 && BETAET && a.nd == 2 && a.dslot[0] == P_BETA && a.dslot[1] == P_BETAET) sc = 1;
@@ -112,6 +113,7 @@ static hipError_t launch_chunked(const hbvx_desc *d, const hbvx_bwd_io *io, hipS
     a.lgMp = lg_members(d->M);
     a.C = chunk_days();
     a.nchunk = (d->T + a.C - 1) / a.C;
+    a.per_xcd = chunk_per_xcd(d->B, a.lgMp);
     const int64_t N = (int64_t)d->B * d->M;
     a.phi = (float *)io->workspace;
     a.abnd = a.phi + (int64_t)a.nchunk * 30 * N;

@@ -2,9 +2,9 @@
 // implicit scheme (hbv_adj_kernels.h), whose forward is the tiled stepper running the Newton solve.
 #include "hbvx_host.h"
 #include "hbv_tiled.h"
-#include "hbv_adj_kernels.h"
 #define HBVX_CHUNK_NO_SHARED_KERNELS
-#include "hbv_chunked.h"
+#include "hbv_chunked.h"        // (first: hbv_adj_kernels.h uses its XCD-aware block map)
+#include "hbv_adj_kernels.h"
 
 using namespace hbvx;
 using namespace hbvx_host;
@@ -215,14 +215,14 @@ extern "C" int hbvx_adj_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void
         ca.abnd = ca.phi + (int64_t)ca.nchunk * 30 * N;
         ca.gpart = ca.abnd + (int64_t)ca.nchunk * 5 * N;
         hipStream_t st = (hipStream_t)stream;
-        const int bpw_c = 64 >> ca.lgMp;
-        dim3 g2((d->B + bpw_c - 1) / bpw_c, ca.nchunk);
-        if (d->n_param == 13) hipLaunchKernelGGL(k_adj_chunk_phi<true>, g2, dim3(64), 0, st, *d, *io, ca.lgMp, ca.C, ca.phi);
-        else hipLaunchKernelGGL(k_adj_chunk_phi<false>, g2, dim3(64), 0, st, *d, *io, ca.lgMp, ca.C, ca.phi);
+        ca.per_xcd = chunk_per_xcd(d->B, ca.lgMp);
+        dim3 g2((unsigned)(8 * ca.per_xcd * ca.nchunk));      // XCD-aware 1-D block map (hbv_chunked.h::chunk_block)
+        if (d->n_param == 13) hipLaunchKernelGGL(k_adj_chunk_phi<true>, g2, dim3(64), 0, st, *d, *io, ca.lgMp, ca.C, ca.phi, ca.per_xcd);
+        else hipLaunchKernelGGL(k_adj_chunk_phi<false>, g2, dim3(64), 0, st, *d, *io, ca.lgMp, ca.C, ca.phi, ca.per_xcd);
         launch_chunk_scan(ca, st);
         store_gate(io, st);      // phi and scan only read; the sweep stores the dynamic gradients
-        if (d->n_param == 13) hipLaunchKernelGGL(k_adj_chunk_sweep<true>, g2, dim3(64), 0, st, *d, *io, ca.lgMp, ca.C, ca.abnd, ca.gpart);
-        else hipLaunchKernelGGL(k_adj_chunk_sweep<false>, g2, dim3(64), 0, st, *d, *io, ca.lgMp, ca.C, ca.abnd, ca.gpart);
+        if (d->n_param == 13) hipLaunchKernelGGL(k_adj_chunk_sweep<true>, g2, dim3(64), 0, st, *d, *io, ca.lgMp, ca.C, ca.abnd, ca.gpart, ca.per_xcd);
+        else hipLaunchKernelGGL(k_adj_chunk_sweep<false>, g2, dim3(64), 0, st, *d, *io, ca.lgMp, ca.C, ca.abnd, ca.gpart, ca.per_xcd);
         launch_chunk_reduce(ca, d->n_param, st);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return hip_fail(e, "hbvx_adj_backward (chunked) launch");

@@ -31,12 +31,14 @@ def gen(T, B, dev, seed=0):
 
 def run(name, steps=5, warmup=2):
     dev = torch.device("cuda:0")
-    if name in ("cfg2", "cfg2dyn", "cfg2dynK", "dmg"):
-        T, B, M = (730, 100, 16) if name == "dmg" else (7300, 671, 16)
+    if name in ("cfg2", "cfg2dyn", "cfg2dynK", "dmg", "dmggraph"):
+        T, B, M = (730, 100, 16) if name.startswith("dmg") else (7300, 671, 16)
         dyn = [] if name == "cfg2" else (["parK0", "parK1"] if name == "cfg2dynK" else ["parBETA", "parBETAET"])
         cfgd = {"nmul": M, "dynamic_params": {"Hbv": dyn}}
-        if name == "dmg":
+        if name.startswith("dmg"):
             cfgd["warm_up"] = 365
+        if name == "dmggraph":
+            cfgd["graph"] = True
         model = hydrodl2_amd.load_model("hbv", "Hbv")(cfgd, dev)
         n_dyn, nf = len(dyn), 11
     elif name == "cfg3":
@@ -129,8 +131,8 @@ def run(name, steps=5, warmup=2):
     kms = {k: sum(v) / steps for k, v in kt.items()}
     ls = B * M * T
     routed = 4 if model.routing else 0
-    b_f = ls * (12 / M + 4 * n_dyn + 4 * nf / M + 28)
-    b_b = ls * (12 / M + 8 * n_dyn + 28 + 4 * max(routed, 1) / M)
+    b_f = ls * (12 / M + 4 * n_dyn + 4 * nf / M + 20)
+    b_b = ls * (12 / M + 8 * n_dyn + 20 + 4 * max(routed, 1) / M)
     res = {"config": name, "T": T, "B": B, "M": M, "n_dyn": n_dyn, "ms_per_step": round(dt * 1e3, 3),
            "lane_steps_per_s": ls / dt, "kernel_ms": {k: round(v, 4) for k, v in kms.items()}}
     if "hbvx_forward" in kms:

@@ -17,8 +17,9 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+name = sys.argv[2] if len(sys.argv) > 2 else "dmg"          # dmg | dmggraph
 dev = torch.device("cuda:0")
-wl = bench.Workload("dmg", dev, seed=7)
+wl = bench.Workload(name, dev, seed=7)
 for _ in range(20):
     wl.step()
 torch.cuda.synchronize()
@@ -28,7 +29,7 @@ for _ in range(steps):
 t_cpu = time.perf_counter() - t0          # host time to ENQUEUE the steps
 torch.cuda.synchronize()
 t_all = time.perf_counter() - t0
-print(f"enqueue {1e3 * t_cpu / steps:.3f} ms/step, wall {1e3 * t_all / steps:.3f} ms/step")
+print(f"{name}: enqueue {1e3 * t_cpu / steps:.3f} ms/step, wall {1e3 * t_all / steps:.3f} ms/step")
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(steps):
