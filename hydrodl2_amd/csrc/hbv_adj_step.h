@@ -238,6 +238,15 @@ HBVX_HD int adj_newton(AdjStep<BETAET> &s, const float *p, const float *xt, floa
 #ifndef ADJ_SOIL_PEEL
 #define ADJ_SOIL_PEEL 1
 #endif
+#ifndef ADJ_SOIL_HH
+#define ADJ_SOIL_HH 1        // third-derivative term in the update (Householder order 3); 0: Halley
+#endif
+#ifndef ADJ_SOIL_LIN
+#define ADJ_SOIL_LIN 0.05f   // residuals below this after the first update are finished by x - g / J; 0: off
+#endif
+#ifndef ADJ_SOIL_KINK
+#define ADJ_SOIL_KINK 1      // start at SM = LP FC when the root lies across that kink from the day's storage
+#endif
 template <bool BETAET>
 struct AdjStaged {
     // ---- block 1: snow.  (y0 - y0t)/dt = sf + refr - melt,  (y1 - y1t)/dt = melt - refr - Isnow
@@ -286,6 +295,26 @@ struct AdjStaged {
     //      the midpoint; the bracket shrinks with the sign of each residual).  Plain Newton cycles across the
     //      kink at FC when a large melt pulse meets a small store (slope 1 + In BETA / FC below, 2 above);
     //      this cannot.  Returns the update count; Peff, ex: at the accepted state.
+    //
+    //      Round 4: ONE update and two residual evaluations on 99.9 % of the wave-days (before: the slowest of a
+    //      wave's 64 lanes asked for a second update on 54 % of them, 2.9 % of the lane-days; statistics of this
+    //      function on bench-shaped forcing, tools/micro/adj_soil_stats.cpp).  What the second update was spent on:
+    //        * smooth days with a large input (10-25 mm into a 100 mm store) where Halley's third-order step leaves
+    //          |G2| = 1e-3 .. 1e-2: the update now also carries the third derivative (Householder's order-3
+    //          step; d3 sw = (BETA - 2) d2 sw / SM, four more multiplications off the chain) -- 2.9 % -> 1.1 %;
+    //        * residuals just above gtol after that update (0.5 % of the lane-days): finished by the Newton step
+    //          from the values the evaluation has already produced, x - g / J, with Peff moved along its slope
+    //          and ex recomputed -- the accepted state is the iterate a second update returns; what is skipped is
+    //          the evaluation that would confirm |G2| <= gtol.  Taken only for |g| < ADJ_SOIL_LIN (0.05) and a
+    //          step that stays inside the bracket (no kink between the two points) and whose own error estimate
+    //          g^2 |G2''| / 2 G2'^2 is below gtol / 4: the true residual there stayed <= 4e-4 on 7.5e6 lane-days of
+    //          the statistics, and tests/test_step_math_host.py evaluates G2 at the returned state of 200 000
+    //          random days (one of them -- an empty store under an evaporation exponent of 0.4 -- is why the
+    //          estimate is part of the test) -- 1.1 % -> 0.64 %;
+    //        * days whose root lies across the kink of the evaporation factor at SM = LP FC from the starting point
+    //          (all of the remaining 0.64 %): G2 at the kink needs one power of the parameters only (wetness LP^BETA,
+    //          ef = 1, no excess), its sign names the root's side, and a day that would cross starts AT the kink on
+    //          the root's piece instead of at y2t -- 0.64 % -> 0.003 %.
     static HBVX_HDM int soil(const float *p, float rf, float Isnow, float PET, float idt, float y2t,
                              float gtol, int max_iter, float &y2, float &Peff, float &ex)
     {
@@ -297,7 +326,9 @@ struct AdjStaged {
         // day constants (off the iteration's dependency chain)
         const float rFC = div_approx_(1.0f, FC), rLF = div_approx_(1.0f, lpfc);
         const float rtB = rt * BETA, B1 = BETA - 1.0f, PB = BETAET ? PET * BE : PET * rLF, E1 = BE - 1.0f;
-        float x = y2t, g, J, H, et;
+        const float B12 = B1 * (BETA - 2.0f), E12 = E1 * (BE - 2.0f);
+        float x = y2t, g, J, H, K, dPx, et;
+        bool force = false, force_low = false;   // first evaluation AT the kink SM = LP FC: the piece is named, not compared
         // Residual, slope and curvature at x in ONE straight block: the iteration is a chain of dependent
         // instructions on a wave that owns its SIMD, so everything that does not have to wait for the powers
         // (1/SM, the masks) or for the residual (slope, curvature) is issued beside them.  Values as in
@@ -316,24 +347,45 @@ struct AdjStaged {
             et = fmin_(SM, pe);
             const float f2 = (((Isnow + rf) - Peff) - ex) - et;
             g = (x - y2t) * idt - f2;
-            // G2' and G2'' between the kinks (the iteration needs a slope, not autograd's tie conventions)
+            // G2', G2'' and G2''' between the kinks (the iteration needs a slope, not autograd's tie conventions)
             const float dP = (e0 <= 0.0f) ? rtB * (sw0 * rSM) : 0.0f;                  // d Peff / d SM
-            const float dEp = (qe <= 1.0f) ? (BETAET ? PB * (ef0 * rSM) : PB) : 0.0f;  // d (PET ef) / d SM
+            const bool lowp = force ? force_low : (qe <= 1.0f);
+            const float dEp = lowp ? (BETAET ? PB * (ef0 * rSM) : PB) : 0.0f;          // d (PET ef) / d SM
             const bool epow = pe < SM;                                                 // et = PET ef
             const bool live = x >= 1e-8f;        // below the clamp of hbv_adj.py:389 the fluxes do not move
             const float Jf = (dP + ((e0 >= 0.0f) ? 1.0f : 0.0f)) + (epow ? dEp : 1.0f);
             J = idt + (live ? Jf : 0.0f);
-            // sw'' = (BETA - 1) sw' / SM, ef'' likewise: four multiplications
-            H = (ADJ_SOIL_HALLEY && live) ? rSM * (B1 * dP + ((BETAET && epow) ? E1 * dEp : 0.0f)) : 0.0f;
+            dPx = live ? dP : 0.0f;
+            // d2 sw = (BETA - 1) d sw / SM, d3 sw = (BETA - 2) d2 sw / SM; the evaporation factor likewise
+            const bool ec = BETAET && epow;
+            H = (ADJ_SOIL_HALLEY && live) ? rSM * (B1 * dP + (ec ? E1 * dEp : 0.0f)) : 0.0f;
+            K = (ADJ_SOIL_HH && live) ? (rSM * rSM) * (B12 * dP + (ec ? E12 * dEp : 0.0f)) : 0.0f;
         };
+        // which side of the evaporation factor's kink holds the root (G2 increasing): the sign of G2(LP FC)
+        bool kabove = false, kcross = false;
+        if (ADJ_SOIL_KINK) {
+            const float swk = fmin_(ADJ_SOIL_POW(fmax_(LP, 1.17549435e-38f), BETA), 1.0f);
+            const float gk = (lpfc - y2t) * idt - ((rt - rt * swk) - fmin_(lpfc, PET));
+            kabove = gk < 0.0f;
+            kcross = ((y2t <= lpfc) == kabove) && lpfc > 1e-8f;
+            x = kcross ? lpfc : y2t;
+            force = kcross;
+            force_low = !kabove;
+        }
         eval();
-        // bracket from the first evaluation (x = y2t)
+        force = false;
+        // bracket from the first evaluation
         const bool below = (FC - y2t) * idt + fmin_(FC, PET) > 0.0f;   // G2(FC) > 0: root < FC
-        float lo = y2t - dt * (ex + et);
+        float lo = kcross ? 0.0f : y2t - dt * (ex + et);                // (the outflow bound holds at y2t only)
         float hi = y2t + dt * rt;
         bool hi_new = below && FC < hi;   // hi is a bound that has not been an iterate yet
         hi = below ? fmin_(hi, FC) : hi;
         lo = below ? lo : fmax_(lo, FC);
+        if (ADJ_SOIL_KINK) {
+            lo = kabove ? fmax_(lo, lpfc) : lo;
+            hi_new = hi_new && (kabove || lpfc >= hi);
+            hi = kabove ? hi : fmin_(hi, lpfc);
+        }
         int it = 0;
         bool more = fabsf(g) > gtol;
         auto update = [&]() __attribute__((always_inline)) {
@@ -341,10 +393,13 @@ struct AdjStaged {
             // Newton's step g / J with Halley's correction g / (J - g H / 2J) -- the powers make G2 smooth between
             // its kinks, and the correction saves the second update (a whole residual evaluation, two powers) on
             // most days -- as ONE reciprocal: g J / (J^2 - g H / 2); Newton's step is kept where the correction
-            // is large (denominator below J^2 / 2)
-            const float JJ = J * J, den = JJ - 0.5f * (g * H);
-            const bool hal = den > 0.5f * JJ;
-            const float dx = (hal ? g * J : g) * div_approx_(1.0f, hal ? den : J);
+            // is large (denominator below J^2 / 2).  With the third derivative: Householder's step of order 3,
+            // g (J^2 - g H / 2) / (J^3 - g J H + g^2 K / 6), under the same guard.
+            const float JJ = J * J, gH = g * H, num = JJ - 0.5f * gH;
+            const bool hal = num > 0.5f * JJ;
+            const float den3 = (J * JJ - gH * J) + (g * g) * (K * (1.0f / 6.0f));
+            const bool hh = ADJ_SOIL_HH && hal && den3 > 0.5f * (J * JJ);
+            const float dx = (hh ? g * num : (hal ? g * J : g)) * div_approx_(1.0f, hh ? den3 : (hal ? num : J));
             lo = (g < 0.0f) ? fmax_(lo, x) : lo;
             hi = (g < 0.0f) ? hi : fmin_(hi, x);
             // a step past FC lands ON FC first: below FC the residual is convex in SM (BETA >= 1), so Newton from the
@@ -365,6 +420,20 @@ struct AdjStaged {
         for (int k = 0; k < ADJ_SOIL_PEEL; k++)
             if (k <= max_iter) update();
 #endif
+        if (ADJ_SOIL_LIN > 0.0f && it <= max_iter) {
+            // the linearised finish (see above): lanes a hair above gtol take the Newton step from what is known
+            const float dxl = g * div_approx_(1.0f, J);
+            const float x2 = x - dxl;
+            const float l2 = (g < 0.0f) ? fmax_(lo, x) : lo, h2 = (g < 0.0f) ? hi : fmin_(hi, x);
+            // ... and only where the step's own error estimate, g^2 |G2''| / 2 G2'^2, is below gtol / 4 (an evaporation
+            // exponent below 1 makes G2 arbitrarily curved next to an empty store)
+            const bool fin = more && fabsf(g) < ADJ_SOIL_LIN && x2 >= l2 && x2 <= h2 &&
+                             (g * g) * fabsf(H) < (0.5f * gtol) * (J * J);
+            Peff = fin ? Peff - dPx * dxl : Peff;
+            x = fin ? x2 : x;
+            ex = fin ? fmax_(x2 - FC, 0.0f) : ex;
+            more = more && !fin;
+        }
         while (adj_any_(more, true) && it <= max_iter) update();
         y2 = x;
         return it;

@@ -62,8 +62,9 @@ class _Captured:
             seen = self.src[slot]
             if seen is not None and seen[0]() is src and seen[1] == src._version:
                 continue
-            with torch.no_grad():
-                dst.copy_(src)
+            # through .data: the static tensors are saved in the captured autograd graph, whose version check must not
+            # see the refresh (their CONTENT is what the replayed kernels read; the graph's nodes hold pointers)
+            dst.data.copy_(src.detach())
             self.src[slot] = (weakref.ref(src), src._version)
 
     def _run(self, module):
@@ -110,7 +111,7 @@ class _Replay(torch.autograd.Function):
             return None, None, torch.zeros_like(cap.p)
         graph, gos, gp = cap.backward_graph(pattern, grads)
         for s, g in zip(gos, (g for g in grads if g is not None)):
-            s.copy_(g)
+            s.data.copy_(g)
         graph.replay()
         return None, None, gp.detach()
 
