@@ -238,14 +238,11 @@ HBVX_HD int adj_newton(AdjStep<BETAET> &s, const float *p, const float *xt, floa
 #ifndef ADJ_SOIL_PEEL
 #define ADJ_SOIL_PEEL 1
 #endif
-#ifndef ADJ_SOIL_HH
-#define ADJ_SOIL_HH 1        // third-derivative term in the update (Householder order 3); 0: Halley
+#ifndef ADJ_SOIL_CLAMP
+#define ADJ_SOIL_CLAMP 3
 #endif
-#ifndef ADJ_SOIL_LIN
-#define ADJ_SOIL_LIN 0.05f   // residuals below this after the first update are finished by x - g / J; 0: off
-#endif
-#ifndef ADJ_SOIL_KINK
-#define ADJ_SOIL_KINK 1      // start at SM = LP FC when the root lies across that kink from the day's storage
+#ifndef ADJ_SOIL_FREE
+#define ADJ_SOIL_FREE 2      // updates taken as plain Halley steps before the bracket is built (0: safeguard every update)
 #endif
 template <bool BETAET>
 struct AdjStaged {
@@ -291,30 +288,27 @@ struct AdjStaged {
     //      G2 is increasing in y2 (Peff, ex and et all grow with SM), so the root is bracketed: it lies in
     //      [y2t - dt (ex + et)(y2t), y2t + dt (Isnow + rf)], and on the FC side that G2(FC) = (FC - y2t)/dt +
     //      min(FC, PET) names (at SM = FC the wetness is 1 and, LP <= 1, so is the evaporation factor: no power
-    //      needed).  Newton from y2t, every update kept inside the bracket (a step that leaves it is replaced by
-    //      the midpoint; the bracket shrinks with the sign of each residual).  Plain Newton cycles across the
-    //      kink at FC when a large melt pulse meets a small store (slope 1 + In BETA / FC below, 2 above);
-    //      this cannot.  Returns the update count; Peff, ex: at the accepted state.
+    //      needed).  Newton from y2t with Halley's correction under the reference's policy (stop at |G2| <= gtol,
+    //      at most max_iter + 1 updates).  Returns the update count; Peff, ex: at the accepted state.
     //
-    //      Round 4: ONE update and two residual evaluations on 99.9 % of the wave-days (before: the slowest of a
-    //      wave's 64 lanes asked for a second update on 54 % of them, 2.9 % of the lane-days; statistics of this
-    //      function on bench-shaped forcing, tools/micro/adj_soil_stats.cpp).  What the second update was spent on:
-    //        * smooth days with a large input (10-25 mm into a 100 mm store) where Halley's third-order step leaves
-    //          |G2| = 1e-3 .. 1e-2: the update now also carries the third derivative (Householder's order-3
-    //          step; d3 sw = (BETA - 2) d2 sw / SM, four more multiplications off the chain) -- 2.9 % -> 1.1 %;
-    //        * residuals just above gtol after that update (0.5 % of the lane-days): finished by the Newton step
-    //          from the values the evaluation has already produced, x - g / J, with Peff moved along its slope
-    //          and ex recomputed -- the accepted state is the iterate a second update returns; what is skipped is
-    //          the evaluation that would confirm |G2| <= gtol.  Taken only for |g| < ADJ_SOIL_LIN (0.05) and a
-    //          step that stays inside the bracket (no kink between the two points) and whose own error estimate
-    //          g^2 |G2''| / 2 G2'^2 is below gtol / 4: the true residual there stayed <= 4e-4 on 7.5e6 lane-days of
-    //          the statistics, and tests/test_step_math_host.py evaluates G2 at the returned state of 200 000
-    //          random days (one of them -- an empty store under an evaporation exponent of 0.4 -- is why the
-    //          estimate is part of the test) -- 1.1 % -> 0.64 %;
-    //        * days whose root lies across the kink of the evaporation factor at SM = LP FC from the starting point
-    //          (all of the remaining 0.64 %): G2 at the kink needs one power of the parameters only (wetness LP^BETA,
-    //          ef = 1, no excess), its sign names the root's side, and a day that would cross starts AT the kink on
-    //          the root's piece instead of at y2t -- 0.64 % -> 0.003 %.
+    //      The soil-moisture wave of the pipelined forward is a lone wave on its SIMD and pays ~8 cycles for EVERY
+    //      instruction of this function, on or off the dependency chain (round 4: eleven builds timed against each
+    //      other, profiles/r04_ab_soil_parts.txt) -- so the common day must be short, not clever:
+    //        * the first ADJ_SOIL_FREE (2) updates are Halley steps with ONE safeguard, the one the hard days need: a
+    //          step that would pass FC from a day whose root lies below it lands ON FC (a melt pulse of hundreds of
+    //          mm into a small store: plain Newton cycles across that kink, slope 1 + In BETA / FC below and 2 above;
+    //          below FC the residual is convex, so Newton from the right end then converges monotonically).  On
+    //          7.5e6 lane-days of bench-shaped forcing (tools/micro/adj_soil_stats.cpp) 97.1 % of the lanes are done
+    //          after one update and all but 0.0005 % after two;
+    //        * a lane that is still unsolved after them finishes inside the full bracket -- built only then, from the
+    //          outflow at y2t kept from the first evaluation and the side of y2t its residual named: every further
+    //          update stays inside it (a step that leaves it becomes its midpoint) and the bracket shrinks with the
+    //          sign of each residual.  tests/test_step_math_host.py: 200 000 adversarial days, |G2| <= gtol within
+    //          the four updates on every one.
+    //      Measured and not kept (same file): a third-derivative term in the update (Householder order 3), a
+    //      Newton finish without the confirming evaluation for residuals just above gtol, and a start AT the kink
+    //      of the evaporation factor for days whose root lies across it -- together they take the wave-days that
+    //      need a second update from 54 % to 0.1 %, and each costs the common day as much as it saves.
     static HBVX_HDM int soil(const float *p, float rf, float Isnow, float PET, float idt, float y2t,
                              float gtol, int max_iter, float &y2, float &Peff, float &ex)
     {
@@ -322,18 +316,13 @@ struct AdjStaged {
         const float BE = BETAET ? p[P_BETAET] : 1.0f;
         const float lpfc = LP * FC;
         const float rt = rf + Isnow;
-        const float dt = (idt == 1.0f) ? 1.0f : div_approx_(1.0f, idt);
         // day constants (off the iteration's dependency chain)
         const float rFC = div_approx_(1.0f, FC), rLF = div_approx_(1.0f, lpfc);
         const float rtB = rt * BETA, B1 = BETA - 1.0f, PB = BETAET ? PET * BE : PET * rLF, E1 = BE - 1.0f;
-        const float B12 = B1 * (BETA - 2.0f), E12 = E1 * (BE - 2.0f);
-        float x = y2t, g, J, H, K, dPx, et;
-        bool force = false, force_low = false;   // first evaluation AT the kink SM = LP FC: the piece is named, not compared
-        // Residual, slope and curvature at x in ONE straight block: the iteration is a chain of dependent
-        // instructions on a wave that owns its SIMD, so everything that does not have to wait for the powers
-        // (1/SM, the masks) or for the residual (slope, curvature) is issued beside them.  Values as in
-        // AdjStep::eval up to the rounding of the quotients (SM/FC by reciprocal: the iteration's acceptance
-        // test is 1e-3, and SM <= FC decides the wetness clamp instead of the power's side of 1).
+        float x = y2t, g, J, H, et;
+        // Residual, slope and curvature at x in ONE straight block.  Values as in AdjStep::eval up to the rounding of
+        // the quotients (SM/FC by reciprocal: the iteration's acceptance test is 1e-3, and SM <= FC decides the
+        // wetness clamp instead of the power's side of 1).
         auto eval = [&]() __attribute__((always_inline)) {
             const float SM = fmax_(x, 1e-8f);
             const float rSM = div_approx_(1.0f, SM);
@@ -347,94 +336,69 @@ struct AdjStaged {
             et = fmin_(SM, pe);
             const float f2 = (((Isnow + rf) - Peff) - ex) - et;
             g = (x - y2t) * idt - f2;
-            // G2', G2'' and G2''' between the kinks (the iteration needs a slope, not autograd's tie conventions)
+            // G2' and G2'' between the kinks (the iteration needs a slope, not autograd's tie conventions)
             const float dP = (e0 <= 0.0f) ? rtB * (sw0 * rSM) : 0.0f;                  // d Peff / d SM
-            const bool lowp = force ? force_low : (qe <= 1.0f);
-            const float dEp = lowp ? (BETAET ? PB * (ef0 * rSM) : PB) : 0.0f;          // d (PET ef) / d SM
+            const float dEp = (qe <= 1.0f) ? (BETAET ? PB * (ef0 * rSM) : PB) : 0.0f;  // d (PET ef) / d SM
             const bool epow = pe < SM;                                                 // et = PET ef
             const bool live = x >= 1e-8f;        // below the clamp of hbv_adj.py:389 the fluxes do not move
             const float Jf = (dP + ((e0 >= 0.0f) ? 1.0f : 0.0f)) + (epow ? dEp : 1.0f);
             J = idt + (live ? Jf : 0.0f);
-            dPx = live ? dP : 0.0f;
-            // d2 sw = (BETA - 1) d sw / SM, d3 sw = (BETA - 2) d2 sw / SM; the evaporation factor likewise
-            const bool ec = BETAET && epow;
-            H = (ADJ_SOIL_HALLEY && live) ? rSM * (B1 * dP + (ec ? E1 * dEp : 0.0f)) : 0.0f;
-            K = (ADJ_SOIL_HH && live) ? (rSM * rSM) * (B12 * dP + (ec ? E12 * dEp : 0.0f)) : 0.0f;
+            // sw'' = (BETA - 1) sw' / SM, ef'' likewise: four multiplications
+            H = (ADJ_SOIL_HALLEY && live) ? rSM * (B1 * dP + ((BETAET && epow) ? E1 * dEp : 0.0f)) : 0.0f;
         };
-        // which side of the evaporation factor's kink holds the root (G2 increasing): the sign of G2(LP FC)
-        bool kabove = false, kcross = false;
-        if (ADJ_SOIL_KINK) {
-            const float swk = fmin_(ADJ_SOIL_POW(fmax_(LP, 1.17549435e-38f), BETA), 1.0f);
-            const float gk = (lpfc - y2t) * idt - ((rt - rt * swk) - fmin_(lpfc, PET));
-            kabove = gk < 0.0f;
-            kcross = ((y2t <= lpfc) == kabove) && lpfc > 1e-8f;
-            x = kcross ? lpfc : y2t;
-            force = kcross;
-            force_low = !kabove;
-        }
+        // Newton's step g / J with Halley's correction g / (J - g H / 2J) -- the powers make G2 smooth between its
+        // kinks, and the correction saves the second update (a whole residual evaluation, two powers) on most days --
+        // as ONE reciprocal: g J / (J^2 - g H / 2); Newton's step is kept where the correction is large
+        // (denominator below J^2 / 2)
+        auto halley = [&]() __attribute__((always_inline)) -> float {
+            const float JJ = J * J, den = JJ - 0.5f * (g * H);
+            const bool hal = den > 0.5f * JJ;
+            return (hal ? g * J : g) * div_approx_(1.0f, hal ? den : J);
+        };
         eval();
-        force = false;
-        // bracket from the first evaluation
+        const float out0 = ex + et;     // outflow at y2t: the lower end of the bracket, should it be needed
+        const bool up0 = g < 0.0f;      // G2(y2t) < 0: the root lies above y2t
         const bool below = (FC - y2t) * idt + fmin_(FC, PET) > 0.0f;   // G2(FC) > 0: root < FC
-        float lo = kcross ? 0.0f : y2t - dt * (ex + et);                // (the outflow bound holds at y2t only)
-        float hi = y2t + dt * rt;
-        bool hi_new = below && FC < hi;   // hi is a bound that has not been an iterate yet
-        hi = below ? fmin_(hi, FC) : hi;
-        lo = below ? lo : fmax_(lo, FC);
-        if (ADJ_SOIL_KINK) {
-            lo = kabove ? fmax_(lo, lpfc) : lo;
-            hi_new = hi_new && (kabove || lpfc >= hi);
-            hi = kabove ? hi : fmin_(hi, lpfc);
-        }
         int it = 0;
         bool more = fabsf(g) > gtol;
-        auto update = [&]() __attribute__((always_inline)) {
+        // free updates: the first without asking the wave whether any lane still needs it (a wave vote and its branch
+        // cost ~100 cycles a day; a day that is already solved -- no input, no evaporation -- is rare), the others
+        // behind a vote; lanes that have converged keep their state
+#pragma unroll
+        for (int k = 0; k < ADJ_SOIL_FREE; k++) {
+            if (k > max_iter || (k >= ADJ_SOIL_PEEL && !adj_any_(more, true))) break;
             it++;
-            // Newton's step g / J with Halley's correction g / (J - g H / 2J) -- the powers make G2 smooth between
-            // its kinks, and the correction saves the second update (a whole residual evaluation, two powers) on
-            // most days -- as ONE reciprocal: g J / (J^2 - g H / 2); Newton's step is kept where the correction
-            // is large (denominator below J^2 / 2).  With the third derivative: Householder's step of order 3,
-            // g (J^2 - g H / 2) / (J^3 - g J H + g^2 K / 6), under the same guard.
-            const float JJ = J * J, gH = g * H, num = JJ - 0.5f * gH;
-            const bool hal = num > 0.5f * JJ;
-            const float den3 = (J * JJ - gH * J) + (g * g) * (K * (1.0f / 6.0f));
-            const bool hh = ADJ_SOIL_HH && hal && den3 > 0.5f * (J * JJ);
-            const float dx = (hh ? g * num : (hal ? g * J : g)) * div_approx_(1.0f, hh ? den3 : (hal ? num : J));
-            lo = (g < 0.0f) ? fmax_(lo, x) : lo;
-            hi = (g < 0.0f) ? hi : fmin_(hi, x);
-            // a step past FC lands ON FC first: below FC the residual is convex in SM (BETA >= 1), so Newton from the
-            // right end converges monotonically; any other step that leaves the bracket becomes its midpoint
-            float xn = x - dx;
-            const bool past = xn > hi && hi_new;
-            xn = (xn >= lo && xn <= hi) ? xn : (past ? hi : 0.5f * (lo + hi));
-            hi_new = hi_new && !past && more;
-            x = more ? xn : x;      // a lane that has converged keeps its state
+            float xn = x - halley();
+            xn = (below && xn > FC) ? FC : xn;      // a step past FC lands ON FC (see above)
+            x = more ? xn : x;
             eval();
             more = fabsf(g) > gtol;
-        };
-#if ADJ_SOIL_PEEL
-        // The first ADJ_SOIL_PEEL updates run without asking the wave whether any lane still needs them: lanes that
-        // have converged keep their state (the update is masked), so the result is that of the loop below, and a
-        // day that is already solved (no input, no evaporation) is rare enough to pay for the missing vote.
-#pragma unroll
-        for (int k = 0; k < ADJ_SOIL_PEEL; k++)
-            if (k <= max_iter) update();
-#endif
-        if (ADJ_SOIL_LIN > 0.0f && it <= max_iter) {
-            // the linearised finish (see above): lanes a hair above gtol take the Newton step from what is known
-            const float dxl = g * div_approx_(1.0f, J);
-            const float x2 = x - dxl;
-            const float l2 = (g < 0.0f) ? fmax_(lo, x) : lo, h2 = (g < 0.0f) ? hi : fmin_(hi, x);
-            // ... and only where the step's own error estimate, g^2 |G2''| / 2 G2'^2, is below gtol / 4 (an evaporation
-            // exponent below 1 makes G2 arbitrarily curved next to an empty store)
-            const bool fin = more && fabsf(g) < ADJ_SOIL_LIN && x2 >= l2 && x2 <= h2 &&
-                             (g * g) * fabsf(H) < (0.5f * gtol) * (J * J);
-            Peff = fin ? Peff - dPx * dxl : Peff;
-            x = fin ? x2 : x;
-            ex = fin ? fmax_(x2 - FC, 0.0f) : ex;
-            more = more && !fin;
         }
-        while (adj_any_(more, true) && it <= max_iter) update();
+        if (adj_any_(more, true) && it <= max_iter) {
+            // the safeguarded finish.  The bracket holds whatever the free updates did: its ends come from y2t alone,
+            // and the current iterate only ever tightens it by the sign of its residual.
+            const float dt = (idt == 1.0f) ? 1.0f : div_approx_(1.0f, idt);
+            float lo = y2t - dt * out0;
+            float hi = y2t + dt * rt;
+            bool hi_new = below && FC < hi;   // hi is a bound that has not been an iterate yet
+            hi = below ? fmin_(hi, FC) : hi;
+            lo = below ? lo : fmax_(lo, FC);
+            lo = up0 ? fmax_(lo, y2t) : lo;
+            hi = up0 ? hi : fmin_(hi, y2t);
+            do {
+                it++;
+                const float dx = halley();
+                lo = (g < 0.0f) ? fmax_(lo, x) : lo;
+                hi = (g < 0.0f) ? hi : fmin_(hi, x);
+                float xn = x - dx;
+                const bool past = xn > hi && hi_new;
+                xn = (xn >= lo && xn <= hi) ? xn : (past ? hi : 0.5f * (lo + hi));
+                hi_new = hi_new && !past && more;
+                x = more ? xn : x;
+                eval();
+                more = fabsf(g) > gtol;
+            } while (adj_any_(more, true) && it <= max_iter);
+        }
         y2 = x;
         return it;
     }

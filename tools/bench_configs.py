@@ -54,8 +54,11 @@ def run(name, steps=5, warmup=2):
         n_dyn, nf = 3, 12
     elif name == "cfg4":
         T, B, M = 7300, 671, 16
+        extra = {}
+        if os.environ.get("HBVX_CFG4_MAXITER"):      # timing floors only (0: exactly one update per day)
+            extra["newton_max_iter"] = int(os.environ["HBVX_CFG4_MAXITER"])
         model = hydrodl2_amd.load_model("hbv_adj", "HbvAdj")(
-            {"nmul": M, "dynamic_params": {"HbvAdj": ["parBETAET"]}}, dev)
+            {"nmul": M, "dynamic_params": {"HbvAdj": ["parBETAET"]}, **extra}, dev)
         n_dyn, nf = 1, 1
     elif name.startswith("grid:"):
         # grid:<hbv|hbv_2>:<B>:<T>  -- 16 members, 3 dynamic parameters for hbv_2, 2 for hbv
