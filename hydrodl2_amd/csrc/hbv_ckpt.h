@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(64) k_bwd_ckpt(const CkptBwdArgs A)
             float p[NPARAM_MAX], ud[NP];
             params_of(cur, p, ud);
             s.SP = st[0]; s.MW = st[1]; s.SM = st[2]; s.SUZ = st[3]; s.SLZ = st[4];
-            s.template fwd<false>(p, nz, ac, elev, 0.0f, 0.0f);
+            s.template fwd<false, true>(p, nz, ac, elev, 0.0f, 0.0f);
             float *row = my + (t - t0) * 7 * 64;
 #pragma unroll
             for (int k = 0; k < 5; k++) row[k * 64] = st[k];
@@ -295,7 +295,7 @@ __global__ void __launch_bounds__(64) k_ckpt_remat(const RematArgs A)
         }
         if (l + 1 < l1) fetch(A.t0 + l + 1);
         s.SP = st[0]; s.MW = st[1]; s.SM = st[2]; s.SUZ = st[3]; s.SLZ = st[4];
-        s.template fwd<false>(p, nz, ac, elev, 0.0f, 0.0f);
+        s.template fwd<false, true>(p, nz, ac, elev, 0.0f, 0.0f);
         if (L.active) {
 #pragma unroll
             for (int k = 0; k < 5; k++) A.traj[((int64_t)k * (tb + 1) + l) * N + L.n] = st[k];

@@ -328,7 +328,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                     if constexpr (MODEL == MODEL_HOURLY) {
                         s.template fwd_rest<false>(p, nz, ac, 0.0f, 0.0f);
                     } else {
-                        s.template fwd_soil<false>(p, nz, 0.0f, 0.0f);
+                        s.template fwd_soil<false, true>(p, nz, 0.0f, 0.0f);
                         s.fwd_cap(p, nz);
                         s.fwd_gw(p, ac);
                     }
@@ -398,7 +398,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                         Step<MODEL, BETAET> s;
                         s.PET = dPET; s.RAIN = dRAIN; s.tosoil = dTS;
                         s.SM = SM;
-                        s.template fwd_soil<false>(p, nz, 0.0f, 0.0f);
+                        s.template fwd_soil<false, true>(p, nz, 0.0f, 0.0f);
                         bc[tt * 128] = s.rech;
                         bc[tt * 128 + 64] = s.exc;
                         q[0] = s.ET; q[64] = s.rech; q[128] = s.exc; q[192] = s.ef;

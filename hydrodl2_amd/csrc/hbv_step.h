@@ -61,6 +61,22 @@ HBVX_HD float div_(float a, float b)
 #endif
 }
 
+// A/B experiment (-DHBVX_Q_APPROX=1): SM2 / (LP FC) as one multiplication by the refined reciprocal -- one dependent
+// instruction behind the storage instead of three, an ulp or two off the correctly rounded quotient.
+#ifndef HBVX_Q_APPROX
+#define HBVX_Q_APPROX 0
+#endif
+HBVX_HD float div_q_(float a, float b)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && HBVX_Q_APPROX
+    float rc = __builtin_amdgcn_rcpf(b);
+    rc = __builtin_fmaf(__builtin_fmaf(-b, rc, 1.0f), rc, rc);
+    return a * rc;
+#else
+    return div_(a, b);
+#endif
+}
+
 // a / b inside the adjoint only (gradients are compared at rtol 1e-3): rcp + multiply.
 HBVX_HD float div_approx_(float a, float b)
 {
@@ -280,7 +296,10 @@ HBVX_HD float pow_fast_(float x, float y)   // x a normal positive number (the c
 HBVX_HD float pow_unit_(float x, float y)
 {
 #if HBVX_POW_UNIT_FAST && !defined(HBVX_POW_F64)
-    return pow_fast_(fmax_(x, 1.17549435e-38f), y);
+    // (no lower clamp on the base: the exponents of this model are positive -- BETA >= 1, BETAET >= 0.3, ALPHA >= 0.5 --
+    // so x = 0 gives log2 = -inf, y * -inf = -inf, 2^-inf = 0, the limit; the storages behind x are >= nearzero anyway.
+    // One dependent instruction less in front of every power.)
+    return pow_fast_(x, y);
 #else
     return pow_step_(x, y);
 #endif
@@ -380,7 +399,14 @@ struct Step {
     // soil: needs SM, RAIN, tosoil, PET; produces rech, exc, ET, ef, SM3   (hbv.py:462-480)
     // USE_AUX: (SM/FC)^BETA and the pre-clamp evaporation factor come from the forward pass
     // (hbvx_fwd_out.aux) instead of two pow calls.
-    template <bool USE_AUX>
+    // CHAIN (the forward time-steppers): the evaporation factor from SM1 instead of SM2 = SM1 - excess.  The
+    // reference divides the storage AFTER the excess has left it (hbv.py:474); but the factor is clamped to [0, 1],
+    // and whenever there is excess (SM1 > FC) both quotients are >= FC / (LP FC) >= 1 and clamp to exactly 1, while
+    // without excess SM2 IS SM1 -- the same bits either way (except for LP within an ulp of 1 on a day with SM1 > 2 FC,
+    // where SM1 - (SM1 - FC) can miss FC by an ulp).  What it buys: the quotient (three dependent instructions,
+    // six with the BETAET power) no longer waits for the excess (three more) on the day-to-day chain of the soil wave,
+    // it runs beside it.  The adjoint's recomputation keeps the reference's form (its masks test the quotient of SM2).
+    template <bool USE_AUX, bool CHAIN = false>
     HBVX_HDM void fwd_soil(const float *p, float nz, float aux_sw0, float aux_ef0)
     {
         const float BETA = p[P_BETA], FC = p[P_FC], LP = p[P_LP];
@@ -394,14 +420,18 @@ struct Step {
         exc = fmax_(e0, 0.0f);
         SM2 = SM1 - exc;
         lpfc = LP * FC;
-        q = div_(SM2, lpfc);
+        q = div_q_((CHAIN && !SAVE_POW) ? SM1 : SM2, lpfc);
         if (BETAET) ef0 = USE_AUX ? aux_ef0 : pow_unit_(q, p[P_BETAET]);
         else ef0 = q;
         ef = fmin_(fmax_(ef0, 0.0f), 1.0f);
         pe = PET * ef;
         ET = fmin_(SM2, pe);
         dd = SM2 - ET;
-        SM3 = fmax_(dd, nz);
+        // SM3 = max(SM2 - min(SM2, pe), nz) (hbv.py:479-480) without the minimum on the day-to-day chain: for
+        // pe <= SM2 both forms subtract pe, otherwise the reference's difference is 0 and this one is negative, and
+        // either way the lower clamp returns nz (nearzero >= 0, check_desc) -- the same bits, one dependent
+        // instruction less per day on the soil wave.  ET and dd (the adjoint's predicate) stay as the reference's.
+        SM3 = fmax_(SM2 - pe, nz);
     }
 
     // capillary rise (1.1p / 2.0): couples SM3 and SLZ                 (hbv_1_1p.py:482-490)
@@ -460,11 +490,11 @@ struct Step {
         Q = (Q0 + Q1) + Q2; // hbv.py:494
     }
 
-    template <bool USE_AUX>
+    template <bool USE_AUX, bool CHAIN = false>
     HBVX_HDM void fwd(const float *p, float nz, float ac, float elev, float aux_sw0, float aux_ef0)
     {
         fwd_snow(p, elev);
-        fwd_soil<USE_AUX>(p, nz, aux_sw0, aux_ef0);
+        fwd_soil<USE_AUX, CHAIN>(p, nz, aux_sw0, aux_ef0);
         fwd_cap(p, nz);
         fwd_gw(p, ac);
     }

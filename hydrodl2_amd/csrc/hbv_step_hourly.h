@@ -167,7 +167,7 @@ struct Step<MODEL_HOURLY, BETAET_UNUSED> {
         Q = ((Q0 + Q1) + Q2) + IE; // :652
     }
 
-    template <bool USE_AUX>
+    template <bool USE_AUX, bool CHAIN = false>     // (CHAIN: the daily models' forward form, hbv_step.h; no effect here)
     HBVX_HDM void fwd(const float *p, float nz, float ac, float elev, float aux_sw0, float aux_ef0)
     {
         fwd_snow(p, elev);

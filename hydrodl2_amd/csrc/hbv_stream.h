@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(64) k_fwd_stream(const StreamArgs A)
                 }
         }
         s.SP = st[0]; s.MW = st[1]; s.SM = st[2]; s.SUZ = st[3]; s.SLZ = st[4];
-        s.template fwd<false>(p, nz, ac, elev, 0.0f, 0.0f);
+        s.template fwd<false, true>(p, nz, ac, elev, 0.0f, 0.0f);
         const unsigned so = (unsigned)t * row4;
         if (TRAJ && !(STREAM_EXP & 4)) {
 #pragma unroll

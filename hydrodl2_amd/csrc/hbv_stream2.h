@@ -397,7 +397,7 @@ __global__ void __launch_bounds__(MW * 64) FWPE k_fwd_stream2(const StreamArgs A
             p[stream_slot<SC>(k)] = u * dsc[k] + dlo[k];
         }
         s.SP = st[0]; s.MW = st[1]; s.SM = st[2]; s.SUZ = st[3]; s.SLZ = st[4];
-        s.template fwd<false>(p, nz, ac, elev, 0.0f, 0.0f);
+        s.template fwd<false, true>(p, nz, ac, elev, 0.0f, 0.0f);
         if (TRJ == 1 && !(STREAM2_EXP & 4)) {
             const unsigned so = (unsigned)t * row4;
 #pragma unroll

@@ -308,7 +308,7 @@ __global__ void __launch_bounds__(512) k_fwd_tiled(const FwdTArgs A)
                     Step<MODEL, BETAET> s;
                     s.P = fP; s.Tf = fT; s.PET = fE;
                     s.SP = st[0]; s.MW = st[1]; s.SM = st[2]; s.SUZ = st[3]; s.SLZ = st[4];
-                    s.template fwd<false>(p, nz, ac, elev, 0.f, 0.f);
+                    s.template fwd<false, true>(p, nz, ac, elev, 0.f, 0.f);
                     if (has_traj) {
                         float *to = out + G.off_tout + tt * 7 * 64 + lane;
 #pragma unroll

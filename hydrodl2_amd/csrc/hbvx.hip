@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(64) k_fwd(const FwdArgs A)
                 if (use_dyn[i]) p[i] = pv;
             }
         s.SP = st[0]; s.MW = st[1]; s.SM = st[2]; s.SUZ = st[3]; s.SLZ = st[4];
-        s.template fwd<false>(p, nz, ac, elev, 0.f, 0.f);
+        s.template fwd<false, true>(p, nz, ac, elev, 0.f, 0.f);
 
         if (ckpt_k) {
             if (t % ckpt_k == 0 && L.active) {
@@ -596,6 +596,7 @@ int hbvx_host::check_desc(const hbvx_desc *d)
     if (!d->x && d->T > 0) return fail(HBVX_E_NULL, "forcing pointer is NULL");   /* an empty record has no forcings */
     if (d->ch_prcp < 0 || d->ch_tmean < 0 || d->ch_pet < 0)
         return fail(HBVX_E_SHAPE, "negative forcing channel");
+    if (!(d->nearzero >= 0.0f)) return fail(HBVX_E_SHAPE, "nearzero must be >= 0 (the storages' lower clamp, hbv.py:54)");
     if ((d->model == HBVX_MODEL_HBV20 || d->model == HBVX_MODEL_HOURLY) && (!d->ac || !d->elev))
         return fail(HBVX_E_NULL, "HBV 2.0 needs ac and elev");
     for (int i = 0; i < d->n_param; i++)

@@ -62,8 +62,8 @@ static void run_fwd(const hbvx_desc &d, const hbvx_fwd_out &o)
                 const float *xr = d.x + (int64_t)t * d.x_t_stride + (int64_t)b * d.x_b_stride;
                 s.P = xr[d.ch_prcp]; s.Tf = xr[d.ch_tmean]; s.PET = xr[d.ch_pet];
                 s.SP = st[0]; s.MW = st[1]; s.SM = st[2]; s.SUZ = st[3]; s.SLZ = st[4];
-                s.template fwd<false>(p, d.nearzero, d.ac ? d.ac[b] : 0.f, d.elev ? d.elev[b] : 0.f,
-                                      0.f, 0.f);
+                s.template fwd<false, true>(p, d.nearzero, d.ac ? d.ac[b] : 0.f, d.elev ? d.elev[b] : 0.f,
+                                            0.f, 0.f);     // the forward time-steppers' form of the soil stage
                 if (o.traj)
                     for (int k = 0; k < 5; k++) o.traj[((int64_t)k * (T + 1) + t) * N + n] = st[k];
                 if (o.aux) {

@@ -162,11 +162,14 @@ def test_hbv2_many_basins(hip_backend):
 
 def test_cfg5_full_size_on_one_gpu(hip_backend, oracle_backend_path):
     """BASELINE config 5 at its stated size on ONE GPU: hbv_2, 100 000 basins x 16 members x 730 days, three
-    dynamic parameters (1.17e9 lane-days; ~70 GB of inputs, trajectory and gradients of the 288 GB), forward +
-    backward through the module.  Finite; basins at both ends and in the middle reproduce, bit for bit in the
-    outputs and to rounding in the gradients, what they give as a six-basin problem (which takes other kernels:
-    pipelined forward + time-parallel adjoint instead of the streaming pair); and three of them agree with the CPU
-    oracle."""
+    dynamic parameters (1.17e9 lane-days; ~60 GB of inputs, trajectory and gradients of the 288 GB), forward +
+    backward through the module, twice: a loss on streamflow (the bench's step: four-wave streaming adjoint) and a
+    loss on EVERY flux key (the twelve-series adjoint).  Finite; then 34 basins -- both ends, and both sides of every
+    boundary between the XCDs' runs of basin groups in the streaming kernels' wave -> basin maps (hbv_stream2.h:
+    s2_lane for the adjoint, 3 125 waves per XCD = 12 500 basins; s2_lane_mw for the eight-wave forward, 391
+    workgroups per XCD = 12 512 basins) -- reproduce, bit for bit in the outputs and the state series and to rounding in
+    the gradients, what they give as a 34-basin problem (other kernels: pipelined forward + time-parallel adjoint), and
+    agree with the CPU oracle in every flux key, one state series and both gradients."""
     import hydrodl2_amd
     from tests import seam
     dev = torch.device("cuda:0")
@@ -182,13 +185,38 @@ def test_cfg5_full_size_on_one_gpu(hip_backend, oracle_backend_path):
     ps = torch.rand((B, 13 * M), generator=g, device=dev).requires_grad_(True)
     xd = {"x_phy": x, "ac_all": torch.rand(B, generator=g, device=dev) * 5000,
           "elev_all": torch.rand(B, generator=g, device=dev) * 3000}
-    out = model(xd, (pd, ps))
-    (out["streamflow"] * w).sum().backward()
-    assert out["streamflow"].shape == (T, B, 1)
-    assert torch.isfinite(out["streamflow"]).all() and torch.isfinite(pd.grad).all() and torch.isfinite(ps.grad).all()
-    sel = torch.tensor([0, 3, 49999, 50002, 99996, 99999], device=dev)
+    picks = [0, 3, 99996, 99999]
+    for c in range(1, 8):
+        picks += [12500 * c - 1, 12500 * c, 12512 * c - 1, 12512 * c]
+    picks = sorted(set(picks))
+    assert len(picks) >= 32
+    sel = torch.tensor(picks, device=dev)
+    keys = [k for k in model.flux_names if k not in ("BFI", "PET_hydro")]
+    wk = {k: 0.25 + 0.5 * torch.rand((T, B, 1), generator=g, device=dev) for k in keys[:3]}   # (three dense weights: 0.9 GB)
 
-    def small(device, lib):
+    def loss_of(out, which, cols=None):
+        if which == "streamflow":
+            return (out["streamflow"] * (w if cols is None else w[:, cols])).sum()
+        tot = 0.0
+        for i, k in enumerate(keys):
+            wt = wk[keys[i % 3]]
+            tot = tot + (out[k] * (wt if cols is None else wt[:, cols])).sum() * (1.0 + 0.1 * i)
+        return tot
+
+    full = {}
+    for which in ("streamflow", "all"):
+        pd.grad = ps.grad = None
+        out = model(xd, (pd, ps))
+        loss_of(out, which).backward()
+        assert out["streamflow"].shape == (T, B, 1)
+        assert torch.isfinite(out["streamflow"]).all() and torch.isfinite(pd.grad).all() and torch.isfinite(ps.grad).all()
+        full[which] = ({k: out[k][:, sel].detach().clone() for k in keys}, pd.grad[:, sel].clone(), ps.grad[sel].clone(),
+                       model.get_states()[2][:, sel].clone())
+        del out
+    pd.grad = ps.grad = None
+    torch.cuda.empty_cache()
+
+    def small(device, lib, which):
         seam.use_library(lib)
         try:
             pd2 = pd.detach()[:, sel].to(device).contiguous().requires_grad_(True)
@@ -197,19 +225,31 @@ def test_cfg5_full_size_on_one_gpu(hip_backend, oracle_backend_path):
                    "elev_all": xd["elev_all"][sel].to(device)}
             m2 = H2(cfgd, torch.device(device))
             o2 = m2(xd2, (pd2, ps2))
-            (o2["streamflow"] * w[:, sel].to(device)).sum().backward()
-            return o2["streamflow"].detach(), pd2.grad, ps2.grad
+            if which == "streamflow":
+                l2 = (o2["streamflow"] * w[:, sel].to(device)).sum()
+            else:
+                l2 = 0.0
+                for i, k in enumerate(keys):
+                    l2 = l2 + (o2[k] * wk[keys[i % 3]][:, sel].to(device)).sum() * (1.0 + 0.1 * i)
+            l2.backward()
+            return {k: o2[k].detach() for k in keys}, pd2.grad, ps2.grad, m2.get_states()[2].detach()
         finally:
             seam.use_library(None)
 
-    q2, gd2, gs2 = small("cuda:0", None)
-    assert torch.equal(out["streamflow"][:, sel], q2)
-    torch.testing.assert_close(pd.grad[:, sel], gd2, rtol=1e-4, atol=1e-6 * float(gd2.abs().max()))
-    torch.testing.assert_close(ps.grad[sel], gs2, rtol=1e-4, atol=1e-6 * float(gs2.abs().max()))
-    qo, gdo, gso = small("cpu", oracle_backend_path)
-    assert_close("streamflow", q2.cpu().numpy(), qo.numpy(), 1e-4, 1e-5)
-    assert_close("g_dyn", gd2.cpu().numpy(), gdo.numpy(), 1e-3, 1e-5)
-    assert_close("g_sta", gs2.cpu().numpy(), gso.numpy(), 1e-3, 1e-5)
+    for which in ("streamflow", "all"):
+        fo, fgd, fgs, fsm = full[which]
+        o2, gd2, gs2, sm2 = small("cuda:0", None, which)
+        for k in keys:
+            assert torch.equal(fo[k], o2[k]), (which, k)
+        assert torch.equal(fsm, sm2), which                       # the soil-moisture series (hbv_2.py:571-575)
+        torch.testing.assert_close(fgd, gd2, rtol=1e-4, atol=1e-6 * float(gd2.abs().max()))
+        torch.testing.assert_close(fgs, gs2, rtol=1e-4, atol=1e-6 * float(gs2.abs().max()))
+        oo, gdo, gso, smo = small("cpu", oracle_backend_path, which)
+        for k in keys:
+            assert_close(f"{which} {k}", o2[k].cpu().numpy(), oo[k].numpy(), 1e-4, 1e-5)
+        assert_close(f"{which} SM series", sm2.cpu().numpy(), smo.numpy(), 1e-4, 1e-5)
+        assert_close(f"{which} g_dyn", gd2.cpu().numpy(), gdo.numpy(), 1e-3, 1e-5)
+        assert_close(f"{which} g_sta", gs2.cpu().numpy(), gso.numpy(), 1e-3, 1e-5)
 
 
 def _slice_problem(prob, pick):

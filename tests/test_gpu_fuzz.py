@@ -51,7 +51,7 @@ def _draw(rng):
     return kw, t0, grad
 
 
-def test_fixed_seed_fuzz_bounds_threshold_flips(hip_backend, oracle_path):
+def test_fixed_seed_fuzz_bounds_threshold_flips(hip_backend, oracle_path, capsys):
     rng = random.Random(SEED)
     flips, detail = 0, []
     for case in range(N_DRAWS):
@@ -75,5 +75,14 @@ def test_fixed_seed_fuzz_bounds_threshold_flips(hip_backend, oracle_path):
                 flipped = True
                 detail.append((case, kw["model"], k, nbad, size))
         flips += flipped
-    print(f"fuzz: {N_DRAWS} draws, {flips} with isolated gradient threshold flips: {detail}")
+    msg = f"fuzz: {N_DRAWS} draws, {flips} with isolated gradient threshold flips (bound {MAX_FLIP_DRAWS}): {detail}"
+    with capsys.disabled():          # in the output the driver tails, pass or fail
+        print("\n" + msg)
+    try:                             # and on file for the round's records
+        import os
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        if os.path.isdir(out):
+            open(os.path.join(out, "fuzz_flips.txt"), "w").write(msg + "\n")
+    except OSError:
+        pass
     assert flips <= MAX_FLIP_DRAWS, detail

@@ -3,7 +3,7 @@
 state W = 256 .. 4096 (B = 4 W basins), `hbv` with the delta-MG dynamic set and `hbv_2` with its three:
 forward / adjoint ms with (a) the library's own dispatch, (b) the streaming kernels forced in both
 directions (packed trajectory), (c) the streaming kernels switched off (pipelined / tiled forward,
-time-parallel adjoint).  One JSON line per (model, W); profiles/r02_grid_sweep.jsonl is this output.
+time-parallel adjoint).  One JSON line per (model, W, T); profiles/r0x_grid_sweep.jsonl is this output.
 
     python tools/grid_sweep.py > gpurun_out/grid_sweep.jsonl
 """
@@ -67,6 +67,11 @@ def one(fam, B, T=730, M=16, steps=4):
 
 
 if __name__ == "__main__":
-    for fam in ("hbv", "hbv_2"):
-        for W in (128, 256, 384, 512, 768, 1024, 1536, 2048, 3072, 4096, 6144):
-            one(fam, 4 * W)
+    # python tools/grid_sweep.py [T ...]   (default 730; at T = 7300 the raw [T,B,ny] tensor and its gradient bound
+    # the sweep: W <= 1536, 35 GB each)
+    for T in ([int(a) for a in sys.argv[1:]] or [730]):
+        Ws = (128, 256, 384, 512, 768, 1024, 1536, 2048, 3072, 4096, 6144) if T <= 1000 else (128, 256, 512, 768, 1024, 1536)
+        for fam in ("hbv", "hbv_2"):
+            for W in Ws:
+                one(fam, 4 * W, T=T, steps=4 if T <= 1000 else 2)
+                torch.cuda.empty_cache()
