@@ -158,28 +158,29 @@ WORKLOADS = {
 LIMITED_BY = {
     "cfg2": ("latency", "forward: 168 workgroups x 7 300 serial days, the soil wave's dependent chain and one barrier per "
                         "8-day tile (tools/pipe_probe.py, DESIGN.md §0); adjoint kernels VALU-issue bound",
-             {"k_bwd_chunk_phi": 0.85, "k_bwd_chunk_sweep": 0.80}, "profiles/r03_sq_counters_cfg2.txt"),
-    "cfg2dyn": ("latency", "as cfg2; the soil wave carries two dynamic powers", {}, "profiles/r03_sq_counters_cfg2.txt"),
+             {"k_bwd_chunk_phi": 1.0, "k_bwd_chunk_sweep": 0.92, "k_fwd_pipe": 0.39}, "profiles/r04_sq_counters_cfg2.txt"),
+    "cfg2dyn": ("latency", "as cfg2; the soil wave carries two dynamic powers", {}, "profiles/r04_sq_counters_cfg2.txt"),
     "cfg3": ("hbm", "14 dynamic rows streamed twice by the two-pass adjoint at 4.3 TB/s per kernel (69 % of the 6.3 TB/s "
                     "this chip copies at); forward balanced between fillers / reducers / drainers",
-             {"k_bwd_chunk_phi": 0.78, "k_bwd_chunk_sweep": 0.72}, "profiles/r03_sq_counters_cfg3.txt"),
-    "cfg4": ("latency", "the soil-moisture wave's Newton iteration: 1 480 of 1 490 cycles per day busy, one wave per SIMD "
-                        "(tools/pipe_probe.py)", {}, "DESIGN.md §0"),
+             {"k_bwd_chunk_phi": 0.76, "k_bwd_chunk_sweep": 0.71, "k_fwd_pipe": 0.48}, "profiles/r04_sq_counters_cfg3.txt"),
+    "cfg4": ("latency", "the soil-moisture wave's Newton iteration: a lone wave on its SIMD, ~8 cycles per instruction, two "
+                        "residual evaluations and one update on 46 % of the wave-days, three and two on the rest "
+                        "(profiles/r04_ab_soil.txt)", {}, "profiles/r04_ab_soil.txt"),
     "cfg4joint": ("latency", "one wave per 64 lanes iterating the reference's joint 5-variable Newton", {}, "DESIGN.md §4"),
-    "cfg5share": ("valu-issue", "streaming adjoint 345-365 VALU per wave-day at 4 waves per SIMD",
-                  {"k_bwd_stream2": 0.75, "k_fwd_stream2": 0.56}, "profiles/r03_sq_counters_cfg5.txt"),
-    "cfg5full": ("valu-issue", "as cfg5share, 25 000 waves", {"k_bwd_stream2": 0.75, "k_fwd_stream2": 0.56},
-                 "profiles/r03_sq_counters_cfg5.txt"),
-    "cfg5": ("valu-issue", "as cfg5share", {"k_bwd_stream2": 0.75, "k_fwd_stream2": 0.56}, "profiles/r03_sq_counters_cfg5.txt"),
+    "cfg5share": ("valu-issue", "streaming adjoint ~345 VALU per wave-day at 4 waves per SIMD",
+                  {"k_bwd_stream2": 0.86, "k_fwd_stream2": 0.53}, "profiles/r04_sq_counters_cfg5.txt"),
+    "cfg5full": ("valu-issue", "as cfg5share, 25 000 waves", {"k_bwd_stream2": 0.86, "k_fwd_stream2": 0.53},
+                 "profiles/r04_sq_counters_cfg5.txt"),
+    "cfg5": ("valu-issue", "as cfg5share", {"k_bwd_stream2": 0.86, "k_fwd_stream2": 0.53}, "profiles/r04_sq_counters_cfg5.txt"),
     "dmg": ("host", "kernels sum to less than the enqueue time of the step's launches (tools/host_overhead.py)", {},
-            "profiles/r03_host_overhead.txt"),
+            "profiles/r04_host_overhead.txt"),
     "dmggraph": ("latency", "two graph launches per step; what is left is the kernels' own time and the gaps between "
                             "the ~20 nodes of the two graphs", {}, "profiles/r04_host_overhead.txt"),
     "hourly": ("latency", "two-stage pipelined forward (1 000 workgroups), gage routing FIR pair-parallel", {}, "DESIGN.md §4"),
     "lstm": ("latency", "per time step one L1-bypassing store -> load hand-off between the workgroups of a row tile "
                         "(~1.2 us) + H/4 MFMAs; 4 % of HBM peak, 12 % of the fp32 MFMA peak", {}, "DESIGN.md §4"),
     "dpl": ("latency", "LSTM recurrence (two persistent kernels) + four fp32 library GEMMs + the HBV calls", {},
-            "profiles/r03_dpl.json"),
+            "profiles/r04_kernel_stats.csv"),
 }
 
 
