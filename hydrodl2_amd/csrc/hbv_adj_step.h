@@ -141,6 +141,7 @@ struct AdjStep {
     // Solve (I/dt - F)^T lam = a by back substitution.
     HBVX_HDM void solve_t(float idt, const float *a, float *lam) const
     {
+        HBVX_ADJ_FMA
         lam[4] = div_approx_(a[4], idt - F44);
         lam[3] = div_approx_(a[3] + F43 * lam[4], idt - F33);
         lam[2] = div_approx_(a[2] + F32 * lam[3], idt - F22);
@@ -447,6 +448,7 @@ template <bool BETAET>
 HBVX_HD void adj_backstep(AdjStep<BETAET> &s, const float *p, const float *x, float idt, float gQ,
                           float *a, float *gp)
 {
+    HBVX_ADJ_FMA
     const float BETA = p[P_BETA], FC = p[P_FC], K0 = p[P_K0], K1 = p[P_K1], K2 = p[P_K2],
                 LP = p[P_LP], CFMAX = p[P_CFMAX], CFR = p[P_CFR];
     s.template eval<true>(x, p);

@@ -316,6 +316,23 @@ HBVX_HD float pow_unit_(float x, float y)
 #endif
 constexpr bool SAVE_POW = HBVX_SAVE_POW != 0;
 
+// HBVX_ADJ_FMA: the library is built with -ffp-contract=off because the FORWARD must round after every operator like the
+// reference does (thresholds branch on those roundings, and the adjoint's recomputation of the forward must land on the
+// same side of every one of them).  The adjoint's OWN arithmetic -- products of weights and incoming adjoints, the
+// gradient sums, the chunk transfer maps -- decides no branch and is compared at rtol 1e-3: there a multiply-add is one
+// fused instruction (a quarter fewer vector instructions in kernels that sit at the VALU issue peak; the fused form
+// rounds once instead of twice, i.e. it is the more accurate of the two).  Clang scopes the pragma to the function
+// body it opens; inlined callees keep their own setting.  g++ (the host build of this header) ignores it.
+#ifndef HBVX_ADJ_FMA_OFF
+#define HBVX_ADJ_FMA _Pragma("clang fp contract(fast)")
+#else
+#define HBVX_ADJ_FMA
+#endif
+#if !defined(__clang__)
+#undef HBVX_ADJ_FMA
+#define HBVX_ADJ_FMA
+#endif
+
 // natural log for the adjoint's d(x**y)/dy = x**y ln x: gradients are compared at rtol 1e-3,
 // the hardware v_log_f32 (1 ulp on log2) is ample.
 HBVX_HD float log_fast_(float v)
@@ -504,6 +521,7 @@ struct Step {
     HBVX_HDM void bwd(const float *p, float nz, const FluxGrad &g, float *a, float *gp,
                      float *gx) const
     {
+        HBVX_ADJ_FMA
         const float BETA = p[P_BETA], FC = p[P_FC], K0 = p[P_K0], K1 = p[P_K1], K2 = p[P_K2],
                     LP = p[P_LP], PERCp = p[P_PERC], CFMAX = p[P_CFMAX], CFR = p[P_CFR],
                     CWH = p[P_CWH];
@@ -523,7 +541,7 @@ struct Step {
             gp[P_RT] += at1 * a1 + at2 * ee;
             float aa1 = at1 * RT;
             float aa0 = (a0 >= -1.0f && a0 <= 1.0f) ? aa1 : 0.0f;
-            gp[P_AC] += -(aa0 / 1000.0f);
+            gp[P_AC] += -(aa0 * 0.001f);     // (the adjoint of a0 = (ac - AC) / 1000: no IEEE division for a gradient)
         }
         float aSLZ0 = aSLZ1;
         float aPERC = g.gPERC + aSLZ1;
@@ -773,6 +791,7 @@ struct Step {
     // a <- J^T a (+ the runoff-series sources s0 = gQ0 + gQ, s1 = gQ1 + gQ, s2 = gQ2 + gQ; zeros for a unit)
     static HBVX_HDM void jt_cap(const JTC &c, float *a, float s0, float s1, float s2)
     {
+        HBVX_ADJ_FMA
         const float sl = c.msl * (c.cS * a[4] + c.K2 * s2);
         const float z3 = c.k1c * a[3] + c.K1 * s1;
         const float z2 = z3 * c.k0c + c.k0m * s0;
@@ -800,6 +819,7 @@ struct Step {
     // is jt_unit<2>.  Replaces a full bwd() for the offset vector of the chunk maps.
     static HBVX_HDM void jt_affine(const JT &c, float *a, float s0, float s1, float s2)
     {
+        HBVX_ADJ_FMA
         const float sl = c.cS * a[4] + c.K2 * s2;
         const float z3 = c.k1c * a[3] + c.K1 * s1;
         const float z2 = z3 * c.k0c + c.k0m * s0;
@@ -822,6 +842,7 @@ struct Step {
     template <int LEVEL>
     static HBVX_HDM void jt_unit(const JT &c, float *a)
     {
+        HBVX_ADJ_FMA
         float ats = 0.0f;
         if (LEVEL >= 1) {
             float U = 0.0f;

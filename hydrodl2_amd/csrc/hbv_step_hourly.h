@@ -176,6 +176,7 @@ struct Step<MODEL_HOURLY, BETAET_UNUSED> {
 
     HBVX_HDM void bwd(const float *p, float nz, const FluxGrad &g, float *a, float *gp, float *gx) const
     {
+        HBVX_ADJ_FMA
         const float dt = dt_();
         const float idt = 24.0f; // adjoint-only reciprocal of dt (gradients: rtol 1e-3)
         const float BETA = p[P_BETA], FC = p[P_FC], K0 = p[P_K0], K1 = p[P_K1], K2 = p[P_K2],
@@ -195,7 +196,7 @@ struct Step<MODEL_HOURLY, BETAET_UNUSED> {
         gp[P_RT] += at1 * a1 + at2 * ee;
         const float aa1 = at1 * RT;
         const float aa0 = (a0 >= -1.0f && a0 <= 1.0f) ? aa1 : 0.0f;
-        gp[P_AC] += -(aa0 / 1000.0f);
+        gp[P_AC] += -(aa0 * 0.001f);
         const float aSLZ0 = as;
         float aPERC = g.gPERC + as * dt;
         // upper box
