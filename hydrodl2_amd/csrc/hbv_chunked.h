@@ -152,16 +152,23 @@ struct ChunkDay {
 // (chunk_dma_dyn) instead of waiting in NP registers for a whole day; chunk_pull_dyn moves them into
 // registers at the start of their day, where the de-scaling consumes them at once.  14-19 registers
 // less at the kernels' pressure peak: config 3's sweep drops under the 168 of three waves per SIMD.
+// DYN == 3 means more than "every parameter dynamic": all NP rows live in ONE tensor with the reference's column
+// order (column i * M + j, hbv.py:201-208; the host checks it and falls back to the generic mode otherwise), so a
+// day's values of a lane are NP words M apart behind one address.  (With a pointer and two 64-bit strides per
+// parameter the kernels needed 14 x 6 scalar registers for addressing alone: 56 lane-spill reads, 70 scalar
+// multiplications and their hazard no-ops per day in config 3's sweep, a third of its instruction stream.)
 template <int NP>
 __device__ __forceinline__ void chunk_dma_dyn(const hbvx_desc &d, const ChunkLane &L, int t, float *lds)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
+    const hbvx_param_src &ps = d.p[0];
+    const float *src = ps.dyn + (int64_t)t * ps.dyn_t_stride + (int64_t)L.b * ps.dyn_b_stride + L.j;
+    const int M = d.M;
 #pragma unroll
     for (int i = 0; i < NP; i++) {
-        const hbvx_param_src &ps = d.p[i];
-        const float *src = ps.dyn + (int64_t)t * ps.dyn_t_stride + (int64_t)L.b * ps.dyn_b_stride + L.j;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                          (__attribute__((address_space(3))) void *)(lds + i * 64), 4, 0, 0);
+        src += M;
     }
 #endif
 }
@@ -212,11 +219,10 @@ __device__ __forceinline__ void chunk_issue(const hbvx_desc &d, const hbvx_bwd_i
             }
     }
     if (DYN == 3 && !LDSDV) {
+        const hbvx_param_src &ps = d.p[0];     // one tensor, column i * M + j (see chunk_dma_dyn)
+        const float *src = ps.dyn + (int64_t)t * ps.dyn_t_stride + (int64_t)L.b * ps.dyn_b_stride + L.j;
 #pragma unroll
-        for (int i = 0; i < NP; i++) {
-            const hbvx_param_src &ps = d.p[i];
-            R.dv[i] = ps.dyn[(int64_t)t * ps.dyn_t_stride + (int64_t)L.b * ps.dyn_b_stride + L.j];
-        }
+        for (int i = 0; i < NP; i++) R.dv[i] = src[i * d.M];
     }
     if (DYN == 2) {
         // branch-free: a static slot re-reads its static value (never used: use_dyn is false)

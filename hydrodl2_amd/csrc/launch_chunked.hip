@@ -127,8 +127,12 @@ static hipError_t launch_chunked(const hbvx_desc *d, const hbvx_bwd_io *io, hipS
             if (d->p[i].dyn) a.dslot[a.nd++] = i;
         return gfull ? launch_chunked_v<1, true>(d, a, st) : launch_chunked_v<1, false>(d, a, st);
     }
+    // "all" mode: every parameter dynamic, no dy_drop mask, no muwts, and all rows in ONE tensor with the reference's
+    // column order (hbv_chunked.h::chunk_dma_dyn addresses them from parameter 0's pointer and strides)
     bool alldyn = ndyn == d->n_param && !d->muwts;
-    for (int i = 0; i < d->n_param && alldyn; i++) alldyn = d->p[i].drop == nullptr;
+    for (int i = 0; i < d->n_param && alldyn; i++)
+        alldyn = d->p[i].drop == nullptr && d->p[i].dyn == d->p[0].dyn + (int64_t)i * d->M &&
+                 d->p[i].dyn_t_stride == d->p[0].dyn_t_stride && d->p[i].dyn_b_stride == d->p[0].dyn_b_stride;
     if (alldyn) return gfull ? launch_chunked_v<3, true>(d, a, st) : launch_chunked_v<3, false>(d, a, st);
     if (ndyn > 0 || d->muwts) return gfull ? launch_chunked_v<2, true>(d, a, st) : launch_chunked_v<2, false>(d, a, st);
     return gfull ? launch_chunked_v<0, true>(d, a, st) : launch_chunked_v<0, false>(d, a, st);
