@@ -144,10 +144,15 @@ __device__ __forceinline__ constexpr int pipe_sc_flag(int X)
 #define DY_USE(X) do { p[X] = dy_##X ? pn_##X : p[X]; } while (0)
 
 // TRAJ: the forward also saves the storage trajectory (and, in HBVX_SAVE_POW builds, the pow results: traj and aux given).
+//   1: through LDS and row-drainer waves (the steppers touch only LDS + VALU);  2: the steppers store it themselves and
+//   every helper that is not a filler reduces (DIRECT below).  Measured (profiles/r04_ab_direct.txt): with 16 members
+//   (4 basins per wave, 5.5 reducer passes per 8-day tile) form 1 is 15 % faster -- a buffer store costs the lone
+//   stepper wave more than the LDS write it replaces; with 4 members (16 basins per wave: 24 passes per tile) the
+//   reducers bind and twice as many of them make form 2 36 % faster.  The host picks by basins per wave.
 // DYN: parameters vary per day: filler waves de-scale them (sigmoid, range, dy_drop blend) into LDS
 // tiles five deep (snow reads tile it, groundwater tile it-2, the fillers write it+2).
 // MANY: more than PIPE_FEWDYN of them: 4-day tiles, the filler waves share the rows round-robin.
-template <int MODEL, bool BETAET, bool TRAJ, bool DYN, bool MANY = false, int SC = 0>
+template <int MODEL, bool BETAET, int TRAJ, bool DYN, bool MANY = false, int SC = 0>
 __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
 {
     // ADJ: the implicit scheme (hbv_adj.py) with the staged solve of hbv_adj_step.h -- its blocks snow -> soil
@@ -210,6 +215,29 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
     }
     auto tile_nt = [&](int tile) { return min(Kt, T - tile * Kt); };
 
+    // DIRECT (TRAJ == 2): the stepper waves store the storages entering each day straight to the trajectory rows -- one
+    // buffer store where they otherwise write the value to LDS for a drainer wave -- so the six drainer waves are free
+    // to reduce.  One descriptor per storage series and tile (base = the row of the tile's
+    // first day, range = the tile's rows: only one tile has to fit 32 bits), day offset in the scalar operand, the
+    // lane's offset constant, out-of-range lanes dropped by the hardware.
+    constexpr bool DIRECT = TRAJ == 2 && !SAVE_POW;
+    const int64_t SRt = (int64_t)(T + 1) * N;
+    auto trj_rsrc = [&](int k, int tile) {
+        return A.ckptK ? __builtin_amdgcn_make_buffer_rsrc(o.traj, 0, -1, 0x00020000)
+                       : __builtin_amdgcn_make_buffer_rsrc(o.traj + k * SRt + (int64_t)tile * Kt * N, 0, (int)(row_bytes * KT),
+                                                           0x00020000);
+    };
+    auto trj_put = [&](__amdgpu_buffer_rsrc_t r, int tile, int tt, int k, float v) __attribute__((always_inline)) {
+        if (A.ckptK) {   // K-day checkpoints: rows [(day / K) * 5 + storage], only the days that are multiples of K
+            const int day = tile * Kt + tt;
+            if (day % A.ckptK == 0)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff,
+                                                      (unsigned)(((int64_t)(day / A.ckptK) * 5 + k) * row_bytes), 0);
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, (unsigned)tt * row_bytes, 0);
+        }
+    };
+
     if (wave == 0) {
         // ------------------------------ snow ------------------------------
         __builtin_amdgcn_s_setprio(3);
@@ -226,6 +254,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                 float *oa = lds + P.oa + (tile & 1) * Kt * 256 + lane;
                 float4 fn = in4[lane];
                 const float *pin = pin_of(tile);
+                const auto rSP = trj_rsrc(0, tile), rMW = trj_rsrc(1, tile);
                 DY_DECL(P_TT); DY_DECL(P_CFMAX); DY_DECL(P_CFR); DY_DECL(P_CWH);
                 if (DYN) { DY_LOAD(P_TT, pin); DY_LOAD(P_CFMAX, pin); DY_LOAD(P_CFR, pin); DY_LOAD(P_CWH, pin); }
                 auto day = [&](int tt, bool more) __attribute__((always_inline)) {
@@ -244,7 +273,10 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                         AdjStaged<BETAET>::snow(p, f.x, f.y, 1.0f, SP, MW, y0, y1, rfv, isn);
                         ab[tt * 128] = rfv;
                         ab[tt * 128 + 64] = isn;
-                        if (TRAJ) { q[128] = SP; q[192] = MW; }
+                        if (TRAJ) {
+                            if (DIRECT) { trj_put(rSP, tile, tt, 0, SP); trj_put(rMW, tile, tt, 1, MW); }
+                            else { q[128] = SP; q[192] = MW; }
+                        }
                         SP = y0; MW = y1;
                     } else {
                         Step<MODEL, BETAET> s;
@@ -254,7 +286,10 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                         ab[tt * 128] = s.RAIN;
                         ab[tt * 128 + 64] = s.tosoil;
                         q[0] = s.SP3; q[64] = s.tosoil;
-                        if (TRAJ) { q[128] = SP; q[192] = MW; }
+                        if (TRAJ) {
+                            if (DIRECT) { trj_put(rSP, tile, tt, 0, SP); trj_put(rMW, tile, tt, 1, MW); }
+                            else { q[128] = SP; q[192] = MW; }
+                        }
                         SP = s.SP3; MW = s.MW3;
                     }
                 };
@@ -288,6 +323,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                 float *oc = lds + P.oc + (tile & 1) * Kt * 448 + lane;
                 float npet = in4[lane].z, nrain = ab[0], nts = ab[64];
                 const float *pin = pin_of(tile);
+                const auto rSM = trj_rsrc(2, tile), rSUZ = trj_rsrc(3, tile), rSLZ = trj_rsrc(4, tile);
                 DY_DECL(P_BETA); DY_DECL(P_FC); DY_DECL(P_LP); DY_DECL(P_BETAET); DY_DECL(P_C);
                 DY_DECL(P_K0); DY_DECL(P_K1); DY_DECL(P_K2); DY_DECL(P_PERC); DY_DECL(P_UZL);
                 DY_DECL(P_RT); DY_DECL(P_AC); DY_DECL(P_F0); DY_DECL(P_FMIN); DY_DECL(P_ALPHA);
@@ -334,10 +370,13 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                     }
                     float *q = ob + tt * OBR * 64;
                     q[0] = s.ET; q[64] = s.rech; q[128] = s.exc; q[192] = s.ef; q[256] = s.cap;
-                    if (TRAJ) { q[320] = SM; if (SAVE_POW) { q[384] = s.sw0; q[448] = s.ef0; } }
+                    if (TRAJ && !DIRECT) { q[320] = SM; if (SAVE_POW) { q[384] = s.sw0; q[448] = s.ef0; } }
                     float *r = oc + tt * 448;
                     r[0] = s.Q; r[64] = s.Q0; r[128] = s.Q1; r[192] = s.Q2; r[256] = s.PERC;
-                    if (TRAJ) { r[320] = SUZ; r[384] = SLZ; }
+                    if (TRAJ) {
+                        if (DIRECT) { trj_put(rSM, tile, tt, 2, SM); trj_put(rSUZ, tile, tt, 3, SUZ); trj_put(rSLZ, tile, tt, 4, SLZ); }
+                        else { r[320] = SUZ; r[384] = SLZ; }
+                    }
                     SM = s.SM4; SUZ = s.SUZ4; SLZ = s.SLZ2;
                 };
                 PIPE_DAYS(nt, day);
@@ -372,6 +411,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                 float *ob = lds + P.ob + (tile & 1) * Kt * OBR * 64 + lane;
                 float npet = in4[lane].z, nrain = ab[0], nts = ab[64];
                 const float *pin = pin_of(tile);
+                const auto rSM = trj_rsrc(2, tile);
                 DY_DECL(P_BETA); DY_DECL(P_FC); DY_DECL(P_LP); DY_DECL(P_BETAET);
                 if (DYN) { DY_LOAD(P_BETA, pin); DY_LOAD(P_FC, pin); DY_LOAD(P_LP, pin); DY_LOAD(P_BETAET, pin); }
                 auto day = [&](int tt, bool more) __attribute__((always_inline)) {
@@ -392,7 +432,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                         AdjStaged<BETAET>::soil(p, dRAIN, dTS, dPET, 1.0f, SM, d.adj_gtol, d.adj_max_iter, y2, Peff, exs);
                         bc[tt * 128] = Peff;
                         bc[tt * 128 + 64] = exs;
-                        if (TRAJ) q[256] = SM;
+                        if (TRAJ) { if (DIRECT) trj_put(rSM, tile, tt, 2, SM); else q[256] = SM; }
                         SM = y2;
                     } else {
                         Step<MODEL, BETAET> s;
@@ -402,7 +442,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                         bc[tt * 128] = s.rech;
                         bc[tt * 128 + 64] = s.exc;
                         q[0] = s.ET; q[64] = s.rech; q[128] = s.exc; q[192] = s.ef;
-                        if (TRAJ) { q[256] = SM; if (SAVE_POW) { q[320] = s.sw0; q[384] = s.ef0; } }
+                        if (TRAJ) { if (DIRECT) trj_put(rSM, tile, tt, 2, SM); else { q[256] = SM; if (SAVE_POW) { q[320] = s.sw0; q[384] = s.ef0; } } }
                         SM = s.SM3;
                     }
                 };
@@ -433,6 +473,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                 float *oc = lds + P.oc + (tile & 1) * Kt * 448 + lane;
                 float nrech = bc[0], nexc = bc[64];
                 const float *pin = pin_of(tile);
+                const auto rSUZ = trj_rsrc(3, tile), rSLZ = trj_rsrc(4, tile);
                 DY_DECL(P_K0); DY_DECL(P_K1); DY_DECL(P_K2); DY_DECL(P_PERC); DY_DECL(P_UZL);
                 if (DYN) { DY_LOAD(P_K0, pin); DY_LOAD(P_K1, pin); DY_LOAD(P_K2, pin); DY_LOAD(P_PERC, pin); DY_LOAD(P_UZL, pin); }
                 auto day = [&](int tt, bool more) __attribute__((always_inline)) {
@@ -451,7 +492,10 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                         float y3, y4, Q;
                         AdjStaged<BETAET>::gw(p, dRECH, dEXC, 1.0f, SUZ, SLZ, y3, y4, Q);
                         q[0] = Q;
-                        if (TRAJ) { q[320] = SUZ; q[384] = SLZ; }
+                        if (TRAJ) {
+                            if (DIRECT) { trj_put(rSUZ, tile, tt, 3, SUZ); trj_put(rSLZ, tile, tt, 4, SLZ); }
+                            else { q[320] = SUZ; q[384] = SLZ; }
+                        }
                         SUZ = y3; SLZ = y4;
                     } else {
                         Step<MODEL, BETAET> s;
@@ -459,7 +503,10 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                         s.SUZ = SUZ; s.SLZ0 = SLZ;
                         s.fwd_gw(p, 0.0f);
                         q[0] = s.Q; q[64] = s.Q0; q[128] = s.Q1; q[192] = s.Q2; q[256] = s.PERC;
-                        if (TRAJ) { q[320] = SUZ; q[384] = SLZ; }
+                        if (TRAJ) {
+                            if (DIRECT) { trj_put(rSUZ, tile, tt, 3, SUZ); trj_put(rSLZ, tile, tt, 4, SLZ); }
+                            else { q[320] = SUZ; q[384] = SLZ; }
+                        }
                         SUZ = s.SUZ4; SLZ = s.SLZ2;
                     }
                 };
@@ -593,6 +640,49 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                 // the soil wave finished tile it-2 before the last barrier; then start tile it+3
                 if (it + 2 < nT) commit(it + 2);
                 if (it + 3 < nT) issue(it + 3);
+                PIPE_BARRIER();
+            }
+        } else if (DIRECT) {
+            // every helper that is not a filler reduces.  Ranks go round the SIMDs -- the stepper-free one, the snow
+            // wave's, the groundwater wave's -- row of waves by row, the soil wave's SIMD last (a tile has at most 6-8
+            // passes, heaviest first: those waves only ever get work when the workgroup is short of others)
+            int rank = -1, nred = 0;
+            for (int pass = 0; pass < 2; pass++)
+                for (int row = 0; row < 4; row++)
+                    for (int qi = 0; qi < 3; qi++) {
+                        const int q = pass == 0 ? (qi == 0 ? 3 : (qi == 1 ? 0 : 2)) : 1;
+                        if (pass == 1 && qi > 0) continue;
+                        const int wv = 4 * row + q + (q < 3 ? 4 : 0);     // waves 4.. (quad 0-2) / 3, 7, 11, 15 (quad 3)
+                        if (wv < 3 || wv >= nw) continue;
+                        const bool fill_w = wv == 3 || (DYN && (wv == 4 || wv == 6));
+                        if (fill_w) continue;
+                        if (wv == wave) rank = nred;
+                        nred++;
+                    }
+            PIPE_BARRIER();
+            for (int it = 0; it < nIt; it++) {
+                const int tA = it - 1, tB = it - 2, tC = CAP ? it - 2 : it - 3;
+                const int ntA = (tA >= 0 && tA < nT) ? tile_nt(tA) : 0;
+                const int ntB = (tB >= 0 && tB < nT) ? tile_nt(tB) : 0;
+                const int ntC = (tC >= 0 && tC < nT) ? tile_nt(tC) : 0;
+                const float *bufA = lds + P.oa + (tA & 1) * Kt * 256;
+                const float *bufB = lds + P.ob + (tB & 1) * Kt * OBR * 64;
+                const float *bufC = lds + P.oc + (tC & 1) * Kt * 448;
+                constexpr int NFC = ADJ ? 1 : 5;   // implicit scheme: Q only (hbv_adj.py:309-317)
+                const int iA = ADJ ? 0 : ntA * 2 * bpw, iB = ADJ ? 0 : ntB * NFB * bpw,
+                          iC = (ADJ && !o.flux) ? 0 : ntC * NFC * bpw;
+                const int pA = (iA + 63) >> 6, pB = (iB + 63) >> 6, pC = (iC + 63) >> 6;
+                const int nR = pA + pB + pC;
+                if (rank >= 0) {
+                    for (int u = rank; u < nR; u += nred) {
+                        if (u < pC)
+                            pipe_reduce_pass<7, NFC, fmapC>(d, o, bufC, tC * Kt, iC, u, lane, lgMp, b0);
+                        else if (u < pC + pB)
+                            pipe_reduce_pass<OBR, NFB, fmapB>(d, o, bufB, tB * Kt, iB, u - pC, lane, lgMp, b0);
+                        else
+                            pipe_reduce_pass<4, 2, fmapA>(d, o, bufA, tA * Kt, iA, u - pC - pB, lane, lgMp, b0);
+                    }
+                }
                 PIPE_BARRIER();
             }
         } else if ((quad == 1 && !(PIPE_Q1 == 1 && DYN && !MANY) && !(PIPE_Q1 == 2 && TRAJ && !MANY)) ||

@@ -58,6 +58,10 @@ bool hbvx_host::try_fwd_pipe(const hbvx_desc *d, const hbvx_fwd_out *out, void *
             pthreads = pthreads < 512 ? 512 : (pthreads > 1024 ? 1024 : (pthreads / 64) * 64);
             if (nd > 0) pthreads = 1024;   // the dynamic-parameter roles assume all 16 waves
             const bool be = d->n_param == 13, tr = out->traj != nullptr, dy = nd > 0;
+            // who stores the trajectory (hbv_pipe.h, TRAJ): the steppers themselves where the reducers are the busy
+            // helpers -- 8 or more basins per wave (ensembles of at most 8 members); HBVX_PIPE_DIRECT=0|1 pins it (tools)
+            const int dflag = env_int("HBVX_PIPE_DIRECT", -1);
+            const bool direct = !SAVE_POW && (dflag >= 0 ? dflag != 0 : bpw_p >= 8);
             hipStream_t st = (hipStream_t)stream;
             hipError_t e;
             // compile-time dynamic sets (hbv_pipe.h, SC): {BETA, BETAET} and {BETA, K0, BETAET}
@@ -76,14 +80,15 @@ bool hbvx_host::try_fwd_pipe(const hbvx_desc *d, const hbvx_fwd_out *out, void *
     } while (0)
 #define PIPE_GO4(MODEL, BE, S1, S2)                                                                \
     do {                                                                                           \
-        if (tr) PIPE_GO3(MODEL, BE, true, S1, S2);                                                 \
-        else PIPE_GO3(MODEL, BE, false, S1, S2);                                                   \
+        if (tr && direct) PIPE_GO3(MODEL, BE, 2, S1, S2);                                          \
+        else if (tr) PIPE_GO3(MODEL, BE, 1, S1, S2);                                               \
+        else PIPE_GO3(MODEL, BE, 0, S1, S2);                                                       \
     } while (0)
             if (adj) {   // at most PIPE_FEWDYN dynamic parameters (pmodel), descriptor flags
 #define PIPE_GO_ADJ(BE)                                                                            \
     do {                                                                                           \
-        if (tr) { if (dy) PIPE_GO(MODEL_HBVADJ, BE, true, true, false, 0); else PIPE_GO(MODEL_HBVADJ, BE, true, false, false, 0); } \
-        else { if (dy) PIPE_GO(MODEL_HBVADJ, BE, false, true, false, 0); else PIPE_GO(MODEL_HBVADJ, BE, false, false, false, 0); } \
+        if (tr) { if (dy) PIPE_GO(MODEL_HBVADJ, BE, 1, true, false, 0); else PIPE_GO(MODEL_HBVADJ, BE, 1, false, false, 0); } \
+        else { if (dy) PIPE_GO(MODEL_HBVADJ, BE, 0, true, false, 0); else PIPE_GO(MODEL_HBVADJ, BE, 0, false, false, 0); } \
     } while (0)
                 if (be) PIPE_GO_ADJ(true);
                 else PIPE_GO_ADJ(false);

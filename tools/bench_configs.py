@@ -61,9 +61,9 @@ def run(name, steps=5, warmup=2):
             {"nmul": M, "dynamic_params": {"HbvAdj": ["parBETAET"]}, **extra}, dev)
         n_dyn, nf = 1, 1
     elif name.startswith("grid:"):
-        # grid:<hbv|hbv_2>:<B>:<T>  -- 16 members, 3 dynamic parameters for hbv_2, 2 for hbv
-        _, fam, Bs, Ts = name.split(":")
-        T, B, M = int(Ts), int(Bs), 16
+        # grid:<hbv|hbv_2>:<B>:<T>[:<M>]  -- M members (16), 3 dynamic parameters for hbv_2, 2 for hbv
+        _, fam, Bs, Ts, *rest = name.split(":")
+        T, B, M = int(Ts), int(Bs), int(rest[0]) if rest else 16
         if fam == "hbv":
             dyn = ["parBETA", "parBETAET"]
             model = hydrodl2_amd.load_model("hbv", "Hbv")({"nmul": M, "dynamic_params": {"Hbv": dyn}}, dev)
