@@ -538,8 +538,11 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
         // share the dynamic rows -- the de-scaling (sigmoid) of a row is ~140 VALU cycles
         // per day, too much for one wave beside the forcings.
         // (in the two-stage pipeline wave 2 has no stage: with many dynamic rows it is a fourth filler)
-        constexpr int NF = (CAP && MANY) ? 4 : 3;   // filler waves when DYN
-        const bool is_fill = wave == 3 || (DYN && (wave == 4 || wave == 6 || (MANY && wave == 2)));
+        // (round 4, many rows: the three waves on the soil wave's SIMD -- idle in this mode -- fill as well.  Probe at
+        // config 3 with four fillers: 694-784 busy of 793 cycles per day, the fused soil + capillary + groundwater
+        // wave 640: the fillers bound the day)
+        constexpr int NF = MANY ? (CAP ? 7 : 6) : 3;   // filler waves when DYN
+        const bool is_fill = wave == 3 || (DYN && (wave == 4 || wave == 6 || (MANY && (wave == 2 || wave == 5 || wave == 9 || wave == 13))));
         const int rbase = DYN ? 8 : 4;   // first reducer wave
         if (is_fill) {
             // Registers hold the tile that goes to LDS next iteration.  Straight-line code (days past
@@ -549,8 +552,12 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
             // the tile, range = the days that exist), the day offset is a scalar operand and the
             // per-lane offset a constant, so issuing a tile costs no vector address arithmetic.
             constexpr int FD = KT;
-            constexpr int NRW = MANY ? (PIPE_MAXDYN + NF - 1) / NF : 1;   // dynamic rows per filler wave
-            const int fidx = wave == 3 ? 0 : (wave == 4 ? 1 : (wave == 6 ? 2 : 3));
+            // many rows: the three fillers on the soil wave's SIMD only get the issue slots that wave leaves (probe: 690-750
+            // busy with two rows each against 350-400 for the others), so they take ONE row each -- rows 0 .. NS-1 -- and
+            // the NF - NS others share the rest round-robin
+            constexpr int NS = MANY ? 3 : 0, NFAST = NF - NS;
+            constexpr int NRW = MANY ? (PIPE_MAXDYN - NS + NFAST - 1) / NFAST : 1;   // dynamic rows per filler wave
+            const int fidx = wave == 3 ? 0 : (wave == 4 ? 1 : (wave == 6 ? 2 : (wave == 2 ? 3 : (CAP ? 4 : 3) + ((wave - 5) >> 2))));
             const bool forc = fidx == 0;
             const int nd = __builtin_popcount(dmask);
             float fx[FD], fy[FD], fz[FD], dv[NRW][FD];
@@ -569,7 +576,9 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
             // (with at most three rows too, the forcing wave comes last in the rotation: with the delta-MG default of
             // two dynamic parameters it stages no row at all -- it was the busiest wave of the workgroup, 453 of 489
             // cycles per day, with forcings AND a row)
-            const int frow = (MANY || PIPE_REBALANCE) ? (fidx + NF - 1) % NF : fidx;
+            const bool slow = MANY && fidx >= NFAST;
+            const int frow = slow ? fidx - NFAST : NS + ((MANY || PIPE_REBALANCE) ? (fidx + NFAST - 1) % NFAST : fidx);
+            const int fstep = slow ? PIPE_MAXDYN : NFAST;      // (a slow filler's second row never exists)
             const float *dsrc[NRW];
             unsigned dvo[NRW];
             int64_t dts[NRW];
@@ -577,7 +586,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
             bool duse[NRW], dyrow[NRW];
 #pragma unroll
             for (int r = 0; r < NRW; r++) {
-                const int k = frow + NF * r;
+                const int k = frow + fstep * r;
                 dyrow[r] = DYN && k < nd;
                 dsrc[r] = d.x; dvo[r] = 0; dts[r] = 0; dlo[r] = dhi[r] = dsta[r] = 0.0f; duse[r] = false;
                 if (dyrow[r]) {
@@ -622,7 +631,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
 #pragma unroll
                 for (int r = 0; r < NRW; r++)
                     if (dyrow[r]) {
-                        float *pin = lds + P.pin + (tile % 5) * FD * PD * 64 + (frow + NF * r) * 64 + lane;
+                        float *pin = lds + P.pin + (tile % 5) * FD * PD * 64 + (frow + fstep * r) * 64 + lane;
 #pragma unroll
                         for (int i = 0; i < FD; i++) {
                             const float u = raw ? sigmoid_dyn_(dv[r][i]) : dv[r][i];
@@ -654,7 +663,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                         if (pass == 1 && qi > 0) continue;
                         const int wv = 4 * row + q + (q < 3 ? 4 : 0);     // waves 4.. (quad 0-2) / 3, 7, 11, 15 (quad 3)
                         if (wv < 3 || wv >= nw) continue;
-                        const bool fill_w = wv == 3 || (DYN && (wv == 4 || wv == 6));
+                        const bool fill_w = wv == 3 || (DYN && (wv == 4 || wv == 6 || (MANY && (wv == 5 || wv == 9 || wv == 13))));
                         if (fill_w) continue;
                         if (wv == wave) rank = nred;
                         nred++;
