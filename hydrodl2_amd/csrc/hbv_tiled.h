@@ -153,6 +153,23 @@ __device__ __forceinline__ float ens_sum_lane16(const float *src, int rot)
     return (t0 + (odd ? t3 : t1)) + (t2 + (odd ? t1 : t3));
 }
 
+// Ensembles of at most 8 members (Mp = 4 or 8: one or two quads) as straight code -- masks by select, no wave-uniform
+// branch around the reads (ens_sum_lane's general form walks sixteen guarded quads: with 16 basins per wave the reducers of
+// the pipelined forward have 24 passes per tile and that walk was most of each).  Same quads, same tree: bit-identical.
+__device__ __forceinline__ float ens_sum_lane_small(const float *src, int M, int lgMp)
+{
+    auto quad = [&](int qi) {
+        const float4 v = *reinterpret_cast<const float4 *>(src + 4 * qi);
+        const int m0 = 4 * qi;
+        const float a = ((m0 < M) ? v.x : 0.0f) + ((m0 + 1 < M) ? v.y : 0.0f);
+        const float b = ((m0 + 2 < M) ? v.z : 0.0f) + ((m0 + 3 < M) ? v.w : 0.0f);
+        return a + b;
+    };
+    const float q0 = quad(0);
+    if (lgMp == 2) return q0;
+    return q0 + quad(1);
+}
+
 // Reduce `items` (= nt * NFS * bpw) basin-series of an output tile and hand each sum to `emit`.
 // Item e -> (bl = e % bpw, ks = (e / bpw) % NFS, tt = e / (bpw * NFS)); values of item e live at
 // buf[(tt * NSER + ks) * 64 + bl * Mp ...].  One lane per item, 64 items per wave and pass: per
@@ -169,7 +186,8 @@ __device__ __forceinline__ void ens_reduce_pass(const float *buf, int items, int
     const int r = ec >> (6 - lgMp);
     const int ks = r % NFS, tt = r / NFS;
     const float *src = buf + (tt * NSER + ks) * 64 + (bl << lgMp);
-    const float v = (lgMp == 4 && M == 16) ? ens_sum_lane16(src, r) : ens_sum_lane(src, M, lgMp, r);
+    const float v = (lgMp == 4 && M == 16) ? ens_sum_lane16(src, r)
+                  : ((lgMp == 2 || lgMp == 3) ? ens_sum_lane_small(src, M, lgMp) : ens_sum_lane(src, M, lgMp, r));
     if (valid) emit(tt, ks, bl, v);
 }
 
