@@ -70,6 +70,36 @@ __device__ __forceinline__ void adj_params(const hbvx_desc &d, const AdjLane &L,
     for (int i = NP; i < NPARAM_MAX; i++) p[i] = 0.0f;
 }
 
+// "Few" mode of the time-parallel kernels (at most ADJ_FEW dynamic parameters, the usual case: config 4 has one): the
+// static parameters are de-scaled once per lane, a day only touches the rows of the wave-uniform slot list -- like
+// hbv_chunked.h's DYN == 1.  The generic form above walks all 13 slots every day behind per-slot flags, pointers and
+// strides: 100+ scalar registers, 177 lane-spill operations per day in the sweep.  u[k] (k < nd): the unit value of
+// dynamic parameter k that was used (for sigmoid').
+#define ADJ_FEW 3
+struct AdjFew {
+    int nd, slot[ADJ_FEW];
+};
+template <int NP>
+__device__ __forceinline__ void adj_params_few(const hbvx_desc &d, const AdjLane &L, int t, bool raw, const AdjFew &F,
+                                               const float *psta, const bool *use_k, float *uk, float *p)
+{
+#pragma unroll
+    for (int i = 0; i < NP; i++) p[i] = psta[i];
+#pragma unroll
+    for (int i = NP; i < NPARAM_MAX; i++) p[i] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < ADJ_FEW; k++)
+        if (k < F.nd) {
+            const hbvx_param_src &s = d.p[F.slot[k]];
+            float v = s.dyn[(int64_t)t * s.dyn_t_stride + (int64_t)L.b * s.dyn_b_stride + L.j];
+            v = raw ? sigmoid_dyn_(v) : v;
+            uk[k] = v;
+            const float pv = descale_(v, s.lo, s.hi);
+            const float cur = slot_get<NP>(p, F.slot[k]);
+            slot_set<NP>(p, F.slot[k], use_k[k] ? pv : cur);
+        }
+}
+
 template <bool BETAET>
 __global__ void __launch_bounds__(64) k_adj_fwd(const AdjFwdArgs A)
 {
@@ -228,9 +258,9 @@ __device__ __forceinline__ void adj_issue(const hbvx_desc &d, const hbvx_bwd_io 
     R.gQ = g;
 }
 
-template <bool BETAET>
+template <bool BETAET, bool FEW = false>
 __global__ void __launch_bounds__(64) k_adj_chunk_phi(const hbvx_desc d, const hbvx_bwd_io io, int lgMp,
-                                                      int C, float *phi_ws, int per_xcd)
+                                                      int C, float *phi_ws, int per_xcd, const AdjFew F)
 {
     constexpr int NP = BETAET ? 13 : 12;
     ChunkBlock blk;                          // XCD-aware block map (hbv_chunked.h)
@@ -241,14 +271,25 @@ __global__ void __launch_bounds__(64) k_adj_chunk_phi(const hbvx_desc d, const h
     const int64_t N = (int64_t)d.B * d.M;
     const bool raw = d.raw_sigmoid != 0;
     const float invM = 1.0f / (float)d.M;
-    float usta[NP];
-    bool use_dyn[NP];
+    float usta[NP];                 // FEW: the static PHYSICAL values
+    bool use_dyn[FEW ? ADJ_FEW : NP];
 #pragma unroll
     for (int i = 0; i < NP; i++) {
         const hbvx_param_src &s = d.p[i];
         float v = s.sta[(int64_t)L.b * s.sta_b_stride + L.j];
         usta[i] = raw ? sigmoid_(v) : v;
-        use_dyn[i] = s.dyn && !(s.drop && s.drop[L.n]);
+        if (FEW) usta[i] = descale_(usta[i], s.lo, s.hi);
+        else use_dyn[i] = s.dyn && !(s.drop && s.drop[L.n]);
+    }
+    if (FEW) {
+#pragma unroll
+        for (int k = 0; k < ADJ_FEW; k++) {
+            use_dyn[k] = false;
+            if (k < F.nd) {
+                const hbvx_param_src &s = d.p[F.slot[k]];
+                use_dyn[k] = !(s.drop && s.drop[L.n]);
+            }
+        }
     }
     float Phi[5][5], phi[5];
 #pragma unroll
@@ -263,7 +304,8 @@ __global__ void __launch_bounds__(64) k_adj_chunk_phi(const hbvx_desc d, const h
         const AdjRaw Rc = Rn;
         if (t > t0) adj_issue(d, io, L, t - 1, N, Rn);     // next day's loads in flight
         float u[NP], p[NPARAM_MAX], x[5];
-        adj_params<NP>(d, L, t, raw, usta, use_dyn, u, p);
+        if (FEW) adj_params_few<NP>(d, L, t, raw, F, usta, use_dyn, u, p);
+        else adj_params<NP>(d, L, t, raw, usta, use_dyn, u, p);
         AdjStep<BETAET> s;
         s.P = Rc.f[0]; s.Tf = Rc.f[1]; s.PET = Rc.f[2];
 #pragma unroll
@@ -294,9 +336,9 @@ __global__ void __launch_bounds__(64) k_adj_chunk_phi(const hbvx_desc d, const h
     }
 }
 
-template <bool BETAET>
+template <bool BETAET, bool FEW = false>
 __global__ void __launch_bounds__(64) k_adj_chunk_sweep(const hbvx_desc d, const hbvx_bwd_io io, int lgMp,
-                                                        int C, const float *abnd, float *gpart, int per_xcd)
+                                                        int C, const float *abnd, float *gpart, int per_xcd, const AdjFew F)
 {
     constexpr int NP = BETAET ? 13 : 12;
     ChunkBlock blk;
@@ -307,15 +349,27 @@ __global__ void __launch_bounds__(64) k_adj_chunk_sweep(const hbvx_desc d, const
     const int64_t N = (int64_t)d.B * d.M;
     const bool raw = d.raw_sigmoid != 0;
     const float invM = 1.0f / (float)d.M;
-    float usta[NP], gsta[NP];
-    bool use_dyn[NP];
+    float usta[NP], gsta[NP];       // FEW: usta holds the static PHYSICAL values
+    bool use_dyn[FEW ? ADJ_FEW : NP];
+    float gused[ADJ_FEW] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int i = 0; i < NP; i++) {
         const hbvx_param_src &s = d.p[i];
         float v = s.sta[(int64_t)L.b * s.sta_b_stride + L.j];
         usta[i] = raw ? sigmoid_(v) : v;
-        use_dyn[i] = s.dyn && !(s.drop && s.drop[L.n]);
+        if (FEW) usta[i] = descale_(usta[i], s.lo, s.hi);
+        else use_dyn[i] = s.dyn && !(s.drop && s.drop[L.n]);
         gsta[i] = 0.0f;
+    }
+    if (FEW) {
+#pragma unroll
+        for (int k = 0; k < ADJ_FEW; k++) {
+            use_dyn[k] = false;
+            if (k < F.nd) {
+                const hbvx_param_src &s = d.p[F.slot[k]];
+                use_dyn[k] = !(s.drop && s.drop[L.n]);
+            }
+        }
     }
     float a[5];
 #pragma unroll
@@ -326,7 +380,8 @@ __global__ void __launch_bounds__(64) k_adj_chunk_sweep(const hbvx_desc d, const
         AdjRaw Rc;
         adj_issue(d, io, L, t, N, Rc);
         float u[NP], p[NPARAM_MAX], x[5], gp[NPARAM_MAX];
-        adj_params<NP>(d, L, t, raw, usta, use_dyn, u, p);
+        if (FEW) adj_params_few<NP>(d, L, t, raw, F, usta, use_dyn, u, p);
+        else adj_params<NP>(d, L, t, raw, usta, use_dyn, u, p);
         AdjStep<BETAET> s;
         s.P = Rc.f[0]; s.Tf = Rc.f[1]; s.PET = Rc.f[2];
 #pragma unroll
@@ -335,6 +390,22 @@ __global__ void __launch_bounds__(64) k_adj_chunk_sweep(const hbvx_desc d, const
 #pragma unroll
         for (int i = 0; i < NPARAM_MAX; i++) gp[i] = 0.0f;
         adj_backstep<BETAET>(s, p, x, 1.0f, gQ, a, gp);
+        if (FEW) {
+#pragma unroll
+            for (int i = 0; i < NP; i++) gsta[i] += gp[i] * (d.p[i].hi - d.p[i].lo);
+#pragma unroll
+            for (int k = 0; k < ADJ_FEW; k++)
+                if (k < F.nd) {
+                    const int sl = F.slot[k];
+                    const float gu = slot_get<NP>(gp, sl) * (d.p[sl].hi - d.p[sl].lo);
+                    const float gr = raw ? gu * (u[k] * (1.0f - u[k])) : gu;
+                    if (io.g[sl].dyn && L.active)
+                        io.g[sl].dyn[(int64_t)t * io.g[sl].dyn_t_stride + (int64_t)L.b * io.g[sl].dyn_b_stride + L.j] =
+                            use_dyn[k] ? gr : 0.0f;
+                    gused[k] += use_dyn[k] ? gu : 0.0f;   // goes to the dynamic rows, not to the static one
+                }
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < NP; i++) {
             const float gu = gp[i] * (d.p[i].hi - d.p[i].lo);
@@ -348,6 +419,12 @@ __global__ void __launch_bounds__(64) k_adj_chunk_sweep(const hbvx_desc d, const
                 gsta[i] += gu;
             }
         }
+    }
+    if (FEW) {
+        // the same daily terms were added to gsta and gused in the same order: exact cancellation
+#pragma unroll
+        for (int k = 0; k < ADJ_FEW; k++)
+            if (k < F.nd) slot_set<NP>(gsta, F.slot[k], slot_get<NP>(gsta, F.slot[k]) - gused[k]);
     }
     if (L.active) {
 #pragma unroll

@@ -217,12 +217,28 @@ extern "C" int hbvx_adj_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void
         hipStream_t st = (hipStream_t)stream;
         ca.per_xcd = chunk_per_xcd(d->B, ca.lgMp);
         dim3 g2((unsigned)(8 * ca.per_xcd * ca.nchunk));      // XCD-aware 1-D block map (hbv_chunked.h::chunk_block)
-        if (d->n_param == 13) hipLaunchKernelGGL(k_adj_chunk_phi<true>, g2, dim3(64), 0, st, *d, *io, ca.lgMp, ca.C, ca.phi, ca.per_xcd);
-        else hipLaunchKernelGGL(k_adj_chunk_phi<false>, g2, dim3(64), 0, st, *d, *io, ca.lgMp, ca.C, ca.phi, ca.per_xcd);
+        // at most ADJ_FEW dynamic parameters: the slot-list instances (hbv_adj_kernels.h, "few" mode)
+        AdjFew few{};
+        const bool is_few = count_dyn(d) <= ADJ_FEW;
+        if (is_few)
+            for (int i = 0; i < d->n_param; i++)
+                if (d->p[i].dyn) few.slot[few.nd++] = i;
+        if (d->n_param == 13) {
+            if (is_few) hipLaunchKernelGGL((k_adj_chunk_phi<true, true>), g2, dim3(64), 0, st, *d, *io, ca.lgMp, ca.C, ca.phi, ca.per_xcd, few);
+            else hipLaunchKernelGGL((k_adj_chunk_phi<true, false>), g2, dim3(64), 0, st, *d, *io, ca.lgMp, ca.C, ca.phi, ca.per_xcd, few);
+        } else {
+            if (is_few) hipLaunchKernelGGL((k_adj_chunk_phi<false, true>), g2, dim3(64), 0, st, *d, *io, ca.lgMp, ca.C, ca.phi, ca.per_xcd, few);
+            else hipLaunchKernelGGL((k_adj_chunk_phi<false, false>), g2, dim3(64), 0, st, *d, *io, ca.lgMp, ca.C, ca.phi, ca.per_xcd, few);
+        }
         launch_chunk_scan(ca, st);
         store_gate(io, st);      // phi and scan only read; the sweep stores the dynamic gradients
-        if (d->n_param == 13) hipLaunchKernelGGL(k_adj_chunk_sweep<true>, g2, dim3(64), 0, st, *d, *io, ca.lgMp, ca.C, ca.abnd, ca.gpart, ca.per_xcd);
-        else hipLaunchKernelGGL(k_adj_chunk_sweep<false>, g2, dim3(64), 0, st, *d, *io, ca.lgMp, ca.C, ca.abnd, ca.gpart, ca.per_xcd);
+        if (d->n_param == 13) {
+            if (is_few) hipLaunchKernelGGL((k_adj_chunk_sweep<true, true>), g2, dim3(64), 0, st, *d, *io, ca.lgMp, ca.C, ca.abnd, ca.gpart, ca.per_xcd, few);
+            else hipLaunchKernelGGL((k_adj_chunk_sweep<true, false>), g2, dim3(64), 0, st, *d, *io, ca.lgMp, ca.C, ca.abnd, ca.gpart, ca.per_xcd, few);
+        } else {
+            if (is_few) hipLaunchKernelGGL((k_adj_chunk_sweep<false, true>), g2, dim3(64), 0, st, *d, *io, ca.lgMp, ca.C, ca.abnd, ca.gpart, ca.per_xcd, few);
+            else hipLaunchKernelGGL((k_adj_chunk_sweep<false, false>), g2, dim3(64), 0, st, *d, *io, ca.lgMp, ca.C, ca.abnd, ca.gpart, ca.per_xcd, few);
+        }
         launch_chunk_reduce(ca, d->n_param, st);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return hip_fail(e, "hbvx_adj_backward (chunked) launch");

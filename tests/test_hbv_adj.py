@@ -66,6 +66,11 @@ CASES = [
     # a 40-day warm-up: long enough for the pipelined kernel, which then runs WITHOUT a flux output and is
     # differentiated through (hbv_adj.py:257-274), followed by 50 main days with a dynamic snow parameter
     dict(T=90, B=5, M=16, seed=84, cfg=dict(nmul=16, warm_up=40, dynamic_params={"HbvAdj": ["parCFMAX"]})),
+    # five dynamic parameters with drops: above ADJ_FEW, the generic instances of the time-parallel adjoint kernels
+    # (hbv_adj_kernels.h; up to three take the slot-list ones)
+    dict(T=44, B=4, M=8, seed=85,
+         cfg=dict(nmul=8, dy_drop=0.3,
+                  dynamic_params={"HbvAdj": ["parBETA", "parK1", "parLP", "parTT", "parBETAET"]})),
 ]
 
 
