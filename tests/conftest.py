@@ -24,7 +24,8 @@ def pytest_configure(config):
 # golden fixtures first, the callers next, contract / launcher tests last -- a contract test can never again stop
 # the run before a parity test (round 2: one value-dependent assertion in test_bench_launch did exactly that).
 _GPU_ORDER = ["test_gpu_parity", "test_gpu_fullsize", "test_hbv_adj", "test_mts", "test_gage_route", "test_lstm",
-              "test_example_dpl", "test_graphed", "test_gpu_fuzz", "test_zero_fill", "test_api_and_abi", "test_bench_launch"]
+              "test_example_dpl", "test_graphed", "test_gpu_fuzz", "test_zero_fill", "test_api_and_abi", "test_gpu_rccl_world1",
+              "test_bench_launch"]
 
 
 def pytest_collection_modifyitems(config, items):
