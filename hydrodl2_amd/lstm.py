@@ -26,6 +26,19 @@ def _gate_perm(H: int, device) -> torch.Tensor:
     return (torch.arange(4, device=device)[None, :] * H + torch.arange(H, device=device)[:, None]).reshape(-1)
 
 
+def _wgrad(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a^T b for a [K, G], b [K, I] with K = T*B in the tens of thousands: the weight gradients.  The library's plain
+    call covers the [G, I] output with a few dozen tiles and walks all of K in each (55 TFLOP/s at K = 73 000, G = 1024,
+    I = 256); cut into S batches along K and summed it runs at 120 (tools/micro/wgrad_gemm.py,
+    profiles/r04_lstm_wgrad.txt).  S: a divisor of K near 8, else the plain product."""
+    K = a.shape[0]
+    if K >= 8192:
+        for S in (8, 10, 9, 12, 6, 7, 5, 4, 16, 14, 15, 11, 13):
+            if K % S == 0:
+                return torch.bmm(a.view(S, K // S, a.shape[1]).transpose(1, 2), b.view(S, K // S, b.shape[1])).sum(0)
+    return a.t() @ b
+
+
 class LstmSeq(torch.autograd.Function):
     """x [T,B,I], W_ih [4H,I], W_hh [4H,H], b_ih, b_hh [4H] -> h [T,B,H], c [T,B,H] (c carries no
     gradient).  `check=True` synchronises and verifies the kernels' hand-off status word."""
@@ -86,11 +99,11 @@ class LstmSeq(torch.autograd.Function):
         gw_ih = gw_hh = gb = None
         if need[1]:
             gw_ih = torch.empty_like(w_ih_p)
-            gw_ih[perm] = dg.t() @ x.reshape(T * B, I)
+            gw_ih[perm] = _wgrad(dg, x.reshape(T * B, I))
         if need[2]:
             gw_hh = torch.zeros_like(w_hh)
             if T > 1:
-                gw_hh[perm] = dg[B:].t() @ h_all[:-1].reshape((T - 1) * B, H)
+                gw_hh[perm] = _wgrad(dg[B:], h_all[:-1].reshape((T - 1) * B, H))
         if need[3] or need[4]:
             gb = torch.empty(4 * H, dtype=dg.dtype, device=dg.device)
             gb[perm] = dg.sum(0)

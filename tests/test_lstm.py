@@ -209,3 +209,18 @@ def test_two_layers_match_torch_on_oracle(oracle_backend):
 @pytest.mark.gpu
 def test_two_layers_match_torch_on_gpu(hip_backend):
     _two_layer("cuda", 40, 21, 9, 64)
+
+
+@pytest.mark.gpu
+def test_weight_gradients_at_split_k_size_match_torch(hip_backend):
+    """T * B = 9 600 rows: above the threshold where lstm._wgrad cuts the weight-gradient products into batches along
+    K (and (T - 1) * B = 9 500 takes a different divisor); same tolerance as the small cases."""
+    _two_layer("cuda", 96, 100, 12, 64)
+
+
+def test_wgrad_split_matches_the_plain_product():
+    from hydrodl2_amd.lstm import _wgrad
+    torch.manual_seed(5)
+    for K in (9600, 9500, 8209):          # divisible by 8 / by 10 only ... / a prime: the plain product
+        a, b = torch.randn(K, 24, dtype=torch.float64), torch.randn(K, 7, dtype=torch.float64)
+        assert torch.allclose(_wgrad(a, b), a.t() @ b, rtol=1e-12, atol=1e-10)
