@@ -243,7 +243,7 @@ struct ChunkArgs; // hbv_chunked.h
 // kernels are a wave per (64 lanes, chunk) walking 64 days, and with the loads at the top of the day that consumes
 // them every day paid a full HBM round trip; the dynamic-parameter rows (any subset) stay in the day itself.
 struct AdjRaw {
-    float f[3], x[5], gQ;
+    float f[3], x[5], gQ, g4;   // gQ + g4 (the routing adjoint's share) is formed where it is used: adj_gq
 };
 __device__ __forceinline__ void adj_issue(const hbvx_desc &d, const hbvx_bwd_io &io, const AdjLane &L, int t, int64_t N,
                                           AdjRaw &R)
@@ -253,9 +253,14 @@ __device__ __forceinline__ void adj_issue(const hbvx_desc &d, const hbvx_bwd_io 
 #pragma unroll
     for (int k = 0; k < 5; k++) R.x[k] = io.traj[((int64_t)k * (d.T + 1) + (t + 1)) * N + L.n];
     const int64_t gi = (int64_t)t * d.B + L.b;
-    float g = io.grad_flux ? io.grad_flux[gi] : 0.0f;
-    if (io.grad_flux4) g += io.grad_flux4[gi];
-    R.gQ = g;
+    // loads only: an add here makes the compiler wait for all of the day's loads where they were just issued
+    // (hbv_chunked.h::chunk_issue, profiles/r04_ab_chunk_prefetch.txt)
+    R.gQ = io.grad_flux ? io.grad_flux[gi] : 0.0f;
+    R.g4 = io.grad_flux4 ? io.grad_flux4[gi] : 0.0f;
+}
+__device__ __forceinline__ float adj_gq(const hbvx_bwd_io &io, const AdjRaw &R)
+{
+    return io.grad_flux4 ? R.gQ + R.g4 : R.gQ;
 }
 
 template <bool BETAET, bool FEW = false>
@@ -310,7 +315,7 @@ __global__ void __launch_bounds__(64) k_adj_chunk_phi(const hbvx_desc d, const h
         s.P = Rc.f[0]; s.Tf = Rc.f[1]; s.PET = Rc.f[2];
 #pragma unroll
         for (int k = 0; k < 5; k++) x[k] = Rc.x[k];
-        const float gQ = Rc.gQ * invM;
+        const float gQ = adj_gq(io, Rc) * invM;
         s.template eval<true>(x, p);
         float lam[5];
 #pragma unroll
@@ -386,7 +391,7 @@ __global__ void __launch_bounds__(64) k_adj_chunk_sweep(const hbvx_desc d, const
         s.P = Rc.f[0]; s.Tf = Rc.f[1]; s.PET = Rc.f[2];
 #pragma unroll
         for (int k = 0; k < 5; k++) x[k] = Rc.x[k];
-        const float gQ = Rc.gQ * invM;
+        const float gQ = adj_gq(io, Rc) * invM;
 #pragma unroll
         for (int i = 0; i < NPARAM_MAX; i++) gp[i] = 0.0f;
         adj_backstep<BETAET>(s, p, x, 1.0f, gQ, a, gp);

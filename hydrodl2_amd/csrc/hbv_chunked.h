@@ -135,6 +135,7 @@ struct ChunkRaw {
     float st[5];     // storages entering the day
     float sw0, ef0;  // saved pow results (HBVX_SAVE_POW builds only)
     float gf[HBVX_MAX_FLUX];
+    float g4[4];     // the routing adjoint's share of the four runoff gradients (grad_flux4), added by chunk_finish
     float dv[NP];    // raw dynamic-parameter values
     float mu;
 };
@@ -200,14 +201,14 @@ __device__ __forceinline__ void chunk_issue(const hbvx_desc &d, const hbvx_bwd_i
         R.sw0 = R.ef0 = 0.0f;   // recomputed by chunk_finish (HBVX_SAVE_POW, hbv_step.h)
     }
     const int64_t fs = (int64_t)T * d.B, go = (int64_t)t * d.B + L.b;
+    // loads only, no arithmetic on what they return: an add here (gf + g4) made the compiler wait for every load of
+    // the day at the spot where they had just been issued -- a full memory round trip per day instead of a prefetch
+    // that flies while the previous day is computed (profiles/r04_ab_chunk_prefetch.txt)
 #pragma unroll
     for (int k = 0; k < HBVX_MAX_FLUX; k++) {
-        float v = 0.0f;
-        if (k < 4 || GFULL) {
-            if (GFULL && k < nf) v = io.grad_flux[k * fs + go];
-            if (k < 4 && io.grad_flux4) v += io.grad_flux4[k * fs + go];
-        }
-        R.gf[k] = v;
+        R.gf[k] = 0.0f;
+        if (GFULL && k < nf) R.gf[k] = io.grad_flux[k * fs + go];
+        if (k < 4) R.g4[k] = io.grad_flux4 ? io.grad_flux4[k * fs + go] : 0.0f;
     }
     R.mu = 0.0f;
     if (DYN == 1) {
@@ -242,8 +243,14 @@ template <int MODEL, bool BETAET, int NP, int DYN, bool GFULL>
 __device__ __forceinline__ void chunk_finish(const hbvx_desc &d, const ChunkRaw<NP> &R, bool raw, float nz,
                                              float ac, float elev, const float *usta, const float *psta,
                                              const bool *use_dyn, int nf, float invM,
-                                             ChunkDay<MODEL, BETAET, NP> &D, int nd, const int *dslot)
+                                             ChunkDay<MODEL, BETAET, NP> &D, int nd, const int *dslot, bool has4)
 {
+    float gf[HBVX_MAX_FLUX];   // (gradient of the flux series or 0) + the routing adjoint's share, as one sum
+#pragma unroll
+    for (int k = 0; k < HBVX_MAX_FLUX; k++) {
+        gf[k] = R.gf[k];
+        if (k < 4 && has4) gf[k] += R.g4[k];
+    }
     D.s.P = R.f[0]; D.s.Tf = R.f[1]; D.s.PET = R.f[2];
     D.s.SP = R.st[0]; D.s.MW = R.st[1]; D.s.SM = R.st[2]; D.s.SUZ = R.st[3]; D.s.SLZ = R.st[4];
     if (DYN == 1) {
@@ -282,20 +289,20 @@ __device__ __forceinline__ void chunk_finish(const hbvx_desc &d, const ChunkRaw<
 #pragma unroll
     for (int i = NP; i < NPARAM_MAX; i++) D.p[i] = 0.0f;
     D.s.template fwd<SAVE_POW>(D.p, nz, ac, elev, R.sw0, R.ef0);
-    D.gq = R.gf[HBVX_F_QSIM];
+    D.gq = gf[HBVX_F_QSIM];
     const float wq = (DYN == 2 && d.muwts) ? R.mu : invM;
     D.g.gQ = D.gq * wq;
-    D.g.gQ0 = R.gf[HBVX_F_Q0] * invM;
-    D.g.gQ1 = R.gf[HBVX_F_Q1] * invM;
-    D.g.gQ2 = R.gf[HBVX_F_Q2] * invM;
-    D.g.gET = GFULL ? R.gf[HBVX_F_AET] * invM : 0.0f;
-    D.g.gSWE = GFULL ? R.gf[HBVX_F_SWE] * invM : 0.0f;
-    D.g.grech = GFULL ? R.gf[HBVX_F_RECHARGE] * invM : 0.0f;
-    D.g.gexc = GFULL ? R.gf[HBVX_F_EXCS] * invM : 0.0f;
-    D.g.gef = GFULL ? R.gf[HBVX_F_EVAPFACTOR] * invM : 0.0f;
-    D.g.gtosoil = GFULL ? R.gf[HBVX_F_TOSOIL] * invM : 0.0f;
-    D.g.gPERC = GFULL ? R.gf[HBVX_F_PERC] * invM : 0.0f;
-    D.g.gcap = (GFULL && nf > HBVX_F_CAPILLARY) ? R.gf[HBVX_F_CAPILLARY] * invM : 0.0f;
+    D.g.gQ0 = gf[HBVX_F_Q0] * invM;
+    D.g.gQ1 = gf[HBVX_F_Q1] * invM;
+    D.g.gQ2 = gf[HBVX_F_Q2] * invM;
+    D.g.gET = GFULL ? gf[HBVX_F_AET] * invM : 0.0f;
+    D.g.gSWE = GFULL ? gf[HBVX_F_SWE] * invM : 0.0f;
+    D.g.grech = GFULL ? gf[HBVX_F_RECHARGE] * invM : 0.0f;
+    D.g.gexc = GFULL ? gf[HBVX_F_EXCS] * invM : 0.0f;
+    D.g.gef = GFULL ? gf[HBVX_F_EVAPFACTOR] * invM : 0.0f;
+    D.g.gtosoil = GFULL ? gf[HBVX_F_TOSOIL] * invM : 0.0f;
+    D.g.gPERC = GFULL ? gf[HBVX_F_PERC] * invM : 0.0f;
+    D.g.gcap = (GFULL && nf > HBVX_F_CAPILLARY) ? gf[HBVX_F_CAPILLARY] * invM : 0.0f;
 }
 
 template <int NP, int DYN>
@@ -376,8 +383,8 @@ __global__ void __launch_bounds__(64) k_bwd_chunk_phi(const ChunkArgs A)
     constexpr bool LDSDV = DYN == 3;
     __shared__ float dvbuf[LDSDV ? NP * 64 : 1];
     ChunkRaw<NP> Rn;
+    if (LDSDV) chunk_dma_dyn<NP>(d, L, t1 - 1, dvbuf);   // before the day's other loads: see the loop
     chunk_issue<NP, DYN, GFULL, LDSDV>(d, io, L, t1 - 1, io.n_flux, Rn, nd_, ds_);
-    if (LDSDV) chunk_dma_dyn<NP>(d, L, t1 - 1, dvbuf);
     for (int t = t1 - 1; t >= t0; t--) {
         ChunkRaw<NP> Rc = Rn;
         if (LDSDV) {
@@ -385,12 +392,16 @@ __global__ void __launch_bounds__(64) k_bwd_chunk_phi(const ChunkArgs A)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // LDS reads done before the DMA rewrites the rows
         }
         if (t > t0) {
-            chunk_issue<NP, DYN, GFULL, LDSDV>(d, io, L, t - 1, io.n_flux, Rn, nd_, ds_); // next day's loads in flight
+            // The DMA goes first: nothing tells the compiler that next day's LDS reads (chunk_pull_dyn) depend on it, but
+            // they come after the copy Rc = Rn, which waits for the loads issued below -- younger than the DMA, and
+            // vector-memory reads return in order.  (Issued after them, the rows were only very likely to have landed:
+            // a build without that copy read stale rows at config 3's full size, profiles/r04_ab_chunk_pingpong.txt.)
             if (LDSDV) chunk_dma_dyn<NP>(d, L, t - 1, dvbuf);
+            chunk_issue<NP, DYN, GFULL, LDSDV>(d, io, L, t - 1, io.n_flux, Rn, nd_, ds_); // next day's loads in flight
         }
         ChunkDay<MODEL, BETAET, NP> D;
         chunk_finish<MODEL, BETAET, NP, DYN, GFULL>(d, Rc, raw, nz, ac, elev, usta, psta, use_dyn,
-                                                    io.n_flux, invM, D, nd_, ds_);
+                                                    io.n_flux, invM, D, nd_, ds_, io.grad_flux4 != nullptr);
         float gp[NPARAM_MAX], gx[3];
 #pragma unroll
         for (int i = 0; i < NPARAM_MAX; i++) gp[i] = 0.0f;
@@ -532,8 +543,8 @@ __global__ void __launch_bounds__(64) k_bwd_chunk_sweep(const ChunkArgs A)
     constexpr bool LDSDV = DYN == 3;
     __shared__ float dvbuf[LDSDV ? NP * 64 : 1];
     ChunkRaw<NP> Rn;
+    if (LDSDV) chunk_dma_dyn<NP>(d, L, t1 - 1, dvbuf);   // before the day's other loads: see the loop
     chunk_issue<NP, DYN, GFULL, LDSDV>(d, io, L, t1 - 1, io.n_flux, Rn, nd_, ds_);
-    if (LDSDV) chunk_dma_dyn<NP>(d, L, t1 - 1, dvbuf);
     for (int t = t1 - 1; t >= t0; t--) {
         ChunkRaw<NP> Rc = Rn;
         if (LDSDV) {
@@ -541,12 +552,12 @@ __global__ void __launch_bounds__(64) k_bwd_chunk_sweep(const ChunkArgs A)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         if (t > t0) {
+            if (LDSDV) chunk_dma_dyn<NP>(d, L, t - 1, dvbuf);   // first: the copy's wait then covers it (k_bwd_chunk_phi)
             chunk_issue<NP, DYN, GFULL, LDSDV>(d, io, L, t - 1, io.n_flux, Rn, nd_, ds_);
-            if (LDSDV) chunk_dma_dyn<NP>(d, L, t - 1, dvbuf);
         }
         ChunkDay<MODEL, BETAET, NP> D;
         chunk_finish<MODEL, BETAET, NP, DYN, GFULL>(d, Rc, raw, nz, ac, elev, usta, psta, use_dyn,
-                                                    io.n_flux, invM, D, nd_, ds_);
+                                                    io.n_flux, invM, D, nd_, ds_, io.grad_flux4 != nullptr);
         if (DYN == 2 && io.grad_muwts && L.active) io.grad_muwts[((int64_t)t * d.B + L.b) * d.M + L.j] = D.gq * D.s.Q;
         float gp[NPARAM_MAX], gx[3];
 #pragma unroll

@@ -83,6 +83,7 @@ __global__ void __launch_bounds__(64) k_bwd_ckpt(const CkptBwdArgs A)
     struct Raw {
         float f[3], dv[NP];
         float gf[HBVX_MAX_FLUX];   // incoming flux-series gradients (adjoint sweep only)
+        float g4[4];               // the routing adjoint's share, added where it is used (hbv_chunked.h::chunk_issue)
     };
     const int64_t fs = (int64_t)T * d.B;
     auto fetch_grad = [&](int t, Raw &R) {
@@ -90,9 +91,8 @@ __global__ void __launch_bounds__(64) k_bwd_ckpt(const CkptBwdArgs A)
         const int64_t go = (int64_t)tc * d.B + L.b;
 #pragma unroll
         for (int k = 0; k < HBVX_MAX_FLUX; k++) {
-            float v = (io.grad_flux && k < nf) ? io.grad_flux[k * fs + go] : 0.0f;
-            if (io.grad_flux4 && k < 4) v += io.grad_flux4[k * fs + go];
-            R.gf[k] = v;
+            R.gf[k] = (io.grad_flux && k < nf) ? io.grad_flux[k * fs + go] : 0.0f;
+            if (k < 4) R.g4[k] = io.grad_flux4 ? io.grad_flux4[k * fs + go] : 0.0f;
         }
     };
     auto fetch = [&](int t, Raw &R) {
@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(64) k_bwd_ckpt(const CkptBwdArgs A)
             s.template fwd<true>(p, nz, ac, elev, row[5 * 64], row[6 * 64]);
 
             FluxGrad g;
-            auto GF = [&](int k) -> float { return cur.gf[k]; };
+            auto GF = [&](int k) -> float { return (k < 4 && io.grad_flux4) ? cur.gf[k] + cur.g4[k < 4 ? k : 0] : cur.gf[k]; };
             const float gq = GF(HBVX_F_QSIM);
             const float wq = mu ? mu[(int64_t)t * d.mu_t_stride] : invM;
             g.gQ = gq * wq;

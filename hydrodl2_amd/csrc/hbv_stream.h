@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(64) k_bwd_stream(const StreamBwdArgs A)
 #pragma unroll
     for (int k = 0; k < 5; k++) a[k] = io.grad_state_out ? io.grad_state_out[k * N + L.n] : 0.0f;
 
-    float fx[D][3], st[D][5], ax[D][2], gf[D][NG], dv[D][3];
+    float fx[D][3], st[D][5], ax[D][2], gf[D][NG], g4[D][4], dv[D][3];   // g4: added where it is used (GF), see hbv_stream2.h
     auto issue = [&](int t, int j) {
         const unsigned tc = (unsigned)max(t, 0);
         const unsigned so = tc * xts, sr = tc * row4, sg = tc * fB;
@@ -355,10 +355,9 @@ __global__ void __launch_bounds__(64) k_bwd_stream(const StreamBwdArgs A)
         else ax[j][0] = ax[j][1] = 0.0f;
 #pragma unroll
         for (int k = 0; k < NG; k++) {
-            float v = 0.0f;
-            if (GFULL) { if (has_gf) v = bload(rgf, gvo, sg + (unsigned)k * fT); }
-            if (k < 4) { if (has_g4) v += bload(rg4, gvo, sg + (unsigned)k * fT); }
-            gf[j][k] = v;
+            gf[j][k] = 0.0f;
+            if (GFULL) { if (has_gf) gf[j][k] = bload(rgf, gvo, sg + (unsigned)k * fT); }
+            if (k < 4) g4[j][k] = has_g4 ? bload(rg4, gvo, sg + (unsigned)k * fT) : 0.0f;
         }
         if (FEW) {
 #pragma unroll
@@ -380,7 +379,11 @@ __global__ void __launch_bounds__(64) k_bwd_stream(const StreamBwdArgs A)
         }
         s.template fwd<SAVE_POW>(p, nz, ac, elev, ax[j][0], ax[j][1]);
         FluxGrad g;
-        auto GF = [&](int k) -> float { return k < NG ? gf[j][k] * invM : 0.0f; };
+        auto GF = [&](int k) -> float {
+            if (k >= NG) return 0.0f;
+            const float v = (k < 4 && has_g4) ? gf[j][k] + g4[j][k < 4 ? k : 0] : gf[j][k];
+            return v * invM;
+        };
         g.gQ = GF(HBVX_F_QSIM); g.gQ0 = GF(HBVX_F_Q0); g.gQ1 = GF(HBVX_F_Q1); g.gQ2 = GF(HBVX_F_Q2);
         g.gET = GF(HBVX_F_AET); g.gSWE = GF(HBVX_F_SWE); g.grech = GF(HBVX_F_RECHARGE);
         g.gexc = GF(HBVX_F_EXCS); g.gef = GF(HBVX_F_EVAPFACTOR); g.gtosoil = GF(HBVX_F_TOSOIL);

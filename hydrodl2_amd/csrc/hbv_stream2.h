@@ -652,8 +652,12 @@ k_bwd_stream2(const StreamBwdArgs A)
 #pragma unroll
     for (int k = 0; k < 5; k++) a[k] = io.grad_state_out ? io.grad_state_out[k * N + L.n] : 0.0f;
 
+    // gf: the gradient of the flux series (or 0); g4: the routing adjoint's share of the four runoff series, added where
+    // the day uses it (GF below) and only if `add4` -- never where the loads are issued: an add there made the compiler
+    // wait for all of the day's loads on the spot (hbv_chunked.h::chunk_issue, profiles/r04_ab_chunk_prefetch.txt)
     struct In {
-        float fx[3], st[5], ax[2], gf[NG], dv[ND > 0 ? ND : 1];
+        float fx[3], st[5], ax[2], gf[NG], g4[4], dv[ND > 0 ? ND : 1];
+        bool add4;
     };
     auto issue = [&](int t, In &I) {
         const unsigned tc = (unsigned)max(t, 0);
@@ -683,11 +687,11 @@ k_bwd_stream2(const StreamBwdArgs A)
         if (!SAVE_POW) I.ax[0] = I.ax[1] = 0.0f;
 #pragma unroll
         for (int k = 0; k < NG; k++) {
-            float v = 0.0f;
-            if (GFULL) { if (has_gf) v = S2Buf::ld(rgf, gvo, sg + (unsigned)k * fT); }
-            if (k < 4) { if (has_g4) v += S2Buf::ld(rg4, gvo, sg + (unsigned)k * fT); }
-            I.gf[k] = v;
+            I.gf[k] = 0.0f;
+            if (GFULL) { if (has_gf) I.gf[k] = S2Buf::ld(rgf, gvo, sg + (unsigned)k * fT); }
+            if (k < 4) I.g4[k] = has_g4 ? S2Buf::ld(rg4, gvo, sg + (unsigned)k * fT) : 0.0f;
         }
+        I.add4 = has_g4;
 #pragma unroll
         for (int k = 0; k < ND; k++) I.dv[k] = S2Buf::ld(S2Buf::rsrc(dbase[k] + tc * dts[k]), dvo[k], 0);
     };
@@ -708,7 +712,11 @@ k_bwd_stream2(const StreamBwdArgs A)
         }
         s.template fwd<SAVE_POW>(p, nz, ac, elev, I.ax[0], I.ax[1]);
         FluxGrad g;
-        auto GF = [&](int k) -> float { return k < NG ? I.gf[k] * invM : 0.0f; };
+        auto GF = [&](int k) -> float {
+            if (k >= NG) return 0.0f;
+            const float v = (k < 4 && I.add4) ? I.gf[k] + I.g4[k < 4 ? k : 0] : I.gf[k];
+            return v * invM;
+        };
         g.gQ = GF(HBVX_F_QSIM); g.gQ0 = GF(HBVX_F_Q0); g.gQ1 = GF(HBVX_F_Q1); g.gQ2 = GF(HBVX_F_Q2);
         g.gET = GF(HBVX_F_AET); g.gSWE = GF(HBVX_F_SWE); g.grech = GF(HBVX_F_RECHARGE);
         g.gexc = GF(HBVX_F_EXCS); g.gef = GF(HBVX_F_EVAPFACTOR); g.gtosoil = GF(HBVX_F_TOSOIL);
@@ -818,7 +826,9 @@ k_bwd_stream2(const StreamBwdArgs A)
                     v = l_gf[k][ln];
                 }
                 I.gf[k] = v;
+                if (k < 4) I.g4[k] = 0.0f;
             }
+            I.add4 = false;   // (this form has already summed the two sources above)
 #pragma unroll
             for (int k = 0; k < ND; k++) I.dv[k] = l_dv[k][ln];
         };
