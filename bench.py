@@ -156,22 +156,28 @@ WORKLOADS = {
 # recurrence: "bound": "hbm"); `limited_by` says what the counters / probes show instead of pretending the HBM
 # fraction is the lever: hbm | valu-issue | latency | host.
 LIMITED_BY = {
-    "cfg2": ("latency", "forward: 168 workgroups x 7 300 serial days, the soil wave's dependent chain and one barrier per "
-                        "8-day tile (tools/pipe_probe.py, DESIGN.md §0); adjoint kernels VALU-issue bound",
-             {"k_bwd_chunk_phi": 1.0, "k_bwd_chunk_sweep": 0.92, "k_fwd_pipe": 0.39}, "profiles/r04_sq_counters_cfg2.txt"),
+    # name: (what limits it, evidence, vector instructions per SIMD and cycle of its kernels -- SQ_INSTS_VALU / SIMD-cycles
+    # from the committed counter passes; a pure fma loop at four waves per SIMD reaches 0.70 -- , evidence file)
+    "cfg2": ("latency", "forward: 168 workgroups x 7 300 serial days, the stepper waves' own ~205 cycles per day + the tile "
+                        "barrier + contention for the workgroup's LDS pipeline (profiles/r04_pipe_helpers_probe.txt); adjoint "
+                        "kernels: 4-5 waves per SIMD, each issuing one instruction per ~6-8 cycles, beside the 3.8 GB gradient "
+                        "fill (5.4 TB/s in that window)",
+             {"k_bwd_chunk_phi": 0.32, "k_bwd_chunk_sweep": 0.32, "k_fwd_pipe": 0.11}, "profiles/r04_sq_counters_cfg2.txt"),
     "cfg2dyn": ("latency", "as cfg2; the soil wave carries two dynamic powers", {}, "profiles/r04_sq_counters_cfg2.txt"),
-    "cfg3": ("hbm", "14 dynamic rows streamed twice by the two-pass adjoint at 4.3 TB/s per kernel (69 % of the 6.3 TB/s "
-                    "this chip copies at); forward balanced between fillers / reducers / drainers",
-             {"k_bwd_chunk_phi": 0.76, "k_bwd_chunk_sweep": 0.71, "k_fwd_pipe": 0.48}, "profiles/r04_sq_counters_cfg3.txt"),
+    "cfg3": ("hbm", "14 dynamic rows streamed twice by the two-pass adjoint: 17.3 GB in 3.6 ms = 4.8 TB/s (76 % of the "
+                    "6.3 TB/s this chip copies at); forward bound by its filler waves",
+             {"k_bwd_chunk_phi": 0.20, "k_bwd_chunk_sweep": 0.17, "k_fwd_pipe": 0.12}, "profiles/r04_sq_counters_cfg3.txt"),
     "cfg4": ("latency", "the soil-moisture wave's Newton iteration: a lone wave on its SIMD, ~8 cycles per instruction, two "
                         "residual evaluations and one update on 46 % of the wave-days, three and two on the rest "
                         "(profiles/r04_ab_soil.txt)", {}, "profiles/r04_ab_soil.txt"),
     "cfg4joint": ("latency", "one wave per 64 lanes iterating the reference's joint 5-variable Newton", {}, "DESIGN.md §4"),
-    "cfg5share": ("valu-issue", "streaming adjoint ~345 VALU per wave-day at 4 waves per SIMD",
-                  {"k_bwd_stream2": 0.86, "k_fwd_stream2": 0.53}, "profiles/r04_sq_counters_cfg5.txt"),
-    "cfg5full": ("valu-issue", "as cfg5share, 25 000 waves", {"k_bwd_stream2": 0.86, "k_fwd_stream2": 0.53},
+    "cfg5share": ("hbm", "design bytes (20 B trajectory + 12 B dynamic rows per lane-day, both ways) at 4.4-4.5 TB/s measured "
+                         "by the counters; the vector pipes are a third busy",
+                  {"k_bwd_stream2": 0.20, "k_fwd_stream2": 0.13}, "profiles/r04_sq_counters_cfg5.txt"),
+    "cfg5full": ("hbm", "as cfg5share at 25 000 waves: forward 5.4 TB/s, adjoint 4.7 TB/s of design bytes (86 / 75 % of the "
+                        "6.3 TB/s this chip copies at)", {"k_bwd_stream2": 0.20, "k_fwd_stream2": 0.13},
                  "profiles/r04_sq_counters_cfg5.txt"),
-    "cfg5": ("valu-issue", "as cfg5share", {"k_bwd_stream2": 0.86, "k_fwd_stream2": 0.53}, "profiles/r04_sq_counters_cfg5.txt"),
+    "cfg5": ("hbm", "as cfg5share", {"k_bwd_stream2": 0.20, "k_fwd_stream2": 0.13}, "profiles/r04_sq_counters_cfg5.txt"),
     "dmg": ("host", "kernels sum to less than the enqueue time of the step's launches (tools/host_overhead.py)", {},
             "profiles/r04_host_overhead.txt"),
     "dmggraph": ("latency", "two graph launches per step; what is left is the kernels' own time and the gaps between "
@@ -188,7 +194,7 @@ def limited_by(name):
     lb, why, busy, src = LIMITED_BY[name]
     out = {"limited_by": lb, "evidence": why, "evidence_file": src}
     if busy:
-        out["valu_busy"] = busy
+        out["valu_per_simd_cycle"] = busy
     return out
 
 

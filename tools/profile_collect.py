@@ -47,8 +47,11 @@ def counter_table(path):
 
 def sq_counters(tag, out):
     """Per-kernel means of the SQ counter passes (tools/diag_pmc.sh <tag>_<cfg>) and the derived figures
-    DESIGN.md quotes: VALU instructions per wave-day and VALU busy = SQ_ACTIVE_INST_VALU x 4 cycles /
-    (SIMDs the kernel can use) / (GRBM_GUI_ACTIVE / 8 XCDs)."""
+    DESIGN.md quotes: vector instructions per SIMD and cycle = SQ_INSTS_VALU / (SIMDs the kernel can use) /
+    (GRBM_GUI_ACTIVE / 8 XCDs).  (Until round 4 this printed "VALU busy" = SQ_ACTIVE_INST_VALU x 4 cycles / SIMD-cycles,
+    on the assumption that a wave64 instruction holds the pipe four cycles; after the prefetch fix that came out at
+    128 % for the transfer-map kernel, and round 3's micro-benchmark had already read 0.70 fma per SIMD and cycle at
+    four waves per SIMD: the assumption was wrong, the old percentages are relative figures only.)"""
     for cfg in ("cfg2", "cfg3", "cfg5"):
         acc = defaultdict(lambda: defaultdict(list))
         dur = defaultdict(list)
@@ -74,12 +77,13 @@ def sq_counters(tag, out):
                 f.write(f"{k}  (median {d:.3f} ms under the profiler)\n")
                 for c in sorted(m):
                     f.write(f"     {c:32s} {m[c] / 1e6:12.3f} M\n")
-                if "GRBM_GUI_ACTIVE" in m and "SQ_ACTIVE_INST_VALU" in m:
+                if "GRBM_GUI_ACTIVE" in m and "SQ_INSTS_VALU" in m:
                     gs, ws = grids.get(k, (0, 0))
                     wgs = gs // ws if ws else 0
                     cus = min(256, wgs) if wgs else 256          # one workgroup per CU at most when the grid is small
-                    busy = m["SQ_ACTIVE_INST_VALU"] * 4 / (cus * 4) / (m["GRBM_GUI_ACTIVE"] / 8)
-                    f.write(f"     -> VALU busy {100 * busy:.0f} % of the cycles of the {cus} CUs the grid covers\n")
+                    rate = m["SQ_INSTS_VALU"] / (cus * 4) / (m["GRBM_GUI_ACTIVE"] / 8)
+                    f.write(f"     -> {rate:.2f} vector instructions per SIMD and cycle on the {cus} CUs the grid covers "
+                            f"(a pure fma loop at four waves per SIMD: 0.70, profiles/r03_issue_rate.txt)\n")
 
 
 def main(tag):
