@@ -81,3 +81,25 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def disassemble(lib: str, symbol_substrings: list[str]) -> dict[str, list[str]]:
+    """Instruction mnemonics + operands of the kernels whose mangled name contains one of the substrings:
+    {symbol: ["v_add_f32 ...", ...]} from llvm-objdump of the library's gfx950 code objects."""
+    out: dict[str, list[str]] = {}
+    with tempfile.TemporaryDirectory() as td:
+        for co in code_objects(lib, td):
+            syms = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "-s", "-W", co], capture_output=True, text=True,
+                                  check=True).stdout
+            want = sorted({ln.split()[-1] for ln in syms.splitlines()
+                           if " FUNC " in ln and any(s in ln.split()[-1] for s in symbol_substrings)})
+            for sym in want:
+                txt = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", f"--disassemble-symbols={sym}", co],
+                                     capture_output=True, text=True, check=True).stdout
+                ins = []
+                for ln in txt.splitlines():
+                    m = re.match(r"^\s+([a-z_0-9]+(?:\s+[^/]*)?)\s*//", ln)
+                    if m:
+                        ins.append(" ".join(m.group(1).split()))
+                out[sym] = ins
+    return out
