@@ -320,7 +320,7 @@ constexpr bool SAVE_POW = HBVX_SAVE_POW != 0;
 // reference does (thresholds branch on those roundings, and the adjoint's recomputation of the forward must land on the
 // same side of every one of them).  The adjoint's OWN arithmetic -- products of weights and incoming adjoints, the
 // gradient sums, the chunk transfer maps -- decides no branch and is compared at rtol 1e-3: there a multiply-add is one
-// fused instruction (a quarter fewer vector instructions in kernels that sit at the VALU issue peak; the fused form
+// fused instruction (a quarter fewer vector instructions in kernels whose waves are bound by their own issue rate; the fused form
 // rounds once instead of twice, i.e. it is the more accurate of the two).  Clang scopes the pragma to the function
 // body it opens; inlined callees keep their own setting.  g++ (the host build of this header) ignores it.
 #ifndef HBVX_ADJ_FMA_OFF

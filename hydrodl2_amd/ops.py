@@ -204,7 +204,7 @@ def _early_grad_buffers(lib, cfg: "StepConfig", ptensors, needs) -> Optional[tup
     return bufs, done
 
 
-# Default: the fill runs BESIDE the adjoint.  The adjoint kernels are bound by VALU issue, the
+# Default: the fill runs BESIDE the adjoint.  The adjoint kernels are bound by instruction issue, the
 # fill by HBM bandwidth, and the only thing that ties them is the static row: static-parameter and routing
 # gradients accumulate into the LAST row of the [T,B,ny] gradient.  So those go to a separate [B,ny] row
 # (the C ABI takes any pointer + stride for them), the big buffer is filled on a second HIP stream while

@@ -6,7 +6,9 @@
 
 For every kernel: each innermost-to-outermost loop body (label .. backward branch) with its
 counts of VALU / transcendental / SALU / VMEM / LDS / lane-spill instructions.  The time loops of
-the steppers are issue-bound, so "VALU per day" is the figure of merit."""
+the steppers are issue-bound (a wave issues one instruction every ~6-8 cycles whatever it is), so instructions and
+s_waitcnt per day are the figures of merit (a vmcnt wait right behind a burst of loads means the
+prefetch does not fly, profiles/r04_ab_chunk_prefetch.txt)."""
 from __future__ import annotations
 
 import re

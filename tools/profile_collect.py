@@ -9,7 +9,7 @@
     profiles/<tag>_bench.json            the bench line of the profiled run
     profiles/<tag>_lstm_kernel_stats.csv, <tag>_lstm.json   tools/bench_lstm.py (sequence LSTM beside torch's)
     profiles/<tag>_dpl_kernel_stats.csv, <tag>_dpl.json     examples/train_dpl.py --lstm fused
-    profiles/<tag>_sq_counters_cfg{2,3,5}.txt   per-kernel SQ counter means (tools/diag_pmc.sh) + derived VALU busy
+    profiles/<tag>_sq_counters_cfg{2,3,5}.txt   per-kernel SQ counter means (tools/diag_pmc.sh) + vector instructions per SIMD and cycle
     profiles/pmc_traffic.json            HBM bytes per ABI call (read by bench.py for roofline.traffic)
 """
 import csv
