@@ -408,7 +408,9 @@ __global__ void k_uh_gamma(const hbvx_route_desc r, float *__restrict__ uh)
 // Routing kernels: thread = (basin, chunk of ROUTE_CHUNK days); the 64 lanes of a wave are 64
 // consecutive basins (256-byte coalesced accesses), the 15-tap window slides through registers,
 // so every input element is read once (plus a 14-day halo per chunk).
+#ifndef ROUTE_CHUNK
 #define ROUTE_CHUNK 32
+#endif
 
 __device__ __forceinline__ void load_uh(const float *__restrict__ uh, int b, int L, float *w)
 {
@@ -419,7 +421,9 @@ __device__ __forceinline__ void load_uh(const float *__restrict__ uh, int b, int
 // uh_conv (uh_routing.py:25-57): y[s,t,b] = sum_k UH[b,k] * q[s,t-k,b], zero history.
 // grid.z = series; the chunk is consumed in groups of ROUTE_GROUP days whose loads are all issued
 // before the first is used (a thread would otherwise have one load in flight at a time).
+#ifndef ROUTE_GROUP
 #define ROUTE_GROUP 8
+#endif
 __global__ void __launch_bounds__(256) k_route_fwd(int T, int B, int S, int L,
                                                    const float *__restrict__ q,
                                                    const float *__restrict__ uh,

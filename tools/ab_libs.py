@@ -15,6 +15,6 @@ for rnd in range(3):
     for l in libs:
         shutil.copy(os.path.join(csrc,l), os.path.join(csrc,'libhbvx.so'))
         outs=[o for o in subprocess.run([sys.executable, os.path.join(root,'tools','bench_configs.py')]+cfgs,capture_output=True,text=True).stdout.strip().split('\n') if o.startswith('{')]
-        res[l].append([(json.loads(o)['config'], json.loads(o)['ms_per_step']) + tuple(v for k, v in json.loads(o)['kernel_ms'].items() if k.endswith(('forward', 'backward')) and 'route' not in k) for o in outs])
+        res[l].append([(json.loads(o)['config'], json.loads(o)['ms_per_step']) + tuple(v for k, v in json.loads(o)['kernel_ms'].items() if k.endswith(('forward', 'backward')) and 'route' not in k) + ((json.loads(o)['kernel_ms'],) if os.environ.get('AB_ALL') else ()) for o in outs])
 shutil.copy(os.path.join(csrc,'libhbvx_base.so'), os.path.join(csrc,'libhbvx.so'))
 for l,v in res.items(): print(l, v)
