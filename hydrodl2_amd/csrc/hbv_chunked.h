@@ -463,33 +463,41 @@ __global__ void __launch_bounds__(64) k_bwd_chunk_scan(const ChunkArgs A)
     float a[5];
 #pragma unroll
     for (int k = 0; k < 5; k++) a[k] = A.io.grad_state_out ? A.io.grad_state_out[k * N + n] : 0.0f;
-    // register ring: the maps of the next chunk are loaded while this one is applied
-    float cur[30], nxt[30];
-    {
-        const float *src = A.phi + ((int64_t)(A.nchunk - 1) * 30) * N + n;
+    // Register ring, SCAN_DEPTH chunks deep: a lane's hop across a chunk is 30 multiply-adds behind 30 loads, and with
+    // one chunk in flight every hop waited a memory round trip (T / C = 115 of them at config 2: 0.1-0.2 ms of a 1.3 ms
+    // adjoint call for 168 waves).  The loop is unrolled by the depth so that every buffer is a fixed set of registers.
+    constexpr int SCAN_DEPTH = 4;
+    float buf[SCAN_DEPTH][30];
+    auto fetch = [&](int c, float *dst) __attribute__((always_inline)) {
+        const float *src = A.phi + ((int64_t)c * 30) * N + n;
 #pragma unroll
-        for (int i = 0; i < 30; i++) nxt[i] = src[(int64_t)i * N];
-    }
-    for (int c = A.nchunk - 1; c >= 0; c--) {
+        for (int i = 0; i < 30; i++) dst[i] = src[(int64_t)i * N];
+    };
 #pragma unroll
-        for (int i = 0; i < 30; i++) cur[i] = nxt[i];
-        if (c > 0) {
-            const float *src = A.phi + ((int64_t)(c - 1) * 30) * N + n;
+    for (int j = 0; j < SCAN_DEPTH; j++)
+        if (A.nchunk - 1 - j >= 0) fetch(A.nchunk - 1 - j, buf[j]);
+    for (int c0 = A.nchunk - 1; c0 >= 0; c0 -= SCAN_DEPTH) {
 #pragma unroll
-            for (int i = 0; i < 30; i++) nxt[i] = src[(int64_t)i * N];
+        for (int j = 0; j < SCAN_DEPTH; j++) {
+            const int c = c0 - j;
+            if (c < 0) break;
+            float cur[30];
+#pragma unroll
+            for (int i = 0; i < 30; i++) cur[i] = buf[j][i];
+            if (c - SCAN_DEPTH >= 0) fetch(c - SCAN_DEPTH, buf[j]);   // its registers are free again
+#pragma unroll
+            for (int k = 0; k < 5; k++) A.abnd[((int64_t)c * 5 + k) * N + n] = a[k];
+            float an[5];
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                float v = cur[25 + i];
+#pragma unroll
+                for (int k = 0; k < 5; k++) v += a[k] * cur[k * 5 + i];
+                an[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < 5; i++) a[i] = an[i];
         }
-#pragma unroll
-        for (int k = 0; k < 5; k++) A.abnd[((int64_t)c * 5 + k) * N + n] = a[k];
-        float an[5];
-#pragma unroll
-        for (int i = 0; i < 5; i++) {
-            float v = cur[25 + i];
-#pragma unroll
-            for (int k = 0; k < 5; k++) v += a[k] * cur[k * 5 + i];
-            an[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < 5; i++) a[i] = an[i];
     }
     if (A.io.grad_state_in) {
 #pragma unroll
