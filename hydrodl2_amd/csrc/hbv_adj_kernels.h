@@ -380,7 +380,8 @@ __global__ void __launch_bounds__(64) k_adj_chunk_sweep(const hbvx_desc d, const
 #pragma unroll
     for (int k = 0; k < 5; k++) a[k] = abnd[((int64_t)chunk * 5 + k) * N + L.n];
     // (no one-day-ahead prefetch here: its nine registers take this kernel from 165 to 171 VGPRs, i.e. from three waves
-    // per SIMD to two -- measured 3.53 instead of 3.15 ms for the adjoint of config 4)
+    // per SIMD to two -- measured 3.53 instead of 3.15 ms for the adjoint of config 4; round 4, slot-list instance, where
+    // the nine fit three waves (154 -> 163): still slower, 2.34 -> 2.51 ms)
     for (int t = t1 - 1; t >= t0; t--) {
         AdjRaw Rc;
         adj_issue(d, io, L, t, N, Rc);
