@@ -44,7 +44,9 @@
 
 namespace hbvx {
 
+#ifndef PIPE_KT
 #define PIPE_KT 8       // days per tile with at most PIPE_FEWDYN dynamic parameters (host and device)
+#endif
 #define PIPE_KT_MANY 4  // ... with more: the staged parameter rows need the LDS
 #define PIPE_FEWDYN 3   // rows staged one per filler wave
 #define PIPE_MAXDYN 18  // rows staged at most (shared by the three or four filler waves)
