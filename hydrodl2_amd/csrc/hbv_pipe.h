@@ -47,6 +47,10 @@ namespace hbvx {
 #ifndef PIPE_KT
 #define PIPE_KT 8       // days per tile with at most PIPE_FEWDYN dynamic parameters (host and device)
 #endif
+#ifndef PIPE_KT_STATIC
+#define PIPE_KT_STATIC 10  // ... without any: no staged parameter rows in LDS, so longer tiles fit (140-145 KB of the 160) and
+#endif                     // the workgroup's barrier comes every ten days: forward 0.98 -> 0.91 ms at config 2, six rounds each
+                           // (profiles/r04_pipe_helpers_probe.txt; eleven days no longer fit)
 #define PIPE_KT_MANY 4  // ... with more: the staged parameter rows need the LDS
 #define PIPE_FEWDYN 3   // rows staged one per filler wave
 #define PIPE_MAXDYN 18  // rows staged at most (shared by the three or four filler waves)
@@ -163,7 +167,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
     constexpr bool ADJ = MODEL == MODEL_HBVADJ;
     constexpr bool PIPE_NO_UNROLL = ADJ;   // a day of the implicit scheme is an iteration, not 70 straight-line instructions
     constexpr bool CAP = MODEL != MODEL_HBV10 && !ADJ;   // two-stage pipeline (see the header comment)
-    constexpr int KT = MANY ? PIPE_KT_MANY : PIPE_KT;
+    constexpr int KT = MANY ? PIPE_KT_MANY : (DYN ? PIPE_KT : PIPE_KT_STATIC);
     constexpr int OBR = CAP ? 8 : 7, NFB = CAP ? 5 : 4;
 #ifdef PIPE_PROBE
     unsigned long long probe_busy = 0, probe_wait = 0, probe_t = __builtin_readcyclecounter();

@@ -22,7 +22,7 @@ bool hbvx_host::try_fwd_pipe(const hbvx_desc *d, const hbvx_fwd_out *out, void *
         const char *fv = getenv("HBVX_FWD");
         const int nd = count_dyn(d);
         const bool many = nd > PIPE_FEWDYN;          // 4-day tiles, several staged rows per filler wave
-        const int Kt = many ? PIPE_KT_MANY : PIPE_KT;
+        const int Kt = many ? PIPE_KT_MANY : (nd > 0 ? PIPE_KT : PIPE_KT_STATIC);
         const bool adj = d->model == HBVX_MODEL_HBVADJ;   // implicit scheme, staged solve (hbvx_adj_forward only)
         const bool cap = d->model != HBVX_MODEL_HBV10 && !adj;
         const int nfl = adj ? 1 : (cap ? 12 : 11);
