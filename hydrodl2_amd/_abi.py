@@ -156,6 +156,8 @@ class Library:
         d.hbvx_ckpt_workspace_bytes.argtypes = [C.POINTER(Desc), C.c_int32]
         d.hbvx_preferred_traj_layout.restype = C.c_int
         d.hbvx_preferred_traj_layout.argtypes = [C.POINTER(Desc)]
+        d.hbvx_last_dispatch.restype = C.c_char_p
+        d.hbvx_last_dispatch.argtypes = [C.c_int]
         d.hbvx_zero.restype = C.c_int
         d.hbvx_zero.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
         d.hbvx_zero_except.restype = C.c_int
@@ -197,6 +199,10 @@ class Library:
     def backward(self, desc: Desc, io: BwdIO, stream: int):
         self._check(self.dll.hbvx_backward(C.byref(desc), C.byref(io), C.c_void_p(stream)),
                     "hbvx_backward")
+
+    def last_dispatch(self, direction: int) -> str:
+        """Kernel family of the last forward (0) / adjoint (1) call (diagnostic, include/hbvx.h)."""
+        return self.dll.hbvx_last_dispatch(direction).decode()
 
     def preferred_traj_layout(self, desc: Desc) -> int:
         return int(self.dll.hbvx_preferred_traj_layout(C.byref(desc)))

@@ -388,14 +388,16 @@ __global__ void __launch_bounds__(64) k_bwd_chunk_phi(const ChunkArgs A)
     for (int t = t1 - 1; t >= t0; t--) {
         ChunkRaw<NP> Rc = Rn;
         if (LDSDV) {
+            // EXPLICIT order, DMA -> LDS read: every vector-memory operation in flight here belongs to day t (its rows'
+            // DMA and the loads of chunk_issue behind it), all of it is consumed below, so waiting for all of it costs
+            // nothing -- and no longer rests on where the compiler happens to wait for the copy above (round 4: a build
+            // without that copy read stale rows at config 3's full size).  tests/test_code_object.py checks the ISA.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             chunk_pull_dyn<NP>(Rc, dvbuf);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // LDS reads done before the DMA rewrites the rows
         }
         if (t > t0) {
-            // The DMA goes first: nothing tells the compiler that next day's LDS reads (chunk_pull_dyn) depend on it, but
-            // they come after the copy Rc = Rn, which waits for the loads issued below -- younger than the DMA, and
-            // vector-memory reads return in order.  (Issued after them, the rows were only very likely to have landed:
-            // a build without that copy read stale rows at config 3's full size, profiles/r04_ab_chunk_pingpong.txt.)
+            // The DMA goes first (oldest of next day's vector-memory operations); next day's vmcnt(0) above covers it.
             if (LDSDV) chunk_dma_dyn<NP>(d, L, t - 1, dvbuf);
             chunk_issue<NP, DYN, GFULL, LDSDV>(d, io, L, t - 1, io.n_flux, Rn, nd_, ds_); // next day's loads in flight
         }
@@ -556,11 +558,12 @@ __global__ void __launch_bounds__(64) k_bwd_chunk_sweep(const ChunkArgs A)
     for (int t = t1 - 1; t >= t0; t--) {
         ChunkRaw<NP> Rc = Rn;
         if (LDSDV) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the rows' DMA has landed (k_bwd_chunk_phi)
             chunk_pull_dyn<NP>(Rc, dvbuf);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         if (t > t0) {
-            if (LDSDV) chunk_dma_dyn<NP>(d, L, t - 1, dvbuf);   // first: the copy's wait then covers it (k_bwd_chunk_phi)
+            if (LDSDV) chunk_dma_dyn<NP>(d, L, t - 1, dvbuf);
             chunk_issue<NP, DYN, GFULL, LDSDV>(d, io, L, t - 1, io.n_flux, Rn, nd_, ds_);
         }
         ChunkDay<MODEL, BETAET, NP> D;

@@ -31,6 +31,24 @@ int hbvx_host::hip_fail(hipError_t e, const char *what)
     return HBVX_E_DEVICE;
 }
 
+// which kernel family took the last forward / adjoint call of the process (diagnostic: the tests assert that the
+// family they mean to check is the one that ran).  The adjoint runs on autograd's thread, the asking test on the
+// main one: process-wide under a mutex, handed out through a per-thread copy.
+static std::mutex g_disp_mu;
+static char g_disp[2][48] = {"", ""};
+void hbvx_host::note_dispatch(int dir, const char *family)
+{
+    std::lock_guard<std::mutex> lock(g_disp_mu);
+    snprintf(g_disp[dir & 1], sizeof g_disp[0], "%s", family);
+}
+extern "C" const char *hbvx_last_dispatch(int direction)
+{
+    static thread_local char out[48];
+    std::lock_guard<std::mutex> lock(g_disp_mu);
+    snprintf(out, sizeof out, "%s", g_disp[direction & 1]);
+    return out;
+}
+
 extern "C" int hbvx_version(void) { return HBVX_ABI_VERSION; }
 extern "C" const char *hbvx_last_error(void) { return g_err; }
 extern "C" const char *hbvx_backend(void) { return hbvx::SAVE_POW ? "hip:gfx950+savepow" : "hip:gfx950"; }
@@ -605,6 +623,23 @@ int hbvx_host::check_desc(const hbvx_desc *d)
         return fail(HBVX_E_NULL, "HBV 2.0 needs ac and elev");
     for (int i = 0; i < d->n_param; i++)
         if (!d->p[i].sta) return fail(HBVX_E_NULL, "static parameter pointer is NULL");
+    // Bounds come from the caller (a model's parameter_bounds table may be edited).  Two short forms of the forward
+    // equal the reference only inside the reference's own tables (hbv.py:88-101, hbv_2_hourly.py:97-119) and are
+    // refused outside them instead of silently computing something else (hbv_step.h):
+    //  * the evaporation factor is taken from the storage BEFORE the excess leaves it (fwd_soil, CHAIN): equal to
+    //    hbv.py:474-477 iff LP <= 1 (with LP > 1 an excess day gives (1 / LP)**BETAET < 1 there, 1 here);
+    //  * the powers run on 2^(y log2 x) without a lower clamp of the base (pow_unit_): x = 0 needs y > 0
+    //    (0 * -inf is NaN where torch's 0**0 is 1), i.e. positive lower bounds of BETA, BETAET, ALPHA.
+    if (d->model != HBVX_MODEL_HBVADJ) {
+        if (!(d->p[P_LP].hi <= 1.0f && d->p[P_LP].lo <= 1.0f))
+            return fail(HBVX_E_UNSUPPORTED, "parLP bounds above 1 are not supported (evaporation factor on an excess day, hbv.py:474-477)");
+        if (!(d->p[P_BETA].lo > 0.0f && d->p[P_BETA].hi > 0.0f))
+            return fail(HBVX_E_UNSUPPORTED, "parBETA bounds must be positive (soil wetness power, hbv.py:462)");
+        if (d->n_param > P_BETAET && !(d->p[P_BETAET].lo > 0.0f && d->p[P_BETAET].hi > 0.0f))
+            return fail(HBVX_E_UNSUPPORTED, "parBETAET bounds must be positive (evaporation factor power, hbv.py:476)");
+        if (d->model == HBVX_MODEL_HOURLY && !(d->p[P_ALPHA].lo > 0.0f && d->p[P_ALPHA].hi > 0.0f))
+            return fail(HBVX_E_UNSUPPORTED, "parALPHA bounds must be positive (infiltration power, hbv_2_hourly.py:590-600)");
+    }
     return HBVX_OK;
 }
 
@@ -697,6 +732,7 @@ extern "C" int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *s
             ca.o = *out;
             ca.lgMp = lg_members(d->M);
             const int bpw_c = 64 >> ca.lgMp;
+            note_dispatch(0, "simple");
             hipError_t ec = launch_variant(d, ca, dim3((d->B + bpw_c - 1) / bpw_c), (hipStream_t)stream,
                                            k_fwd<MODEL_HBV10, false>, k_fwd<MODEL_HBV10, true>,
                                            k_fwd<MODEL_HBV11P, true>, k_fwd<MODEL_HBV20, true>, k_fwd<MODEL_HOURLY, true>);
@@ -719,6 +755,7 @@ extern "C" int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *s
     a.lgMp = lg_members(d->M);
     const int bpw = 64 >> a.lgMp;
     dim3 grid((d->B + bpw - 1) / bpw);
+    note_dispatch(0, "simple");
     hipError_t e = launch_variant(d, a, grid, (hipStream_t)stream,
                                   k_fwd<MODEL_HBV10, false>, k_fwd<MODEL_HBV10, true>,
                                   k_fwd<MODEL_HBV11P, true>, k_fwd<MODEL_HBV20, true>, k_fwd<MODEL_HOURLY, true>);
@@ -755,6 +792,7 @@ extern "C" int hbvx_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *st
     const int bpw = 64 >> a.lgMp;
     dim3 grid((d->B + bpw - 1) / bpw);
     store_gate(io, (hipStream_t)stream);
+    note_dispatch(1, "simple");
     hipError_t e = launch_variant(d, a, grid, (hipStream_t)stream,
                                   k_bwd<MODEL_HBV10, false>, k_bwd<MODEL_HBV10, true>,
                                   k_bwd<MODEL_HBV11P, true>, k_bwd<MODEL_HBV20, true>, k_bwd<MODEL_HOURLY, true>);

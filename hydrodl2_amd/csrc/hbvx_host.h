@@ -22,6 +22,8 @@ namespace hbvx_host {
 
 int fail(int code, const char *msg);
 int hip_fail(hipError_t e, const char *what);
+// hbvx_last_dispatch (include/hbvx.h): the kernel family that took the call; dir 0 forward, 1 adjoint
+void note_dispatch(int dir, const char *family);
 int env_int(const char *name, int dflt);
 int lg_members(int M);
 int count_dyn(const hbvx_desc *d);

@@ -142,6 +142,7 @@ bool hbvx_host::try_bwd_chunked(const hbvx_desc *d, const hbvx_bwd_io *io, void 
 {
     if (io->workspace && chunked_applicable(d) && io->workspace_bytes >= hbvx_backward_workspace_bytes(d)) {
         hipError_t e = launch_chunked(d, io, (hipStream_t)stream);
+        note_dispatch(1, "chunked");
         *rc = e != hipSuccess ? hip_fail(e, "hbvx_backward (chunked) launch") : HBVX_OK;
         return true;
     }

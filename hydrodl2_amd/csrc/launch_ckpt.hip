@@ -166,6 +166,11 @@ bool hbvx_host::try_bwd_ckpt(const hbvx_desc *d, const hbvx_bwd_io *io, void *st
             }
             flip ^= 1;
         }
+        {   // the blocks' own adjoint family (the last inner call left it) behind the block driver's name
+            char both[48];
+            snprintf(both, sizeof both, "ckpt-block:%s", hbvx_last_dispatch(1));
+            note_dispatch(1, both);
+        }
         *rc = HBVX_OK;
         return true;
     }
@@ -188,6 +193,7 @@ bool hbvx_host::try_bwd_ckpt(const hbvx_desc *d, const hbvx_bwd_io *io, void *st
     else if (m == HBVX_MODEL_HOURLY) hipLaunchKernelGGL((k_bwd_ckpt<MODEL_HOURLY, true>), grid, dim3(64), lds, st, a);
     else hipLaunchKernelGGL((k_bwd_ckpt<MODEL_HBV20, true>), grid, dim3(64), lds, st, a);
     hipError_t e = hipGetLastError();
+    note_dispatch(1, "ckpt-lds");
     *rc = e != hipSuccess ? hip_fail(e, "hbvx_backward (checkpoints) launch") : HBVX_OK;
     return true;
 }

@@ -101,6 +101,7 @@ bool hbvx_host::try_fwd_pipe(const hbvx_desc *d, const hbvx_fwd_out *out, void *
 #undef PIPE_GO4
 #undef PIPE_GO3
 #undef PIPE_GO
+            note_dispatch(0, "pipe");
             *rc = e != hipSuccess ? hip_fail(e, "hbvx_forward (pipelined) launch") : HBVX_OK;
             return true;
         }

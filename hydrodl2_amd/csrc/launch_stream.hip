@@ -217,6 +217,7 @@ bool hbvx_host::try_fwd_stream(const hbvx_desc *d, const hbvx_fwd_out *out, void
 #undef STREAM_GO
     }
     hipError_t e = hipGetLastError();
+    note_dispatch(0, P.sc >= 0 ? "stream2" : "stream");
     *rc = e != hipSuccess ? hip_fail(e, "hbvx_forward (stream) launch") : HBVX_OK;
     return true;
 }
@@ -271,6 +272,7 @@ bool hbvx_host::try_bwd_stream(const hbvx_desc *d, const hbvx_bwd_io *io, void *
 #undef STREAM_GO
     }
     hipError_t e = hipGetLastError();
+    note_dispatch(1, P.sc >= 0 ? "stream2" : "stream");
     *rc = e != hipSuccess ? hip_fail(e, "hbvx_backward (stream) launch") : HBVX_OK;
     return true;
 }

@@ -104,6 +104,7 @@ bool hbvx_host::try_fwd_tiled(const hbvx_desc *d, const hbvx_fwd_out *out, void 
             constexpr bool LIMIT256 = false;
             hipError_t e = dyn ? LAUNCH_TILED_V(k_fwd_tiled, d, ta, grid_t, lds, (hipStream_t)stream, true)
                                : LAUNCH_TILED_V(k_fwd_tiled, d, ta, grid_t, lds, (hipStream_t)stream, false);
+            note_dispatch(0, "tiled");
             *rc = e != hipSuccess ? hip_fail(e, "hbvx_forward (tiled) launch") : HBVX_OK;
             return true;
         }
@@ -133,6 +134,7 @@ bool hbvx_host::try_bwd_tiled(const hbvx_desc *d, const hbvx_bwd_io *io, void *s
                     return gfull ? LAUNCH_TILED_V(k_bwd_tiled, d, ta, grid_t, lds, st_, false, true)
                                  : LAUNCH_TILED_V(k_bwd_tiled, d, ta, grid_t, lds, st_, false, false);
                 }();
+            note_dispatch(1, "tiled");
             *rc = e != hipSuccess ? hip_fail(e, "hbvx_backward (tiled) launch") : HBVX_OK;
             return true;
         }

@@ -223,6 +223,10 @@ const char *hbvx_last_error(void);
 const char *hbvx_backend(void);         /* "hip:gfx950" or "cpu-oracle" */
 uint64_t hbvx_sizeof(int which);        /* 0 desc, 1 fwd_out, 2 bwd_io, 3 route_desc,
                                            4 param_src, 5 param_grad, 6 gage_desc: layout check */
+/* Diagnostic: the kernel family that took the process's last hbvx_forward (direction 0) / hbvx_backward (1) call --
+ * "pipe", "stream2", "stream", "tiled", "simple", "chunked", "ckpt-block:<family>", "ckpt-lds"; "oracle" in the CPU
+ * restatement.  The parity tests assert that the family they mean to pin against the reference is the one that ran. */
+const char *hbvx_last_dispatch(int direction);
 
 /* The trajectory layout this library wants for the problem (grid size, dynamic set): pass the
  * value in hbvx_fwd_out.traj_layout and hbvx_bwd_io.traj_layout.  HBVX_TRAJ_ROWS is always accepted. */

@@ -45,6 +45,7 @@ uint64_t hbvx_ckpt_workspace_bytes(const hbvx_desc *d, int32_t K) { (void)d; (vo
 /* the oracle keeps the plain row layout of the trajectory */
 int hbvx_preferred_traj_layout(const hbvx_desc *d) { (void)d; return HBVX_TRAJ_ROWS; }
 const char *hbvx_last_error(void) { return g_err; }
+const char *hbvx_last_dispatch(int direction) { (void)direction; return "oracle"; }
 const char *hbvx_backend(void) { return "cpu-oracle"; }
 
 uint64_t hbvx_sizeof(int which)

@@ -23,9 +23,32 @@ def pytest_configure(config):
 # Order of the GPU tier (the driver runs `pytest -x -q -m gpu`): parity against the oracle and the reference's
 # golden fixtures first, the callers next, contract / launcher tests last -- a contract test can never again stop
 # the run before a parity test (round 2: one value-dependent assertion in test_bench_launch did exactly that).
-_GPU_ORDER = ["test_gpu_parity", "test_gpu_fullsize", "test_hbv_adj", "test_mts", "test_gage_route", "test_lstm",
+_GPU_ORDER = ["test_gpu_parity", "test_uh_routing", "test_gpu_fullsize", "test_hbv_adj", "test_mts", "test_gage_route", "test_lstm",
               "test_example_dpl", "test_graphed", "test_gpu_fuzz", "test_zero_fill", "test_api_and_abi", "test_gpu_rccl_world1",
               "test_bench_launch"]
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """The measured worst error of every parity comparison of the session (tests/abi_util.py::REPORT: name, max
+    abs error, max error / tolerance, elements outside, size) -> gpurun_out/parity_report_<tier>.txt, worst first:
+    the stated tolerances are checked AND their head-room is on file."""
+    try:
+        from tests.abi_util import REPORT
+    except Exception:  # noqa: BLE001
+        return
+    out = os.path.join(ROOT, "gpurun_out")
+    if not REPORT or not os.path.isdir(out):
+        return
+    tier = "gpu" if "not gpu" not in (session.config.getoption("-m") or "") and (session.config.getoption("-m") or "") else "cpu"
+    worst = {}
+    for name, err, ratio, nbad, size in REPORT:
+        w = worst.get(name)
+        if w is None or ratio > w[1]:
+            worst[name] = (err, ratio, nbad, size)
+    with open(os.path.join(out, f"parity_report_{tier}.txt"), "w") as f:
+        f.write(f"# {len(REPORT)} comparisons, {len(worst)} distinct names; columns: max|err|/tol  max|err|  outside  size  name\n")
+        for name, (err, ratio, nbad, size) in sorted(worst.items(), key=lambda kv: -kv[1][1]):
+            f.write(f"{ratio:9.4f} {err:11.3e} {nbad:6d} {size:10d}  {name}\n")
 
 
 def pytest_collection_modifyitems(config, items):

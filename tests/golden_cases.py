@@ -102,7 +102,22 @@ CASES = {
                                 T=100, B=6, G=2, seed=30, loss="all", torch_seed=5),
     "hourly_static_cold": dict(model="Hbv_2_hourly", config=_cfg("Hbv_2_hourly", 2), T=60, B=5, G=2,
                                seed=31, loss="all", cold=True),
+    # --- long records (T >= 256) with a loss: the time-parallel adjoint (64-day chunks, T >= 128), the streaming
+    # adjoint and the checkpointed adjoint meet the reference's own autograd tape, not only the oracle.
+    "hbv_long_static": dict(model="Hbv", config=_cfg("Hbv", 16), T=400, B=6, seed=41, loss="all"),
+    "hbv_long_dyn2": dict(model="Hbv", config=_cfg("Hbv", 16, ("parBETA", "parBETAET"), warm_up=40), T=400, B=6,
+                          seed=42, loss="all"),
+    "hbv_long_m4_xgrad": dict(model="Hbv", config=_cfg("Hbv", 4, ("parK0",)), T=300, B=9, seed=43, loss="all",
+                              x_grad=True),
+    "hbv11p_long_dyn_all": dict(model="Hbv_1_1p", config=_cfg("Hbv_1_1p", 16, PHY_NAMES["Hbv_1_1p"]), T=256, B=5,
+                                seed=44, loss="all"),
+    "hbv2_long_dyn3": dict(model="Hbv_2", config=_cfg("Hbv_2", 16, ("parBETA", "parK0", "parBETAET")), T=256, B=8,
+                           seed=45, loss="all"),
+    "hbv2_long_routing": dict(model="Hbv_2", config=_cfg("Hbv_2", 4, ("parBETA", "parBETAET"), routing=True), T=300,
+                              B=7, seed=46, loss="streamflow"),
 }
+
+LONG_CASES = [n for n, c in CASES.items() if "_long_" in n]
 
 FLUX_KEYS_BASE = [
     "streamflow", "srflow", "ssflow", "gwflow", "AET_hydro", "PET_hydro", "SWE",

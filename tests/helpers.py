@@ -7,14 +7,14 @@ import numpy as np
 import torch
 
 from . import golden_cases as gc
+from .abi_util import GROUP_FLOOR, REPORT, ROUTE_ATOL_REL, column_groups
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 # Stated tolerances (fp32; pow / sum-order / sigmoid differ by ulps between
 # implementations).  BASELINE.md §2 proposal: fluxes rtol 1e-4 / atol 1e-5,
 # gradients rtol 1e-3 / atol 1e-6 relative to the gradient's scale.
-FLUX_RTOL, FLUX_ATOL = 1e-4, 1e-5
-GRAD_RTOL, GRAD_ATOL_REL = 1e-3, 1e-6
+from .abi_util import FLUX_ATOL, FLUX_RTOL, GRAD_ATOL_REL, GRAD_RTOL  # noqa: E402  (one statement of the tolerances)
 
 
 def load_golden(name):
@@ -102,6 +102,7 @@ def compare(name: str, res: dict, ref, report=None, flux_rtol=FLUX_RTOL, flux_at
             grad_rtol=GRAD_RTOL, grad_atol_rel=GRAD_ATOL_REL):
     """Assert `res` matches the golden record `ref` within the stated tolerances."""
     bad = []
+    nmul = (gc.CASES[name]["config"] or {}).get("nmul", 1) if name in gc.CASES else 1
     for key in ref.files:
         if key in ("torch_version", "loss"):
             continue
@@ -110,12 +111,20 @@ def compare(name: str, res: dict, ref, report=None, flux_rtol=FLUX_RTOL, flux_at
         if a.size == 0:
             continue
         if key.startswith("grad/"):
-            scale = max(np.abs(b).max(), 1e-30)
+            # 1e-6 x the largest gradient of the element's own parameter group (the nmul members of one physical
+            # parameter; a routing column, a forcing channel, a gage-routing parameter are groups of their own)
+            w = b.shape[-1]
+            labels = np.arange(w) if key in ("grad/x_phy", "grad/p_distr") else column_groups(w, nmul)
+            colmax = np.abs(b).reshape(-1, w).max(0)
+            floor = max(GROUP_FLOOR * colmax.max(), 1e-30)
+            scale = np.array([max(colmax[labels == g].max(), floor) * (ROUTE_ATOL_REL / GRAD_ATOL_REL if g < 0 else 1.0)
+                              for g in labels])
             tol = grad_atol_rel * scale + grad_rtol * np.abs(b)
         else:
             tol = flux_atol + flux_rtol * np.abs(b)
         err = np.abs(a - b)
         nbad = int((err > tol).sum())
+        REPORT.append((f"{name}:{key}", float(err.max()), float((err / tol).max()), nbad, a.size))
         if report is not None:
             report.append((key, float(err.max()), float((err / (np.abs(b) + 1e-12)).max()), nbad,
                            a.size))

@@ -22,6 +22,7 @@ extern "C" int hbvx_version(void) { return HBVX_ABI_VERSION; }
 extern "C" int hbvx_preferred_traj_layout(const hbvx_desc *) { return HBVX_TRAJ_ROWS; }
 extern "C" uint64_t hbvx_ckpt_workspace_bytes(const hbvx_desc *, int32_t) { return 0; }
 extern "C" const char *hbvx_last_error(void) { return g_err; }
+extern "C" const char *hbvx_last_dispatch(int) { return "host-steptest"; }
 extern "C" const char *hbvx_backend(void) { return "cpu-steptest"; }
 extern "C" uint64_t hbvx_sizeof(int w)
 {

@@ -112,6 +112,42 @@ def test_hip_library_rejects_bad_descriptors():
         lib.forward(d, o, 0)
 
 
+def test_hip_library_refuses_bounds_outside_the_short_forms():
+    """The forward's evaporation factor (from the storage before the excess leaves it) and its powers (no lower clamp
+    of the base) equal the reference only for LP <= 1 and positive lower bounds of BETA / BETAET / ALPHA
+    (csrc/hbv_step.h::fwd_soil, pow_unit_; hbv.py:462-477): a caller-edited parameter_bounds table outside that is
+    refused by check_desc with a message, before any launch."""
+    import numpy as np
+    import __graft_entry__ as ge
+    from tests.abi_util import BOUNDS
+    lib = _abi.Library(ge.build_hip())
+    buf = np.zeros(64, np.float32)
+
+    def desc(model, names, **edit):
+        d = _abi.Desc()
+        d.abi_version, d.model, d.T, d.B, d.M, d.n_param = _abi.ABI_VERSION, model, 4, 2, 4, len(names)
+        d.x = buf.ctypes.data
+        d.ch_prcp, d.ch_tmean, d.ch_pet = 0, 1, 2
+        d.nearzero = 1e-5
+        d.ac = d.elev = buf.ctypes.data
+        for i, n in enumerate(names):
+            d.p[i].sta = buf.ctypes.data
+            d.p[i].lo, d.p[i].hi = edit.get(n, BOUNDS[n])
+        return d
+    from tests.golden_cases import PHY_NAMES
+    hbv = PHY_NAMES["Hbv"] + ["parBETAET"]
+    o = _abi.FwdOut()
+    with pytest.raises(_abi.HbvxError, match="state_out"):          # the reference's own table passes the bounds check
+        lib.forward(desc(_abi.MODEL_HBV10, hbv), o, 0)
+    for names, model, edit, msg in [
+            (hbv, _abi.MODEL_HBV10, {"parLP": (0.2, 1.5)}, "parLP"),
+            (hbv, _abi.MODEL_HBV10, {"parBETA": (0.0, 6.0)}, "parBETA "),
+            (hbv, _abi.MODEL_HBV10, {"parBETAET": (0.0, 5.0)}, "parBETAET"),
+            (PHY_NAMES["Hbv_2_hourly"], _abi.MODEL_HOURLY, {"parALPHA": (-0.5, 5.0)}, "parALPHA")]:
+        with pytest.raises(_abi.HbvxError, match=msg):
+            lib.forward(desc(model, names, **edit), o, 0)
+
+
 def test_product_fails_loudly_without_gpu_tensors():
     from hydrodl2_amd import _lib
     from tests import seam

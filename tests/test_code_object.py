@@ -83,3 +83,40 @@ def test_the_adjoints_prefetch_is_not_waited_for_where_it_is_issued():
         for a, b in bursts:
             waits = [ins[i] for i in range(a, min(b + 6, len(ins))) if ins[i].startswith("s_waitcnt") and "vmcnt" in ins[i]]
             assert not waits, f"{sym}: {waits} between / right behind the loads at instructions {a}..{b}"
+
+
+def _is_dma(x: str) -> bool:
+    return x.startswith("global_load_lds") or (x.startswith("buffer_load") and x.endswith(" lds"))
+
+
+def test_lds_dma_rows_are_waited_for_before_they_are_read():
+    """Kernels that bring a day's rows HBM -> LDS by LDS-DMA (no registers while in flight) read them back with
+    ds_read at the top of the day's loop.  Nothing but a `s_waitcnt vmcnt` orders the two: round 4 had a build whose
+    LDS reads ran ahead of the DMA and read STALE rows at config 3's full size.  The chunk kernels now say it in the
+    source (an explicit vmcnt(0): everything in flight there is the day's own input), the streaming adjoint relies on
+    the compiler's own tracking of `buffer_load ... lds` (counted vmcnt(n), one per DMA'd row).  Either way the ISA
+    must show, in the day loop (the widest loop that holds the DMA), a vmcnt wait between the loop head and its first ds_read."""
+    if not os.path.exists(LIB):
+        pytest.skip("libhbvx.so not built")
+    import kernel_resources
+    dis = kernel_resources.disassemble_addr(LIB, ["k_bwd_chunk_phiILi1ELb1ELi3E", "k_bwd_chunk_sweepILi1ELb1ELi3E",
+                                                  "k_bwd_stream2I"])
+    assert len(dis) >= 6 + 40, sorted(dis)
+    checked = 0
+    for sym, ins in dis.items():
+        loops = [(h, b) for h, b in kernel_resources.loops_of(ins) if any(_is_dma(x) for _, x in ins[h:b + 1])]
+        if not loops:
+            assert "k_bwd_stream2" in sym, f"{sym}: no loop with an LDS-DMA"    # (some streaming forms load to registers)
+            continue
+        h, b = max(loops, key=lambda hb: hb[1] - hb[0])     # the day loop (inner backward branches: its conditionals)
+        body = [x for _, x in ins[h:b + 1]]
+        first_read = next((i for i, x in enumerate(body) if x.startswith("ds_read")), None)
+        assert first_read is not None, f"{sym}: DMA loop without a ds_read"
+        first_dma = next(i for i, x in enumerate(body) if _is_dma(x))
+        assert first_read < first_dma, f"{sym}: the loop does not start with the read-back of the previous DMA"
+        waits = [x for x in body[:first_read] if x.startswith("s_waitcnt") and "vmcnt" in x]
+        assert waits, f"{sym}: no vmcnt wait between the loop head and {body[first_read]!r}"
+        if "chunk" in sym:
+            assert any("vmcnt(0)" in w for w in waits), f"{sym}: the explicit vmcnt(0) is gone: {waits}"
+        checked += 1
+    assert checked >= 6 + 20

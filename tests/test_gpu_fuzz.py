@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 from . import golden_cases as gc
-from .abi_util import assert_close, make_problem, run_problem
+from .abi_util import compare_runs, make_problem, run_problem
 
 pytestmark = pytest.mark.gpu
 
@@ -59,15 +59,13 @@ def test_fixed_seed_fuzz_bounds_threshold_flips(hip_backend, oracle_path, capsys
         prob = make_problem(**kw)
         got = run_problem(prob, None, device="cuda:0", x_grad=grad, backward=grad, t0=t0)
         want = run_problem(prob, oracle_path, device="cpu", x_grad=grad, backward=grad, t0=t0)
-        for k in ("flux", "routed", "state_out"):
-            if k in want:
-                assert_close(f"draw {case} {kw} {k}", got[k], want[k], 1e-4, 1e-5)
+        compare_runs(prob, got, want, label=f"draw {case} {kw}", keys=("flux", "routed", "state_out"))
         flipped = False
         for k in ("g_params", "g_x", "g_muwts"):
             if not (grad and k in want and want[k] is not None):
                 continue
             try:
-                assert_close(k, got[k], want[k], 1e-3, 1e-5)
+                compare_runs(prob, got, want, keys=(k,))
             except AssertionError as e:
                 m = re.search(r"(\d+)/(\d+) outside tol", str(e))
                 nbad, size = int(m.group(1)), int(m.group(2))

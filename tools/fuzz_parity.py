@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 from tests import golden_cases as gc  # noqa: E402
-from tests.abi_util import assert_close, make_problem, run_problem  # noqa: E402
+from tests.abi_util import compare_runs, make_problem, run_problem  # noqa: E402
 
 
 def main():
@@ -55,12 +55,7 @@ def main():
             grad = rng.random() < 0.75            # the rest: inference (no trajectory kept, other kernel variants)
             got = run_problem(prob, None, device="cuda:0", x_grad=grad, backward=grad, t0=t0)
             want = run_problem(prob, ge.ORACLE_LIB, device="cpu", x_grad=grad, backward=grad, t0=t0)
-            for k in ("flux", "routed", "state_out"):
-                if k in want:
-                    assert_close(k, got[k], want[k], 1e-4, 1e-5)
-            for k in ("g_params", "g_x", "g_muwts"):
-                if grad and k in want and want[k] is not None:
-                    assert_close(k, got[k], want[k], 1e-3, 1e-5)
+            compare_runs(prob, got, want, keys=("flux", "routed", "state_out", "g_params", "g_x", "g_muwts"))
             status = "ok"
         except AssertionError as e:
             bad += 1

@@ -103,3 +103,42 @@ def disassemble(lib: str, symbol_substrings: list[str]) -> dict[str, list[str]]:
                         ins.append(" ".join(m.group(1).split()))
                 out[sym] = ins
     return out
+
+
+def disassemble_addr(lib: str, symbol_substrings: list[str]) -> dict[str, list[tuple[int, str]]]:
+    """Like disassemble(), with each instruction's address: {symbol: [(addr, "s_waitcnt vmcnt(0)"), ...]}."""
+    out: dict[str, list[tuple[int, str]]] = {}
+    with tempfile.TemporaryDirectory() as td:
+        for co in code_objects(lib, td):
+            syms = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "-s", "-W", co], capture_output=True, text=True,
+                                  check=True).stdout
+            want = sorted({ln.split()[-1] for ln in syms.splitlines()
+                           if " FUNC " in ln and any(s in ln.split()[-1] for s in symbol_substrings)})
+            for sym in want:
+                txt = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", f"--disassemble-symbols={sym}", co],
+                                     capture_output=True, text=True, check=True).stdout
+                ins = []
+                for ln in txt.splitlines():
+                    m = re.match(r"^\s+([a-z_0-9]+(?:\s+[^/]*)?)\s*//\s*([0-9A-Fa-f]+):", ln)
+                    if m:
+                        ins.append((int(m.group(2), 16), " ".join(m.group(1).split())))
+                out[sym] = ins
+    return out
+
+
+def loops_of(ins: list[tuple[int, str]]) -> list[tuple[int, int]]:
+    """(head index, branch index) of every backward branch of a disassemble_addr() listing.  SOPP branches carry a
+    signed 16-bit dword offset relative to the next instruction (printed unsigned by llvm-objdump)."""
+    index = {a: i for i, (a, _) in enumerate(ins)}
+    out = []
+    for i, (a, x) in enumerate(ins):
+        if x.startswith(("s_cbranch", "s_branch")):
+            try:
+                off = int(x.split()[-1])
+            except ValueError:
+                continue
+            off = off - 65536 if off >= 32768 else off
+            tgt = a + 4 + 4 * off
+            if tgt in index and index[tgt] <= i:
+                out.append((index[tgt], i))
+    return out
