@@ -24,7 +24,8 @@ Rank 0 prints ONE JSON line.  `value` = whole-job basin-ensemble-timesteps/s.  A
 carries `secondary` (configs 2-dyn, 3, 4 -- staged and under the reference's joint Newton policy --, one GPU's share of 5,
 config 5 at full size, the deltaMG minibatch shape, Hbv_2_hourly with gage routing, the sequence LSTM and one
 examples/train_dpl.py step; driver-timed in the same run, each with what limits it: `limited_by`) and
-`cpu_baseline` (the C/OpenMP oracle port and the pure-torch eager restatement on the host cores).
+`cpu_baseline` (the pure-torch eager restatement of the reference's path on the host cores -- `value` -- with the
+C/OpenMP oracle port beside it); every timed entry carries its per-step samples (`step_samples`: n, median, min, max).
 """
 from __future__ import annotations
 
@@ -41,6 +42,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 CKPT_K = 64             # checkpoint interval assumed by SURVEY.md §8d's algorithmic byte count
+SEC_STEPS = 10          # timed steps of every secondary configuration (median of >= 10)
 
 
 # --------------------------------------------------------------------------------------------
@@ -138,6 +140,12 @@ WORKLOADS = {
     "cfg5share": ("hbv_2", "Hbv_2", 730, 12500, 16, ["parBETA", "parK0", "parBETAET"]),
     # configs[4] at its stated size on ONE GPU (~70 GB of its 288): what `--config cfg5 --gpus 1` runs
     "cfg5full": ("hbv_2", "Hbv_2", 730, 100000, 16, ["parBETA", "parK0", "parBETAET"]),
+    # the same with north_star's checkpoint-and-rematerialise adjoint (module key `adjoint_checkpoint` = K days): the
+    # forward keeps 20 / K bytes per lane-day instead of 20, the streaming adjoint recomputes its K-day segment in LDS
+    # (csrc/hbv_stream2_ckpt.h); Hbv_2.get_states() then returns the final storages, not the series
+    "cfg5share_ck4": ("hbv_2", "Hbv_2", 730, 12500, 16, ["parBETA", "parK0", "parBETAET"], {"adjoint_checkpoint": 4}),
+    "cfg5full_ck4": ("hbv_2", "Hbv_2", 730, 100000, 16, ["parBETA", "parK0", "parBETAET"], {"adjoint_checkpoint": 4}),
+    "cfg5full_ck8": ("hbv_2", "Hbv_2", 730, 100000, 16, ["parBETA", "parK0", "parBETAET"], {"adjoint_checkpoint": 8}),
     # the deltaMG minibatch shape of SURVEY §8d: 100 basins, 365 warm-up + 365 days
     "dmg": ("hbv", "Hbv", 730, 100, 16, ["parBETA", "parBETAET"], {"warm_up": 365}),
     # the same step through captured HIP graphs (module key `graph`: hydrodl2_amd/graphed.py) -- opt-in, for steps whose
@@ -167,9 +175,10 @@ LIMITED_BY = {
     "cfg3": ("hbm", "14 dynamic rows streamed twice by the two-pass adjoint: 17.3 GB in 3.6 ms = 4.8 TB/s (76 % of the "
                     "6.3 TB/s this chip copies at); forward bound by its filler waves",
              {"k_bwd_chunk_phi": 0.20, "k_bwd_chunk_sweep": 0.17, "k_fwd_pipe": 0.12}, "profiles/r04_sq_counters_cfg3.txt"),
-    "cfg4": ("latency", "the soil-moisture wave's Newton iteration: a lone wave on its SIMD, ~8 cycles per instruction, two "
-                        "residual evaluations and one update on 46 % of the wave-days, three and two on the rest "
-                        "(profiles/r04_ab_soil.txt)", {}, "profiles/r04_ab_soil.txt"),
+    "cfg4": ("latency", "the soil-moisture wave's scalar Newton / Halley iteration: a lone wave on its SIMD, ~8 cycles per "
+                        "instruction; 97.1 % of the lane-days are solved by one free update but the slowest of a wave's 64 "
+                        "lanes asks for a second on 54 % of the wave-days (profiles/r04_ab_soil.txt)", {},
+             "profiles/r04_ab_soil.txt"),
     "cfg4joint": ("latency", "one wave per 64 lanes iterating the reference's joint 5-variable Newton", {}, "DESIGN.md §4"),
     "cfg5share": ("hbm", "design bytes (20 B trajectory + 12 B dynamic rows per lane-day, both ways) at 4.4-4.5 TB/s measured "
                          "by the counters; the vector pipes are a third busy",
@@ -191,10 +200,12 @@ LIMITED_BY = {
 
 
 def limited_by(name):
+    """What binds the configuration.  These are RECORDED findings (the committed counter / probe files named in
+    `evidence_file`, taken with the profiler), not measurements of this run: the keys say so."""
     lb, why, busy, src = LIMITED_BY[name]
-    out = {"limited_by": lb, "evidence": why, "evidence_file": src}
+    out = {"limited_by": lb, "evidence_recorded": why, "evidence_file": src}
     if busy:
-        out["valu_per_simd_cycle"] = busy
+        out["valu_per_simd_cycle_recorded"] = busy
     return out
 
 
@@ -297,9 +308,23 @@ class Workload:
         return fwd, passes * one + 4.0 * nd
 
 
+def _median(v):
+    s = sorted(v)
+    n = len(s)
+    return s[n // 2] if n % 2 else 0.5 * (s[n // 2 - 1] + s[n // 2])
+
+
 def timed_steps(wl, steps, warmup, dev, world, after_step=None):
+    """W untimed + K timed steps; returns (seconds for the K steps, per-call avg ms from per-launch HIP events).
+
+    The K steps are ONE timed region (barrier + synchronize on both sides: the contract's `value`).  Inside it every
+    step leaves a HIP event on the launch stream and a host time stamp -- no synchronisation -- so the record also
+    carries the per-step samples (median of >= 10): `timed_steps.samples` = {n, median / min / max of
+    the device time between consecutive step events, the host's enqueue time per step}.  A step that the whole-
+    region mean hides (round 4: 11.9 ms mean against 3 ms of kernels in the driver's run of cfg5share) shows as `max`."""
     timed_steps.device_mallocs = 0
-    """W untimed + K timed steps with per-launch HIP events; returns (seconds, per-call avg ms)."""
+    timed_steps.samples = None
+    import gc
     import torch
     import torch.distributed as dist
     from hydrodl2_amd import ops
@@ -308,26 +333,50 @@ def timed_steps(wl, steps, warmup, dev, world, after_step=None):
         if after_step:
             after_step()
     ops.KERNEL_EVENTS = []          # per-launch HIP events on the launch stream
+    # no collector pause inside the timed steps: the previous workload's cycles (autograd graphs, module caches) are
+    # reclaimed here, and the cyclic collector stays off until the region ends
+    gc.collect()
+    gc_was = gc.isenabled()
+    gc.disable()
     if world > 1:
         dist.barrier()
     mallocs0 = 0
-    if dev.type == "cuda":
+    cuda = dev.type == "cuda"
+    marks, host = [], []
+    if cuda:
         torch.cuda.synchronize()
         mallocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        marks.append(e)
     t0 = time.perf_counter()
     for _ in range(steps):
+        h0 = time.perf_counter()
         wl.step()
         if after_step:
             after_step()
-    if dev.type == "cuda":
+        host.append(time.perf_counter() - h0)
+        if cuda:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            marks.append(e)
+    if cuda:
         torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if dev.type == "cuda":
+    if gc_was:
+        gc.enable()
+    if cuda:
         # a hipMalloc inside the timed region (the caching allocator still growing: tens of GB at cfg5) is a
         # host stall of tens to hundreds of ms that no kernel time shows; reported so that a step time can be trusted
         timed_steps.device_mallocs = torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - mallocs0
+        dev_ms = [a.elapsed_time(b) for a, b in zip(marks, marks[1:])]
+        timed_steps.samples = {"n": len(dev_ms), "ms_median": round(_median(dev_ms), 4), "ms_min": round(min(dev_ms), 4),
+                               "ms_max": round(max(dev_ms), 4), "ms_mean_region": round(1e3 * dt / steps, 4),
+                               "host_enqueue_ms_median": round(1e3 * _median(host), 4),
+                               "host_enqueue_ms_max": round(1e3 * max(host), 4),
+                               "what": "device time between consecutive end-of-step HIP events on the launch stream"}
     events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
     per = {}
     for name, e0, e1 in events:
@@ -813,12 +862,19 @@ def main():
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": what, "name": args.config, "basins_total": B_total if strong else B_total * world,
-                       "basins_per_gpu": B_rank, "nmul": wl.M, "days": wl.T,
+                       "basins_per_gpu": B_rank,
+                       "basins_per_rank": [(lambda ab: ab[1] - ab[0])(sharding.basin_range(B_total, world, r)) if strong
+                                           else B_total for r in range(world)],
+                       "nmul": wl.M, "days": wl.T,
                        "parallelism": f"basin-shard x{world}"},
             # the number of ranks the collective itself summed over (validate_collective), not the launcher's word
             "rccl_ranks": collective["ranks_summed"], "collective_check": collective,
             "rank_ms_per_step": rank_ms, "allreduce_ms": ar_ms,
             "device_mallocs_in_timed_steps": timed_steps.device_mallocs,
+            # per-step samples inside the one timed region (rank 0): median / min / max; `ms_per_step` above is the
+            # contract's figure, the region's wall time / K, max over ranks
+            "step_samples": timed_steps.samples,
+            "kernel_sum_ms": round(sum(kavg.values()), 4),
         }
         if dev.type == "cuda" and "hbvx_forward" in kavg:
             # Dominant kernel = the one kernel behind hbvx_forward (rocprofv3 --stats: the largest single
@@ -863,14 +919,21 @@ def main():
             try:
                 w2 = (LstmWorkload(dev, 7) if name == "lstm" else DplWorkload(dev, 7) if name == "dpl"
                       else Workload(name, dev, seed=7))
-                dt2, k2 = timed_steps(w2, 5, 3, dev, 1)
-                ms2 = 1e3 * dt2 / 5
+                dt2, k2 = timed_steps(w2, SEC_STEPS, 3, dev, 1)
+                smp = timed_steps.samples
+                # the MEDIAN of >= 10 timed steps (per-step device time, HIP events); the mean over the
+                # region and the slowest step stand beside it
+                ms2 = smp["ms_median"] if smp else 1e3 * dt2 / SEC_STEPS
                 if name in ("lstm", "dpl"):
                     e = w2.entry(ms2, k2)
                 else:
-                    e = {"config": name, "T": w2.T, "B": w2.B, "M": w2.M, "n_dyn": w2.n_dyn, "steps": 5,
+                    e = {"config": name, "T": w2.T, "B": w2.B, "M": w2.M, "n_dyn": w2.n_dyn,
                          "ms_per_step": round(ms2, 4), "lane_steps_per_s": w2.lane_steps / (ms2 * 1e-3)}
                     e.update(roofline_entry(w2, k2, ms2))
+                e["steps"] = SEC_STEPS
+                e["ms_per_step_is"] = "median of the per-step samples"
+                e["step_samples"] = smp
+                e["kernel_sum_ms"] = round(sum(k2.values()), 4)
                 e["device_mallocs_in_timed_steps"] = timed_steps.device_mallocs
                 sec.append(e)
                 print(f"[bench] {name}: {ms2:.3f} ms/step", file=sys.stderr, flush=True)
@@ -882,12 +945,19 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         print("[bench] cpu baselines ...", file=sys.stderr, flush=True)
-        cb = cpu_baseline_port(671, 16, min(args.cpu_sample_days, 7300))
-        print(f"[bench] oracle port: {cb['value']:.3g} lane-steps/s; eager restatement ...", file=sys.stderr, flush=True)
+        # `value` = the reference-equivalent CPU path (PyTorch eager, one ATen call per operator per day + the autograd
+        # tape: kind "restatement"); the C / OpenMP oracle port -- a far better CPU program than the
+        # reference is -- stands beside it under "port".  If no eager pass finishes in its budget the port is the value.
+        port = cpu_baseline_port(671, 16, min(args.cpu_sample_days, 7300))
+        print(f"[bench] oracle port: {port['value']:.3g} lane-steps/s; eager restatement ...", file=sys.stderr, flush=True)
         try:
-            cb["eager"] = cpu_baseline_eager(671, 16)
+            cb = cpu_baseline_eager(671, 16)
         except Exception as ex:
-            cb["eager"] = {"error": repr(ex)[:200]}
+            cb = {"error": repr(ex)[:200], "kind": "restatement"}
+        if "value" in cb:
+            cb["port"] = port
+        else:
+            cb = dict(port, eager=cb)
         res["cpu_baseline"] = cb
     if rank == 0:
         print(json.dumps(res))

@@ -484,17 +484,22 @@ __global__ void __launch_bounds__(256) k_route_bwd(int T, int B, int S, int L,
                                                    const float *__restrict__ q,
                                                    const float *__restrict__ uh,
                                                    const float *__restrict__ gy,
-                                                   float *__restrict__ gq, float *__restrict__ ws)
+                                                   float *__restrict__ gq, double *__restrict__ ws)
 {
     const int b = blockIdx.x * 64 + (threadIdx.x & 63);
     const int chunk = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int t0 = chunk * ROUTE_CHUNK;
     if (b >= B || t0 >= T) return;
     const int t1 = min(T, t0 + ROUTE_CHUNK);
-    float w[HBVX_UH_MAXLEN], gw[HBVX_UH_MAXLEN];
+    // The tap gradients are summed in DOUBLE: what leaves this path is sum_k gw[k] w_k (ln t_k - <ln t>), whose weights
+    // sum to zero (the hydrograph is normalised), so the common part of the gw[k] -- nearly all of them when the
+    // inflow is smooth -- cancels and float32 sums (eps x ~1e+2) left 1e-6 where the result is 1e-4: 0.7 % off the
+    // float64 value on hbv_ties' route_b, twenty times the reference's own error (round 5).
+    float w[HBVX_UH_MAXLEN];
+    double gw[HBVX_UH_MAXLEN];
     load_uh(uh, b, L, w);
 #pragma unroll
-    for (int k = 0; k < HBVX_UH_MAXLEN; k++) gw[k] = 0.0f;
+    for (int k = 0; k < HBVX_UH_MAXLEN; k++) gw[k] = 0.0;
     for (int s = 0; s < S; s++) {
     const float *qs = q + (int64_t)s * T * B + b;
     const float *gs = gy + (int64_t)s * T * B + b;
@@ -520,10 +525,11 @@ __global__ void __launch_bounds__(256) k_route_bwd(int T, int B, int S, int L,
             gwin[HBVX_UH_MAXLEN - 1] = vg[j];
             qwin[0] = vq[j];
             float acc = 0.0f;
+            const double g0 = on ? (double)gwin[0] : 0.0;
 #pragma unroll
             for (int k = 0; k < HBVX_UH_MAXLEN; k++) {
                 acc += w[k] * gwin[k];
-                gw[k] += on ? gwin[0] * qwin[k] : 0.0f;
+                gw[k] = fma(g0, (double)qwin[k], gw[k]);
             }
             if (on) gqs[(int64_t)(tg + j) * B] = acc;
 #pragma unroll
@@ -545,16 +551,16 @@ __global__ void __launch_bounds__(256) k_route_bwd(int T, int B, int S, int L,
 // d w_k / d theta = w_k (t_k - sum_j w_j t_j) / theta^2    in the normalisation)
 __global__ void __launch_bounds__(1024) k_route_bwd_params(const hbvx_route_desc r, int nchunk,
                                                            const float *__restrict__ uh,
-                                                           const float *__restrict__ ws,
+                                                           const double *__restrict__ ws,
                                                            float *grad_ra, float *grad_rb)
 {
-    __shared__ float red[16][64];
+    __shared__ double red[16][64];
     const int bl = threadIdx.x & 63, k = threadIdx.x >> 6;
     const int b = blockIdx.x * 64 + bl;
     const int B = r.B, L = r.L;
-    float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
     if (b < B && k < L) {
-        const float *src = ws + (int64_t)k * B + b;
+        const double *src = ws + (int64_t)k * B + b;
         const int64_t cs = (int64_t)L * B;
         int c = 0;
         for (; c + 3 < nchunk; c += 4) {
@@ -571,25 +577,27 @@ __global__ void __launch_bounds__(1024) k_route_bwd_params(const hbvx_route_desc
     float ua, ub, a, bb;
     route_ab(r, b, ua, ub, a, bb);
     const float theta = fmaxf(bb, 0.0f) + 0.5f;
-    float w[HBVX_UH_MAXLEN], gw[HBVX_UH_MAXLEN];
-    float mlt = 0.0f, mt = 0.0f;
+    // the finish in double as well: the cancellation happens HERE (sum_j c_j = 0), on sums that are now exact to 1e-16
+    double w[HBVX_UH_MAXLEN], gw[HBVX_UH_MAXLEN];
+    double mlt = 0.0, mt = 0.0;
 #pragma unroll
     for (int j = 0; j < HBVX_UH_MAXLEN; j++) {
-        gw[j] = (j < L) ? red[j][bl] : 0.0f;
-        w[j] = (j < L) ? uh[(int64_t)b * L + j] : 0.0f;
-        const float tk = (float)j + 0.5f;
-        mlt += w[j] * logf(tk);
+        gw[j] = (j < L) ? red[j][bl] : 0.0;
+        w[j] = (j < L) ? (double)uh[(int64_t)b * L + j] : 0.0;
+        const double tk = (double)j + 0.5;
+        mlt += w[j] * log(tk);
         mt += w[j] * tk;
     }
-    float gaa = 0.0f, gth = 0.0f;
+    double gaa = 0.0, gth = 0.0;
+    const double th2 = (double)theta * (double)theta;
 #pragma unroll
     for (int j = 0; j < HBVX_UH_MAXLEN; j++) {
-        const float tk = (float)j + 0.5f;
-        gaa += gw[j] * w[j] * (logf(tk) - mlt);
-        gth += gw[j] * w[j] * ((tk - mt) / (theta * theta));
+        const double tk = (double)j + 0.5;
+        gaa += gw[j] * w[j] * (log(tk) - mlt);
+        gth += gw[j] * w[j] * ((tk - mt) / th2);
     }
-    float ga = (a > 0.0f) ? gaa : 0.0f;   // relu backward (uh_routing.py:11-14)
-    float gb = (bb > 0.0f) ? gth : 0.0f;
+    float ga = (a > 0.0f) ? (float)gaa : 0.0f;   // relu backward (uh_routing.py:11-14)
+    float gb = (bb > 0.0f) ? (float)gth : 0.0f;
     float gua = ga * (r.a_hi - r.a_lo), gub = gb * (r.b_hi - r.b_lo);
     if (r.raw_sigmoid) {
         gua *= ua * (1.0f - ua);
@@ -775,6 +783,7 @@ extern "C" int hbvx_backward(const hbvx_desc *d, const hbvx_bwd_io *io, void *st
     if (d->T == 0) return HBVX_OK;
     if (io->traj_layout != HBVX_TRAJ_ROWS) {
         if (HBVX_TRAJ_KIND(io->traj_layout) == HBVX_TRAJ_CKPT) {
+            if (try_bwd_stream_ckpt(d, io, stream, &rc)) return rc;
             if (try_bwd_ckpt(d, io, stream, &rc)) return rc;
             return fail(HBVX_E_UNSUPPORTED, "checkpoints: no adjoint kernel for this call");
         }
@@ -832,7 +841,7 @@ static int route_chunks(const hbvx_route_desc *r) { return (r->T + ROUTE_CHUNK -
 extern "C" uint64_t hbvx_route_workspace_bytes(const hbvx_route_desc *r)
 {
     if (!r || r->T <= 0 || r->B <= 0) return 0;
-    return (uint64_t)route_chunks(r) * (uint64_t)r->L * (uint64_t)r->B * sizeof(float);
+    return (uint64_t)route_chunks(r) * (uint64_t)r->L * (uint64_t)r->B * sizeof(double);    // (8-byte aligned: torch's allocations are)
 }
 
 extern "C" int hbvx_route_backward(const hbvx_route_desc *r, const float *q, const float *uh,
@@ -849,10 +858,10 @@ extern "C" int hbvx_route_backward(const hbvx_route_desc *r, const float *q, con
         return fail(HBVX_E_NULL, "route workspace missing or too small");
     const int nchunk = route_chunks(r);
     hipLaunchKernelGGL(k_route_bwd, dim3((r->B + 63) / 64, (nchunk + 3) / 4), dim3(256), 0, st, r->T,
-                       r->B, r->S, r->L, q, uh, grad_q_rout, grad_q, want_p ? (float *)workspace : nullptr);
+                       r->B, r->S, r->L, q, uh, grad_q_rout, grad_q, want_p ? (double *)workspace : nullptr);
     if (want_p)
         hipLaunchKernelGGL(k_route_bwd_params, dim3((r->B + 63) / 64), dim3(1024), 0, st, *r, nchunk,
-                           uh, (const float *)workspace, grad_ra, grad_rb);
+                           uh, (const double *)workspace, grad_ra, grad_rb);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "hbvx_route_backward launch");
     return HBVX_OK;

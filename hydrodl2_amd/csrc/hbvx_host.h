@@ -50,6 +50,10 @@ inline void store_gate(const hbvx_bwd_io *io, hipStream_t st)
     if (io->store_gate) (void)hipStreamWaitEvent(st, (hipEvent_t)io->store_gate, 0);
 }
 bool try_bwd_stream(const hbvx_desc *d, const hbvx_bwd_io *io, void *stream, int *rc);
+// HBVX_TRAJ_CKPT with the segment in LDS (hbv_stream2_ckpt.h): whether it takes this problem (then no scratch is
+// wanted: hbvx_ckpt_workspace_bytes returns 0), and the launch
+bool stream_ckpt_applicable(const hbvx_desc *d, int K);
+bool try_bwd_stream_ckpt(const hbvx_desc *d, const hbvx_bwd_io *io, void *stream, int *rc);
 // launch_tiled.hip
 bool try_fwd_tiled(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream, int *rc);
 bool try_bwd_tiled(const hbvx_desc *d, const hbvx_bwd_io *io, void *stream, int *rc);

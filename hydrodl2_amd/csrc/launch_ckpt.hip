@@ -88,6 +88,7 @@ void launch_remat(K kern, const RematArgs &a, dim3 grid, hipStream_t st) { hipLa
 extern "C" uint64_t hbvx_ckpt_workspace_bytes(const hbvx_desc *d, int32_t K)
 {
     if (!d || d->T <= 0 || d->B <= 0 || d->M <= 0 || (K != 4 && K != 8 && K != 16)) return 0;
+    if (!check_desc(d) && stream_ckpt_applicable(d, K)) return 0;     // the segment stays in LDS: no scratch
     return plan(d, K).total;
 }
 

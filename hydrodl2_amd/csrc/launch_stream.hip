@@ -3,6 +3,7 @@
 // instantiate).
 #include "hbvx_host.h"
 #include "hbv_stream2.h"
+#include "hbv_stream2_ckpt.h"
 
 using namespace hbvx;
 using namespace hbvx_host;
@@ -135,6 +136,21 @@ void go_bwd2(int trj, bool gfull, const StreamBwdArgs &sa, dim3 grid, hipStream_
     } else {
         if (gfull) hipLaunchKernelGGL((k_bwd_stream2<MODEL, BE, 1, SC, true, true>), grid, dim3(64), 0, st, sa);
         else hipLaunchKernelGGL((k_bwd_stream2<MODEL, BE, 1, SC, false, true>), grid, dim3(64), 0, st, sa);
+    }
+}
+
+// the on-chip checkpoint adjoint (hbv_stream2_ckpt.h): LDS bytes of a wave, launch
+template <int MODEL, bool BE, int SC>
+void go_bwd2c(bool gfull, int K, const StreamBwdArgs &sa, dim3 grid, hipStream_t st, hipError_t *err)
+{
+    constexpr int NP = NParamT<MODEL, BE>::value;
+    const int lds = s2c_lds_floats<NP, StreamDyn<SC>::nd>(K) * (int)sizeof(float);
+    if (gfull) {
+        *err = set_dynamic_lds((const void *)k_bwd_stream2_ckpt<MODEL, BE, SC, true>, lds);
+        if (*err == hipSuccess) hipLaunchKernelGGL((k_bwd_stream2_ckpt<MODEL, BE, SC, true>), grid, dim3(64), lds, st, sa, K);
+    } else {
+        *err = set_dynamic_lds((const void *)k_bwd_stream2_ckpt<MODEL, BE, SC, false>, lds);
+        if (*err == hipSuccess) hipLaunchKernelGGL((k_bwd_stream2_ckpt<MODEL, BE, SC, false>), grid, dim3(64), lds, st, sa, K);
     }
 }
 
@@ -274,5 +290,51 @@ bool hbvx_host::try_bwd_stream(const hbvx_desc *d, const hbvx_bwd_io *io, void *
     hipError_t e = hipGetLastError();
     note_dispatch(1, P.sc >= 0 ? "stream2" : "stream");
     *rc = e != hipSuccess ? hip_fail(e, "hbvx_backward (stream) launch") : HBVX_OK;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// HBVX_TRAJ_CKPT on large grids: the streaming adjoint that keeps its K-day segment in LDS (hbv_stream2_ckpt.h).
+// Same admission as the streaming pair on the packed trajectory -- a compiled dynamic set, forcing channels adjacent,
+// one day's rows within a descriptor -- from the same grid size on (HBVX_CKPT_ONCHIP = 1 / 0: always / never, tests
+// and tools).  Small grids keep the block-wise path: their adjoint wants the time-parallel kernels.
+// ---------------------------------------------------------------------------------------------
+bool hbvx_host::stream_ckpt_applicable(const hbvx_desc *d, int K)
+{
+    if (K != 4 && K != 8 && K != 16) return false;
+    const int want = env_int("HBVX_CKPT_ONCHIP", -1);
+    if (want == 0) return false;
+    const StreamPlan P = plan_stream(d);
+    if (!(P.ok && P.sc >= 0 && P.packed_ok)) return false;
+    if (want == 1) return true;
+    return !adjoint_pinned_elsewhere() && P.wgs >= stream_min(P, true, true);
+}
+
+bool hbvx_host::try_bwd_stream_ckpt(const hbvx_desc *d, const hbvx_bwd_io *io, void *stream, int *rc)
+{
+    const int K = HBVX_TRAJ_CKPT_DAYS(io->traj_layout);
+    if (!stream_ckpt_applicable(d, K) || !(io->grad_flux || io->grad_flux4)) return false;
+    const StreamPlan P = plan_stream(d);
+    const int64_t lim = (int64_t)1 << 32;
+    for (int i = 0; i < d->n_param; i++)
+        if (d->p[i].dyn && io->g[i].dyn &&
+            !(io->g[i].dyn_t_stride >= 0 && (int64_t)d->B * io->g[i].dyn_b_stride * 4 < lim))
+            return false;
+    StreamBwdArgs sa;
+    sa.d = *d;
+    sa.io = *io;
+    sa.lgMp = P.lg;
+    sa.nd = P.nd;
+    for (int k = 0; k < 3; k++) sa.dslot[k] = k < P.nd ? P.dslot[k] : 0;
+    sa.per_xcd = (int)((P.wgs + 7) / 8);
+    const dim3 grid2((unsigned)(8 * sa.per_xcd));
+    hipStream_t st = (hipStream_t)stream;
+    store_gate(io, st);          // single pass: the one kernel stores
+    hipError_t e = hipSuccess;
+    const bool gfull = io->grad_flux != nullptr;
+    STREAM2_DISPATCH(go_bwd2c, d, P.sc, gfull, K, sa, grid2, st, &e);
+    if (e == hipSuccess) e = hipGetLastError();
+    note_dispatch(1, "ckpt-stream2");
+    *rc = e != hipSuccess ? hip_fail(e, "hbvx_backward (on-chip checkpoints) launch") : HBVX_OK;
     return true;
 }

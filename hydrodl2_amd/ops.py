@@ -383,15 +383,24 @@ def _fill_desc(cfg: StepConfig, x, state_in, muwts, ac, elev, ptensors) -> _abi.
 # part of the memo key, so a knob changed between two calls on the same module is seen (a stale TRAJ_PACKED under
 # HBVX_STREAM=0 made hbvx_forward refuse the call; a stale workspace size silently demoted the adjoint).
 _MEMO_ENV = ("HBVX_KERNEL", "HBVX_FWD", "HBVX_BWD", "HBVX_STREAM", "HBVX_STREAM_MIN", "HBVX_STREAM_MW_MIN", "HBVX_CHUNK",
-             "HBVX_CKPT_BLOCK", "HBVX_CKPT_SCRATCH_MB", "HBVX_CKPT_BLOCKWISE")
+             "HBVX_CKPT_BLOCK", "HBVX_CKPT_SCRATCH_MB", "HBVX_CKPT_BLOCKWISE", "HBVX_CKPT_ONCHIP")
+# os.environ.get() encodes the key and decodes the value on every call (~1 us; ten knobs x several memo look-ups per
+# step is a tenth of the delta-MG minibatch's enqueue time): read the mapping underneath it, plain bytes -> bytes
+_ENV_DATA = getattr(os.environ, "_data", None)
+_MEMO_ENV_B = tuple(os.fsencode(k) for k in _MEMO_ENV)
+
+
+def _env_key() -> tuple:
+    if isinstance(_ENV_DATA, dict):
+        return tuple(map(_ENV_DATA.get, _MEMO_ENV_B))
+    return tuple(os.environ.get(k) for k in _MEMO_ENV)
 
 
 def _cached(cfg: StepConfig, key, fn):
     """Per-config memo for the library's size / layout queries (functions of the shape and the knobs above, not of
     the pointers)."""
     memo = cfg.__dict__.setdefault("_memo", {})
-    env = os.environ
-    key = (key, tuple(env.get(k) for k in _MEMO_ENV))
+    key = (key, _env_key())
     v = memo.get(key)
     if v is None:
         v = memo[key] = fn()

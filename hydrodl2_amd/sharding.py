@@ -22,25 +22,53 @@ def basin_range(n_basins: int, world: int, rank: int) -> tuple[int, int]:
     return b0, min(b0 + per, n_basins)
 
 
+# x_dict entries by NAME and the axis their basins sit on (the reference's layouts: hbv.py:284-300, hbv_2.py:324-345).
+# muwts is [T,B,nmul], [1,B,nmul] (axis 1) or [B,nmul] (axis 0).  A key that is not listed is an error, not a guess:
+# round 4's `shape[1] == B` heuristic mis-sliced a [B,n] tensor whenever n happened to equal B.
+_BASIN_AXIS = {'x_phy': 1, 'ac_all': 0, 'elev_all': 0, 'areas': 0}
+# entries that couple basins and cannot be cut by a contiguous basin block (the hourly model's units -> gages
+# topology and its per-pair routing parameters, hbv_2_hourly.py:819-850; SURVEY.md §8e: out of scope)
+_COUPLED = ('outlet_topo', 'x_phy_high_freq', 'x_phy_low_freq')
+
+
 def shard_inputs(x_dict: dict, parameters, world: int, rank: int):
     """Slice the basin axis of an `x_dict` / `parameters` pair as the reference lays them out:
-    x_phy [T,B,3], muwts [T,B,nmul], ac_all/elev_all [B]; parameters [T,B,ny] or the HBV 2.0
-    tuple ([T,B,*], [B,*])."""
+    x_phy [T,B,3], muwts [T,B,nmul] | [1,B,nmul] | [B,nmul], ac_all / elev_all / areas [B]; parameters [T,B,ny] or
+    the HBV 2.0 tuple ([T,B,*], [B,*]).  Raises on anything it cannot shard by a contiguous block of basins -- an
+    unknown tensor key, the hourly model's `outlet_topo` / three-tensor tuple (units feed gages across blocks) --
+    instead of passing it through or dropping it."""
     B = x_dict['x_phy'].shape[1]
     b0, b1 = basin_range(B, world, rank)
     xs = {}
     for k, v in x_dict.items():
         if not torch.is_tensor(v):
             xs[k] = v
-        elif v.dim() >= 2 and v.shape[1] == B and k not in ('ac_all', 'elev_all'):
-            xs[k] = v[:, b0:b1].contiguous()
-        elif v.dim() >= 1 and v.shape[0] == B:
-            xs[k] = v[b0:b1].contiguous()
+            continue
+        if k in _COUPLED:
+            raise NotImplementedError(f"shard_inputs: '{k}' couples basins (gage routing / multi-timescale inputs); "
+                                      "shard the units by gage upstream of this helper")
+        if k == 'muwts':
+            axis = 0 if v.dim() == 2 else 1
+        elif k in _BASIN_AXIS:
+            axis = _BASIN_AXIS[k]
         else:
-            xs[k] = v
+            raise KeyError(f"shard_inputs: no basin axis known for x_dict['{k}'] (shape {tuple(v.shape)}); "
+                           f"known keys: {sorted(_BASIN_AXIS) + ['muwts']}")
+        if v.dim() <= axis or v.shape[axis] != B:
+            raise ValueError(f"shard_inputs: x_dict['{k}'] has shape {tuple(v.shape)}, expected {B} basins on axis {axis}")
+        xs[k] = v.narrow(axis, b0, b1 - b0).contiguous()
     if isinstance(parameters, (tuple, list)):
-        ps = (parameters[0][:, b0:b1].contiguous(), parameters[1][b0:b1].contiguous())
+        if len(parameters) != 2:
+            raise NotImplementedError(f"shard_inputs: a {len(parameters)}-tensor parameter tuple (the hourly model's "
+                                      "per-pair routing parameters) cannot be cut by basin blocks")
+        pd, pst = parameters
+        if pd.dim() != 3 or pd.shape[1] != B or pst.dim() != 2 or pst.shape[0] != B:
+            raise ValueError(f"shard_inputs: HBV 2.0 parameters must be ([T,{B},*], [{B},*]), got "
+                             f"{tuple(pd.shape)}, {tuple(pst.shape)}")
+        ps = (pd[:, b0:b1].contiguous(), pst[b0:b1].contiguous())
     else:
+        if parameters.dim() != 3 or parameters.shape[1] != B:
+            raise ValueError(f"shard_inputs: parameters must be [T,{B},ny], got {tuple(parameters.shape)}")
         ps = parameters[:, b0:b1].contiguous()
     return xs, ps
 
@@ -105,32 +133,52 @@ class AsyncBucket:
     right after the HBV adjoint) while the part that is produced last (the LSTM) is still being
     computed -- the overlap SURVEY.md §8f rank 4 asks for."""
 
-    _live = 0    # buckets in flight: each gets its own persistent staging buffer
+    # Staging slots in flight.  A bucket takes the lowest FREE slot in start() and gives it back in finish() (also
+    # when the wait raises): with a plain counter, start A, start B, finish A, start C handed C the slot -- and with
+    # the same size the very buffer -- of B while B's all-reduce was still in flight (ADVICE r4).
+    _busy: set = set()
 
     def __init__(self, tensors: Sequence[torch.Tensor], group=None):
         self.tensors, self.group = list(tensors), group
         self.flat = self.work = None
+        self.slot = None
 
     def start(self) -> "AsyncBucket":
+        if self.work is not None:
+            raise RuntimeError("AsyncBucket.start() called twice without finish()")
         if dist.is_initialized() and dist.get_world_size(self.group) > 1:
             # the staging buffer persists between steps like the blocking path's (one per bucket in flight: the
             # step's early and late buckets overlap in time)
-            self.flat = _bucket(self.tensors, tag=f"async{AsyncBucket._live}")
-            AsyncBucket._live += 1
-            self.work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            slot = 0
+            while slot in AsyncBucket._busy:
+                slot += 1
+            AsyncBucket._busy.add(slot)
+            self.slot = slot
+            try:
+                self.flat = _bucket(self.tensors, tag=f"async{slot}")
+                self.work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            except BaseException:
+                self._release()
+                raise
         return self
+
+    def _release(self) -> None:
+        if self.slot is not None:
+            AsyncBucket._busy.discard(self.slot)
+        self.slot = self.flat = self.work = None
 
     def finish(self) -> None:
         if self.work is None:
             return
-        self.work.wait()
-        off = 0
-        for t in self.tensors:
-            n = t.numel()
-            t.copy_(self.flat[off:off + n].view_as(t))
-            off += n
-        AsyncBucket._live -= 1
-        self.flat = self.work = None
+        try:
+            self.work.wait()
+            off = 0
+            for t in self.tensors:
+                n = t.numel()
+                t.copy_(self.flat[off:off + n].view_as(t))
+                off += n
+        finally:
+            self._release()
 
 
 def gather_basins(local: torch.Tensor, n_basins: int, dim: int, group=None) -> torch.Tensor:

@@ -62,6 +62,27 @@ uint64_t hbvx_sizeof(int which)
     }
 }
 
+/* Conditioning probe (tests/test_conditioning.py): the step's powers perturbed by +-`ulps` units in the last place,
+ * the sign from a hash of the operands (the same operands give the same perturbation, so the adjoint's recomputed
+ * forward sees what the forward saw).  0 = libm's powf, the oracle proper.  What a comparison of the perturbed run
+ * with the plain one measures is the sensitivity of the reference's OWN float32 trajectory to the last bit of its
+ * pow -- the noise floor any other pow implementation (torch's vectorised CPU pow, the GPU's) sits on. */
+static int g_pow_noise = 0;
+void hbvo_set_pow_noise(int ulps) { g_pow_noise = ulps; }
+static inline float step_powf(float x, float y)
+{
+    float r = powf(x, y);
+    if (g_pow_noise && r > 0.0f && r < 3.0e38f) {
+        union { float f; uint32_t u; } a, b, c;
+        a.f = x; b.f = y; c.f = r;
+        uint32_t h = (a.u * 2654435761u) ^ (b.u * 2246822519u);
+        h ^= h >> 15;
+        if (h & 1u) c.u += (uint32_t)g_pow_noise; else c.u -= (uint32_t)g_pow_noise;
+        r = c.f;
+    }
+    return r;
+}
+
 int hbvo_num_threads(void)
 {
 #ifdef _OPENMP
@@ -168,7 +189,7 @@ static void step_fwd(int model, int has_betaet, float nz, const float *p, float 
     s->MW3 = s->MW2 - s->tosoil;
     /* hbv.py:462-472 */
     s->r = s->SM / FC;
-    s->sw0 = powf(s->r, BETA);
+    s->sw0 = step_powf(s->r, BETA);
     s->sw = clamp01(s->sw0);
     s->rt = s->RAIN + s->tosoil;
     s->rech = s->rt * s->sw;
@@ -179,7 +200,7 @@ static void step_fwd(int model, int has_betaet, float nz, const float *p, float 
     /* hbv.py:474-480 ; hbv_1_1p.py:473-480 */
     s->lpfc = LP * FC;
     s->q = s->SM2 / s->lpfc;
-    s->ef0 = has_betaet ? powf(s->q, p[HBVX_P_BETAET]) : s->q;
+    s->ef0 = has_betaet ? step_powf(s->q, p[HBVX_P_BETAET]) : s->q;
     s->ef = clamp01(s->ef0);
     s->pe = s->PET * s->ef;
     s->ET = fminf(s->SM2, s->pe);
@@ -488,12 +509,12 @@ static void hstep_fwd(float nz, const float *p, float ac, float elev, hstep_t *s
     s->s = fminf(fmaxf(s->r, 0.0f), (float)(1.0 - 0.01));
     s->fmin_ = FMIN * F0;
     s->oms = 1.0f - s->s;
-    s->pw = powf(s->oms, ALPHA);
+    s->pw = step_powf(s->oms, ALPHA);
     s->fcap = s->fmin_ + (F0 - s->fmin_) * s->pw;
     s->infil = fminf(s->W, s->fcap);
     s->ie0 = s->W - s->fcap;
     s->IE = fmaxf(s->ie0, 0.0f);
-    s->sw0 = powf(s->r, BETA);
+    s->sw0 = step_powf(s->r, BETA);
     s->sw = clamp01(s->sw0);
     s->rech = s->infil * s->sw;
     s->SM1 = s->SM + (s->infil - s->rech) * dt;
@@ -503,7 +524,7 @@ static void hstep_fwd(float nz, const float *p, float ac, float elev, hstep_t *s
     s->SM2 = s->SM1 - s->exc * dt;
     s->lpfc = LP * FC;
     s->q = s->SM2 / s->lpfc;
-    s->ef0 = powf(s->q, BE);
+    s->ef0 = step_powf(s->q, BE);
     s->ef = clamp01(s->ef0);
     s->pe = s->PET * s->ef;
     s->pedt = s->pe * dt;

@@ -203,7 +203,7 @@ def _zero_length_record(device):
     ny = n * M + 2
     p = torch.randn((1, B, ny), device=dev)
     x = torch.zeros((0, B, 3), device=dev)
-    srcs = [ParamSource(slot=i, lo=0.0, hi=1.0, tensor_idx=0, sta_off=i * M, sta_bs=ny) for i in range(n)]
+    srcs = [ParamSource(slot=i, lo=0.5, hi=1.0, tensor_idx=0, sta_off=i * M, sta_bs=ny) for i in range(n)]   # (positive bounds: check_desc)
     cfg = StepConfig(model=_abi.MODEL_HBV10, n_param=n, n_flux=11, T=0, t0=0, B=B, M=M, raw_sigmoid=True,
                      channels=(0, 1, 2), nearzero=1e-5, params=srcs)
     state_in = torch.rand((5, B, M), device=dev)

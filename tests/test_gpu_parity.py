@@ -247,7 +247,7 @@ def test_zero_except_matches_definition(rows, width, r0, r1, gw, keep, hip_backe
 @pytest.mark.parametrize("name,K", [("hbv_dyn2", 8), ("hbv_static_m16", 16), ("hbv11p_dyn_all", 4), ("hbv2_dyn3", 8),
                                     ("hbv_warmup_states", 4), ("hbv_m3_xgrad", 8), ("hbv_muwts", 8),
                                     ("hourly_dyn3", 16), ("hbv2_dyn3_routing", 4)])
-@pytest.mark.parametrize("how", ["block512", "block16", "lds"])
+@pytest.mark.parametrize("how", ["block512", "block16", "lds", "onchip"])
 def test_checkpointed_adjoint_on_gpu(name, K, how, hip_backend, monkeypatch):
     """HBVX_TRAJ_CKPT on the GPU against the reference's fixtures: the streaming forward writes the
     checkpoints where it has an instance (the delta-MG dynamic sets), the generic one-wave forward
@@ -259,6 +259,8 @@ def test_checkpointed_adjoint_on_gpu(name, K, how, hip_backend, monkeypatch):
         monkeypatch.setenv("HBVX_CKPT_BLOCK", "16")
     if how == "lds":          # the serial fallback that needs no scratch
         monkeypatch.setenv("HBVX_CKPT_BLOCKWISE", "0")
+    if how == "onchip":       # the streaming adjoint with its segment in LDS, where it has an instance (else the block path)
+        monkeypatch.setenv("HBVX_CKPT_ONCHIP", "1")
     ref = load_golden(name)
     res = run_case(name, "cuda:0")
     if "states" in res and res["states"].shape != ref["states"].shape:
@@ -291,6 +293,10 @@ LONG_ENVS = {
     "ckpt8-blocks": ({"HBVX_CKPT_DAYS": "8", "HBVX_CKPT_BLOCK": "128"}, {"ckpt-block:chunked"}),
     "ckpt4-lds": ({"HBVX_CKPT_DAYS": "4", "HBVX_CKPT_BLOCKWISE": "0"}, {"ckpt-lds"}),
     "ckpt16-stream": ({"HBVX_CKPT_DAYS": "16", "HBVX_STREAM_MIN": "1"}, None),
+    # the streaming adjoint that keeps its K-day segment in LDS (hbv_stream2_ckpt.h), forced onto these small grids
+    "ckpt4-onchip": ({"HBVX_CKPT_DAYS": "4", "HBVX_CKPT_ONCHIP": "1"}, {"ckpt-stream2"}),
+    "ckpt8-onchip": ({"HBVX_CKPT_DAYS": "8", "HBVX_CKPT_ONCHIP": "1"}, {"ckpt-stream2"}),
+    "ckpt16-onchip": ({"HBVX_CKPT_DAYS": "16", "HBVX_CKPT_ONCHIP": "1"}, {"ckpt-stream2"}),
 }
 
 
@@ -306,10 +312,15 @@ def test_long_golden_case_under_every_adjoint(name, env_id, hip_backend, monkeyp
     if "states" in res and res["states"].shape != ref["states"].shape:
         res["states"] = ref["states"]        # Hbv_2 under adjoint_checkpoint: the series is not kept
     compare(name, res, ref)
-    dyn = gc.CASES[name]["config"]["dynamic_params"][gc.CASES[name]["model"]]
-    has_stream2 = tuple(dyn) in ((), ("parBETA", "parBETAET"), ("parBETA", "parK0", "parBETAET"))
+    model = gc.CASES[name]["model"]
+    dyn = tuple(gc.CASES[name]["config"]["dynamic_params"][model])
+    # the compiled dynamic sets of hbv_stream2.h (launch_stream.hip::plan_stream): per model
+    has_stream2 = dyn == () or (dyn == ("parBETA", "parBETAET") and model in ("Hbv", "Hbv_1_1p")) or (
+        dyn == ("parBETA", "parK0", "parBETAET") and model == "Hbv_2")
     if want_bwd == {"stream2"} and not has_stream2:
         want_bwd = {"chunked", "stream"}     # no second-generation instance for this dynamic set
+    if want_bwd == {"ckpt-stream2"} and not has_stream2:
+        want_bwd = {"ckpt-block:chunked"}
     if want_bwd is not None:
         assert bwd in want_bwd, f"{name} [{env_id}]: adjoint ran {bwd!r} (forward {fwd!r}), meant {want_bwd}"
     print(f"{name} [{env_id}]: forward {fwd}, adjoint {bwd}")

@@ -94,3 +94,67 @@ def test_basin_range_covers_everything():
             spans = [basin_range(B, world, r) for r in range(world)]
             assert spans[0][0] == 0 and spans[-1][1] == B
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def test_shard_inputs_slices_by_name_and_refuses_what_it_cannot_cut():
+    """Named keys, not shapes: a [B, n] tensor with n == B is cut on axis 0 (round 4's `shape[1] == B` test cut it on
+    axis 1); the hourly model's three-tensor tuple / outlet_topo and unknown tensor keys raise instead of being
+    dropped or passed through whole."""
+    from hydrodl2_amd.sharding import shard_inputs
+    T, B, M = 6, 8, 8          # nmul == B on purpose
+    x = {"x_phy": torch.arange(T * B * 3.0).reshape(T, B, 3), "muwts": torch.arange(B * M * 1.0).reshape(B, M),
+         "ac_all": torch.arange(B * 1.0), "elev_all": torch.arange(B * 1.0) + 100, "note": "not a tensor"}
+    pd, pst = torch.arange(T * B * 2.0).reshape(T, B, 2), torch.arange(B * B * 1.0).reshape(B, B)
+    xs, (pd1, ps1) = shard_inputs(x, (pd, pst), 3, 1)         # ceil split: 3 + 3 + 2
+    assert torch.equal(xs["x_phy"], x["x_phy"][:, 3:6]) and torch.equal(xs["muwts"], x["muwts"][3:6])
+    assert torch.equal(xs["ac_all"], x["ac_all"][3:6]) and torch.equal(xs["elev_all"], x["elev_all"][3:6])
+    assert xs["note"] == "not a tensor"
+    assert torch.equal(pd1, pd[:, 3:6]) and torch.equal(ps1, pst[3:6]) and ps1.shape == (3, B)
+    xs, p1 = shard_inputs({"x_phy": x["x_phy"], "muwts": torch.ones(1, B, M)}, torch.zeros(T, B, 5), 3, 2)
+    assert xs["muwts"].shape == (1, 2, M) and p1.shape == (T, 2, 5)
+    with pytest.raises(NotImplementedError, match="3-tensor"):
+        shard_inputs(x, (pd, pst, torch.zeros(4, 3)), 2, 0)
+    with pytest.raises(NotImplementedError, match="outlet_topo"):
+        shard_inputs(dict(x, outlet_topo=torch.ones(2, B)), (pd, pst), 2, 0)
+    with pytest.raises(KeyError, match="obs"):
+        shard_inputs(dict(x, obs=torch.ones(T, B)), (pd, pst), 2, 0)
+    with pytest.raises(ValueError, match="ac_all"):
+        shard_inputs(dict(x, ac_all=torch.ones(B + 1)), (pd, pst), 2, 0)
+    with pytest.raises(ValueError, match="parameters"):
+        shard_inputs(x, torch.zeros(T, B + 1, 4), 2, 0)
+
+
+def _bucket_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hydrodl2_amd.sharding import AsyncBucket
+    n = 1000
+    a, b, c = (torch.full((n,), float(v + rank)) for v in (1, 10, 100))
+    A, Bk, Ck = AsyncBucket([a]), AsyncBucket([b]), AsyncBucket([c])
+    A.start()
+    Bk.start()
+    A.finish()
+    Ck.start()            # same size as B, B still in flight: must not land in B's staging buffer
+    slots = (Bk.slot, Ck.slot)
+    Bk.finish()
+    Ck.finish()
+    if rank == 0:
+        q.put((a[0].item(), b[0].item(), c[0].item(), slots, sorted(AsyncBucket._busy)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_async_buckets_in_flight_never_share_a_staging_buffer():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    a, b, c, slots, busy = q.get(timeout=120)
+    for p_ in procs:
+        p_.join(timeout=60)
+        assert p_.exitcode == 0
+    assert (a, b, c) == (1 + 2, 10 + 11, 100 + 101)
+    assert slots[0] != slots[1] and busy == []
