@@ -34,10 +34,34 @@ namespace hbvx {
 template <int SC> struct StreamDyn { static constexpr int nd = 0; };
 template <> struct StreamDyn<1> { static constexpr int nd = 2; };
 template <> struct StreamDyn<2> { static constexpr int nd = 3; };
+// SC == 3: ANY set of up to three dynamic parameters, as a wave-uniform run-time slot list (StreamArgs.nd / .dslot,
+// slots in parameter order).  The parameter vector stays in registers: it is only ever indexed by constants, a
+// run-time slot goes through a compare chain on a scalar (s2_put / s2_get: ~3 scalar + 1 vector instruction per
+// candidate slot).  What the compile-time sets save over this form is exactly those chains (~50 vector instructions
+// per day and parameter); what this form replaces is the first-generation kernel (hbv_stream.h): 5.1 ms where a
+// compiled set runs 1.6 ms at 4 096 wavefronts.
+template <> struct StreamDyn<3> { static constexpr int nd = 3; };
 template <int SC>
 __host__ __device__ constexpr int stream_slot(int k)
 {
     return SC == 1 ? (k == 0 ? P_BETA : P_BETAET) : (k == 0 ? P_BETA : (k == 1 ? P_K0 : P_BETAET));
+}
+
+template <int NP>
+__device__ __forceinline__ void s2_put(float *p, int slot, float v)
+{
+#pragma unroll
+    for (int i = 0; i < NP; i++)
+        if (slot == i) p[i] = v;
+}
+template <int NP>
+__device__ __forceinline__ float s2_get(const float *p, int slot)
+{
+    float r = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NP; i++)
+        if (slot == i) r = p[i];
+    return r;
 }
 
 #ifndef STREAM2_D
@@ -323,14 +347,17 @@ __global__ void __launch_bounds__(MW * 64) FWPE k_fwd_stream2(const StreamArgs A
     // per lane: range and offset of the day's value, or (0, static value) where dy_drop masked the basin --
     // the reference's `dyn * (1 - mask) + static * mask` (hbv.py:246), no lane mask to keep in SGPRs
     float dlo[ND > 0 ? ND : 1], dsc[ND > 0 ? ND : 1];
+    const int nd = SC == 3 ? A.nd : ND;                 // SC == 3: a run-time list of nd <= 3 slots (wave-uniform)
+    int dsl[ND > 0 ? ND : 1];
 #pragma unroll
     for (int k = 0; k < ND; k++) {
-        const hbvx_param_src &ps = d.p[stream_slot<SC>(k)];
-        dbase[k] = ps.dyn;
+        dsl[k] = SC == 3 ? A.dslot[k < nd ? k : 0] : stream_slot<SC>(k);
+        const hbvx_param_src &ps = d.p[dsl[k]];
+        dbase[k] = ps.dyn ? ps.dyn : d.x;
         dvo[k] = (unsigned)((L.b * ps.dyn_b_stride + L.j) * 4);
         dts[k] = ps.dyn_t_stride;
         const bool use = !(ps.drop && ps.drop[L.b]);
-        dlo[k] = use ? ps.lo : p[stream_slot<SC>(k)];
+        dlo[k] = use ? ps.lo : (SC == 3 ? s2_get<NP>(p, dsl[k]) : p[stream_slot<SC>(k)]);
         dsc[k] = use ? ps.hi - ps.lo : 0.0f;
     }
     // outputs
@@ -381,20 +408,27 @@ __global__ void __launch_bounds__(MW * 64) FWPE k_fwd_stream2(const StreamArgs A
             fx[j][2] = S2Buf::ld(rx, xvo, so + ce * 4);
         }
 #pragma unroll
-        for (int k = 0; k < ND; k++) dv[j][k] = S2Buf::ld(S2Buf::rsrc(dbase[k] + tc * dts[k]), dvo[k], 0);
+        for (int k = 0; k < ND; k++)
+            if (SC != 3 || k < nd) dv[j][k] = S2Buf::ld(S2Buf::rsrc(dbase[k] + tc * dts[k]), dvo[k], 0);
     };
+    // XVEC: a basin's three forcing values are adjacent and arrive as one 12-byte load; `ident`: already in
+    // (prcp, tmean, pet) order, else three wave-uniform picks put them there (config key `variables`)
+    const bool ident = cp == 0 && ct == 1 && ce == 2;
     auto day = [&](int t, int j) {
         Step<MODEL, BETAET> s;
         if (XVEC) {
             const s2_f3 v = {fx[j][0], fx[j][1], fx[j][2]};
-            s.P = v.x; s.Tf = v.y; s.PET = v.z;   // XVEC: channels in (prcp, tmean, pet) order
+            if (ident) { s.P = v.x; s.Tf = v.y; s.PET = v.z; }
+            else { s.P = s2_pick(v, cp); s.Tf = s2_pick(v, ct); s.PET = s2_pick(v, ce); }
         } else {
             s.P = fx[j][0]; s.Tf = fx[j][1]; s.PET = fx[j][2];
         }
 #pragma unroll
         for (int k = 0; k < ND; k++) {
+            if (SC == 3 && k >= nd) continue;
             const float u = raw ? sigmoid_dyn_(dv[j][k]) : dv[j][k];
-            p[stream_slot<SC>(k)] = u * dsc[k] + dlo[k];
+            if (SC == 3) s2_put<NP>(p, dsl[k], u * dsc[k] + dlo[k]);
+            else p[stream_slot<SC>(k)] = u * dsc[k] + dlo[k];
         }
         s.SP = st[0]; s.MW = st[1]; s.SM = st[2]; s.SUZ = st[3]; s.SLZ = st[4];
         s.template fwd<false, true>(p, nz, ac, elev, 0.0f, 0.0f);
@@ -628,16 +662,19 @@ k_bwd_stream2(const StreamBwdArgs A)
     // the adjoint is short of VGPRs, not SGPRs: range / offset stay wave-uniform, the dy_drop mask a lane mask
     float dlo[ND > 0 ? ND : 1], dsc[ND > 0 ? ND : 1], dsta[ND > 0 ? ND : 1];
     bool duse[ND > 0 ? ND : 1];
+    const int nd = SC == 3 ? A.nd : ND;                 // SC == 3: a run-time list of nd <= 3 slots (wave-uniform)
+    int dsl[ND > 0 ? ND : 1];
 #pragma unroll
     for (int k = 0; k < ND; k++) {
-        const int sl = stream_slot<SC>(k);
+        const int sl = SC == 3 ? A.dslot[k < nd ? k : 0] : stream_slot<SC>(k);
+        dsl[k] = sl;
         const hbvx_param_src &ps = d.p[sl];
-        dbase[k] = ps.dyn;
+        dbase[k] = ps.dyn ? ps.dyn : d.x;
         dvo[k] = (unsigned)((L.b * ps.dyn_b_stride + L.j) * 4);
         dts[k] = ps.dyn_t_stride;
         dlo[k] = ps.lo;
         dsc[k] = ps.hi - ps.lo;
-        dsta[k] = p[sl];
+        dsta[k] = SC == 3 ? s2_get<NP>(p, sl) : p[stream_slot<SC>(k)];
         duse[k] = !(ps.drop && ps.drop[L.b]);
         const bool dg = io.g[sl].dyn != nullptr;
         gdbase[k] = dg ? io.g[sl].dyn : const_cast<float *>(d.x);
@@ -693,13 +730,16 @@ k_bwd_stream2(const StreamBwdArgs A)
         }
         I.add4 = has_g4;
 #pragma unroll
-        for (int k = 0; k < ND; k++) I.dv[k] = S2Buf::ld(S2Buf::rsrc(dbase[k] + tc * dts[k]), dvo[k], 0);
+        for (int k = 0; k < ND; k++)
+            if (SC != 3 || k < nd) I.dv[k] = S2Buf::ld(S2Buf::rsrc(dbase[k] + tc * dts[k]), dvo[k], 0);
     };
+    const bool ident = cp == 0 && ct == 1 && ce == 2;   // (see the forward)
     auto day = [&](int t, const In &I) {
         Step<MODEL, BETAET> s;
         if (XVEC) {
             const s2_f3 v = {I.fx[0], I.fx[1], I.fx[2]};
-            s.P = v.x; s.Tf = v.y; s.PET = v.z;   // XVEC: channels in (prcp, tmean, pet) order
+            if (ident) { s.P = v.x; s.Tf = v.y; s.PET = v.z; }
+            else { s.P = s2_pick(v, cp); s.Tf = s2_pick(v, ct); s.PET = s2_pick(v, ce); }
         } else {
             s.P = I.fx[0]; s.Tf = I.fx[1]; s.PET = I.fx[2];
         }
@@ -707,8 +747,12 @@ k_bwd_stream2(const StreamBwdArgs A)
         float ud[ND > 0 ? ND : 1];
 #pragma unroll
         for (int k = 0; k < ND; k++) {
+            ud[k] = 0.0f;
+            if (SC == 3 && k >= nd) continue;
             ud[k] = raw ? sigmoid_dyn_(I.dv[k]) : I.dv[k];
-            p[stream_slot<SC>(k)] = duse[k] ? ud[k] * dsc[k] + dlo[k] : dsta[k];
+            const float pv = duse[k] ? ud[k] * dsc[k] + dlo[k] : dsta[k];
+            if (SC == 3) s2_put<NP>(p, dsl[k], pv);
+            else p[stream_slot<SC>(k)] = pv;
         }
         s.template fwd<SAVE_POW>(p, nz, ac, elev, I.ax[0], I.ax[1]);
         FluxGrad g;
@@ -727,6 +771,21 @@ k_bwd_stream2(const StreamBwdArgs A)
         s.bwd(p, nz, g, a, gp, gx);
         // static slots: physical-space sums (the range factor and sigmoid' are applied once, at the
         // end); a dynamic slot contributes to the static row only where dy_drop masked the basin
+        if constexpr (SC == 3) {
+            // run-time slots: the day's gradient of each listed slot leaves through its row (and is taken out of the
+            // static sum where the lane's basin uses the dynamic value), then every slot adds to its static sum
+#pragma unroll
+            for (int k = 0; k < ND; k++) {
+                if (k >= nd) continue;
+                const float gpk = s2_get<NP>(gp, dsl[k]);
+                const float gu = gpk * dsc[k];
+                const float gr = raw ? gu * (ud[k] * (1.0f - ud[k])) : gu;
+                S2Buf::st(S2Buf::rsrc(gdbase[k] + t * gdts[k]), gdvo[k], 0, duse[k] ? gr : 0.0f);
+                s2_put<NP>(gp, dsl[k], duse[k] ? 0.0f : gpk);
+            }
+#pragma unroll
+            for (int i = 0; i < NP; i++) S2_ACC_ADD(i, gp[i]);
+        } else {
 #pragma unroll
         for (int i = 0; i < NP; i++) {
             bool dyn_slot = false;
@@ -742,6 +801,7 @@ k_bwd_stream2(const StreamBwdArgs A)
                 S2Buf::st(S2Buf::rsrc(gdbase[kd] + t * gdts[kd]), gdvo[kd], 0, duse[kd] ? gr : 0.0f);
                 S2_ACC_ADD(i, duse[kd] ? 0.0f : gp[i]);
             }
+        }
         }
         if (has_gx) {
             const float act = L.active ? 1.0f : 0.0f;
@@ -798,7 +858,8 @@ k_bwd_stream2(const StreamBwdArgs A)
                 else if (k < 4 && has_g4) S2Buf::ld_lds<4>(rg4, l_gf[k], gvo, sg + (unsigned)k * fT);
             }
 #pragma unroll
-            for (int k = 0; k < ND; k++) S2Buf::ld_lds<4>(S2Buf::rsrc(dbase[k] + tc * dts[k]), l_dv[k], dvo[k], 0);
+            for (int k = 0; k < ND; k++)
+                if (SC != 3 || k < nd) S2Buf::ld_lds<4>(S2Buf::rsrc(dbase[k] + tc * dts[k]), l_dv[k], dvo[k], 0);
         };
         auto pull = [&](int t, In &I) {
             if (XVEC) {
@@ -830,7 +891,7 @@ k_bwd_stream2(const StreamBwdArgs A)
             }
             I.add4 = false;   // (this form has already summed the two sources above)
 #pragma unroll
-            for (int k = 0; k < ND; k++) I.dv[k] = l_dv[k][ln];
+            for (int k = 0; k < ND; k++) I.dv[k] = (SC != 3 || k < nd) ? l_dv[k][ln] : 0.0f;
         };
         arm(T - 1);
         for (int t = T - 1; t >= 0; t--) {

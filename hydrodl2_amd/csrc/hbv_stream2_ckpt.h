@@ -98,16 +98,21 @@ k_bwd_stream2_ckpt(const StreamBwdArgs A, const int K)
     unsigned dvo[NDA], gdvo[NDA];
     float dlo[NDA], dsc[NDA], dsta[NDA];
     bool duse[NDA];
+    const int nd = SC == 3 ? A.nd : ND;                 // SC == 3: a run-time list of nd <= 3 slots (hbv_stream2.h)
+    int dsl[NDA];
+    const int cp = d.ch_prcp, ct = d.ch_tmean, ce = d.ch_pet;
+    const bool ident = cp == 0 && ct == 1 && ce == 2;   // forcing channels already in (prcp, tmean, pet) order
 #pragma unroll
     for (int k = 0; k < ND; k++) {
-        const int sl = stream_slot<SC>(k);
+        const int sl = SC == 3 ? A.dslot[k < nd ? k : 0] : stream_slot<SC>(k);
+        dsl[k] = sl;
         const hbvx_param_src &ps = d.p[sl];
-        dbase[k] = ps.dyn;
+        dbase[k] = ps.dyn ? ps.dyn : d.x;
         dvo[k] = (unsigned)((L.b * ps.dyn_b_stride + L.j) * 4);
         dts[k] = ps.dyn_t_stride;
         dlo[k] = ps.lo;
         dsc[k] = ps.hi - ps.lo;
-        dsta[k] = p[sl];
+        dsta[k] = SC == 3 ? s2_get<NP>(p, sl) : p[stream_slot<SC>(k)];
         duse[k] = !(ps.drop && ps.drop[L.b]);
         const bool dg = io.g[sl].dyn != nullptr;
         gdbase[k] = dg ? io.g[sl].dyn : const_cast<float *>(d.x);
@@ -126,9 +131,10 @@ k_bwd_stream2_ckpt(const StreamBwdArgs A, const int K)
     struct RIn { s2_f3 x; float dv[NDA]; };
     struct BIn { s2_f3 x; float gf[NG], g4[4]; };
     auto issueR = [&](int t, RIn &I) {
-        I.x = S2Buf::ld3(rx, xvo, (unsigned)t * xts);      // (the plan admits (prcp, tmean, pet) adjacent only)
+        I.x = S2Buf::ld3(rx, xvo, (unsigned)t * xts);      // (the plan admits three adjacent channels only)
 #pragma unroll
-        for (int k = 0; k < ND; k++) I.dv[k] = S2Buf::ld(S2Buf::rsrc(dbase[k] + (int64_t)t * dts[k]), dvo[k], 0);
+        for (int k = 0; k < ND; k++)
+            if (SC != 3 || k < nd) I.dv[k] = S2Buf::ld(S2Buf::rsrc(dbase[k] + (int64_t)t * dts[k]), dvo[k], 0);
     };
     auto issueB = [&](int t, BIn &I) {
         I.x = S2Buf::ld3(rx, xvo, (unsigned)t * xts);
@@ -149,14 +155,19 @@ k_bwd_stream2_ckpt(const StreamBwdArgs A, const int K)
 
     auto day = [&](int t, int l, const BIn &I) {
         Step<MODEL, BETAET> s;
-        s.P = I.x.x; s.Tf = I.x.y; s.PET = I.x.z;
+        if (ident) { s.P = I.x.x; s.Tf = I.x.y; s.PET = I.x.z; }
+        else { s.P = s2_pick(I.x, cp); s.Tf = s2_pick(I.x, ct); s.PET = s2_pick(I.x, ce); }
         const float *row = seg_st + l * 5 * 64;
         s.SP = row[0]; s.MW = row[64]; s.SM = row[128]; s.SUZ = row[192]; s.SLZ = row[256];
         float ud[NDA];
 #pragma unroll
         for (int k = 0; k < ND; k++) {
+            ud[k] = 0.0f;
+            if (SC == 3 && k >= nd) continue;
             ud[k] = seg_ud[(l * ND + k) * 64];
-            p[stream_slot<SC>(k)] = duse[k] ? ud[k] * dsc[k] + dlo[k] : dsta[k];
+            const float pv = duse[k] ? ud[k] * dsc[k] + dlo[k] : dsta[k];
+            if (SC == 3) s2_put<NP>(p, dsl[k], pv);
+            else p[stream_slot<SC>(k)] = pv;
         }
         s.template fwd<false>(p, nz, ac, elev, 0.0f, 0.0f);
         FluxGrad g;
@@ -173,6 +184,19 @@ k_bwd_stream2_ckpt(const StreamBwdArgs A, const int K)
 #pragma unroll
         for (int i = 0; i < NPARAM_MAX; i++) gp[i] = 0.0f;
         s.bwd(p, nz, g, a, gp, gx);
+        if constexpr (SC == 3) {
+#pragma unroll
+            for (int k = 0; k < ND; k++) {
+                if (k >= nd) continue;
+                const float gpk = s2_get<NP>(gp, dsl[k]);
+                const float gu = gpk * dsc[k];
+                const float gr = raw ? gu * (ud[k] * (1.0f - ud[k])) : gu;
+                S2Buf::st(S2Buf::rsrc(gdbase[k] + (int64_t)t * gdts[k]), gdvo[k], 0, duse[k] ? gr : 0.0f);
+                s2_put<NP>(gp, dsl[k], duse[k] ? 0.0f : gpk);
+            }
+#pragma unroll
+            for (int i = 0; i < NP; i++) acc[i * 64] += gp[i];
+        } else {
 #pragma unroll
         for (int i = 0; i < NP; i++) {
             bool dyn_slot = false;
@@ -189,14 +213,15 @@ k_bwd_stream2_ckpt(const StreamBwdArgs A, const int K)
                 acc[i * 64] += duse[kd] ? 0.0f : gp[i];
             }
         }
+        }
         if (has_gx) {
             const float act = L.active ? 1.0f : 0.0f;
             float gs[3] = {gx[0] * act, gx[1] * act, gx[2] * act};
             ens_sum_dpp<3>(gs, lgMp);
             const unsigned so = (unsigned)t * xts;
-            S2Buf::st(rgx, gxvo, so, gs[0]);
-            S2Buf::st(rgx, gxvo, so + 4, gs[1]);
-            S2Buf::st(rgx, gxvo, so + 8, gs[2]);
+            S2Buf::st(rgx, gxvo, so + cp * 4, gs[0]);
+            S2Buf::st(rgx, gxvo, so + ct * 4, gs[1]);
+            S2Buf::st(rgx, gxvo, so + ce * 4, gs[2]);
         }
     };
 
@@ -222,13 +247,17 @@ k_bwd_stream2_ckpt(const StreamBwdArgs A, const int K)
             for (int k = 0; k < 5; k++) row[k * 64] = st[k];
 #pragma unroll
             for (int k = 0; k < ND; k++) {
+                if (SC == 3 && k >= nd) continue;
                 const float u = raw ? sigmoid_dyn_(rc.dv[k]) : rc.dv[k];
                 seg_ud[(l * ND + k) * 64] = u;
-                p[stream_slot<SC>(k)] = duse[k] ? u * dsc[k] + dlo[k] : dsta[k];
+                const float pv = duse[k] ? u * dsc[k] + dlo[k] : dsta[k];
+                if (SC == 3) s2_put<NP>(p, dsl[k], pv);
+                else p[stream_slot<SC>(k)] = pv;
             }
             if (t + 1 < t1) {
                 Step<MODEL, BETAET> s;
-                s.P = rc.x.x; s.Tf = rc.x.y; s.PET = rc.x.z;
+                if (ident) { s.P = rc.x.x; s.Tf = rc.x.y; s.PET = rc.x.z; }
+                else { s.P = s2_pick(rc.x, cp); s.Tf = s2_pick(rc.x, ct); s.PET = s2_pick(rc.x, ce); }
                 s.SP = st[0]; s.MW = st[1]; s.SM = st[2]; s.SUZ = st[3]; s.SLZ = st[4];
                 s.template fwd<false, true>(p, nz, ac, elev, 0.0f, 0.0f);
                 st[0] = s.SP3; st[1] = s.MW3; st[2] = s.SM4; st[3] = s.SUZ4; st[4] = s.SLZ2;

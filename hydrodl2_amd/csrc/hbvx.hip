@@ -1045,17 +1045,32 @@ __global__ void __launch_bounds__(256) k_zero_nt(zero_f4 *__restrict__ p, uint64
         __builtin_nontemporal_store(z, &p[i]);
 }
 
+// Small and ragged pieces go through a kernel too, never hipMemsetAsync: captured into a HIP graph (graph=True), the
+// memset node of a 1 944-byte static-parameter gradient replayed as a no-op on this stack -- the adjoint then added
+// its sums to stale memory (round 5: tests/test_graphed.py, Hbv_2's [B, ws] gradient).  A kernel node replays.
+__global__ void __launch_bounds__(256) k_zero_bytes(unsigned char *__restrict__ p, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0;
+}
+static hipError_t zero_bytes(void *ptr, uint64_t n, hipStream_t st)
+{
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(k_zero_bytes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (unsigned char *)ptr, n);
+    return hipGetLastError();
+}
+
 extern "C" int hbvx_zero(void *ptr, uint64_t bytes, void *stream)
 {
     if (!ptr && bytes) return fail(HBVX_E_NULL, "hbvx_zero: buffer is NULL");
     hipStream_t st = (hipStream_t)stream;
     const uint64_t head = ((uintptr_t)ptr & 15) ? 16 - ((uintptr_t)ptr & 15) : 0;
     if (bytes < 4096 || head >= bytes) {
-        hipError_t e = hipMemsetAsync(ptr, 0, bytes, st);
+        hipError_t e = zero_bytes(ptr, bytes, st);
         return e == hipSuccess ? 0 : hip_fail(e, "hbvx_zero");
     }
     hipError_t e = hipSuccess;
-    if (head) e = hipMemsetAsync(ptr, 0, head, st);
+    if (head) e = zero_bytes(ptr, head, st);
     const uint64_t n16 = (bytes - head) / 16, tail = (bytes - head) - n16 * 16;
     // one 16-byte store per thread: on MI355X 6.6 TB/s against 5.3 for a grid-stride loop on a few thousand
     // workgroups (3.8 GB: 0.58 ms against 0.72 ms for torch's fill)
@@ -1063,7 +1078,7 @@ extern "C" int hbvx_zero(void *ptr, uint64_t bytes, void *stream)
     const int blocks = (int)(want < 0x7fffffffull ? want : 0x7fffffffull);
     hipLaunchKernelGGL(k_zero_nt, dim3(blocks), dim3(256), 0, st, (zero_f4 *)((char *)ptr + head), n16);
     if (e == hipSuccess) e = hipGetLastError();
-    if (e == hipSuccess && tail) e = hipMemsetAsync((char *)ptr + head + n16 * 16, 0, tail, st);
+    if (e == hipSuccess && tail) e = zero_bytes((char *)ptr + head + n16 * 16, tail, st);
     return e == hipSuccess ? 0 : hip_fail(e, "hbvx_zero");
 }
 

@@ -15,7 +15,7 @@ struct StreamPlan {
     int lg;
     int64_t wgs;    // wavefronts of state
     int nd;
-    int sc;         // compile-time dynamic set of hbv_stream2.h (0 none, 1, 2) or -1: first generation only
+    int sc;         // dynamic set of hbv_stream2.h: 0 none, 1 / 2 compiled sets, 3 run-time list of <= 3 slots; -1: first generation only
     bool xvec;      // three adjacent forcing channels
     bool gen1_ok;   // first generation: whole dynamic tensors within 32-bit offsets
     bool rows_ok;   // row trajectory: every offset fits 32 bits
@@ -51,10 +51,13 @@ StreamPlan plan_stream(const hbvx_desc *d)
          : (mask == ((1u << P_BETA) | (1u << P_BETAET)) && be &&
             (d->model == HBVX_MODEL_HBV10 || d->model == HBVX_MODEL_HBV11P)) ? 1
          : (mask == ((1u << P_BETA) | (1u << P_K0) | (1u << P_BETAET)) &&
-            (d->model == HBVX_MODEL_HBV20 || d->model == HBVX_MODEL_HOURLY)) ? 2 : -1;
+            (d->model == HBVX_MODEL_HBV20 || d->model == HBVX_MODEL_HOURLY)) ? 2 : 3;   // (P.nd <= 3 is part of P.ok)
+    if (env_int("HBVX_STREAM_SLOTLIST", 0) && P.sc > 0) P.sc = 3;   // tests: the run-time list on a compiled set
     const int c0 = d->ch_prcp, c1 = d->ch_tmean, c2 = d->ch_pet;
-    // second generation: the forcing channels in (prcp, tmean, pet) order, a basin's three values adjacent
-    P.xvec = c0 == 0 && c1 == 1 && c2 == 2 && d->x_b_stride >= 3;
+    // second generation: a basin's three forcing values adjacent (one 12-byte load), the channels any permutation of
+    // {0, 1, 2} (the kernels pick; config key `variables`)
+    P.xvec = (unsigned)c0 < 3u && (unsigned)c1 < 3u && (unsigned)c2 < 3u && c0 != c1 && c0 != c2 && c1 != c2 &&
+             d->x_b_stride >= 3;
     if (!P.xvec) P.sc = -1;
     P.rows_ok = 5 * (int64_t)(d->T + 1) * N * 4 < lim;
     P.packed_ok = N * 20 < lim;
@@ -159,14 +162,19 @@ void go_bwd2c(bool gfull, int K, const StreamBwdArgs &sa, dim3 grid, hipStream_t
     do {                                                                                             \
         const int m_ = (d)->model;                                                                   \
         const bool be_ = (d)->n_param == 13;                                                         \
-        if (m_ == HBVX_MODEL_HBV10 && !be_) GO<MODEL_HBV10, false, 0>(__VA_ARGS__);                  \
+        if (m_ == HBVX_MODEL_HBV10 && !be_ && (sc) == 3) GO<MODEL_HBV10, false, 3>(__VA_ARGS__);     \
+        else if (m_ == HBVX_MODEL_HBV10 && !be_) GO<MODEL_HBV10, false, 0>(__VA_ARGS__);             \
         else if (m_ == HBVX_MODEL_HBV10 && (sc) == 0) GO<MODEL_HBV10, true, 0>(__VA_ARGS__);         \
+        else if (m_ == HBVX_MODEL_HBV10 && (sc) == 3) GO<MODEL_HBV10, true, 3>(__VA_ARGS__);         \
         else if (m_ == HBVX_MODEL_HBV10) GO<MODEL_HBV10, true, 1>(__VA_ARGS__);                      \
         else if (m_ == HBVX_MODEL_HBV11P && (sc) == 0) GO<MODEL_HBV11P, true, 0>(__VA_ARGS__);       \
+        else if (m_ == HBVX_MODEL_HBV11P && (sc) == 3) GO<MODEL_HBV11P, true, 3>(__VA_ARGS__);       \
         else if (m_ == HBVX_MODEL_HBV11P) GO<MODEL_HBV11P, true, 1>(__VA_ARGS__);                    \
         else if (m_ == HBVX_MODEL_HBV20 && (sc) == 0) GO<MODEL_HBV20, true, 0>(__VA_ARGS__);         \
+        else if (m_ == HBVX_MODEL_HBV20 && (sc) == 3) GO<MODEL_HBV20, true, 3>(__VA_ARGS__);         \
         else if (m_ == HBVX_MODEL_HBV20) GO<MODEL_HBV20, true, 2>(__VA_ARGS__);                      \
         else if ((sc) == 0) GO<MODEL_HOURLY, true, 0>(__VA_ARGS__);                                  \
+        else if ((sc) == 3) GO<MODEL_HOURLY, true, 3>(__VA_ARGS__);                                  \
         else GO<MODEL_HOURLY, true, 2>(__VA_ARGS__);                                                 \
     } while (0)
 

@@ -53,7 +53,16 @@ class Hbv_2(HbvModule):
     def get_states(self):
         return self._state_cache  # hbv_2.py:142-150
 
+    _graph_state_attrs = ('_state_cache',)
+
     def forward(self, x_dict: dict[str, torch.Tensor], parameters):
+        """Reference: hbv_2.py:324-390.  `graph=True`: the call's launches replayed as HIP graphs (graphed.py)."""
+        if self.graph and x_dict['x_phy'].is_cuda:
+            from hydrodl2_amd.graphed import graphed_forward
+            return graphed_forward(self, x_dict, parameters)
+        return self._forward_eager(x_dict, parameters)
+
+    def _forward_eager(self, x_dict: dict[str, torch.Tensor], parameters):
         """Reference: hbv_2.py:324-390 + `_PBM` :392-670."""
         x = x_dict['x_phy']
         ac = x_dict['ac_all'].to(torch.float32).contiguous()

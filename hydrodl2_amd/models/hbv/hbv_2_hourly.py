@@ -44,6 +44,7 @@ class Hbv_2_hourly(HbvModule):
                                        'route_tau': [0, 48.0]}  # :120-124
         self._qs_buffer = []
         self._max_history = 100
+        self._topo_cache, self._eye_cache = {}, {}
         super().__init__(config, device)
         self.routing_parameter_bounds = {'route_a': [0, 5.0], 'route_b': [0, 12.0]}  # :116-119
         self._state_cache = None
@@ -95,7 +96,32 @@ class Hbv_2_hourly(HbvModule):
                                         sta_off=i * M, sta_bs=ws))
         return srcs
 
+    _graph_state_attrs = ('_state_cache',)
+    _graph_structural = ('outlet_topo', 'areas')     # their content shapes the launch sequence (the pair lists)
+
     def forward(self, x_dict: dict[str, torch.Tensor], parameters):
+        """Reference: hbv_2_hourly.py:376-449.  `graph=True`: HIP-graph replay (graphed.py)."""
+        if self.graph and x_dict['x_phy'].is_cuda:
+            from hydrodl2_amd.graphed import graphed_forward
+            return graphed_forward(self, x_dict, parameters)
+        return self._forward_eager(x_dict, parameters)
+
+    def _topology(self, tag, outlet_topo, areas, T, lag, bounds):
+        """GageTopology of (outlet_topo, areas), built once per pair of tensor objects + versions: building it
+        costs a `nonzero` (a host synchronisation) and a handful of small kernels per call, and cannot be captured
+        into a graph.  Keyed by identity and version counter; weak references guard against a recycled id()."""
+        import weakref
+        key = (tag, id(outlet_topo), outlet_topo._version, id(areas), areas._version, T, lag)
+        hit = self._topo_cache.get(key)
+        if hit is not None and hit[0]() is outlet_topo and hit[1]() is areas:
+            return hit[2]
+        topo = GageTopology.from_outlet_topo(outlet_topo, areas, T, lag, bounds)
+        if len(self._topo_cache) > 8:
+            self._topo_cache.clear()
+        self._topo_cache[key] = (weakref.ref(outlet_topo), weakref.ref(areas), topo)
+        return topo
+
+    def _forward_eager(self, x_dict: dict[str, torch.Tensor], parameters):
         """Reference: hbv_2_hourly.py:376-449."""
         x = x_dict['x_phy']
         self.muwts = x_dict.get('muwts', None)
@@ -136,9 +162,11 @@ class Hbv_2_hourly(HbvModule):
         Qs = flux[_abi.F_QSIM][:, :, 0]                                   # [T,B] rate per day
         if self.routing:                                                  # :684-700
             rb_ = self.routing_parameter_bounds
-            topo = GageTopology.from_outlet_topo(
-                torch.eye(ngrid, device=x.device), torch.ones(ngrid, device=x.device), T, False,
-                (rb_['route_a'], rb_['route_b'], (0.0, 0.0)))
+            eye = self._eye_cache.get((ngrid, str(x.device)))
+            if eye is None:
+                eye = self._eye_cache[(ngrid, str(x.device))] = (torch.eye(ngrid, device=x.device),
+                                                                 torch.ones(ngrid, device=x.device))
+            topo = self._topology('self', eye[0], eye[1], T, False, (rb_['route_a'], rb_['route_b'], (0.0, 0.0)))
             dp = torch.cat([p_route, torch.zeros_like(p_route[:, :1])], dim=1)
             Qs = GageRoute.apply(topo, Qs, dp)
         Qs = (Qs * self.dt).unsqueeze(-1)                                 # :741
@@ -162,7 +190,6 @@ class Hbv_2_hourly(HbvModule):
         hydrograph of 72 taps shifted by route_tau, summed per gage and normalised by the upstream
         area (hbv_2_hourly.py:800-855).  Qs [T,U,1] -> [T,G,1]."""
         b = self.distr_parameter_bounds
-        topo = GageTopology.from_outlet_topo(
-            outlet_topo, areas, int(Qs.shape[0]), self.lag_uh,
-            (b['route_a'], b['route_b'], b['route_tau']))
+        topo = self._topology('gages', outlet_topo, areas, int(Qs.shape[0]), self.lag_uh,
+                              (b['route_a'], b['route_b'], b['route_tau']))
         return GageRoute.apply(topo, Qs[:, :, 0], p_distr).unsqueeze(-1)

@@ -57,6 +57,7 @@ class HbvAdj(torch.nn.Module):
         # AdjStaged; the three blocks run as a wave pipeline).  'joint': the reference's modified Newton on all five
         # unknowns (hbv_adj.py:507-581), kept as the policy cross-check; newton_stop applies to it only.
         self.newton_solver = 'staged'
+        self.graph = False           # replay the call's launches as HIP graphs (hydrodl2_amd/graphed.py); opt-in
         self.parameter_bounds = {
             'parBETA': [1.0, 6.0], 'parFC': [50, 1000], 'parK0': [0.05, 0.9],
             'parK1': [0.01, 0.5], 'parK2': [0.001, 0.2], 'parLP': [0.2, 1],
@@ -80,6 +81,7 @@ class HbvAdj(torch.nn.Module):
             self.newton_gtol = config.get('newton_gtol', self.newton_gtol)
             self.newton_max_iter = config.get('newton_max_iter', self.newton_max_iter)
             self.newton_stop = config.get('newton_stop', self.newton_stop)
+            self.graph = bool(config.get('graph', self.graph))
             if self.newton_stop not in ('lane', 'global'):
                 raise ValueError("newton_stop must be 'lane' or 'global'")
             # The solver never follows from the mere PRESENCE of another key: 'staged' unless asked otherwise.  The one
@@ -106,9 +108,25 @@ class HbvAdj(torch.nn.Module):
         """hbv_adj.py:182-189: one Bernoulli(dy_drop) per LANE of the member-major batch
         (index j*B + b); returned in this package's basin-major lane order (b*M + j)."""
         pmat = torch.ones([1, ngrid * self.nmul]) * self.dy_drop
-        drmask = torch.bernoulli(pmat)
+        drmask = torch.bernoulli(pmat)      # drawn even for dy_drop == 0: same consumption of the host generator
+        if self.dy_drop <= 0:
+            return None                     # nothing dropped: no mask, no host-to-device copy per call
         m = drmask.reshape(self.nmul, ngrid).t().contiguous().reshape(-1)
         return m.to(torch.uint8).to(device)
+
+    def _advance_rng(self, ngrid: int) -> None:
+        """Consume the CPU generator as one call of forward() does (one draw per dynamic parameter)."""
+        for _ in self.dynamic_params:
+            self._lane_drop_mask(ngrid, torch.device('cpu'))
+
+    def _settings_key(self):
+        return (self.nmul, tuple(self.parameter_bounds), tuple(self.dynamic_params), bool(self.routing),
+                tuple(self.variables), float(self.nearzero), int(self.warm_up), float(self.dy_drop),
+                float(self.newton_gtol), int(self.newton_max_iter), self.newton_stop, self.newton_solver,
+                tuple(map(tuple, self.parameter_bounds.values())),
+                tuple(map(tuple, self.routing_parameter_bounds.values())))
+
+    _graph_state_attrs = ()
 
     def _sources(self, T_total, B, ny, t_first, sta_row, dy_list, device):
         M = self.nmul
@@ -125,6 +143,13 @@ class HbvAdj(torch.nn.Module):
         return srcs
 
     def forward(self, x_dict: dict[str, torch.Tensor], parameters: torch.Tensor):
+        """hbv_adj.py:227-330.  `graph=True`: HIP-graph replay of the call (graphed.py)."""
+        if self.graph and x_dict['x_phy'].is_cuda:
+            from hydrodl2_amd.graphed import graphed_forward
+            return graphed_forward(self, x_dict, parameters)
+        return self._forward_eager(x_dict, parameters)
+
+    def _forward_eager(self, x_dict: dict[str, torch.Tensor], parameters: torch.Tensor):
         """hbv_adj.py:227-330."""
         x = x_dict['x_phy']
         T_total, B = x.shape[0], x.shape[1]

@@ -2,6 +2,8 @@
 implementation of the ABI; used to compare implementations on identical descriptors."""
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -24,7 +26,7 @@ MODEL_ID = {"Hbv": _abi.MODEL_HBV10, "Hbv_1_1p": _abi.MODEL_HBV11P, "Hbv_2": _ab
 
 
 def make_problem(model="Hbv", T=40, B=5, M=4, dyn=(), betaet=False, drop_frac=0.0, seed=1,
-                 routing=True, muwts=False, cold=False, raw_scale=1.0):
+                 routing=True, muwts=False, cold=False, raw_scale=1.0, channels=(0, 1, 2)):
     """numpy inputs + a builder of (cfg, tensors) for a raw [T,B,ny] parameter tensor."""
     names = list(PHY_NAMES[model])
     if model == "Hbv" and (betaet or "parBETAET" in dyn):
@@ -37,6 +39,13 @@ def make_problem(model="Hbv", T=40, B=5, M=4, dyn=(), betaet=False, drop_frac=0.
     if model == "Hbv_2_hourly":  # per-step depths of an hourly record
         prob["x"] = prob["x"] * np.array([1.0 / 8.0, 1.0, 1.0 / 24.0], np.float32)
         prob["routing"] = routing = False  # its 72-tap routing is not the library's 15-tap one
+    # `channels`: where (prcp, tmean, pet) sit in the last axis of x (config key `variables` of the modules)
+    prob["channels"] = tuple(channels)
+    if tuple(channels) != (0, 1, 2):
+        xp = np.empty_like(prob["x"])
+        for std, pos in enumerate(channels):
+            xp[:, :, pos] = prob["x"][:, :, std]
+        prob["x"] = xp
     prob["params"] = synth.raw_parameters(T, B, ny, seed, raw_scale)
     prob["gflux"] = synth.loss_weights((12 if model != "Hbv" else 11, T, B), seed, 40)
     prob["grouted"] = synth.loss_weights((4, T, B), seed, 41)
@@ -79,8 +88,9 @@ def run_problem(prob, lib_path, device="cpu", x_grad=False, backward=True, t0=0,
                     ps.drop = torch.from_numpy(prob["drop"][prob["dyn"].index(name)]).to(dev)
             srcs.append(ps)
         nf = 11 if prob["model"] == "Hbv" else 12
-        cfg = StepConfig(model=MODEL_ID[prob["model"]], n_param=n, n_flux=nf, T=Tc, t0=t0, B=B,
-                         M=M, raw_sigmoid=True, channels=(0, 1, 2), nearzero=1e-5, params=srcs)
+        ckpt = int(os.environ.get("HBVX_CKPT_DAYS", "0") or 0) if backward else 0    # (the modules' knob, for ABI-level runs)
+        cfg = StepConfig(model=MODEL_ID[prob["model"]], n_param=n, n_flux=nf, T=Tc, t0=t0, B=B, ckpt_days=ckpt,
+                         M=M, raw_sigmoid=True, channels=prob.get("channels", (0, 1, 2)), nearzero=1e-5, params=srcs)
         if prob["routing"]:
             off = (T - 1) * B * ny + n * M
             cfg.route = RouteSource(0, off, off + 1, ny, [0, 2.9], [0, 6.5])
@@ -92,7 +102,7 @@ def run_problem(prob, lib_path, device="cpu", x_grad=False, backward=True, t0=0,
         res = {"flux": flux.detach().cpu().numpy(), "state_out": state_out.cpu().numpy()}
         if routed is not None:
             res["routed"] = routed.detach().cpu().numpy()
-        if traj is not None and keep_traj:    # always compared in the row layout [5, T+1, N]
+        if traj is not None and keep_traj and not ckpt:    # always compared in the row layout [5, T+1, N]
             res["traj"] = torch.stack([v.reshape(Tc + 1, B * M) for v in
                                        state_series(traj, po.traj_layout, Tc, B, M)]).cpu().numpy()
         if backward:

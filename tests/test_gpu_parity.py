@@ -198,13 +198,26 @@ STREAM2_CASES = [
     dict(model="Hbv_2_hourly", T=100, B=19, M=4, dyn=("parBETA", "parK0", "parBETAET")),
     dict(model="Hbv", T=50, B=5, M=64, dyn=()),
     dict(model="Hbv", T=45, B=130, M=1, dyn=("parBETA", "parBETAET")),
+    # run-time slot lists (hbv_stream2.h, SC == 3): the sets without a compiled instance -- one, two and three
+    # parameters, with and without BETAET in the table, dy_drop masks -- and permuted forcing channels
+    dict(model="Hbv", T=140, B=9, M=16, dyn=("parBETA",)),
+    dict(model="Hbv", T=133, B=10, M=16, dyn=("parK0", "parBETAET"), drop_frac=0.3),
+    dict(model="Hbv_1_1p", T=90, B=21, M=5, dyn=("parK0", "parTT", "parFC"), drop_frac=0.4),
+    dict(model="Hbv_2", T=150, B=11, M=16, dyn=("parBETA", "parBETAET")),
+    dict(model="Hbv_2", T=70, B=70, M=2, dyn=("parAC", "parRT", "parC"), drop_frac=0.3),
+    dict(model="Hbv_2_hourly", T=100, B=19, M=4, dyn=("parF0", "parALPHA")),
+    dict(model="Hbv", T=77, B=12, M=16, dyn=("parBETA", "parBETAET"), channels=(2, 0, 1)),
+    dict(model="Hbv_2", T=64, B=9, M=8, dyn=("parFC",), channels=(1, 2, 0)),
+    dict(model="Hbv", T=60, B=6, M=16, dyn=(), channels=(0, 2, 1)),
 ]
 
 
 @pytest.mark.parametrize("layout_env", [{"HBVX_STREAM_MIN": "1"},
                                         {"HBVX_STREAM_MIN": "1", "HBVX_STREAM_MW_MIN": "1"},
-                                        {"HBVX_STREAM_MIN": "1", "HBVX_BWD": "tiled"}],
-                         ids=["packed", "packed-8wave", "rows"])
+                                        {"HBVX_STREAM_MIN": "1", "HBVX_BWD": "tiled"},
+                                        {"HBVX_STREAM_MIN": "1", "HBVX_STREAM_SLOTLIST": "1"},
+                                        {"HBVX_STREAM_MIN": "1", "HBVX_CKPT_DAYS": "4", "HBVX_CKPT_ONCHIP": "1"}],
+                         ids=["packed", "packed-8wave", "rows", "slotlist", "ckpt4-onchip"])
 @pytest.mark.parametrize("kw", STREAM2_CASES, ids=lambda k: f"{k['model']}-B{k['B']}-M{k['M']}-{len(k['dyn'])}dyn")
 def test_stream2_matches_oracle(kw, layout_env, hip_backend, oracle_path, monkeypatch):
     """Second-generation streaming kernels (hbv_stream2.h) forced onto small problems: packed
@@ -215,8 +228,12 @@ def test_stream2_matches_oracle(kw, layout_env, hip_backend, oracle_path, monkey
         monkeypatch.setenv(k, v)
     prob = make_problem(seed=21, **kw)
     got = run_problem(prob, None, device="cuda:0", x_grad=True)
+    fwd, bwd = hip_backend.last_dispatch(0), hip_backend.last_dispatch(1)
     want = run_problem(prob, oracle_path, device="cpu", x_grad=True)
     compare_runs(prob, got, want)
+    # every set of at most three dynamic parameters, any order of three adjacent channels: the second generation
+    want_bwd = "tiled" if "HBVX_BWD" in layout_env else ("ckpt-stream2" if "HBVX_CKPT_DAYS" in layout_env else "stream2")
+    assert (fwd, bwd) == ("stream2", want_bwd), (fwd, bwd)
 
 
 @pytest.mark.gpu
