@@ -32,6 +32,13 @@ class Hbv_2(HbvModule):
         self.lenF = 15  # hbv_2.py:52
         super().__init__(config, device)
         self._state_cache = None
+        if self.adjoint_checkpoint:
+            # not silent: this key trades the state series for memory
+            import warnings
+            warnings.warn(f"Hbv_2(adjoint_checkpoint={self.adjoint_checkpoint}): only {self.adjoint_checkpoint}-day "
+                          "checkpoints of the storages are kept, so get_states() returns the FINAL storages as a "
+                          "one-step series [1,B,nmul] x 5, not the reference's full series (hbv_2.py:571-575,628)",
+                          stacklevel=2)
 
     def _read_config(self, config: dict) -> None:
         super()._read_config(config)

@@ -1,5 +1,7 @@
 mkdir -p gpurun_out
-python -m pytest tests/test_gpu_parity.py tests/test_uh_routing.py tests/test_gpu_fullsize.py tests/test_mts.py tests/test_graphed.py tests/test_gpu_fuzz.py tests/test_api_and_abi.py -m gpu -q -p no:cacheprovider > gpurun_out/r05_gputier_2.log 2>&1
-tail -3 gpurun_out/r05_gputier_2.log
-python tools/bench_one.py cfg5share cfg5share_ck4 cfg5full cfg5full_ck4 cfg5full_ck8 --steps 10 --rounds 2 > gpurun_out/r05_ckpt_ab.jsonl 2> gpurun_out/r05_ckpt_ab.err
-tail -4 gpurun_out/r05_ckpt_ab.jsonl | cut -c1-400
+python -m pytest tests/test_graphed.py tests/test_gpu_parity.py -m gpu -q -p no:cacheprovider -k "graph or stream2 or long_golden or checkpointed" > gpurun_out/r05_gputier_3.log 2>&1
+tail -3 gpurun_out/r05_gputier_3.log
+HBVX_CKPT_ONCHIP=0 python tools/bench_one.py cfg5full_ck4 --steps 10 > gpurun_out/r05_ckpt_block.jsonl 2>> gpurun_out/r05_ckpt_ab.err
+cut -c1-300 gpurun_out/r05_ckpt_block.jsonl
+python bench.py --steps 20 --warmup 5 > gpurun_out/r05_bench_1.json 2> gpurun_out/r05_bench_1.err
+tail -15 gpurun_out/r05_bench_1.err

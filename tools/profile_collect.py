@@ -28,7 +28,7 @@ CALLS = {
     "hbvx_route_forward": ["k_route_fwd", "k_uh_gamma"],
     "hbvx_route_backward": ["k_route_bwd"],
     "hbvx_bfi": ["k_bfi"],
-    "hbvx_zero": ["k_zero_nt", "k_zero_gaps"],
+    "hbvx_zero": ["k_zero_nt", "k_zero_gaps", "k_zero_bytes"],
 }
 
 
