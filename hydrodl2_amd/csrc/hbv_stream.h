@@ -34,7 +34,7 @@ struct StreamArgs {
     hbvx_fwd_out o;
     int lgMp;
     int nd;
-    int dslot[3];
+    int dslot[6];      // first generation: up to 3; hbv_stream2.h run-time lists: up to STREAM2_LIST_MAX
     int per_xcd;   // hbv_stream2.h: basin groups per XCD (grid = 8 * per_xcd)
 };
 
@@ -250,7 +250,7 @@ struct StreamBwdArgs {
     hbvx_bwd_io io;
     int lgMp;
     int nd;
-    int dslot[3];
+    int dslot[6];      // first generation: up to 3; hbv_stream2.h run-time lists: up to STREAM2_LIST_MAX
     int per_xcd;
 };
 

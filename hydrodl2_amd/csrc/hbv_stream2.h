@@ -34,33 +34,53 @@ namespace hbvx {
 template <int SC> struct StreamDyn { static constexpr int nd = 0; };
 template <> struct StreamDyn<1> { static constexpr int nd = 2; };
 template <> struct StreamDyn<2> { static constexpr int nd = 3; };
-// SC == 3: ANY set of up to three dynamic parameters, as a wave-uniform run-time slot list (StreamArgs.nd / .dslot,
+// SC >= 3: ANY set of up to three dynamic parameters, as a wave-uniform run-time slot list (StreamArgs.nd / .dslot,
 // slots in parameter order).  The parameter vector stays in registers: it is only ever indexed by constants, a
 // run-time slot goes through a compare chain on a scalar (s2_put / s2_get: ~3 scalar + 1 vector instruction per
 // candidate slot).  What the compile-time sets save over this form is exactly those chains (~50 vector instructions
 // per day and parameter); what this form replaces is the first-generation kernel (hbv_stream.h): 5.1 ms where a
 // compiled set runs 1.6 ms at 4 096 wavefronts.
 template <> struct StreamDyn<3> { static constexpr int nd = 3; };
+// SC == 4: the same for four to six parameters (more rows in flight and staged; above six the tiled forward and the
+// time-parallel adjoint keep the problem: 15.2 ms against 6.4 for a two-parameter sibling at 4 096 wavefronts)
+#define STREAM2_LIST_MAX 6
+template <> struct StreamDyn<4> { static constexpr int nd = STREAM2_LIST_MAX; };
 template <int SC>
 __host__ __device__ constexpr int stream_slot(int k)
 {
     return SC == 1 ? (k == 0 ? P_BETA : P_BETAET) : (k == 0 ? P_BETA : (k == 1 ? P_K0 : P_BETAET));
 }
 
+// Run-time slot -> a parameter array that must stay in registers (constant indices only).  `slot` is wave-uniform (a
+// kernel argument), so this is a scalar branch tree ending in ONE vector move -- not a chain of NP compare + select
+// pairs: on waves that issue one instruction every ~6-8 cycles whatever its kind, 16 selects per access cost the
+// adjoint 45 % (profiles/r05_slotlist_ab.jsonl: 3.44 ms against the compiled set's 2.08 at 4 096 wavefronts).  The
+// empty asm statement keeps the optimiser from turning the branches back into selects (a side effect cannot be
+// speculated).
+#define S2_SLOT_CASES(OP)                                                                                   \
+    OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7) OP(8) OP(9) OP(10) OP(11) OP(12) OP(13) OP(14) OP(15) \
+    OP(16) OP(17) OP(18)
+static_assert(NPARAM_MAX <= 19, "S2_SLOT_CASES lists 19 slots");
 template <int NP>
 __device__ __forceinline__ void s2_put(float *p, int slot, float v)
 {
-#pragma unroll
-    for (int i = 0; i < NP; i++)
-        if (slot == i) p[i] = v;
+    switch (slot) {
+#define S2_PUT_CASE(i) case i: if (i < NP) { asm volatile("" ::: "memory"); p[i < NP ? i : 0] = v; } break;
+        S2_SLOT_CASES(S2_PUT_CASE)
+#undef S2_PUT_CASE
+    default: break;
+    }
 }
 template <int NP>
 __device__ __forceinline__ float s2_get(const float *p, int slot)
 {
     float r = 0.0f;
-#pragma unroll
-    for (int i = 0; i < NP; i++)
-        if (slot == i) r = p[i];
+    switch (slot) {
+#define S2_GET_CASE(i) case i: if (i < NP) { asm volatile("" ::: "memory"); r = p[i < NP ? i : 0]; } break;
+        S2_SLOT_CASES(S2_GET_CASE)
+#undef S2_GET_CASE
+    default: break;
+    }
     return r;
 }
 
@@ -298,8 +318,11 @@ __device__ __forceinline__ float s2_ens_sum16(const float *f, bool b0, bool b1)
 #ifndef STREAM2_FD
 #define STREAM2_FD 8
 #endif
+// (the six-slot list of the capillary / hourly models needs more than the 128 registers of four waves per SIMD)
 template <int MODEL, bool BETAET, int TRJ, int SC, bool XVEC, int MW = 1>
-__global__ void __launch_bounds__(MW * 64) FWPE k_fwd_stream2(const StreamArgs A)
+__global__ void __launch_bounds__(MW * 64)
+__attribute__((amdgpu_waves_per_eu((SC == 4 && MW == 1 && (MODEL == MODEL_HBV20 || MODEL == MODEL_HOURLY)) ? 3 : 4)))
+k_fwd_stream2(const StreamArgs A)
 {
     constexpr int NP = NParamT<MODEL, BETAET>::value;
     constexpr int NF = MODEL == MODEL_HBV10 ? 11 : 12;
@@ -347,17 +370,17 @@ __global__ void __launch_bounds__(MW * 64) FWPE k_fwd_stream2(const StreamArgs A
     // per lane: range and offset of the day's value, or (0, static value) where dy_drop masked the basin --
     // the reference's `dyn * (1 - mask) + static * mask` (hbv.py:246), no lane mask to keep in SGPRs
     float dlo[ND > 0 ? ND : 1], dsc[ND > 0 ? ND : 1];
-    const int nd = SC == 3 ? A.nd : ND;                 // SC == 3: a run-time list of nd <= 3 slots (wave-uniform)
+    const int nd = SC >= 3 ? A.nd : ND;                 // SC >= 3: a run-time list of nd <= 3 slots (wave-uniform)
     int dsl[ND > 0 ? ND : 1];
 #pragma unroll
     for (int k = 0; k < ND; k++) {
-        dsl[k] = SC == 3 ? A.dslot[k < nd ? k : 0] : stream_slot<SC>(k);
+        dsl[k] = SC >= 3 ? A.dslot[k < nd ? k : 0] : stream_slot<SC>(k);
         const hbvx_param_src &ps = d.p[dsl[k]];
         dbase[k] = ps.dyn ? ps.dyn : d.x;
         dvo[k] = (unsigned)((L.b * ps.dyn_b_stride + L.j) * 4);
         dts[k] = ps.dyn_t_stride;
         const bool use = !(ps.drop && ps.drop[L.b]);
-        dlo[k] = use ? ps.lo : (SC == 3 ? s2_get<NP>(p, dsl[k]) : p[stream_slot<SC>(k)]);
+        dlo[k] = use ? ps.lo : (SC >= 3 ? s2_get<NP>(p, dsl[k]) : p[stream_slot<SC>(k)]);
         dsc[k] = use ? ps.hi - ps.lo : 0.0f;
     }
     // outputs
@@ -409,7 +432,7 @@ __global__ void __launch_bounds__(MW * 64) FWPE k_fwd_stream2(const StreamArgs A
         }
 #pragma unroll
         for (int k = 0; k < ND; k++)
-            if (SC != 3 || k < nd) dv[j][k] = S2Buf::ld(S2Buf::rsrc(dbase[k] + tc * dts[k]), dvo[k], 0);
+            if (SC < 3 || k < nd) dv[j][k] = S2Buf::ld(S2Buf::rsrc(dbase[k] + tc * dts[k]), dvo[k], 0);
     };
     // XVEC: a basin's three forcing values are adjacent and arrive as one 12-byte load; `ident`: already in
     // (prcp, tmean, pet) order, else three wave-uniform picks put them there (config key `variables`)
@@ -425,9 +448,9 @@ __global__ void __launch_bounds__(MW * 64) FWPE k_fwd_stream2(const StreamArgs A
         }
 #pragma unroll
         for (int k = 0; k < ND; k++) {
-            if (SC == 3 && k >= nd) continue;
+            if (SC >= 3 && k >= nd) continue;
             const float u = raw ? sigmoid_dyn_(dv[j][k]) : dv[j][k];
-            if (SC == 3) s2_put<NP>(p, dsl[k], u * dsc[k] + dlo[k]);
+            if (SC >= 3) s2_put<NP>(p, dsl[k], u * dsc[k] + dlo[k]);
             else p[stream_slot<SC>(k)] = u * dsc[k] + dlo[k];
         }
         s.SP = st[0]; s.MW = st[1]; s.SM = st[2]; s.SUZ = st[3]; s.SLZ = st[4];
@@ -575,10 +598,11 @@ __global__ void __launch_bounds__(MW * 64) FWPE k_fwd_stream2(const StreamArgs A
 
 // waves per SIMD the adjoint is compiled for: three (<= 168 VGPRs) wherever that needs no spill; the
 // hourly step and the capillary models with all twelve gradient series live keep two
-template <int MODEL, bool GFULL>
+template <int MODEL, bool GFULL, int SC = 0>
 constexpr int s2_bwd_waves()
 {
-    return (MODEL == MODEL_HOURLY || ((MODEL == MODEL_HBV20 || MODEL == MODEL_HBV11P) && GFULL)) ? 2 : STREAM2_BWD_WAVES;
+    return (MODEL == MODEL_HOURLY || ((MODEL == MODEL_HBV20 || MODEL == MODEL_HBV11P) && GFULL) ||
+            (MODEL == MODEL_HBV20 && SC == 4)) ? 2 : STREAM2_BWD_WAVES;
 }
 
 // W4: compiled for four waves per SIMD (<= 128 VGPRs, a few spilled values) instead of three.  Slower
@@ -586,7 +610,7 @@ constexpr int s2_bwd_waves()
 // waves for 3 072 slots) otherwise pays a whole extra round for the overflow: measured 2.45 -> 2.15 ms
 // there, 1.94 -> 2.20 ms at 3 072 waves.  The host picks per grid (launch_stream.hip).
 template <int MODEL, bool BETAET, int TRJ, int SC, bool GFULL, bool XVEC, bool W4 = false>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W4 ? 4 : s2_bwd_waves<MODEL, GFULL>())))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W4 ? 4 : s2_bwd_waves<MODEL, GFULL, SC>())))
 k_bwd_stream2(const StreamBwdArgs A)
 {
     constexpr int NP = NParamT<MODEL, BETAET>::value;
@@ -661,12 +685,12 @@ k_bwd_stream2(const StreamBwdArgs A)
     unsigned dvo[ND > 0 ? ND : 1], gdvo[ND > 0 ? ND : 1];
     // the adjoint is short of VGPRs, not SGPRs: range / offset stay wave-uniform, the dy_drop mask a lane mask
     float dlo[ND > 0 ? ND : 1], dsc[ND > 0 ? ND : 1], dsta[ND > 0 ? ND : 1];
-    bool duse[ND > 0 ? ND : 1];
-    const int nd = SC == 3 ? A.nd : ND;                 // SC == 3: a run-time list of nd <= 3 slots (wave-uniform)
+    bool duse[ND > 0 ? ND : 1], dmasked[ND > 0 ? ND : 1];     // dmasked: the slot has a dy_drop mask at all (wave-uniform)
+    const int nd = SC >= 3 ? A.nd : ND;                 // SC >= 3: a run-time list of nd <= 3 slots (wave-uniform)
     int dsl[ND > 0 ? ND : 1];
 #pragma unroll
     for (int k = 0; k < ND; k++) {
-        const int sl = SC == 3 ? A.dslot[k < nd ? k : 0] : stream_slot<SC>(k);
+        const int sl = SC >= 3 ? A.dslot[k < nd ? k : 0] : stream_slot<SC>(k);
         dsl[k] = sl;
         const hbvx_param_src &ps = d.p[sl];
         dbase[k] = ps.dyn ? ps.dyn : d.x;
@@ -674,8 +698,9 @@ k_bwd_stream2(const StreamBwdArgs A)
         dts[k] = ps.dyn_t_stride;
         dlo[k] = ps.lo;
         dsc[k] = ps.hi - ps.lo;
-        dsta[k] = SC == 3 ? s2_get<NP>(p, sl) : p[stream_slot<SC>(k)];
+        dsta[k] = SC >= 3 ? s2_get<NP>(p, sl) : p[stream_slot<SC>(k)];
         duse[k] = !(ps.drop && ps.drop[L.b]);
+        dmasked[k] = ps.drop != nullptr;
         const bool dg = io.g[sl].dyn != nullptr;
         gdbase[k] = dg ? io.g[sl].dyn : const_cast<float *>(d.x);
         gdvo[k] = (dg && L.active) ? (unsigned)((L.b * io.g[sl].dyn_b_stride + L.j) * 4) : OOB;
@@ -731,7 +756,7 @@ k_bwd_stream2(const StreamBwdArgs A)
         I.add4 = has_g4;
 #pragma unroll
         for (int k = 0; k < ND; k++)
-            if (SC != 3 || k < nd) I.dv[k] = S2Buf::ld(S2Buf::rsrc(dbase[k] + tc * dts[k]), dvo[k], 0);
+            if (SC < 3 || k < nd) I.dv[k] = S2Buf::ld(S2Buf::rsrc(dbase[k] + tc * dts[k]), dvo[k], 0);
     };
     const bool ident = cp == 0 && ct == 1 && ce == 2;   // (see the forward)
     auto day = [&](int t, const In &I) {
@@ -748,10 +773,10 @@ k_bwd_stream2(const StreamBwdArgs A)
 #pragma unroll
         for (int k = 0; k < ND; k++) {
             ud[k] = 0.0f;
-            if (SC == 3 && k >= nd) continue;
+            if (SC >= 3 && k >= nd) continue;
             ud[k] = raw ? sigmoid_dyn_(I.dv[k]) : I.dv[k];
             const float pv = duse[k] ? ud[k] * dsc[k] + dlo[k] : dsta[k];
-            if (SC == 3) s2_put<NP>(p, dsl[k], pv);
+            if (SC >= 3) s2_put<NP>(p, dsl[k], pv);
             else p[stream_slot<SC>(k)] = pv;
         }
         s.template fwd<SAVE_POW>(p, nz, ac, elev, I.ax[0], I.ax[1]);
@@ -771,7 +796,7 @@ k_bwd_stream2(const StreamBwdArgs A)
         s.bwd(p, nz, g, a, gp, gx);
         // static slots: physical-space sums (the range factor and sigmoid' are applied once, at the
         // end); a dynamic slot contributes to the static row only where dy_drop masked the basin
-        if constexpr (SC == 3) {
+        if constexpr (SC >= 3) {
             // run-time slots: the day's gradient of each listed slot leaves through its row (and is taken out of the
             // static sum where the lane's basin uses the dynamic value), then every slot adds to its static sum
 #pragma unroll
@@ -781,7 +806,9 @@ k_bwd_stream2(const StreamBwdArgs A)
                 const float gu = gpk * dsc[k];
                 const float gr = raw ? gu * (ud[k] * (1.0f - ud[k])) : gu;
                 S2Buf::st(S2Buf::rsrc(gdbase[k] + t * gdts[k]), gdvo[k], 0, duse[k] ? gr : 0.0f);
-                s2_put<NP>(gp, dsl[k], duse[k] ? 0.0f : gpk);
+                // with a dy_drop mask the masked basins' share stays in the static sum; without one (wave-uniform) the
+                // slot's static sum is simply discarded at the end
+                if (dmasked[k]) s2_put<NP>(gp, dsl[k], duse[k] ? 0.0f : gpk);
             }
 #pragma unroll
             for (int i = 0; i < NP; i++) S2_ACC_ADD(i, gp[i]);
@@ -859,7 +886,7 @@ k_bwd_stream2(const StreamBwdArgs A)
             }
 #pragma unroll
             for (int k = 0; k < ND; k++)
-                if (SC != 3 || k < nd) S2Buf::ld_lds<4>(S2Buf::rsrc(dbase[k] + tc * dts[k]), l_dv[k], dvo[k], 0);
+                if (SC < 3 || k < nd) S2Buf::ld_lds<4>(S2Buf::rsrc(dbase[k] + tc * dts[k]), l_dv[k], dvo[k], 0);
         };
         auto pull = [&](int t, In &I) {
             if (XVEC) {
@@ -891,7 +918,7 @@ k_bwd_stream2(const StreamBwdArgs A)
             }
             I.add4 = false;   // (this form has already summed the two sources above)
 #pragma unroll
-            for (int k = 0; k < ND; k++) I.dv[k] = (SC != 3 || k < nd) ? l_dv[k][ln] : 0.0f;
+            for (int k = 0; k < ND; k++) I.dv[k] = (SC < 3 || k < nd) ? l_dv[k][ln] : 0.0f;
         };
         arm(T - 1);
         for (int t = T - 1; t >= 0; t--) {
@@ -929,6 +956,7 @@ k_bwd_stream2(const StreamBwdArgs A)
         for (int i = 0; i < NP; i++) {
             if (!io.g[i].sta) continue;
             const hbvx_param_src &s = d.p[i];
+            if (SC >= 3 && s.dyn && !s.drop) continue;     // a dynamic slot without a mask has no static share
             float gr = S2_ACC_GET(i) * (s.hi - s.lo);
             if (raw) {
                 const float u = sigmoid_(s.sta[(int64_t)L.b * s.sta_b_stride + L.j]);

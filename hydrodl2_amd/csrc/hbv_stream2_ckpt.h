@@ -97,14 +97,14 @@ k_bwd_stream2_ckpt(const StreamBwdArgs A, const int K)
     int64_t dts[NDA], gdts[NDA];
     unsigned dvo[NDA], gdvo[NDA];
     float dlo[NDA], dsc[NDA], dsta[NDA];
-    bool duse[NDA];
-    const int nd = SC == 3 ? A.nd : ND;                 // SC == 3: a run-time list of nd <= 3 slots (hbv_stream2.h)
+    bool duse[NDA], dmasked[NDA];
+    const int nd = SC >= 3 ? A.nd : ND;                 // SC >= 3: a run-time list of nd <= 3 slots (hbv_stream2.h)
     int dsl[NDA];
     const int cp = d.ch_prcp, ct = d.ch_tmean, ce = d.ch_pet;
     const bool ident = cp == 0 && ct == 1 && ce == 2;   // forcing channels already in (prcp, tmean, pet) order
 #pragma unroll
     for (int k = 0; k < ND; k++) {
-        const int sl = SC == 3 ? A.dslot[k < nd ? k : 0] : stream_slot<SC>(k);
+        const int sl = SC >= 3 ? A.dslot[k < nd ? k : 0] : stream_slot<SC>(k);
         dsl[k] = sl;
         const hbvx_param_src &ps = d.p[sl];
         dbase[k] = ps.dyn ? ps.dyn : d.x;
@@ -112,8 +112,9 @@ k_bwd_stream2_ckpt(const StreamBwdArgs A, const int K)
         dts[k] = ps.dyn_t_stride;
         dlo[k] = ps.lo;
         dsc[k] = ps.hi - ps.lo;
-        dsta[k] = SC == 3 ? s2_get<NP>(p, sl) : p[stream_slot<SC>(k)];
+        dsta[k] = SC >= 3 ? s2_get<NP>(p, sl) : p[stream_slot<SC>(k)];
         duse[k] = !(ps.drop && ps.drop[L.b]);
+        dmasked[k] = ps.drop != nullptr;
         const bool dg = io.g[sl].dyn != nullptr;
         gdbase[k] = dg ? io.g[sl].dyn : const_cast<float *>(d.x);
         gdvo[k] = (dg && L.active) ? (unsigned)((L.b * io.g[sl].dyn_b_stride + L.j) * 4) : OOB;
@@ -134,7 +135,7 @@ k_bwd_stream2_ckpt(const StreamBwdArgs A, const int K)
         I.x = S2Buf::ld3(rx, xvo, (unsigned)t * xts);      // (the plan admits three adjacent channels only)
 #pragma unroll
         for (int k = 0; k < ND; k++)
-            if (SC != 3 || k < nd) I.dv[k] = S2Buf::ld(S2Buf::rsrc(dbase[k] + (int64_t)t * dts[k]), dvo[k], 0);
+            if (SC < 3 || k < nd) I.dv[k] = S2Buf::ld(S2Buf::rsrc(dbase[k] + (int64_t)t * dts[k]), dvo[k], 0);
     };
     auto issueB = [&](int t, BIn &I) {
         I.x = S2Buf::ld3(rx, xvo, (unsigned)t * xts);
@@ -163,10 +164,10 @@ k_bwd_stream2_ckpt(const StreamBwdArgs A, const int K)
 #pragma unroll
         for (int k = 0; k < ND; k++) {
             ud[k] = 0.0f;
-            if (SC == 3 && k >= nd) continue;
+            if (SC >= 3 && k >= nd) continue;
             ud[k] = seg_ud[(l * ND + k) * 64];
             const float pv = duse[k] ? ud[k] * dsc[k] + dlo[k] : dsta[k];
-            if (SC == 3) s2_put<NP>(p, dsl[k], pv);
+            if (SC >= 3) s2_put<NP>(p, dsl[k], pv);
             else p[stream_slot<SC>(k)] = pv;
         }
         s.template fwd<false>(p, nz, ac, elev, 0.0f, 0.0f);
@@ -184,7 +185,7 @@ k_bwd_stream2_ckpt(const StreamBwdArgs A, const int K)
 #pragma unroll
         for (int i = 0; i < NPARAM_MAX; i++) gp[i] = 0.0f;
         s.bwd(p, nz, g, a, gp, gx);
-        if constexpr (SC == 3) {
+        if constexpr (SC >= 3) {
 #pragma unroll
             for (int k = 0; k < ND; k++) {
                 if (k >= nd) continue;
@@ -192,7 +193,7 @@ k_bwd_stream2_ckpt(const StreamBwdArgs A, const int K)
                 const float gu = gpk * dsc[k];
                 const float gr = raw ? gu * (ud[k] * (1.0f - ud[k])) : gu;
                 S2Buf::st(S2Buf::rsrc(gdbase[k] + (int64_t)t * gdts[k]), gdvo[k], 0, duse[k] ? gr : 0.0f);
-                s2_put<NP>(gp, dsl[k], duse[k] ? 0.0f : gpk);
+                if (dmasked[k]) s2_put<NP>(gp, dsl[k], duse[k] ? 0.0f : gpk);     // (hbv_stream2.h::k_bwd_stream2)
             }
 #pragma unroll
             for (int i = 0; i < NP; i++) acc[i * 64] += gp[i];
@@ -247,11 +248,11 @@ k_bwd_stream2_ckpt(const StreamBwdArgs A, const int K)
             for (int k = 0; k < 5; k++) row[k * 64] = st[k];
 #pragma unroll
             for (int k = 0; k < ND; k++) {
-                if (SC == 3 && k >= nd) continue;
+                if (SC >= 3 && k >= nd) continue;
                 const float u = raw ? sigmoid_dyn_(rc.dv[k]) : rc.dv[k];
                 seg_ud[(l * ND + k) * 64] = u;
                 const float pv = duse[k] ? u * dsc[k] + dlo[k] : dsta[k];
-                if (SC == 3) s2_put<NP>(p, dsl[k], pv);
+                if (SC >= 3) s2_put<NP>(p, dsl[k], pv);
                 else p[stream_slot<SC>(k)] = pv;
             }
             if (t + 1 < t1) {
@@ -281,6 +282,7 @@ k_bwd_stream2_ckpt(const StreamBwdArgs A, const int K)
         for (int i = 0; i < NP; i++) {
             if (!io.g[i].sta) continue;
             const hbvx_param_src &s = d.p[i];
+            if (SC >= 3 && s.dyn && !s.drop) continue;     // a dynamic slot without a mask has no static share
             float gr = acc[i * 64] * (s.hi - s.lo);
             if (raw) {
                 const float u = sigmoid_(s.sta[(int64_t)L.b * s.sta_b_stride + L.j]);

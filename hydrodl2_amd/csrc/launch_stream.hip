@@ -20,7 +20,7 @@ struct StreamPlan {
     bool gen1_ok;   // first generation: whole dynamic tensors within 32-bit offsets
     bool rows_ok;   // row trajectory: every offset fits 32 bits
     bool packed_ok; // packed trajectory / checkpoints: one day's rows fit 32 bits (descriptors rebased per day)
-    int dslot[3];
+    int dslot[6];
 };
 
 StreamPlan plan_stream(const hbvx_desc *d)
@@ -32,7 +32,7 @@ StreamPlan plan_stream(const hbvx_desc *d)
     const int64_t N = (int64_t)d->B * d->M, lim = (int64_t)1 << 32;
     P.nd = count_dyn(d);
     const int nf = (d->model == HBVX_MODEL_HBV10) ? 11 : 12;
-    P.ok = use_tiled(d) && env_int("HBVX_STREAM", 1) != 0 && P.nd <= 3 && !d->muwts && d->T > 0 &&
+    P.ok = use_tiled(d) && env_int("HBVX_STREAM", 1) != 0 && P.nd <= STREAM2_LIST_MAX && !d->muwts && d->T > 0 &&
            (int64_t)nf * d->T * d->B * 4 < lim &&
            ((int64_t)d->T * d->x_t_stride + (int64_t)d->B * d->x_b_stride) * 4 < lim;
     P.gen1_ok = true;
@@ -41,7 +41,7 @@ StreamPlan plan_stream(const hbvx_desc *d)
     for (int i = 0; i < d->n_param; i++)
         if (d->p[i].dyn) {
             mask |= 1u << i;
-            if (k < 3) P.dslot[k++] = i;
+            if (k < 6) P.dslot[k++] = i;
             // one day's row per descriptor (the kernels rebase it every day): the tensor itself may exceed 4 GiB
             P.gen1_ok = P.gen1_ok && ((int64_t)d->T * d->p[i].dyn_t_stride + (int64_t)d->B * d->p[i].dyn_b_stride) * 4 < lim;
             P.ok = P.ok && d->p[i].dyn_t_stride >= 0 && (int64_t)d->B * d->p[i].dyn_b_stride * 4 < lim;
@@ -51,8 +51,8 @@ StreamPlan plan_stream(const hbvx_desc *d)
          : (mask == ((1u << P_BETA) | (1u << P_BETAET)) && be &&
             (d->model == HBVX_MODEL_HBV10 || d->model == HBVX_MODEL_HBV11P)) ? 1
          : (mask == ((1u << P_BETA) | (1u << P_K0) | (1u << P_BETAET)) &&
-            (d->model == HBVX_MODEL_HBV20 || d->model == HBVX_MODEL_HOURLY)) ? 2 : 3;   // (P.nd <= 3 is part of P.ok)
-    if (env_int("HBVX_STREAM_SLOTLIST", 0) && P.sc > 0) P.sc = 3;   // tests: the run-time list on a compiled set
+            (d->model == HBVX_MODEL_HBV20 || d->model == HBVX_MODEL_HOURLY)) ? 2 : (P.nd <= 3 ? 3 : 4);   // (nd <= 6: P.ok)
+    if (env_int("HBVX_STREAM_SLOTLIST", 0) && P.sc > 0 && P.sc < 3) P.sc = 3;   // tests: the run-time list on a compiled set
     const int c0 = d->ch_prcp, c1 = d->ch_tmean, c2 = d->ch_pet;
     // second generation: a basin's three forcing values adjacent (one 12-byte load), the channels any permutation of
     // {0, 1, 2} (the kernels pick; config key `variables`)
@@ -61,7 +61,7 @@ StreamPlan plan_stream(const hbvx_desc *d)
     if (!P.xvec) P.sc = -1;
     P.rows_ok = 5 * (int64_t)(d->T + 1) * N * 4 < lim;
     P.packed_ok = N * 20 < lim;
-    if (P.sc < 0) P.ok = P.ok && P.gen1_ok && P.rows_ok;
+    if (P.sc < 0) P.ok = P.ok && P.gen1_ok && P.rows_ok && P.nd <= 3;     // (the first generation lists three slots)
     return P;
 }
 
@@ -129,9 +129,11 @@ void go_bwd2(int trj, bool gfull, const StreamBwdArgs &sa, dim3 grid, hipStream_
 {
     // the W4 form exists for the 4-series gradient of the explicit daily models (the hourly step and
     // the 12-series form spill too much at 128 registers)
-    if (trj == 2 && !gfull && MODEL != MODEL_HOURLY && four_waves_pay((int64_t)sa.per_xcd * 8)) {
-        hipLaunchKernelGGL((k_bwd_stream2<MODEL, BE, 2, SC, false, true, MODEL != MODEL_HOURLY>), grid, dim3(64), 0, st, sa);
-        return;
+    if constexpr (SC != 4) {      // (no four-wave form of the six-slot list: it would spill most of them)
+        if (trj == 2 && !gfull && MODEL != MODEL_HOURLY && four_waves_pay((int64_t)sa.per_xcd * 8)) {
+            hipLaunchKernelGGL((k_bwd_stream2<MODEL, BE, 2, SC, false, true, MODEL != MODEL_HOURLY>), grid, dim3(64), 0, st, sa);
+            return;
+        }
     }
     if (trj == 2) {
         if (gfull) hipLaunchKernelGGL((k_bwd_stream2<MODEL, BE, 2, SC, true, true>), grid, dim3(64), 0, st, sa);
@@ -147,13 +149,17 @@ template <int MODEL, bool BE, int SC>
 void go_bwd2c(bool gfull, int K, const StreamBwdArgs &sa, dim3 grid, hipStream_t st, hipError_t *err)
 {
     constexpr int NP = NParamT<MODEL, BE>::value;
-    const int lds = s2c_lds_floats<NP, StreamDyn<SC>::nd>(K) * (int)sizeof(float);
-    if (gfull) {
-        *err = set_dynamic_lds((const void *)k_bwd_stream2_ckpt<MODEL, BE, SC, true>, lds);
-        if (*err == hipSuccess) hipLaunchKernelGGL((k_bwd_stream2_ckpt<MODEL, BE, SC, true>), grid, dim3(64), lds, st, sa, K);
+    if constexpr (SC == 4) {      // (admission keeps the six-slot lists off this path: stream_ckpt_applicable)
+        *err = hipErrorInvalidValue;
     } else {
-        *err = set_dynamic_lds((const void *)k_bwd_stream2_ckpt<MODEL, BE, SC, false>, lds);
-        if (*err == hipSuccess) hipLaunchKernelGGL((k_bwd_stream2_ckpt<MODEL, BE, SC, false>), grid, dim3(64), lds, st, sa, K);
+        const int lds = s2c_lds_floats<NP, StreamDyn<SC>::nd>(K) * (int)sizeof(float);
+        if (gfull) {
+            *err = set_dynamic_lds((const void *)k_bwd_stream2_ckpt<MODEL, BE, SC, true>, lds);
+            if (*err == hipSuccess) hipLaunchKernelGGL((k_bwd_stream2_ckpt<MODEL, BE, SC, true>), grid, dim3(64), lds, st, sa, K);
+        } else {
+            *err = set_dynamic_lds((const void *)k_bwd_stream2_ckpt<MODEL, BE, SC, false>, lds);
+            if (*err == hipSuccess) hipLaunchKernelGGL((k_bwd_stream2_ckpt<MODEL, BE, SC, false>), grid, dim3(64), lds, st, sa, K);
+        }
     }
 }
 
@@ -162,7 +168,14 @@ void go_bwd2c(bool gfull, int K, const StreamBwdArgs &sa, dim3 grid, hipStream_t
     do {                                                                                             \
         const int m_ = (d)->model;                                                                   \
         const bool be_ = (d)->n_param == 13;                                                         \
-        if (m_ == HBVX_MODEL_HBV10 && !be_ && (sc) == 3) GO<MODEL_HBV10, false, 3>(__VA_ARGS__);     \
+        if ((sc) == 4) {                                                                             \
+            if (m_ == HBVX_MODEL_HBV10 && !be_) GO<MODEL_HBV10, false, 4>(__VA_ARGS__);              \
+            else if (m_ == HBVX_MODEL_HBV10) GO<MODEL_HBV10, true, 4>(__VA_ARGS__);                  \
+            else if (m_ == HBVX_MODEL_HBV11P) GO<MODEL_HBV11P, true, 4>(__VA_ARGS__);                \
+            else if (m_ == HBVX_MODEL_HBV20) GO<MODEL_HBV20, true, 4>(__VA_ARGS__);                  \
+            else GO<MODEL_HOURLY, true, 4>(__VA_ARGS__);                                             \
+        }                                                                                            \
+        else if (m_ == HBVX_MODEL_HBV10 && !be_ && (sc) == 3) GO<MODEL_HBV10, false, 3>(__VA_ARGS__); \
         else if (m_ == HBVX_MODEL_HBV10 && !be_) GO<MODEL_HBV10, false, 0>(__VA_ARGS__);             \
         else if (m_ == HBVX_MODEL_HBV10 && (sc) == 0) GO<MODEL_HBV10, true, 0>(__VA_ARGS__);         \
         else if (m_ == HBVX_MODEL_HBV10 && (sc) == 3) GO<MODEL_HBV10, true, 3>(__VA_ARGS__);         \
@@ -216,7 +229,7 @@ bool hbvx_host::try_fwd_stream(const hbvx_desc *d, const hbvx_fwd_out *out, void
     sa.lgMp = P.lg;
     sa.nd = P.nd;
     sa.per_xcd = 0;
-    for (int k = 0; k < 3; k++) sa.dslot[k] = k < P.nd ? P.dslot[k] : 0;
+    for (int k = 0; k < 6; k++) sa.dslot[k] = k < P.nd ? P.dslot[k] : 0;
     const bool tr = out->traj != nullptr, few = P.nd > 0;
     dim3 grid_s((unsigned)P.wgs);
     hipStream_t st = (hipStream_t)stream;
@@ -271,7 +284,7 @@ bool hbvx_host::try_bwd_stream(const hbvx_desc *d, const hbvx_bwd_io *io, void *
     sa.lgMp = P.lg;
     sa.nd = P.nd;
     sa.per_xcd = 0;
-    for (int k = 0; k < 3; k++) sa.dslot[k] = k < P.nd ? P.dslot[k] : 0;
+    for (int k = 0; k < 6; k++) sa.dslot[k] = k < P.nd ? P.dslot[k] : 0;
     const bool few = P.nd > 0, gfull = io->grad_flux != nullptr;
     dim3 grid_s((unsigned)P.wgs);
     hipStream_t st = (hipStream_t)stream;
@@ -313,7 +326,7 @@ bool hbvx_host::stream_ckpt_applicable(const hbvx_desc *d, int K)
     const int want = env_int("HBVX_CKPT_ONCHIP", -1);
     if (want == 0) return false;
     const StreamPlan P = plan_stream(d);
-    if (!(P.ok && P.sc >= 0 && P.packed_ok)) return false;
+    if (!(P.ok && P.sc >= 0 && P.sc != 4 && P.packed_ok)) return false;
     if (want == 1) return true;
     return !adjoint_pinned_elsewhere() && P.wgs >= stream_min(P, true, true);
 }
@@ -333,7 +346,7 @@ bool hbvx_host::try_bwd_stream_ckpt(const hbvx_desc *d, const hbvx_bwd_io *io, v
     sa.io = *io;
     sa.lgMp = P.lg;
     sa.nd = P.nd;
-    for (int k = 0; k < 3; k++) sa.dslot[k] = k < P.nd ? P.dslot[k] : 0;
+    for (int k = 0; k < 6; k++) sa.dslot[k] = k < P.nd ? P.dslot[k] : 0;
     sa.per_xcd = (int)((P.wgs + 7) / 8);
     const dim3 grid2((unsigned)(8 * sa.per_xcd));
     hipStream_t st = (hipStream_t)stream;

@@ -209,6 +209,11 @@ STREAM2_CASES = [
     dict(model="Hbv", T=77, B=12, M=16, dyn=("parBETA", "parBETAET"), channels=(2, 0, 1)),
     dict(model="Hbv_2", T=64, B=9, M=8, dyn=("parFC",), channels=(1, 2, 0)),
     dict(model="Hbv", T=60, B=6, M=16, dyn=(), channels=(0, 2, 1)),
+    # four to six slots (SC == 4)
+    dict(model="Hbv", T=140, B=9, M=16, dyn=("parBETA", "parFC", "parK0", "parLP", "parBETAET"), drop_frac=0.3),
+    dict(model="Hbv_1_1p", T=90, B=21, M=5, dyn=("parK0", "parTT", "parFC", "parC")),
+    dict(model="Hbv_2", T=150, B=11, M=16, dyn=("parBETA", "parK0", "parBETAET", "parRT", "parAC", "parUZL"), drop_frac=0.4),
+    dict(model="Hbv_2_hourly", T=100, B=19, M=4, dyn=("parF0", "parALPHA", "parFMIN", "parBETA")),
 ]
 
 
@@ -233,6 +238,8 @@ def test_stream2_matches_oracle(kw, layout_env, hip_backend, oracle_path, monkey
     compare_runs(prob, got, want)
     # every set of at most three dynamic parameters, any order of three adjacent channels: the second generation
     want_bwd = "tiled" if "HBVX_BWD" in layout_env else ("ckpt-stream2" if "HBVX_CKPT_DAYS" in layout_env else "stream2")
+    if want_bwd == "ckpt-stream2" and len(kw["dyn"]) > 3:
+        want_bwd = "ckpt-block:stream2"     # the six-slot lists have no on-chip checkpoint form: block-wise re-materialisation
     assert (fwd, bwd) == ("stream2", want_bwd), (fwd, bwd)
 
 
@@ -333,7 +340,7 @@ def test_long_golden_case_under_every_adjoint(name, env_id, hip_backend, monkeyp
     dyn = tuple(gc.CASES[name]["config"]["dynamic_params"][model])
     # hbv_stream2.h holds every set of at most three dynamic parameters (two compiled sets, the rest as a run-time slot
     # list: launch_stream.hip::plan_stream); more than three stay on the first generation / the time-parallel adjoint
-    has_stream2 = len(dyn) <= 3
+    has_stream2 = len(dyn) <= 6
     if want_bwd == {"stream2"} and not has_stream2:
         want_bwd = {"chunked", "stream"}     # no second-generation instance for this dynamic set
     if want_bwd == {"ckpt-stream2"} and not has_stream2:
