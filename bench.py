@@ -134,6 +134,8 @@ WORKLOADS = {
     # name: (model file, class, T, B, M, dynamic parameters or "all", routed series with gradient)
     "cfg2": ("hbv", "Hbv", 7300, 671, 16, []),
     "cfg2dyn": ("hbv", "Hbv", 7300, 671, 16, ["parBETA", "parBETAET"]),
+    # config 2 with learned ensemble weights (x_dict['muwts'], hbv.py:508-511): Qsim is the weighted sum of the members
+    "cfg2mu": ("hbv", "Hbv", 7300, 671, 16, [], {"muwts": True}),
     "cfg3": ("hbv_1_1p", "Hbv_1_1p", 7300, 671, 16, "all"),
     "cfg4": ("hbv_adj", "HbvAdj", 7300, 671, 16, ["parBETAET"]),
     "cfg5": ("hbv_2", "Hbv_2", 730, 100000, 16, ["parBETA", "parK0", "parBETAET"]),
@@ -172,6 +174,8 @@ LIMITED_BY = {
                         "fill (5.4 TB/s in that window)",
              {"k_bwd_chunk_phi": 0.32, "k_bwd_chunk_sweep": 0.32, "k_fwd_pipe": 0.11}, "profiles/r04_sq_counters_cfg2.txt"),
     "cfg2dyn": ("latency", "as cfg2; the soil wave carries two dynamic powers", {}, "profiles/r04_sq_counters_cfg2.txt"),
+    "cfg2mu": ("latency", "as cfg2; the ensemble weights are one staged row of the pipelined forward (round 5), the adjoint "
+                          "takes the generic time-parallel instances", {}, "profiles/r05_slotlist_ab.jsonl"),
     "cfg3": ("hbm", "14 dynamic rows streamed twice by the two-pass adjoint: 17.3 GB in 3.6 ms = 4.8 TB/s (76 % of the "
                     "6.3 TB/s this chip copies at); forward bound by its filler waves",
              {"k_bwd_chunk_phi": 0.20, "k_bwd_chunk_sweep": 0.17, "k_fwd_pipe": 0.12}, "profiles/r04_sq_counters_cfg3.txt"),
@@ -218,6 +222,7 @@ class Workload:
         fam, cls, T0, B0, M0, dyn = WORKLOADS[name][:6]
         extra = dict(WORKLOADS[name][6]) if len(WORKLOADS[name]) > 6 else {}
         gages = int(extra.pop("gages", 0))       # (not a module key: the synthetic gage topology of `hourly`)
+        with_mu = bool(extra.pop("muwts", False))  # (not a module key either: an input)
         self.name, self.T, self.B, self.M = name, T or T0, B or B0, M or M0
         T, B, M = self.T, self.B, self.M
         C = hydrodl2_amd.load_model(fam, cls)
@@ -232,6 +237,9 @@ class Workload:
         g.manual_seed(seed)
         x = synth_forcing(T, B, dev, g)
         self.xd = {"x_phy": x}
+        if with_mu:
+            u = torch.rand((T, B, M), generator=g, device=dev) + 0.25
+            self.xd["muwts"] = (u / u.sum(-1, keepdim=True)).contiguous()
         self.extra_bytes = (0.0, 0.0)       # per launch, beyond the recurrence: (forward, backward)
         out_cols = B
         if cls == "Hbv_2_hourly":
@@ -913,7 +921,7 @@ def main():
         # the other BASELINE configs under the same clock: 5 timed steps each, same event timing
         sec = []
         print(f"[bench] headline done: {ms_per_step:.3f} ms/step; secondary configs ...", file=sys.stderr, flush=True)
-        for name in ("cfg2dyn", "cfg3", "cfg4", "cfg4joint", "cfg5share", "cfg5full", "dmg", "dmggraph", "hourly", "lstm", "dpl"):
+        for name in ("cfg2dyn", "cfg2mu", "cfg3", "cfg4", "cfg4joint", "cfg5share", "cfg5full", "dmg", "dmggraph", "hourly", "lstm", "dpl"):
             if name == args.config:
                 continue
             try:

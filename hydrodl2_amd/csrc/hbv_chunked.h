@@ -180,7 +180,10 @@ __device__ __forceinline__ void chunk_pull_dyn(ChunkRaw<NP> &R, const float *lds
     for (int i = 0; i < NP; i++) R.dv[i] = lds[i * 64 + (threadIdx.x & 63)];
 }
 
-template <int NP, int DYN, bool GFULL, bool LDSDV = false>
+// MU: the call carries learned ensemble weights (d.muwts) -- a template flag of the static and slot-list modes
+// (as a run-time flag it cost those instances 3-12 registers and the delta-MG default its fourth wave per SIMD); the
+// generic mode (DYN == 2) tests the pointer at run time, the "all" mode never has them.
+template <int NP, int DYN, bool GFULL, bool LDSDV = false, bool MU = false>
 __device__ __forceinline__ void chunk_issue(const hbvx_desc &d, const hbvx_bwd_io &io,
                                             const ChunkLane &L, int t, int nf, ChunkRaw<NP> &R,
                                             int nd, const int *dslot)
@@ -235,11 +238,13 @@ __device__ __forceinline__ void chunk_issue(const hbvx_desc &d, const hbvx_bwd_i
             const int64_t ts = dy ? ps.dyn_t_stride : 0, bs = dy ? ps.dyn_b_stride : ps.sta_b_stride;
             R.dv[i] = base[(int64_t)t * ts + (int64_t)L.b * bs + L.j];
         }
-        if (d.muwts) R.mu = d.muwts[(int64_t)t * d.mu_t_stride + (int64_t)L.b * d.mu_b_stride + L.j];
     }
+    // learned ensemble weights: in every mode but "all" (round 5: with static or few dynamic parameters they used to
+    // force the generic instances -- 2.55 ms against 1.31 for config 2's adjoint)
+    if ((MU || DYN == 2) && d.muwts) R.mu = d.muwts[(int64_t)t * d.mu_t_stride + (int64_t)L.b * d.mu_b_stride + L.j];
 }
 
-template <int MODEL, bool BETAET, int NP, int DYN, bool GFULL>
+template <int MODEL, bool BETAET, int NP, int DYN, bool GFULL, bool MU = false>
 __device__ __forceinline__ void chunk_finish(const hbvx_desc &d, const ChunkRaw<NP> &R, bool raw, float nz,
                                              float ac, float elev, const float *usta, const float *psta,
                                              const bool *use_dyn, int nf, float invM,
@@ -290,7 +295,7 @@ __device__ __forceinline__ void chunk_finish(const hbvx_desc &d, const ChunkRaw<
     for (int i = NP; i < NPARAM_MAX; i++) D.p[i] = 0.0f;
     D.s.template fwd<SAVE_POW>(D.p, nz, ac, elev, R.sw0, R.ef0);
     D.gq = gf[HBVX_F_QSIM];
-    const float wq = (DYN == 2 && d.muwts) ? R.mu : invM;
+    const float wq = ((MU || DYN == 2) && d.muwts) ? R.mu : invM;
     D.g.gQ = D.gq * wq;
     D.g.gQ0 = gf[HBVX_F_Q0] * invM;
     D.g.gQ1 = gf[HBVX_F_Q1] * invM;
@@ -349,7 +354,7 @@ struct SlotCombo {
     const int ds_[3] = {SC ? SlotCombo<SC>::s0 : (A).dslot[0], SC ? SlotCombo<SC>::s1 : (A).dslot[1], \
                         SC ? SlotCombo<SC>::s2 : (A).dslot[2]}
 
-template <int MODEL, bool BETAET, int DYN, bool GFULL, int SC = 0>
+template <int MODEL, bool BETAET, int DYN, bool GFULL, int SC = 0, bool MU = false>
 __global__ void __launch_bounds__(64) k_bwd_chunk_phi(const ChunkArgs A)
 {
     CHUNK_SLOTS(A);
@@ -384,7 +389,7 @@ __global__ void __launch_bounds__(64) k_bwd_chunk_phi(const ChunkArgs A)
     __shared__ float dvbuf[LDSDV ? NP * 64 : 1];
     ChunkRaw<NP> Rn;
     if (LDSDV) chunk_dma_dyn<NP>(d, L, t1 - 1, dvbuf);   // before the day's other loads: see the loop
-    chunk_issue<NP, DYN, GFULL, LDSDV>(d, io, L, t1 - 1, io.n_flux, Rn, nd_, ds_);
+    chunk_issue<NP, DYN, GFULL, LDSDV, MU>(d, io, L, t1 - 1, io.n_flux, Rn, nd_, ds_);
     for (int t = t1 - 1; t >= t0; t--) {
         ChunkRaw<NP> Rc = Rn;
         if (LDSDV) {
@@ -399,10 +404,10 @@ __global__ void __launch_bounds__(64) k_bwd_chunk_phi(const ChunkArgs A)
         if (t > t0) {
             // The DMA goes first (oldest of next day's vector-memory operations); next day's vmcnt(0) above covers it.
             if (LDSDV) chunk_dma_dyn<NP>(d, L, t - 1, dvbuf);
-            chunk_issue<NP, DYN, GFULL, LDSDV>(d, io, L, t - 1, io.n_flux, Rn, nd_, ds_); // next day's loads in flight
+            chunk_issue<NP, DYN, GFULL, LDSDV, MU>(d, io, L, t - 1, io.n_flux, Rn, nd_, ds_); // next day's loads in flight
         }
         ChunkDay<MODEL, BETAET, NP> D;
-        chunk_finish<MODEL, BETAET, NP, DYN, GFULL>(d, Rc, raw, nz, ac, elev, usta, psta, use_dyn,
+        chunk_finish<MODEL, BETAET, NP, DYN, GFULL, MU>(d, Rc, raw, nz, ac, elev, usta, psta, use_dyn,
                                                     io.n_flux, invM, D, nd_, ds_, io.grad_flux4 != nullptr);
         float gp[NPARAM_MAX], gx[3];
 #pragma unroll
@@ -522,7 +527,7 @@ __device__ __forceinline__ float chunk_ens_sum(float v, int lgMp)
 // (64/Mp) separate 64-byte pieces of misaligned 904-byte rows (partial-line writes: profiles/
 // r02_pmc_calibration.csv shows what those cost).  The host sets it when every parameter's gradient
 // lives in one tensor with the reference's column order (column = i*M + j, hbv.py:201-208).
-template <int MODEL, bool BETAET, int DYN, bool GFULL, int SC = 0, bool ROWST = false>
+template <int MODEL, bool BETAET, int DYN, bool GFULL, int SC = 0, bool ROWST = false, bool MU = false>
 __global__ void __launch_bounds__(64) k_bwd_chunk_sweep(const ChunkArgs A)
 {
     CHUNK_SLOTS(A);
@@ -554,7 +559,7 @@ __global__ void __launch_bounds__(64) k_bwd_chunk_sweep(const ChunkArgs A)
     __shared__ float dvbuf[LDSDV ? NP * 64 : 1];
     ChunkRaw<NP> Rn;
     if (LDSDV) chunk_dma_dyn<NP>(d, L, t1 - 1, dvbuf);   // before the day's other loads: see the loop
-    chunk_issue<NP, DYN, GFULL, LDSDV>(d, io, L, t1 - 1, io.n_flux, Rn, nd_, ds_);
+    chunk_issue<NP, DYN, GFULL, LDSDV, MU>(d, io, L, t1 - 1, io.n_flux, Rn, nd_, ds_);
     for (int t = t1 - 1; t >= t0; t--) {
         ChunkRaw<NP> Rc = Rn;
         if (LDSDV) {
@@ -564,12 +569,12 @@ __global__ void __launch_bounds__(64) k_bwd_chunk_sweep(const ChunkArgs A)
         }
         if (t > t0) {
             if (LDSDV) chunk_dma_dyn<NP>(d, L, t - 1, dvbuf);
-            chunk_issue<NP, DYN, GFULL, LDSDV>(d, io, L, t - 1, io.n_flux, Rn, nd_, ds_);
+            chunk_issue<NP, DYN, GFULL, LDSDV, MU>(d, io, L, t - 1, io.n_flux, Rn, nd_, ds_);
         }
         ChunkDay<MODEL, BETAET, NP> D;
-        chunk_finish<MODEL, BETAET, NP, DYN, GFULL>(d, Rc, raw, nz, ac, elev, usta, psta, use_dyn,
+        chunk_finish<MODEL, BETAET, NP, DYN, GFULL, MU>(d, Rc, raw, nz, ac, elev, usta, psta, use_dyn,
                                                     io.n_flux, invM, D, nd_, ds_, io.grad_flux4 != nullptr);
-        if (DYN == 2 && io.grad_muwts && L.active) io.grad_muwts[((int64_t)t * d.B + L.b) * d.M + L.j] = D.gq * D.s.Q;
+        if ((MU || DYN == 2) && io.grad_muwts && L.active) io.grad_muwts[((int64_t)t * d.B + L.b) * d.M + L.j] = D.gq * D.s.Q;
         float gp[NPARAM_MAX], gx[3];
 #pragma unroll
         for (int i = 0; i < NPARAM_MAX; i++) gp[i] = 0.0f;

@@ -102,9 +102,11 @@ struct PipeLds {
 // first (global flux index = nibble i of FMAP), then NSER - NFS storage series.  Everything that
 // indexes the layout is a compile-time constant.
 //   pipe_reduce_pass: ensemble means of 64 (day, series, basin) items -> flux series
+//   muq: learned ensemble weights (hbv.py:508-511): the stepper staged Qsim x weight, so series QSIM is the plain SUM
+//   over the members, every other series the mean (what hbv_tiled.h does: same products, same add tree)
 template <int NSER, int NFS, unsigned FMAP>
 __device__ __forceinline__ void pipe_reduce_pass(const hbvx_desc &d, const hbvx_fwd_out &o, const float *buf,
-                                                 int t0, int items, int pass, int lane, int lgMp, int b0)
+                                                 int t0, int items, int pass, int lane, int lgMp, int b0, bool muq = false)
 {
     const int T = d.T, B = d.B;
     const float invM = 1.0f / (float)d.M;
@@ -112,7 +114,8 @@ __device__ __forceinline__ void pipe_reduce_pass(const hbvx_desc &d, const hbvx_
     ens_reduce_pass<NSER, NFS>(buf, items, pass * 64, lane, d.M, lgMp, [&](int tt, int ks, int bl, float acc) {
         const int kk = (int)((FMAP >> (4 * ks)) & 0xFu);
         const unsigned off = b0 + bl < B ? (unsigned)(((kk * T + (t0 + tt)) * B + b0 + bl) * 4) : 0xFFFFFFFFu;
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc * invM), r, off, 0, 0);
+        const float v = (muq && kk == HBVX_F_QSIM) ? acc : acc * invM;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
     });
 }
 
@@ -202,7 +205,12 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
 #pragma unroll
         for (int i = 0; i < NP; i++) dmask |= d.p[i].dyn ? (1u << i) : 0u;
     }
-    const int PD = DYN ? (MANY ? __builtin_popcount(dmask) : PIPE_FEWDYN) : 0;   // staged rows per day
+    // learned ensemble weights `muwts` [T,B,nmul] travel as one more staged row behind the dynamic parameters' (raw: no
+    // sigmoid, no range): the stage that forms Qsim multiplies, the reducers SUM that series (hbv.py:508-511)
+    const bool has_mu = DYN && !ADJ && d.muwts != nullptr;
+    const int mrow = __builtin_popcount(dmask);
+    const int ix_mu = has_mu ? mrow * 64 : 0;
+    const int PD = DYN ? (MANY ? mrow + (has_mu ? 1 : 0) : PIPE_FEWDYN) : 0;   // staged rows per day
     const PipeLds P(Kt, PD, CAP);
     const float nz = d.nearzero;
     const float ac = (MODEL == MODEL_HBV20 || MODEL == MODEL_HOURLY) ? d.ac[L.b] : 0.0f;
@@ -378,7 +386,9 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                     q[0] = s.ET; q[64] = s.rech; q[128] = s.exc; q[192] = s.ef; q[256] = s.cap;
                     if (TRAJ && !DIRECT) { q[320] = SM; if (SAVE_POW) { q[384] = s.sw0; q[448] = s.ef0; } }
                     float *r = oc + tt * 448;
-                    r[0] = s.Q; r[64] = s.Q0; r[128] = s.Q1; r[192] = s.Q2; r[256] = s.PERC;
+                    // (the weight is read where it is used: it only scales an OUTPUT, off the day-to-day chain, and a
+                    // prefetch register for it pushed three instances of this stage over their 128)
+                    r[0] = has_mu ? s.Q * pin[tt * PD * 64 + ix_mu] : s.Q; r[64] = s.Q0; r[128] = s.Q1; r[192] = s.Q2; r[256] = s.PERC;
                     if (TRAJ) {
                         if (DIRECT) { trj_put(rSM, tile, tt, 2, SM); trj_put(rSUZ, tile, tt, 3, SUZ); trj_put(rSLZ, tile, tt, 4, SLZ); }
                         else { r[320] = SUZ; r[384] = SLZ; }
@@ -508,7 +518,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                         s.rech = dRECH; s.exc = dEXC;
                         s.SUZ = SUZ; s.SLZ0 = SLZ;
                         s.fwd_gw(p, 0.0f);
-                        q[0] = s.Q; q[64] = s.Q0; q[128] = s.Q1; q[192] = s.Q2; q[256] = s.PERC;
+                        q[0] = has_mu ? s.Q * pin[tt * PD * 64 + ix_mu] : s.Q; q[64] = s.Q0; q[128] = s.Q1; q[192] = s.Q2; q[256] = s.PERC;
                         if (TRAJ) {
                             if (DIRECT) { trj_put(rSUZ, tile, tt, 3, SUZ); trj_put(rSLZ, tile, tt, 4, SLZ); }
                             else { q[320] = SUZ; q[384] = SLZ; }
@@ -589,13 +599,18 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
             unsigned dvo[NRW];
             int64_t dts[NRW];
             float dlo[NRW], dhi[NRW], dsta[NRW];
-            bool duse[NRW], dyrow[NRW];
+            bool duse[NRW], dyrow[NRW], murow[NRW];
 #pragma unroll
             for (int r = 0; r < NRW; r++) {
                 const int k = frow + fstep * r;
-                dyrow[r] = DYN && k < nd;
+                murow[r] = has_mu && k == nd;               // the ensemble weights: the row behind the parameters'
+                dyrow[r] = (DYN && k < nd) || murow[r];
                 dsrc[r] = d.x; dvo[r] = 0; dts[r] = 0; dlo[r] = dhi[r] = dsta[r] = 0.0f; duse[r] = false;
-                if (dyrow[r]) {
+                if (murow[r]) {
+                    dsrc[r] = d.muwts;
+                    dvo[r] = (unsigned)((L.b * d.mu_b_stride + L.j) * 4);
+                    dts[r] = d.mu_t_stride;
+                } else if (dyrow[r]) {
                     int slot = 0;
                     for (int i = 0, c = 0; i < NP; i++)
                         if ((dmask >> i) & 1u) { if (c == k) slot = i; c++; }
@@ -641,7 +656,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
 #pragma unroll
                         for (int i = 0; i < FD; i++) {
                             const float u = raw ? sigmoid_dyn_(dv[r][i]) : dv[r][i];
-                            pin[i * PD * 64] = duse[r] ? descale_(u, dlo[r], dhi[r]) : dsta[r];
+                            pin[i * PD * 64] = murow[r] ? dv[r][i] : (duse[r] ? descale_(u, dlo[r], dhi[r]) : dsta[r]);
                         }
                     }
             };
@@ -691,7 +706,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                 if (rank >= 0) {
                     for (int u = rank; u < nR; u += nred) {
                         if (u < pC)
-                            pipe_reduce_pass<7, NFC, fmapC>(d, o, bufC, tC * Kt, iC, u, lane, lgMp, b0);
+                            pipe_reduce_pass<7, NFC, fmapC>(d, o, bufC, tC * Kt, iC, u, lane, lgMp, b0, has_mu);
                         else if (u < pC + pB)
                             pipe_reduce_pass<OBR, NFB, fmapB>(d, o, bufB, tB * Kt, iB, u - pC, lane, lgMp, b0);
                         else
@@ -807,7 +822,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
                 // heaviest passes first (C: 5 series), so the tail of the round-robin is light
                 for (int u = w; u < nR; u += NDR) {
                     if (u < pC)
-                        pipe_reduce_pass<7, NFC, fmapC>(d, o, bufC, tC * Kt, iC, u, lane, lgMp, b0);
+                        pipe_reduce_pass<7, NFC, fmapC>(d, o, bufC, tC * Kt, iC, u, lane, lgMp, b0, has_mu);
                     else if (u < pC + pB)
                         pipe_reduce_pass<OBR, NFB, fmapB>(d, o, bufB, tB * Kt, iB, u - pC, lane, lgMp, b0);
                     else

@@ -47,9 +47,10 @@ static hipError_t launch_chunked_t(const ChunkArgs &a, hipStream_t st)
     dim3 g2((unsigned)(8 * a.per_xcd * a.nchunk));      // XCD-aware 1-D block map (hbv_chunked.h::chunk_block)
     // the two slot lists users actually run get compile-time slots (hbv_chunked.h::SlotCombo)
     int sc = 0;
-    if (DYN == 1 && MODEL == MODEL_HBV10 && BETAET && a.nd == 2 && a.dslot[0] == P_BETA && a.dslot[1] == P_BETAET) sc = 1;
-    if (DYN == 1 && (MODEL == MODEL_HBV20 || MODEL == MODEL_HOURLY) && a.nd == 3 && a.dslot[0] == P_BETA && a.dslot[1] == P_K0 &&
-        a.dslot[2] == P_BETAET)
+    const bool mu = d.muwts != nullptr;     // (the compiled slot combos have no MU instance: the slot-list form below)
+    if (!mu && DYN == 1 && MODEL == MODEL_HBV10 && BETAET && a.nd == 2 && a.dslot[0] == P_BETA && a.dslot[1] == P_BETAET) sc = 1;
+    if (!mu && DYN == 1 && (MODEL == MODEL_HBV20 || MODEL == MODEL_HOURLY) && a.nd == 3 && a.dslot[0] == P_BETA &&
+        a.dslot[1] == P_K0 && a.dslot[2] == P_BETAET)
         sc = 2;
     if constexpr (DYN == 1 && MODEL == MODEL_HBV10 && BETAET) {
         if (sc == 1) {
@@ -71,6 +72,17 @@ static hipError_t launch_chunked_t(const ChunkArgs &a, hipStream_t st)
         hipLaunchKernelGGL(k_bwd_chunk_reduce, dim3((unsigned)((N + 255) / 256), d.n_param), dim3(256), 0, st,
                            a, d.n_param);
         return hipGetLastError();
+    }
+    if constexpr (DYN == 0 || DYN == 1) {
+        if (d.muwts) {    // learned ensemble weights: the MU instances of the static / slot-list modes (hbv_chunked.h)
+            hipLaunchKernelGGL((k_bwd_chunk_phi<MODEL, BETAET, DYN, GFULL, 0, true>), g2, dim3(64), 0, st, a);
+            hipLaunchKernelGGL(k_bwd_chunk_scan, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, st, a);
+            store_gate(&a.io, st);
+            hipLaunchKernelGGL((k_bwd_chunk_sweep<MODEL, BETAET, DYN, GFULL, 0, false, true>), g2, dim3(64), 0, st, a);
+            hipLaunchKernelGGL(k_bwd_chunk_reduce, dim3((unsigned)((N + 255) / 256), d.n_param), dim3(256), 0, st,
+                               a, d.n_param);
+            return hipGetLastError();
+        }
     }
     hipLaunchKernelGGL((k_bwd_chunk_phi<MODEL, BETAET, DYN, GFULL>), g2, dim3(64), 0, st, a);
     hipLaunchKernelGGL(k_bwd_chunk_scan, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, st, a);
@@ -122,7 +134,7 @@ static hipError_t launch_chunked(const hbvx_desc *d, const hbvx_bwd_io *io, hipS
     a.nd = 0;
     a.dslot[0] = a.dslot[1] = a.dslot[2] = 0;
     const int ndyn = count_dyn(d);
-    if (ndyn > 0 && ndyn <= CHUNK_FEW && !d->muwts) {   // few dynamic parameters: slot-list kernels
+    if (ndyn > 0 && ndyn <= CHUNK_FEW) {   // few dynamic parameters: slot-list kernels (muwts: a run-time flag in them)
         for (int i = 0; i < d->n_param; i++)
             if (d->p[i].dyn) a.dslot[a.nd++] = i;
         return gfull ? launch_chunked_v<1, true>(d, a, st) : launch_chunked_v<1, false>(d, a, st);
@@ -134,7 +146,7 @@ static hipError_t launch_chunked(const hbvx_desc *d, const hbvx_bwd_io *io, hipS
         alldyn = d->p[i].drop == nullptr && d->p[i].dyn == d->p[0].dyn + (int64_t)i * d->M &&
                  d->p[i].dyn_t_stride == d->p[0].dyn_t_stride && d->p[i].dyn_b_stride == d->p[0].dyn_b_stride;
     if (alldyn) return gfull ? launch_chunked_v<3, true>(d, a, st) : launch_chunked_v<3, false>(d, a, st);
-    if (ndyn > 0 || d->muwts) return gfull ? launch_chunked_v<2, true>(d, a, st) : launch_chunked_v<2, false>(d, a, st);
+    if (ndyn > 0) return gfull ? launch_chunked_v<2, true>(d, a, st) : launch_chunked_v<2, false>(d, a, st);
     return gfull ? launch_chunked_v<0, true>(d, a, st) : launch_chunked_v<0, false>(d, a, st);
 }
 

@@ -20,10 +20,13 @@ bool hbvx_host::try_fwd_pipe(const hbvx_desc *d, const hbvx_fwd_out *out, void *
         // HBV 1.0 / 1.1p / 2.0, at most PIPE_MAXDYN dynamic parameters, flux requested: pipelined
         // forward (hbv_pipe.h; three stages for HBV 1.0, two for the capillary models)
         const char *fv = getenv("HBVX_FWD");
-        const int nd = count_dyn(d);
+        const bool adj = d->model == HBVX_MODEL_HBVADJ;   // implicit scheme, staged solve (hbvx_adj_forward only)
+        // staged rows per day: the dynamic parameters' and, behind them, the learned ensemble weights `muwts`
+        // (hbv_pipe.h: has_mu); "nd" below counts both
+        const bool mu = d->muwts != nullptr && !adj;
+        const int nd = count_dyn(d) + (mu ? 1 : 0);
         const bool many = nd > PIPE_FEWDYN;          // 4-day tiles, several staged rows per filler wave
         const int Kt = many ? PIPE_KT_MANY : (nd > 0 ? PIPE_KT : PIPE_KT_STATIC);
-        const bool adj = d->model == HBVX_MODEL_HBVADJ;   // implicit scheme, staged solve (hbvx_adj_forward only)
         const bool cap = d->model != HBVX_MODEL_HBV10 && !adj;
         const int nfl = adj ? 1 : (cap ? 12 : 11);
         // per-lane and per-tile byte offsets are 32-bit in the pipelined kernel
@@ -32,6 +35,8 @@ bool hbvx_host::try_fwd_pipe(const hbvx_desc *d, const hbvx_fwd_out *out, void *
             if (d->p[i].dyn)
                 off32 = off32 && ((int64_t)d->B * d->p[i].dyn_b_stride + (int64_t)Kt * d->p[i].dyn_t_stride) * 4 <
                                      (int64_t)1 << 31;
+        if (mu) off32 = off32 && ((int64_t)d->B * d->mu_b_stride + (int64_t)Kt * d->mu_t_stride) * 4 < (int64_t)1 << 31 &&
+                        d->mu_t_stride >= 0;
         const int64_t wgs_p = ((int64_t)d->B + (64 >> lg_members(d->M)) - 1) / (64 >> lg_members(d->M));
         const bool pmodel = d->model == HBVX_MODEL_HBV10 || d->model == HBVX_MODEL_HBV11P ||
                             d->model == HBVX_MODEL_HBV20 || d->model == HBVX_MODEL_HOURLY ||
@@ -42,7 +47,7 @@ bool hbvx_host::try_fwd_pipe(const hbvx_desc *d, const hbvx_fwd_out *out, void *
                                ? HBVX_TRAJ_CKPT_DAYS(out->traj_layout) : 0;
         const bool ckpt_fits = !ckpt_k || ((int64_t)((d->T + ckpt_k - 1) / ckpt_k) * 5 * d->B * d->M * 4 < (int64_t)1 << 32);
         if (ckpt_fits && use_tiled(d) && !(fv && !strcmp(fv, "tiled")) && pmodel && off32 &&
-            nd <= PIPE_MAXDYN && (int)lds <= LDS_BUDGET && wgs_p < 4096 && !d->muwts && (out->flux || adj) && d->T >= 4 * Kt &&
+            nd <= PIPE_MAXDYN && (int)lds <= LDS_BUDGET && wgs_p < 4096 && !(adj && d->muwts) && (out->flux || adj) && d->T >= 4 * Kt &&
             (adj ? !ckpt_k : (ckpt_k ? true : aux_matches_traj(out))) &&
             (int64_t)d->B * d->M * 4 * Kt < (int64_t)1 << 31 &&
             (int64_t)nfl * d->T * d->B * 4 < (int64_t)1 << 31) {

@@ -78,9 +78,10 @@ def test_the_adjoints_prefetch_is_not_waited_for_where_it_is_issued():
     if not os.path.exists(LIB):
         pytest.skip("libhbvx.so not built")
     import kernel_resources
-    kernels = ["k_bwd_chunk_phiILi0ELb0ELi0ELb0ELi0E", "k_bwd_chunk_sweepILi0ELb0ELi0ELb0ELi0ELb0E",
-               "k_bwd_chunk_phiILi0ELb1ELi1ELb0ELi1E", "k_bwd_chunk_sweepILi0ELb1ELi1ELb0ELi1ELb0E",
-               "k_bwd_chunk_phiILi4ELb1ELi1ELb0ELi2E", "k_adj_chunk_phiILb1ELb1E"]
+    # (trailing ...ELb0EE: the instances without learned ensemble weights, MU = false)
+    kernels = ["k_bwd_chunk_phiILi0ELb0ELi0ELb0ELi0ELb0EE", "k_bwd_chunk_sweepILi0ELb0ELi0ELb0ELi0ELb0ELb0EE",
+               "k_bwd_chunk_phiILi0ELb1ELi1ELb0ELi1ELb0EE", "k_bwd_chunk_sweepILi0ELb1ELi1ELb0ELi1ELb0ELb0EE",
+               "k_bwd_chunk_phiILi4ELb1ELi1ELb0ELi2ELb0EE", "k_adj_chunk_phiILb1ELb1E"]
     dis = kernel_resources.disassemble(LIB, kernels)
     assert len(dis) == len(kernels), sorted(dis)
     for sym, ins in dis.items():

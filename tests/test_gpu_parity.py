@@ -348,3 +348,27 @@ def test_long_golden_case_under_every_adjoint(name, env_id, hip_backend, monkeyp
     if want_bwd is not None:
         assert bwd in want_bwd, f"{name} [{env_id}]: adjoint ran {bwd!r} (forward {fwd!r}), meant {want_bwd}"
     print(f"{name} [{env_id}]: forward {fwd}, adjoint {bwd}")
+
+
+@pytest.mark.parametrize("model,dyn,drop", [("Hbv", (), 0.0), ("Hbv", ("parBETA", "parBETAET"), 0.3),
+                                            ("Hbv", ("parBETA", "parK0", "parBETAET"), 0.0), ("Hbv_1_1p", ("parC",), 0.0),
+                                            ("Hbv_2", ("parBETA", "parK0", "parBETAET", "parRT"), 0.2)])
+@pytest.mark.parametrize("M,B,T", [(16, 37, 211), (5, 19, 64)])
+def test_pipelined_forward_with_ensemble_weights_equals_tiled(M, B, T, model, dyn, drop, hip_backend, oracle_path, monkeypatch):
+    """Learned ensemble weights `muwts` (hbv.py:508-511) in the pipelined forward: the weights travel as one more
+    staged row (few / compiled-set / many-row instances: 1, 3, 4, 2 and 5 rows here), the stage that forms Qsim
+    multiplies, the reducers sum that series.  Bit-identical to the tiled kernel (round 4: muwts forced the slow one),
+    and equal to the oracle."""
+    prob = make_problem(model=model, T=T, B=B, M=M, dyn=dyn, betaet=("parBETAET" in dyn and model == "Hbv"), drop_frac=drop,
+                        seed=27, muwts=True)
+    a = run_problem(prob, None, device="cuda:0", backward=True)
+    assert hip_backend.last_dispatch(0) == "pipe"
+    monkeypatch.setenv("HBVX_FWD", "tiled")
+    b = run_problem(prob, None, device="cuda:0", backward=True)
+    assert hip_backend.last_dispatch(0) == "tiled"
+    for k in ("flux", "routed", "state_out", "traj", "g_params", "g_muwts"):
+        if k in b:
+            assert np.array_equal(a[k], b[k]), k
+    monkeypatch.delenv("HBVX_FWD")
+    want = run_problem(prob, oracle_path, device="cpu", backward=True)
+    compare_runs(prob, a, want)
