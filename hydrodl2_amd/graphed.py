@@ -25,7 +25,8 @@ Restrictions (each raises): dy_drop > 0 (the masks are drawn on the host per cal
 the eager path does (hbv.py:240), so a script's random stream does not depend on the switch.  Outputs are views of
 static buffers: they are overwritten by the module's next call with the same shape (the contract of
 torch.cuda.make_graphed_callables).  The gradients handed to autograd are COPIES of the static gradient buffers: a
-leaf's `.grad` may be accumulated into across steps.
+leaf's `.grad` may be accumulated into across steps.  That copy is why the switch is for SMALL steps only:
+at the headline shape (a 3.8 GB gradient) the graphed step takes 4.05 ms against 2.45 ms eager (round 5 measurement).
 """
 from __future__ import annotations
 
