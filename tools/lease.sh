@@ -1,8 +1,5 @@
 mkdir -p gpurun_out
-python tools/bench_one.py cfg2 cfg2graph cfg2 cfg2graph --steps 20 > gpurun_out/r05_cfg2graph.jsonl 2> gpurun_out/r05_cfg2graph.err
-python - <<'PY'
-import json
-for l in open('gpurun_out/r05_cfg2graph.jsonl'):
-    r=json.loads(l); print(r['config'], r['ms_median'], r['ms_min'], r['ms_max'], r['host_enqueue_ms_median'])
-PY
-tail -3 gpurun_out/r05_cfg2graph.err
+python -m pytest tests -m gpu -q -p no:cacheprovider > gpurun_out/r05_gputier_10.log 2>&1
+tail -3 gpurun_out/r05_gputier_10.log
+grep -E "^(FAILED|ERROR)" gpurun_out/r05_gputier_10.log | cut -c1-200 | head
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r05_smoke.log 2>&1; tail -1 gpurun_out/r05_smoke.log
