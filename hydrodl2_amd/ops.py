@@ -184,7 +184,11 @@ def _grad_like(lib, p: torch.Tensor, cfg: "StepConfig", tensor_idx: int) -> torc
 # wait longer for memory) with a much wider spread (1.15-2.2 ms under the profiler).  Off by default: the gain
 # is small and the forward's time stops being a property of the forward.  The buffers are handed to
 # backward through the autograd context (first backward only; a second one over a retained graph fills
-# its own).
+# its own).  Re-measured in round 5 with today's kernels (profiles/r05_earlyzero.txt): the MEDIAN step drops
+# 2.40 -> 1.95 ms at config 2, but the buffers are allocated on the side stream and the caching allocator cannot
+# recycle a block another stream still owns: every other step pays a hipMalloc (region mean 2.44 ms, one multi-second
+# stall).  Two safer ownership schemes were tried (caller's pool + stream wait; buffers held until the fill's event):
+# no net gain / worse.  Stays off.
 _EARLY_ZERO = os.environ.get("HBVX_EARLY_ZERO", "0") not in ("", "0")
 _EARLY_ZERO_MIN = 1 << 26     # elements: below 256 MB the stream switch costs the host more than the fill costs the GPU
 _SIDE_STREAMS: dict = {}

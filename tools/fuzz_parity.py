@@ -48,7 +48,8 @@ def main():
                   drop_frac=rng.choice([0.0, 0.0, 0.3]) if dyn else 0.0,
                   muwts=(rng.random() < 0.2 and model == "Hbv"), cold=rng.random() < 0.3,
                   betaet=("parBETAET" in names and model == "Hbv"),
-                  routing=rng.random() < 0.8, raw_scale=rng.choice([1.0, 1.0, 2.5]))
+                  routing=rng.random() < 0.8, raw_scale=rng.choice([1.0, 1.0, 2.5]),
+                  channels=rng.choice([(0, 1, 2)] * 4 + [(2, 0, 1), (1, 2, 0), (0, 2, 1)]))
         t0 = rng.randint(1, max(1, T // 2)) if (rng.random() < 0.3 and T > 4) else 0   # warm-up offset
         try:
             prob = make_problem(**kw)
@@ -56,14 +57,16 @@ def main():
             got = run_problem(prob, None, device="cuda:0", x_grad=grad, backward=grad, t0=t0)
             want = run_problem(prob, ge.ORACLE_LIB, device="cpu", x_grad=grad, backward=grad, t0=t0)
             compare_runs(prob, got, want, keys=("flux", "routed", "state_out", "g_params", "g_x", "g_muwts"))
-            status = "ok"
+            from hydrodl2_amd import _lib
+            lib = _lib.get_library()
+            status = "ok " + lib.last_dispatch(0) + "/" + (lib.last_dispatch(1) if grad else "-")
         except AssertionError as e:
             bad += 1
             status = "MISMATCH " + str(e)[:300]
         except Exception as e:  # noqa: BLE001
             bad += 1
             status = "ERROR " + repr(e)[:300]
-        print(f"[{case:3d}] {status:12.300s} {model} T={T} B={B} M={M} dyn={len(dyn)}:{mode} drop={kw['drop_frac']} "
+        print(f"[{case:3d}] {status:28.300s} {model} T={T} B={B} M={M} dyn={len(dyn)}:{mode} drop={kw['drop_frac']} "
               f"muwts={kw['muwts']} cold={kw['cold']} routing={kw['routing']} scale={kw['raw_scale']} t0={t0} grad={grad} seed={kw['seed']}", flush=True)
     print(f"{n_cases - bad}/{n_cases} cases agree, {time.time() - t_start:.0f} s", flush=True)
     return 1 if bad else 0
