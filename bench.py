@@ -136,6 +136,9 @@ WORKLOADS = {
     "cfg2dyn": ("hbv", "Hbv", 7300, 671, 16, ["parBETA", "parBETAET"]),
     # config 2 with learned ensemble weights (x_dict['muwts'], hbv.py:508-511): Qsim is the weighted sum of the members
     "cfg2mu": ("hbv", "Hbv", 7300, 671, 16, [], {"muwts": True}),
+    # the headline with module key grad_buffer='persistent' (opt-in): the dense zero fill of the [T,B,ny] gradient -- what
+    # the autograd contract costs -- happens once instead of every step
+    "cfg2persist": ("hbv", "Hbv", 7300, 671, 16, [], {"grad_buffer": "persistent"}),
     "cfg3": ("hbv_1_1p", "Hbv_1_1p", 7300, 671, 16, "all"),
     "cfg4": ("hbv_adj", "HbvAdj", 7300, 671, 16, ["parBETAET"]),
     "cfg5": ("hbv_2", "Hbv_2", 730, 100000, 16, ["parBETA", "parK0", "parBETAET"]),
@@ -174,6 +177,8 @@ LIMITED_BY = {
                         "fill (5.4 TB/s in that window)",
              {"k_bwd_chunk_phi": 0.32, "k_bwd_chunk_sweep": 0.32, "k_fwd_pipe": 0.11}, "profiles/r04_sq_counters_cfg2.txt"),
     "cfg2dyn": ("latency", "as cfg2; the soil wave carries two dynamic powers", {}, "profiles/r04_sq_counters_cfg2.txt"),
+    "cfg2persist": ("latency", "as cfg2 without the per-step 3.8 GB gradient fill (and without its share of HBM beside the "
+                               "adjoint)", {}, "profiles/r05_persist_ab.jsonl"),
     "cfg2mu": ("latency", "as cfg2; the ensemble weights are one staged row of the pipelined forward (round 5), the adjoint "
                           "takes the generic time-parallel instances", {}, "profiles/r05_slotlist_ab.jsonl"),
     "cfg3": ("hbm", "14 dynamic rows streamed twice by the two-pass adjoint: 17.3 GB in 3.6 ms = 4.8 TB/s (76 % of the "
@@ -921,7 +926,7 @@ def main():
         # the other BASELINE configs under the same clock: 5 timed steps each, same event timing
         sec = []
         print(f"[bench] headline done: {ms_per_step:.3f} ms/step; secondary configs ...", file=sys.stderr, flush=True)
-        for name in ("cfg2dyn", "cfg2mu", "cfg3", "cfg4", "cfg4joint", "cfg5share", "cfg5full", "dmg", "dmggraph", "hourly", "lstm", "dpl"):
+        for name in ("cfg2dyn", "cfg2mu", "cfg2persist", "cfg3", "cfg4", "cfg4joint", "cfg5share", "cfg5full", "dmg", "dmggraph", "hourly", "lstm", "dpl"):
             if name == args.config:
                 continue
             try:

@@ -63,6 +63,11 @@ class HbvModule(torch.nn.Module):
         # not in the reference: replay the call's launch sequence (forward and backward) as HIP graphs captured per
         # input shape -- for steps whose kernels are shorter than their enqueue time (hydrodl2_amd/graphed.py)
         self.graph = False
+        # 'fresh' (default): every backward returns a newly allocated, zero-filled gradient for `parameters`, as
+        # autograd does.  'persistent': the dense [T,B,ny] gradient lives in a buffer the module keeps per input
+        # shape and only the parts that change are rewritten (ops._overlapped_grad_buffers) -- valid until the next
+        # backward with that shape; not for gradient accumulation across calls on a leaf tensor.
+        self.grad_buffer = 'fresh'
 
         self.states, self._states_cache = None, None
         self._cfg_cache, self._pmat_cache = {}, {}     # per input shape: step configs / Bernoulli probabilities
@@ -96,7 +101,7 @@ class HbvModule(torch.nn.Module):
     # -- configuration --------------------------------------------------
     # config key -> attribute of the same name; absent keys keep the constructor default
     _CONFIG_KEYS = ('warm_up', 'warm_up_states', 'dy_drop', 'variables', 'routing', 'comprout',
-                    'nearzero', 'nmul', 'cache_states', 'adjoint_checkpoint', 'check_finite', 'graph')
+                    'nearzero', 'nmul', 'cache_states', 'adjoint_checkpoint', 'check_finite', 'graph', 'grad_buffer')
 
     def _read_config(self, config: dict) -> None:
         """Same keys and defaults as hbv.py:110-125; `dynamic_params` is REQUIRED once a config is
@@ -217,13 +222,13 @@ class HbvModule(torch.nn.Module):
         key = (T_total, ngrid, ny, warm_up, M, n, tuple(self.dynamic_params), bool(self.routing), self._model_id,
                tuple(self.variables), float(self.nearzero), int(self.adjoint_checkpoint),
                tuple(map(tuple, self.parameter_bounds.values())),
-               tuple(map(tuple, self.routing_parameter_bounds.values())), str(device))
+               tuple(map(tuple, self.routing_parameter_bounds.values())), str(device), str(self.grad_buffer))
         hit = self._cfg_cache.get(key)
         if hit is not None:
             return hit
         base = dict(model=self._model_id, n_param=n, n_flux=self._n_flux(), B=ngrid, M=M,
                     raw_sigmoid=True, channels=self._channels(), nearzero=float(self.nearzero),
-                    ckpt_days=int(self.adjoint_checkpoint))
+                    ckpt_days=int(self.adjoint_checkpoint), persistent_grad=self._persistent_grad())
         cfg_w = None
         if warm_up > 0:     # hbv.py:327-346: all parameters static from row warm_up-1, states only
             cfg_w = StepConfig(T=warm_up, t0=0, want_flux=False, **base)
@@ -243,12 +248,17 @@ class HbvModule(torch.nn.Module):
         self._cfg_cache[key] = (cfg_w, cfg)
         return cfg_w, cfg
 
+    def _persistent_grad(self) -> bool:
+        if self.grad_buffer not in ('fresh', 'persistent'):
+            raise ValueError("grad_buffer must be 'fresh' or 'persistent'")
+        return self.grad_buffer == 'persistent'
+
     def _settings_key(self):
         """Everything besides the input shapes that decides what a call launches (key of the step-config and graph
         caches)."""
         return (self.nmul, len(self.parameter_bounds), tuple(self.dynamic_params), bool(self.routing), self._model_id,
                 tuple(self.variables), float(self.nearzero), int(self.adjoint_checkpoint), int(self.warm_up),
-                bool(self.warm_up_states), float(self.dy_drop), bool(self.comprout),
+                bool(self.warm_up_states), float(self.dy_drop), bool(self.comprout), str(self.grad_buffer),
                 tuple(map(tuple, self.parameter_bounds.values())),
                 tuple(map(tuple, self.routing_parameter_bounds.values())))
 

@@ -77,6 +77,7 @@ class StepConfig:
     mu_t0: Optional[int] = None  # first row of muwts used by this call (None: same as t0)
     want_bfi: bool = False     # also return BFI (hbv.py:562-567) from the same autograd node (no second Function)
     ckpt_days: int = 0         # 4 / 8 / 16: keep K-day checkpoints instead of the trajectory (memory-lean adjoint)
+    persistent_grad: bool = False   # module key grad_buffer='persistent': see _overlapped_grad_buffers
 
 
 def _device_guard(fn):
@@ -256,6 +257,28 @@ def _overlapped_grad_buffers(lib, cfg: "StepConfig", ptensors, needs):
               and all(o >= base for o in offs) and cols is not None and (cols[0] == 0 or few_dyn))
         if not ok:
             gp.append(_grad_like(lib, p, cfg, i)); rows.append(None); bases.append(0)
+            continue
+        if cfg.persistent_grad:
+            # grad_buffer='persistent' (opt-in): the [T,B,W] gradient lives in a buffer this configuration keeps.  All
+            # of it but the last row and the dynamic columns is zero and STAYS zero (nothing ever writes there), the
+            # dynamic columns are overwritten by every adjoint, the last row is reset below -- so the dense zero fill
+            # the autograd contract costs (3.8 GB per step at config 2, and the bandwidth it takes from the adjoint
+            # beside it) happens once.  The contract of a captured graph's static outputs: the tensor handed to
+            # autograd is valid until this module's next backward with the same shapes (no gradient accumulation across
+            # calls on a leaf).  The memo keeps the STORAGE and hands out a fresh tensor each time, so that autograd's
+            # AccumulateGrad may adopt it (a tensor someone else references would be cloned: 3.8 GB).
+            memo = cfg.__dict__.setdefault("_memo", {})
+            key = ("pgrad", i, tuple(p.shape), str(p.device))
+            st = memo.get(key)
+            if st is None:
+                big = _zeros_like(lib, p)
+                memo[key] = big.untyped_storage()
+            else:
+                big = torch.empty(0, dtype=p.dtype, device=p.device).set_(st, 0, p.shape)
+                big[-1].zero_()
+            gp.append(big)
+            rows.append(torch.zeros_like(p[0]))
+            bases.append(base)
             continue
         # on the caller's stream and pool: it is also where it dies
         big = torch.empty_like(p)
@@ -604,9 +627,9 @@ class HbvPath(torch.autograd.Function):
                 fill_done = start_fill()       # (nothing ran in between: the fill simply starts now)
             if fill_done is not None:
                 torch.cuda.current_stream(dev).wait_event(fill_done)
-                for big, row in zip(gp, rows):
-                    if row is not None:
-                        big[-1] += row
+            for big, row in zip(gp, rows):      # (also without a fill: the persistent buffers have separate rows too)
+                if row is not None:
+                    big[-1] += row
 
         gq = None
         if g_routed is not None and cfg.route is not None:
@@ -844,9 +867,9 @@ class HbvAdjPath(torch.autograd.Function):
         _call(lib, 'hbvx_adj_backward', lib.adj_backward, desc, io, stream)
         if fill_done is not None:
             torch.cuda.current_stream(dev).wait_event(fill_done)
-            for big, row in zip(gp, rows):
-                if row is not None:
-                    big[-1] += row
+        for big, row in zip(gp, rows):
+            if row is not None:
+                big[-1] += row
         return (None, None, gs_in, *gp)
 
 

@@ -397,3 +397,37 @@ def test_gated_fill_with_dynamic_columns_is_equivalent(dy_drop, hip_backend, mon
     dyn_cols[0:M] = True
     dyn_cols[12 * M:13 * M] = True
     assert float(g1[:-1][:, :, ~dyn_cols].abs().max()) == 0.0 and float(g1[:-1][:, :, dyn_cols].abs().max()) > 0.0
+
+
+@pytest.mark.parametrize("dyn,dy_drop,warm_up", [([], 0.0, 0), (["parBETA", "parBETAET"], 0.4, 50)])
+def test_persistent_gradient_buffer_equals_fresh(dyn, dy_drop, warm_up, hip_backend):
+    """Module key grad_buffer='persistent': the [T,B,ny] gradient is written into a buffer the module keeps (zero-filled
+    once; every step rewrites the dynamic columns and the last row only).  Bit-identical to the default over three steps
+    with new inputs, new dy_drop masks and two loss patterns -- and the SAME storage every step (that is the contract)."""
+    import hydrodl2_amd
+    from hydrodl2_amd import ops
+    dev = torch.device("cuda:0")
+    T, B, M = 400, 1000, 16
+    conf = {"nmul": M, "dy_drop": dy_drop, "warm_up": warm_up, "dynamic_params": {"Hbv": dyn}}
+    C = hydrodl2_amd.load_model("hbv", "Hbv")
+    fresh, keep = C(dict(conf), dev), C(dict(conf, grad_buffer="persistent"), dev)
+    ptrs = []
+    for rnd in range(3):
+        x, p, w = _gen(T, B, fresh.learnable_param_count, 31 + rnd, dev)
+        assert p.numel() >= ops._EARLY_ZERO_MIN
+        keys = ("streamflow",) if rnd != 1 else ("streamflow", "SWE", "BFI")
+        res = []
+        for m in (fresh, keep):
+            torch.manual_seed(5 + rnd)        # the dy_drop masks come from the CPU generator
+            pl = p.detach().clone().requires_grad_(True)
+            out = m({"x_phy": x}, pl)
+            loss = sum((out[k] * (w[-out[k].shape[0]:] if out[k].dim() == 3 else 1.0)).sum() for k in keys)
+            loss.backward()
+            res.append(pl.grad.clone())
+            if m is keep:
+                ptrs.append(pl.grad.untyped_storage().data_ptr())
+            del pl, out, loss
+        assert torch.equal(res[0], res[1]), f"round {rnd}"
+    assert len(set(ptrs)) == 1, ptrs
+    with pytest.raises(ValueError, match="grad_buffer"):
+        C(dict(conf, grad_buffer="sometimes"), dev)({"x_phy": x}, p)
