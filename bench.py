@@ -139,6 +139,7 @@ WORKLOADS = {
     # the headline with module key grad_buffer='persistent' (opt-in): the dense zero fill of the [T,B,ny] gradient -- what
     # the autograd contract costs -- happens once instead of every step
     "cfg2persist": ("hbv", "Hbv", 7300, 671, 16, [], {"grad_buffer": "persistent"}),
+    "cfg2dynpersist": ("hbv", "Hbv", 7300, 671, 16, ["parBETA", "parBETAET"], {"grad_buffer": "persistent"}),
     "cfg3": ("hbv_1_1p", "Hbv_1_1p", 7300, 671, 16, "all"),
     "cfg4": ("hbv_adj", "HbvAdj", 7300, 671, 16, ["parBETAET"]),
     "cfg5": ("hbv_2", "Hbv_2", 730, 100000, 16, ["parBETA", "parK0", "parBETAET"]),
