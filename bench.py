@@ -142,6 +142,7 @@ WORKLOADS = {
     "cfg2dynpersist": ("hbv", "Hbv", 7300, 671, 16, ["parBETA", "parBETAET"], {"grad_buffer": "persistent"}),
     "cfg3": ("hbv_1_1p", "Hbv_1_1p", 7300, 671, 16, "all"),
     "cfg4": ("hbv_adj", "HbvAdj", 7300, 671, 16, ["parBETAET"]),
+    "cfg4persist": ("hbv_adj", "HbvAdj", 7300, 671, 16, ["parBETAET"], {"grad_buffer": "persistent"}),
     "cfg5": ("hbv_2", "Hbv_2", 730, 100000, 16, ["parBETA", "parK0", "parBETAET"]),
     "cfg5share": ("hbv_2", "Hbv_2", 730, 12500, 16, ["parBETA", "parK0", "parBETAET"]),
     # configs[4] at its stated size on ONE GPU (~70 GB of its 288): what `--config cfg5 --gpus 1` runs

@@ -58,6 +58,8 @@ class HbvAdj(torch.nn.Module):
         # unknowns (hbv_adj.py:507-581), kept as the policy cross-check; newton_stop applies to it only.
         self.newton_solver = 'staged'
         self.graph = False           # replay the call's launches as HIP graphs (hydrodl2_amd/graphed.py); opt-in
+        self.grad_buffer = 'fresh'   # 'persistent': the [T,B,ny] gradient in a buffer kept per shape (core/hbv_module.py)
+        self._cfg_cache = {}
         self.parameter_bounds = {
             'parBETA': [1.0, 6.0], 'parFC': [50, 1000], 'parK0': [0.05, 0.9],
             'parK1': [0.01, 0.5], 'parK2': [0.001, 0.2], 'parLP': [0.2, 1],
@@ -82,6 +84,9 @@ class HbvAdj(torch.nn.Module):
             self.newton_max_iter = config.get('newton_max_iter', self.newton_max_iter)
             self.newton_stop = config.get('newton_stop', self.newton_stop)
             self.graph = bool(config.get('graph', self.graph))
+            self.grad_buffer = config.get('grad_buffer', self.grad_buffer)
+            if self.grad_buffer not in ('fresh', 'persistent'):
+                raise ValueError("grad_buffer must be 'fresh' or 'persistent'")
             if self.newton_stop not in ('lane', 'global'):
                 raise ValueError("newton_stop must be 'lane' or 'global'")
             # The solver never follows from the mere PRESENCE of another key: 'staged' unless asked otherwise.  The one
@@ -123,7 +128,7 @@ class HbvAdj(torch.nn.Module):
         return (self.nmul, tuple(self.parameter_bounds), tuple(self.dynamic_params), bool(self.routing),
                 tuple(self.variables), float(self.nearzero), int(self.warm_up), float(self.dy_drop),
                 float(self.newton_gtol), int(self.newton_max_iter), self.newton_stop, self.newton_solver,
-                tuple(map(tuple, self.parameter_bounds.values())),
+                str(self.grad_buffer), tuple(map(tuple, self.parameter_bounds.values())),
                 tuple(map(tuple, self.routing_parameter_bounds.values())))
 
     _graph_state_attrs = ()
@@ -160,23 +165,38 @@ class HbvAdj(torch.nn.Module):
         ny = parameters.shape[2]
         ch = (self.variables.index('prcp'), self.variables.index('tmean'),
               self.variables.index('pet'))
-        base = dict(model=_abi.MODEL_HBVADJ, n_param=n, n_flux=1, B=B, M=M, raw_sigmoid=True,
-                    channels=ch, nearzero=float(self.nearzero),
-                    adj_gtol=float(self.newton_gtol), adj_max_iter=int(self.newton_max_iter),
-                    adj_stop=2 if self.newton_solver == 'staged' else (1 if self.newton_stop == 'global' else 0))
-        state = None  # zeros (hbv_adj.py:254)
         wu = self.warm_up
-        if wu > 0:  # hbv_adj.py:257-274: static parameters from row warm_up-1, differentiable
-            cfg_w = StepConfig(T=wu, t0=0, want_flux=False, **base)
-            cfg_w.params = self._sources(T_total, B, ny, 0, wu - 1, [], x.device)
+        # The step configurations are functions of the shapes and the settings: built once and reused when no dy_drop
+        # masks ride on them (their memo then also carries the persistent gradient buffer, grad_buffer='persistent')
+        key = (T_total, B, ny, str(x.device), self._settings_key())
+        hit = self._cfg_cache.get(key) if self.dy_drop <= 0 else None
+        if hit is not None:
+            cfg_w, cfg = hit
+            self._advance_rng(B)                     # the draws _sources would have made (hbv_adj.py:182-189)
+        else:
+            base = dict(model=_abi.MODEL_HBVADJ, n_param=n, n_flux=1, B=B, M=M, raw_sigmoid=True,
+                        channels=ch, nearzero=float(self.nearzero),
+                        adj_gtol=float(self.newton_gtol), adj_max_iter=int(self.newton_max_iter),
+                        adj_stop=2 if self.newton_solver == 'staged' else (1 if self.newton_stop == 'global' else 0),
+                        persistent_grad=self.grad_buffer == 'persistent')
+            cfg_w = None
+            if wu > 0:  # hbv_adj.py:257-274: static parameters from row warm_up-1, differentiable
+                cfg_w = StepConfig(T=wu, t0=0, want_flux=False, **base)
+                cfg_w.params = self._sources(T_total, B, ny, 0, wu - 1, [], x.device)
+            cfg = StepConfig(T=T_total - wu, t0=wu, **base)
+            cfg.params = self._sources(T_total, B, ny, wu, T_total - 1, self.dynamic_params, x.device)
+            if self.routing:
+                off = (T_total - 1) * B * ny + n * M  # hbv_adj.py:151-153: last row only
+                cfg.route = RouteSource(0, off, off + 1, ny,
+                                        self.routing_parameter_bounds['rout_a'],
+                                        self.routing_parameter_bounds['rout_b'])
+            if self.dy_drop <= 0:
+                if len(self._cfg_cache) > 8:
+                    self._cfg_cache.clear()
+                self._cfg_cache[key] = (cfg_w, cfg)
+        state = None  # zeros (hbv_adj.py:254)
+        if cfg_w is not None:
             _, _, state = HbvAdjPath.apply(cfg_w, x, None, parameters)
-        cfg = StepConfig(T=T_total - wu, t0=wu, **base)
-        cfg.params = self._sources(T_total, B, ny, wu, T_total - 1, self.dynamic_params, x.device)
-        if self.routing:
-            off = (T_total - 1) * B * ny + n * M  # hbv_adj.py:151-153: last row only
-            cfg.route = RouteSource(0, off, off + 1, ny,
-                                    self.routing_parameter_bounds['rout_a'],
-                                    self.routing_parameter_bounds['rout_b'])
         flux, routed, _ = HbvAdjPath.apply(cfg, x, state, parameters)
         q = routed if routed is not None else flux
         return {'flow_sim': q[0].unsqueeze(-1)}

@@ -431,3 +431,31 @@ def test_persistent_gradient_buffer_equals_fresh(dyn, dy_drop, warm_up, hip_back
     assert len(set(ptrs)) == 1, ptrs
     with pytest.raises(ValueError, match="grad_buffer"):
         C(dict(conf, grad_buffer="sometimes"), dev)({"x_phy": x}, p)
+
+
+def test_persistent_gradient_buffer_of_the_implicit_scheme(hip_backend):
+    """`HbvAdj` with grad_buffer='persistent' (its step configurations are cached per shape, so the buffer survives
+    the call): gradients bit-identical to the default over three steps, one storage."""
+    import hydrodl2_amd
+    from hydrodl2_amd import ops
+    dev = torch.device("cuda:0")
+    T, B, M = 400, 1000, 16
+    conf = {"nmul": M, "dynamic_params": {"HbvAdj": ["parBETAET"]}}
+    C = hydrodl2_amd.load_model("hbv_adj", "HbvAdj")
+    fresh, keep = C(dict(conf), dev), C(dict(conf, grad_buffer="persistent"), dev)
+    ptrs = []
+    for rnd in range(3):
+        x, p, w = _gen(T, B, fresh.learnable_param_count, 41 + rnd, dev)
+        assert p.numel() >= ops._EARLY_ZERO_MIN
+        res = []
+        for m in (fresh, keep):
+            torch.manual_seed(9 + rnd)
+            pl = p.detach().clone().requires_grad_(True)
+            out = m({"x_phy": x}, pl)
+            (out["flow_sim"] * w).sum().backward()
+            res.append(pl.grad.clone())
+            if m is keep:
+                ptrs.append(pl.grad.untyped_storage().data_ptr())
+            del pl, out
+        assert torch.equal(res[0], res[1]), f"round {rnd}"
+    assert len(set(ptrs[1:])) == 1, ptrs      # (the first step's tensor may be a copy autograd made; from then on: one storage)
