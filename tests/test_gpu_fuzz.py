@@ -65,7 +65,7 @@ def test_fixed_seed_fuzz_bounds_threshold_flips(hip_backend, oracle_path, capsys
             if not (grad and k in want and want[k] is not None):
                 continue
             try:
-                compare_runs(prob, got, want, keys=(k,))
+                compare_runs(prob, got, want, label=f"draw {case} [gradient; threshold flips are counted, not refused]", keys=(k,))
             except AssertionError as e:
                 m = re.search(r"(\d+)/(\d+) outside tol", str(e))
                 nbad, size = int(m.group(1)), int(m.group(2))
