@@ -1,7 +1,8 @@
+#!/bin/bash
+# scratch lease script (rewritten per lease): root cause of the round-4 outlier + the round's profile passes
+set -o pipefail
 mkdir -p gpurun_out
-python -m pytest tests -m gpu -q -p no:cacheprovider > gpurun_out/r05_gputier_14.log 2>&1
-tail -3 gpurun_out/r05_gputier_14.log
-grep -E "^(FAILED|ERROR)" gpurun_out/r05_gputier_14.log | cut -c1-200 | head
-python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r05_smoke.log 2>&1; tail -1 gpurun_out/r05_smoke.log
-python bench.py --steps 20 --warmup 5 > gpurun_out/r05_bench_final.json 2> gpurun_out/r05_bench_final.err
-grep "\[bench\]" gpurun_out/r05_bench_final.err | tail -20
+python3 tools/gc_stall.py cfg5share > gpurun_out/r05_gc_stall.jsonl 2> gpurun_out/r05_gc_stall.err && \
+timeout -k 10 900 bash tools/profile_round.sh r05f > gpurun_out/r05f_profile.log 2>&1
+echo "exit $?"
+tail -5 gpurun_out/r05_gc_stall.jsonl
