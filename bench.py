@@ -205,6 +205,9 @@ LIMITED_BY = {
     "hourly": ("latency", "two-stage pipelined forward (1 000 workgroups), gage routing FIR pair-parallel", {}, "DESIGN.md §4"),
     "lstm": ("latency", "per time step one L1-bypassing store -> load hand-off between the workgroups of a row tile "
                         "(~1.2 us) + H/4 MFMAs; 4 % of HBM peak, 12 % of the fp32 MFMA peak", {}, "DESIGN.md §4"),
+    "dplgraph": ("latency", "as dpl with no host in the step: one graph launch; what is left is the kernels' own time "
+                            "(LSTM recurrence 4.0 ms, library GEMMs 1.6 ms, HBV 0.3 ms, element-wise / Adam 0.3 ms)", {},
+                 "profiles/r05_dpl_graph.txt"),
     "dpl": ("latency", "LSTM recurrence (two persistent kernels) + four fp32 library GEMMs + the HBV calls", {},
             "profiles/r04_kernel_stats.csv"),
 }
@@ -497,24 +500,38 @@ class DplWorkload:
     basins x 16) -> 1 - NSE -> backward -> Adam, one rank (the bucketed all-reduce is a no-op at world 1)."""
     name, cls = "dpl", "train_dpl"
 
-    def __init__(self, dev, seed):
+    def __init__(self, dev, seed, graph=False):
         import importlib.util
         spec = importlib.util.spec_from_file_location("train_dpl", os.path.join(ROOT, "examples", "train_dpl.py"))
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
-        self.step, self.info = mod.make_trainer(dev)
+        self.graph = graph
+        self.name = "dplgraph" if graph else "dpl"
+        self.step, self.info = mod.make_trainer(dev, graph=graph, tune_gemm=graph)
 
     def entry(self, ms, kms):
         i = self.info
         hbv = sum(v for k, v in kms.items() if "lstm" not in k)
         lstm = sum(v for k, v in kms.items() if "lstm" in k)
-        e = {"config": "dpl", "what": "examples/train_dpl.py step: LSTM-256 -> Hbv -> 1-NSE -> Adam (fused LSTM kernels)",
+        e = {"config": self.name,
+             "what": "examples/train_dpl.py step: LSTM-256 -> Hbv -> 1-NSE -> Adam (fused LSTM kernels)"
+                     + ("; the whole step replayed as ONE captured HIP graph with TunableOp's GEMM picks (--graph --tune-gemm)"
+                        if self.graph else ""),
              "T": i["T"], "B": i["B"], "M": i["M"], "steps": 5, "ms_per_step": round(ms, 4),
              "lane_steps_per_s": i["T"] * i["B"] * i["M"] / (ms * 1e-3),
              "hbv_calls_ms": round(hbv, 4), "lstm_kernels_ms": round(lstm, 4),
              "kernel_ms": {k: round(v, 4) for k, v in kms.items()}}
-        e.update(limited_by("dpl"))
+        e.update(limited_by(self.name))
         return e
+
+
+def make_workload(name, dev, seed=7):
+    """Any named workload of the bench (tools/bench_one.py)."""
+    if name == "lstm":
+        return LstmWorkload(dev, seed)
+    if name in ("dpl", "dplgraph"):
+        return DplWorkload(dev, seed, graph=name == "dplgraph")
+    return Workload(name, dev, seed=seed)
 
 
 # --------------------------------------------------------------------------------------------
@@ -928,18 +945,17 @@ def main():
         # the other BASELINE configs under the same clock: 5 timed steps each, same event timing
         sec = []
         print(f"[bench] headline done: {ms_per_step:.3f} ms/step; secondary configs ...", file=sys.stderr, flush=True)
-        for name in ("cfg2dyn", "cfg2mu", "cfg2persist", "cfg3", "cfg4", "cfg4joint", "cfg5share", "cfg5full", "dmg", "dmggraph", "hourly", "lstm", "dpl"):
+        for name in ("cfg2dyn", "cfg2mu", "cfg2persist", "cfg3", "cfg4", "cfg4joint", "cfg5share", "cfg5full", "dmg", "dmggraph", "hourly", "lstm", "dpl", "dplgraph"):
             if name == args.config:
                 continue
             try:
-                w2 = (LstmWorkload(dev, 7) if name == "lstm" else DplWorkload(dev, 7) if name == "dpl"
-                      else Workload(name, dev, seed=7))
+                w2 = make_workload(name, dev, 7)
                 dt2, k2 = timed_steps(w2, SEC_STEPS, 3, dev, 1)
                 smp = timed_steps.samples
                 # the MEDIAN of >= 10 timed steps (per-step device time, HIP events); the mean over the
                 # region and the slowest step stand beside it
                 ms2 = smp["ms_median"] if smp else 1e3 * dt2 / SEC_STEPS
-                if name in ("lstm", "dpl"):
+                if name in ("lstm", "dpl", "dplgraph"):
                     e = w2.entry(ms2, k2)
                 else:
                     e = {"config": name, "T": w2.T, "B": w2.B, "M": w2.M, "n_dyn": w2.n_dyn,

@@ -3,7 +3,7 @@
 the caller side, outside the reference repository -- delta-MG style).
 
     python examples/train_dpl.py [--basins 100] [--rho 365] [--warm-up 365] [--nmul 16] [--steps 20]
-                                 [--lstm fused|torch] [--tune-gemm]
+                                 [--lstm fused|torch] [--graph] [--tune-gemm]
     python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 examples/train_dpl.py ...
 
 A small LSTM maps normalised forcings + static attributes to the raw parameter tensor [T,B,ny];
@@ -46,11 +46,18 @@ class ParamNet(torch.nn.Module):
         return self.out(h)
 
 
-def nse_loss(sim, obs):
-    """mean over basins of 1 - NSE; sim/obs [T,B].  Returns (sum over local basins, count)."""
+def nse_loss(sim, obs, inv_den=None):
+    """mean over basins of 1 - NSE; sim/obs [T,B].  Returns (sum over local basins, count).  `inv_den`: the
+    reciprocal of the observations' sum of squares about their mean per basin (a constant of the data set:
+    nse_inv_den) -- without it it is formed here."""
     num = ((sim - obs) ** 2).sum(0)
-    den = ((obs - obs.mean(0, keepdim=True)) ** 2).sum(0) + 1e-6
-    return (num / den).sum(), sim.shape[1]
+    if inv_den is None:
+        inv_den = nse_inv_den(obs)
+    return (num * inv_den).sum(), sim.shape[1]
+
+
+def nse_inv_den(obs):
+    return 1.0 / (((obs - obs.mean(0, keepdim=True)) ** 2).sum(0) + 1e-6)
 
 
 def synth(T, B, n_attr, dev, seed):
@@ -68,9 +75,18 @@ def synth(T, B, n_attr, dev, seed):
 
 
 def make_trainer(dev, basins=100, rho=365, warm_up=365, nmul=16, hidden=256, lstm="fused", world=1, rank=0,
-                 overlap_wanted=True):
+                 overlap_wanted=True, graph=False, capturable=False, tune_gemm=False):
     """The training step as a closure (bench.py times it as the `dpl` workload; main() below runs it):
-    returns (step, info) with step() -> mean loss of the step."""
+    returns (step, info) with step() -> mean loss of the step.
+
+    graph=True (one process, fused LSTM): the WHOLE step -- network, HBV forward, loss, backward, gradient scaling,
+    Adam -- is captured once into one HIP graph and step() is a replay plus the read-back of the loss.  Three eager
+    steps run first (lazy initialisation, Adam's state); their losses are info["eager_losses"], so that the sequence
+    eager_losses + [step() ...] is the loss curve of the same training run.  Adam runs with capturable=True (its
+    step count lives on the device); capturable=True alone selects that optimiser for an eager run to compare with.
+    tune_gemm=True with graph=True: torch's TunableOp picks the library solution of every GEMM shape during the three
+    eager steps (the output layer's 194-wide GEMMs run 2.4x faster than the default pick); the capture records those
+    picks and TunableOp is switched off again -- inside a graph the choice costs the host nothing."""
     T, B, M = warm_up + rho, basins, nmul
     dyn = ["parBETA", "parBETAET"]
     cfg = {"nmul": M, "warm_up": warm_up, "dynamic_params": {"Hbv": dyn}}
@@ -89,10 +105,15 @@ def make_trainer(dev, basins=100, rho=365, warm_up=365, nmul=16, hidden=256, lst
     z = torch.cat([(x - mean) / std, attrs[None].expand(T, -1, -1)], -1)
     with torch.no_grad():
         obs = Hbv(cfg, dev)({"x_phy": x}, truth(z))["streamflow"][:, :, 0]
+        inv_den = nse_inv_den(obs)
 
     torch.manual_seed(2)                       # same initial network on every rank
     net = ParamNet(3 + n_attr, hidden, ny, fused=lstm == "fused").to(dev)
-    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    if graph and (world > 1 or lstm != "fused" or dev.type != "cuda"):
+        raise ValueError("graph=True: one process on the GPU with the fused LSTM (the all-reduce is not captured)")
+    # on the GPU the fused Adam: one kernel for all parameters instead of ~30 (each node of a captured step costs ~5 us)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=bool(graph or capturable),
+                           fused=True if dev.type == "cuda" else None)
     params = [p for p in net.parameters()]
 
     # Backward produces gradients output-layer-first: net.out right after the HBV adjoint, then the
@@ -116,7 +137,7 @@ def make_trainer(dev, basins=100, rho=365, warm_up=365, nmul=16, hidden=256, lst
         opt.zero_grad(set_to_none=True)
         raw = net(z)
         sim = phy({"x_phy": x}, raw)["streamflow"][:, :, 0]
-        loss_sum, count = nse_loss(sim, obs)
+        loss_sum, count = nse_loss(sim, obs, inv_den)
         stats = torch.stack([loss_sum.detach(), torch.tensor(float(count), device=dev)])
         pending.clear()
         pending["stats"] = stats
@@ -128,12 +149,63 @@ def make_trainer(dev, basins=100, rho=365, warm_up=365, nmul=16, hidden=256, lst
         else:
             # one bucketed all-reduce: [loss sum, basin count, every network gradient]
             sharding.all_reduce_sum_([stats] + [p.grad for p in params])
-        for p in params:
-            p.grad /= stats[1]
+        torch._foreach_div_([p.grad for p in params], stats[1])
         opt.step()
         return float(stats[0] / stats[1])
 
-    return step, {"T": T, "B": B, "M": M, "ny": ny, "overlap": overlap}
+    info = {"T": T, "B": B, "M": M, "ny": ny, "overlap": overlap, "graph": bool(graph)}
+    if not graph:
+        return step, info
+
+    count_t = torch.tensor(float(b1 - b0), device=dev)       # the loss normaliser: a constant of the capture
+
+    def body():
+        raw = net(z)
+        sim = phy({"x_phy": x}, raw)["streamflow"][:, :, 0]
+        loss_sum, _ = nse_loss(sim, obs, inv_den)
+        loss_sum.backward()
+        torch._foreach_div_([p.grad for p in params], count_t)
+        opt.step()
+        return loss_sum.detach() / count_t
+
+    if tune_gemm:
+        enable_tunable_gemm(write_file=False)
+    cur = torch.cuda.current_stream(dev)
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(cur)
+    eager_losses = []
+    with torch.cuda.stream(side):                              # warm-up off the capture, as torch's recipe asks
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            eager_losses.append(float(body()))
+    cur.wait_stream(side)
+    opt.zero_grad(set_to_none=True)                            # the captured backward creates the .grad tensors in the pool
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        static_loss = body()
+    # the capture pass enqueued nothing (a capture records), so the model is where the three eager steps left it
+    if tune_gemm:
+        import torch.cuda.tunable as tunable
+        tunable.enable(False)
+    info["eager_losses"] = eager_losses
+    info["graph_handle"] = g
+
+    def step_graphed():
+        g.replay()
+        return float(static_loss)
+
+    return step_graphed, info
+
+
+def enable_tunable_gemm(write_file=True):
+    """torch's TunableOp: every new GEMM shape is timed against the library's solutions once (<= 1 s per shape)."""
+    import torch.cuda.tunable as tunable
+    tunable.enable(True)
+    tunable.tuning_enable(True)
+    tunable.set_max_tuning_duration(1000)       # ms per GEMM shape
+    # the results file TunableOp writes at exit: out of the working directory
+    tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"),
+                                      "tunableop_dpl.csv" if write_file else f"tunableop_dpl_{os.getpid()}.csv"))
 
 
 def main():
@@ -150,6 +222,9 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="one blocking all-reduce after the whole backward pass instead of sending the output "
                          "layer's gradients while the LSTM backward is still running")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the whole step (network, HBV, loss, backward, Adam) into one HIP graph and replay it "
+                         "(one process, fused LSTM)")
     ap.add_argument("--tune-gemm", action="store_true",
                     help="let torch's TunableOp pick the hipBLASLt/rocBLAS solution of every GEMM shape during "
                          "the warm-up steps (the LSTM's weight-gradient GEMMs have K = T*B: the default "
@@ -169,16 +244,13 @@ def main():
     if world > 1:
         dist.init_process_group(args.backend or ("nccl" if on_gpu else "gloo"))
 
-    if args.tune_gemm and on_gpu:
-        import torch.cuda.tunable as tunable
-        tunable.enable(True)
-        tunable.set_max_tuning_duration(1000)       # ms per GEMM shape
-        tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), "tunableop_dpl.csv"))
+    if args.tune_gemm and on_gpu and not args.graph:
+        enable_tunable_gemm()
 
     step, info = make_trainer(dev, args.basins, args.rho, args.warm_up, args.nmul, args.hidden, args.lstm, world, rank,
-                              not args.no_overlap)
+                              not args.no_overlap, graph=args.graph, tune_gemm=args.tune_gemm and args.graph)
     T, B, M, overlap = info["T"], info["B"], info["M"], info["overlap"]
-    losses = [step() for _ in range(3)]        # warm-up
+    losses = list(info.get("eager_losses", [])) + [step() for _ in range(3)]        # warm-up
     ops.KERNEL_EVENTS = [] if on_gpu else None
     if on_gpu:
         torch.cuda.synchronize()
@@ -196,6 +268,7 @@ def main():
     if rank == 0:
         print(json.dumps({"basins": B, "nmul": M, "days": T, "world": world, "ms_per_step": round(dt * 1e3, 3),
                           "lstm": args.lstm, "hidden": args.hidden, "tuned_gemm": bool(args.tune_gemm),
+                          "graph": bool(args.graph),
                           "allreduce": "overlapped (2 buckets)" if overlap else "blocking (1 bucket)",
                           "hbv_calls_ms": None if hbv_ms is None else round(hbv_ms, 3),
                           "lstm_kernels_ms": None if not lstm_ms else round(lstm_ms, 3),

@@ -24,12 +24,27 @@ static uint64_t lstm_slab_bytes(const hbvx_lstm_desc *d, bool backward)
     return (uint64_t)d->T * ntile * d->H * LSTM_ROWS * (backward ? 4 : 1) * sizeof(float);
 }
 
+// Arms the workspace of one launch: the error word's line zeroed, every exchange word the sentinel 0xFFFFFFFF
+// (lstm_seq.h).  A KERNEL, not hipMemsetAsync: the launch sequence is captured into HIP graphs (examples/train_dpl.py
+// --graph), and a captured memset node of this runtime was seen not to replay -- slabs that keep
+// the previous replay's words would hand stale h to the consumers without any error.
+typedef unsigned lstm_u4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) k_lstm_arm(lstm_u4 *__restrict__ p, uint64_t n16, uint64_t zero16)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+        const unsigned v = i < zero16 ? 0u : 0xFFFFFFFFu;
+        __builtin_nontemporal_store(lstm_u4{v, v, v, v}, p + i);
+    }
+}
+
 static hipError_t lstm_prepare(const hbvx_lstm_desc *d, void *workspace, bool backward, hipStream_t st)
 {
-    hipError_t e = hipMemsetAsync(workspace, 0, lstm_counter_bytes(d), st);
-    if (e != hipSuccess) return e;
-    // every exchange word starts as the sentinel 0xFFFFFFFF (lstm_seq.h)
-    return hipMemsetAsync((char *)workspace + lstm_counter_bytes(d), 0xFF, lstm_slab_bytes(d, backward), st);
+    const uint64_t n16 = (lstm_counter_bytes(d) + lstm_slab_bytes(d, backward)) / 16;   // both multiples of 16
+    const uint64_t want = (n16 + 255) / 256;
+    const unsigned grid = (unsigned)(want < 8192 ? (want ? want : 1) : 8192);
+    hipLaunchKernelGGL(k_lstm_arm, dim3(grid), dim3(256), 0, st, (lstm_u4 *)workspace, n16, lstm_counter_bytes(d) / 16);
+    return hipGetLastError();
 }
 
 extern "C" uint64_t hbvx_lstm_workspace_bytes(const hbvx_lstm_desc *d)
@@ -93,7 +108,7 @@ extern "C" int hbvx_lstm_forward(const hbvx_lstm_desc *d, const float *w_hh, con
         return fail(HBVX_E_NULL, "lstm workspace missing or too small");
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = lstm_prepare(d, workspace, false, st);
-    if (e != hipSuccess) return hip_fail(e, "hbvx_lstm_forward memset");
+    if (e != hipSuccess) return hip_fail(e, "hbvx_lstm_forward arm");
     LstmArgs a{};
     a.T = d->T; a.B = d->B; a.ntile = (d->B + LSTM_ROWS - 1) / LSTM_ROWS;
     a.w_hh = w_hh; a.gx = gx; a.gates = gates; a.c_all = c_all; a.h_all = h_all;
@@ -126,7 +141,7 @@ extern "C" int hbvx_lstm_backward(const hbvx_lstm_desc *d, const float *w_hh, co
         return fail(HBVX_E_NULL, "lstm workspace missing or too small");
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = lstm_prepare(d, workspace, true, st);
-    if (e != hipSuccess) return hip_fail(e, "hbvx_lstm_backward memset");
+    if (e != hipSuccess) return hip_fail(e, "hbvx_lstm_backward arm");
     LstmArgs a{};
     a.T = d->T; a.B = d->B; a.ntile = (d->B + LSTM_ROWS - 1) / LSTM_ROWS;
     a.w_hh = w_hh; a.gx = gates; a.gates = grad_gates; a.c_in = c_all; a.dh = grad_h;

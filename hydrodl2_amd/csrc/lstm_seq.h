@@ -19,7 +19,7 @@
 //
 // Hand-off between the waves of a row tile, once per time step: the exchange buffer holds one slab per
 // time step and row tile, never reused inside a launch and filled with the sentinel word 0xFFFFFFFF by
-// the host (hipMemsetAsync) before the launch.  A producer writes its slice with sc1 stores (write
+// k_lstm_arm (lstm.hip) before the launch.  A producer writes its slice with sc1 stores (write
 // through, 4-byte granules are atomic) and goes on; a consumer re-issues its sc1 loads of the slab (L1
 // bypassed: MI355X_MICROARCH.md "inter-workgroup visibility") until none of the words it needs is the
 // sentinel -- the payload is its own flag, there are no counters, fences or barriers on the path, and a
@@ -29,6 +29,12 @@
 // fit) and a launch never holds more workgroups than that, so all partners are resident.  Every spin
 // is bounded: on a time-out the wave gives up, sets the error word (hbvx_lstm_check) and poisons its
 // outputs.
+//
+// Measured and not kept (round 5, profiles/r05_lstm_xcd.jsonl; T = 730, B = 100, H = 256): a row tile's workgroups on
+// ONE XCD (blocks b, b + 8, ... under the observed round-robin dispatch) with hand-off stores that stay in that XCD's L2
+// (plain instead of sc1): forward 1.81 -> 1.67 ms, backward 2.28 -> 2.23; the mapping alone 1.71 / 2.66.  4 % of the
+// pair for a protocol whose correctness would hang on placement (a run-time XCC_ID handshake could guard it): the
+// hand-off's price sits in the consumer CU's memory queue, not in which cache serves it.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -47,8 +53,8 @@ struct LstmArgs {
     const float *c_in;               // backward: c_all
     const float *dh;                 // backward: grad_h [T,B,H]
     float *c_all, *h_all;            // forward outputs [T,B,H]
-    float *xch;                      // exchange slabs, one per time step and row tile, sentinel-filled by the host
-    unsigned *cnt;                   // cnt[0] = error word (zeroed by the host)
+    float *xch;                      // exchange slabs, one per time step and row tile, sentinel-filled by k_lstm_arm
+    unsigned *cnt;                   // cnt[0] = error word (zeroed by k_lstm_arm)
     unsigned spin_limit;             // polls before a hand-off gives up (LSTM_SPIN_LIMIT; lowered by the fault-injection test)
     int drop_wg;                     // fault injection (tests): this workgroup never publishes its slab; -1: none
 };

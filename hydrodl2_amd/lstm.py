@@ -21,9 +21,20 @@ from ._lib import get_library
 from . import ops
 
 
+_PERM = {}
+
+
 def _gate_perm(H: int, device) -> torch.Tensor:
-    """Row index that turns torch's gate-major [4H] (i|f|g|o blocks) into (unit, gate) order."""
-    return (torch.arange(4, device=device)[None, :] * H + torch.arange(H, device=device)[:, None]).reshape(-1)
+    """Row index that turns torch's gate-major [4H] (i|f|g|o blocks) into (unit, gate) order (one tensor per hidden
+    size and device, built on first use: four small launches less per call)."""
+    key = (H, str(device))
+    hit = _PERM.get(key)
+    if hit is None:
+        if torch.cuda.is_available() and torch.device(device).type == "cuda" and torch.cuda.is_current_stream_capturing():
+            # a tensor created inside a capture belongs to that graph's pool: do not keep it
+            return (torch.arange(4, device=device)[None, :] * H + torch.arange(H, device=device)[:, None]).reshape(-1)
+        hit = _PERM[key] = (torch.arange(4, device=device)[None, :] * H + torch.arange(H, device=device)[:, None]).reshape(-1)
+    return hit
 
 
 def _wgrad(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:

@@ -48,6 +48,29 @@ def test_dpl_example_fused_and_torch_lstm_agree(hip_backend, monkeypatch):
         assert abs(a - b) <= 2e-3 * max(abs(b), 1e-3), curves
 
 
+@pytest.mark.gpu
+def test_dpl_whole_step_graph_follows_the_eager_run(hip_backend):
+    """examples/train_dpl.py --graph: the whole step (network, HBV, loss, backward, Adam) replayed as one captured HIP
+    graph gives the loss curve of the eager run with the same (capturable) optimiser -- the same kernels in the same
+    order, so step for step the same numbers; the LSTM's exchange slabs are re-armed by a kernel on every replay (a
+    replay that reused stale slabs would not follow the eager curve past the first replayed step)."""
+    import torch
+    mod = _load()
+    dev = torch.device("cuda:0")
+    kw = dict(basins=20, rho=60, warm_up=30, nmul=4, hidden=64)
+    step, _ = mod.make_trainer(dev, capturable=True, **kw)
+    eager = [step() for _ in range(8)]
+    gstep, info = mod.make_trainer(dev, graph=True, **kw)
+    graphed = list(info["eager_losses"]) + [gstep() for _ in range(5)]
+    assert all(l == l for l in graphed)
+    assert graphed[:3] == eager[:3], (eager, graphed)            # the three eager steps before the capture
+    for a, b in zip(graphed[3:], eager[3:]):
+        assert abs(a - b) <= 1e-5 * max(abs(b), 1e-3), (eager, graphed)
+    assert graphed[-1] < graphed[0]
+    with pytest.raises(ValueError, match="graph=True"):
+        mod.make_trainer(dev, graph=True, lstm="torch", **kw)
+
+
 def _dpl_worker(rank, world, port, oracle, q, extra=()):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))

@@ -27,7 +27,7 @@ def main():
     from hydrodl2_amd import _lib
     for rnd in range(args.rounds):
         for name in args.names:
-            wl = bench.Workload(name, dev, seed=7)
+            wl = bench.make_workload(name, dev, 7)
             dt, kms = bench.timed_steps(wl, args.steps, args.warmup, dev, 1)
             lib = _lib.get_library()
             smp = bench.timed_steps.samples
@@ -35,7 +35,7 @@ def main():
                    "ms_mean_region": smp["ms_mean_region"], "host_enqueue_ms_median": smp["host_enqueue_ms_median"],
                    "kernel_ms": {k: round(v, 4) for k, v in kms.items()},
                    "dispatch": [lib.last_dispatch(0), lib.last_dispatch(1)],
-                   "lane_steps_per_s": wl.lane_steps / (smp["ms_median"] * 1e-3),
+                   "lane_steps_per_s": (wl.lane_steps / (smp["ms_median"] * 1e-3)) if hasattr(wl, "lane_steps") else None,
                    "device_mallocs": bench.timed_steps.device_mallocs,
                    "env": {k: v for k, v in os.environ.items() if k.startswith("HBVX_")}}
             print(json.dumps(rec), flush=True)

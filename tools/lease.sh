@@ -1,8 +1,8 @@
 #!/bin/bash
-# scratch lease script (rewritten per lease): root cause of the round-4 outlier + the round's profile passes
+# scratch lease script (rewritten per lease)
 set -o pipefail
 mkdir -p gpurun_out
-python3 tools/gc_stall.py cfg5share > gpurun_out/r05_gc_stall.jsonl 2> gpurun_out/r05_gc_stall.err && \
-timeout -k 10 900 bash tools/profile_round.sh r05f > gpurun_out/r05f_profile.log 2>&1
-echo "exit $?"
-tail -5 gpurun_out/r05_gc_stall.jsonl
+timeout -k 10 300 python3 tools/bench_one.py dpl dplgraph --rounds 2 --steps 10 > gpurun_out/r05_dpl_graph3.jsonl 2> gpurun_out/r05_dpl_graph3.err
+echo "bench rc $?"
+cut -c1-200 gpurun_out/r05_dpl_graph3.jsonl
+tail -3 gpurun_out/r05_dpl_graph3.err
