@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 MAX_PARAM = 20
 GAGE_MAXLEN = 72
 NSTATE = 5
@@ -59,7 +59,8 @@ class Desc(C.Structure):
 
 class FwdOut(C.Structure):
     _fields_ = [("flux", _fp), ("state_out", _fp), ("traj", _fp), ("aux", _fp),
-                ("n_flux", C.c_int32), ("traj_layout", C.c_int32)]
+                ("n_flux", C.c_int32), ("traj_layout", C.c_int32),
+                ("zero_ptr", _fp), ("zero_bytes", C.c_uint64), ("zero_state", _fp)]
 
 
 class BwdIO(C.Structure):
@@ -156,6 +157,10 @@ class Library:
         d.hbvx_ckpt_workspace_bytes.argtypes = [C.POINTER(Desc), C.c_int32]
         d.hbvx_preferred_traj_layout.restype = C.c_int
         d.hbvx_preferred_traj_layout.argtypes = [C.POINTER(Desc)]
+        d.hbvx_zero_in_launch.restype = C.c_int
+        d.hbvx_zero_in_launch.argtypes = []
+        d.hbvx_zero_rest.restype = C.c_int
+        d.hbvx_zero_rest.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
         d.hbvx_last_dispatch.restype = C.c_char_p
         d.hbvx_last_dispatch.argtypes = [C.c_int]
         d.hbvx_zero.restype = C.c_int
@@ -199,6 +204,14 @@ class Library:
     def backward(self, desc: Desc, io: BwdIO, stream: int):
         self._check(self.dll.hbvx_backward(C.byref(desc), C.byref(io), C.c_void_p(stream)),
                     "hbvx_backward")
+
+    def zero_rest(self, ptr: int, nbytes: int, state_ptr: int, stream: int):
+        """Zero what the forward's launch left of FwdOut.zero_ptr (include/hbvx.h)."""
+        self._check(self.dll.hbvx_zero_rest(C.c_void_p(ptr), nbytes, C.c_void_p(state_ptr), C.c_void_p(stream)), "hbvx_zero_rest")
+
+    def zero_in_launch(self) -> bool:
+        """Whether the last forward call of this thread wrote FwdOut.zero_ptr inside its own launch (include/hbvx.h)."""
+        return bool(self.dll.hbvx_zero_in_launch())
 
     def last_dispatch(self, direction: int) -> str:
         """Kernel family of the last forward (0) / adjoint (1) call (diagnostic, include/hbvx.h)."""

@@ -79,7 +79,52 @@ struct PipeArgs {
     int lgMp;
     int Kt;
     int ckptK;   // HBVX_TRAJ_CKPT: keep only the storages entering every ckptK-th day ([ceil(T/K),5,N]); 0: rows
+    // hbvx_fwd_out.zero_ptr: blocks nwg .. gridDim.x-1 of the launch take no part in the recurrence -- they sit on the CUs
+    // the 168-workgroup latency chain leaves idle and write the caller's zeros, a 256 KB piece per wave at a time, until
+    // the recurrence's workgroups have finished (fill_state[1]); fill_state[0] counts the pieces claimed.  fill_n16 = 0: none
+    void *fill_ptr;
+    unsigned *fill_state;
+    unsigned long long fill_n16;
+    int nwg;          // workgroups of the recurrence
+    int fill_waves;   // waves of a fill workgroup that write (the others leave at once): the fill's share of HBM
 };
+
+typedef float pipe_f4 __attribute__((ext_vector_type(4)));
+constexpr unsigned PIPE_FILL_PIECE16 = HBVX_ZERO_PIECE / 16;   // 16-byte stores per piece
+
+// The last stage of a recurrence workgroup has stored its final storages: one count per workgroup.
+__device__ __forceinline__ void pipe_signal_done(const PipeArgs &A)
+{
+    if (A.fill_n16 && (threadIdx.x & 63) == 0)
+        __hip_atomic_fetch_add(A.fill_state + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The fill role of k_fwd_pipe's surplus workgroups.  Every wave for itself: look whether the recurrence is still running,
+// claim the next piece, write it with nontemporal 16-byte stores (a wave instruction = 1 KB contiguous).  A claimed piece
+// is always completed, so fill_state[0] pieces are zero when the launch ends.  No LDS, no barrier: the workgroup leaves
+// through here.
+__device__ __forceinline__ void pipe_fill_role(const PipeArgs &A)
+{
+    const unsigned lane = threadIdx.x & 63;
+    if ((int)(threadIdx.x >> 6) >= A.fill_waves) return;
+    const unsigned long long npiece = (A.fill_n16 + PIPE_FILL_PIECE16 - 1) / PIPE_FILL_PIECE16;
+    pipe_f4 *base = static_cast<pipe_f4 *>(A.fill_ptr);
+    const pipe_f4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (;;) {
+        unsigned done = 0, c = 0;
+        if (lane == 0) done = __hip_atomic_load(A.fill_state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__builtin_amdgcn_readfirstlane(done) >= (unsigned)A.nwg) return;
+        if (lane == 0) c = __hip_atomic_fetch_add(A.fill_state, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c = __builtin_amdgcn_readfirstlane(c);
+        if (c >= npiece) return;
+        const unsigned long long i0 = (unsigned long long)c * PIPE_FILL_PIECE16;
+        const unsigned long long left = A.fill_n16 - i0;
+        const unsigned n = left < PIPE_FILL_PIECE16 ? (unsigned)left : PIPE_FILL_PIECE16;
+        pipe_f4 *p = base + i0;
+#pragma unroll 4
+        for (unsigned i = lane; i < n; i += 64) __builtin_nontemporal_store(z, p + i);
+    }
+}
 
 // LDS layout in floats for Kt days per tile
 struct PipeLds {
@@ -188,6 +233,10 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
 #endif
     constexpr int NP = NParamT<MODEL, BETAET>::value;
     extern __shared__ __align__(16) float lds[];
+    if (A.fill_n16 && (int)blockIdx.x >= A.nwg) {
+        pipe_fill_role(A);
+        return;
+    }
     const hbvx_desc &d = A.d;
     const hbvx_fwd_out &o = A.o;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -402,6 +451,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
             }
             PIPE_BARRIER();
         }
+        pipe_signal_done(A);
         if (L.active) {
             o.state_out[2 * N + L.n] = SM;
             o.state_out[3 * N + L.n] = SUZ;
@@ -530,6 +580,7 @@ __global__ void __launch_bounds__(1024) k_fwd_pipe(const PipeArgs A)
             }
             PIPE_BARRIER();
         }
+        pipe_signal_done(A);
         if (L.active) {
             o.state_out[3 * N + L.n] = SUZ;
             o.state_out[4 * N + L.n] = SLZ;

@@ -41,6 +41,8 @@ void hbvx_host::note_dispatch(int dir, const char *family)
     std::lock_guard<std::mutex> lock(g_disp_mu);
     snprintf(g_disp[dir & 1], sizeof g_disp[0], "%s", family);
 }
+extern "C" int hbvx_zero_in_launch(void) { return hbvx_host::zero_taken() ? 1 : 0; }
+
 extern "C" const char *hbvx_last_dispatch(int direction)
 {
     static thread_local char out[48];
@@ -717,7 +719,35 @@ int hbvx_host::count_dyn(const hbvx_desc *d)
     return nd;
 }
 
+int hbvx_host::device_cu_count()
+{
+    static int n_cu[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (n_cu[dev] == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        n_cu[dev] = v;
+    }
+    return n_cu[dev];
+}
+
+bool &hbvx_host::zero_taken()
+{
+    static thread_local bool taken = false;
+    return taken;
+}
+
+static int forward_dispatch(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream);
+
 extern "C" int hbvx_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream)
+{
+    zero_taken() = false;
+    if (out && out->zero_ptr && !out->zero_state) return fail(HBVX_E_NULL, "zero_ptr needs zero_state");
+    return forward_dispatch(d, out, stream);
+}
+
+static int forward_dispatch(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream)
 {
     int rc = check_desc(d);
     if (rc) return rc;
@@ -1080,6 +1110,42 @@ extern "C" int hbvx_zero(void *ptr, uint64_t bytes, void *stream)
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess && tail) e = zero_bytes((char *)ptr + head + n16 * 16, tail, st);
     return e == hipSuccess ? 0 : hip_fail(e, "hbvx_zero");
+}
+
+// hbvx_zero_rest (include/hbvx.h): what the forward's fill workgroups left of hbvx_fwd_out.zero_ptr.  The first missing piece
+// is a device-side number (zero_state[0]), so the grid covers the whole buffer and the threads in front of it leave: eight
+// 16-byte stores per thread, a wave instruction = 1 KB contiguous.
+__global__ void __launch_bounds__(256) k_zero_rest(zero_f4 *__restrict__ p, uint64_t n16, const unsigned *__restrict__ state)
+{
+    const uint64_t npiece = (n16 + HBVX_ZERO_PIECE / 16 - 1) / (HBVX_ZERO_PIECE / 16);
+    const uint64_t claimed = state[0];
+    const uint64_t start = (claimed < npiece ? claimed : npiece) * (HBVX_ZERO_PIECE / 16);
+    const uint64_t i0 = (uint64_t)blockIdx.x * 2048 + threadIdx.x;
+    if (i0 + 2048 <= start) return;
+    const zero_f4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint64_t i = i0 + (uint64_t)k * 256;
+        if (i >= start && i < n16) __builtin_nontemporal_store(z, &p[i]);
+    }
+}
+
+extern "C" int hbvx_zero_rest(void *ptr, uint64_t bytes, const void *zero_state, void *stream)
+{
+    if (!bytes) return HBVX_OK;
+    if (!ptr || !zero_state) return fail(HBVX_E_NULL, "hbvx_zero_rest: buffer or state is NULL");
+    if ((uintptr_t)ptr & 15) return fail(HBVX_E_SHAPE, "hbvx_zero_rest: buffer must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const uint64_t n16 = bytes / 16, tail = bytes - n16 * 16;
+    hipError_t e = hipSuccess;
+    if (n16) {
+        const uint64_t blocks = (n16 + 2047) / 2048;
+        if (blocks > 0x7fffffffull) return fail(HBVX_E_SHAPE, "hbvx_zero_rest: buffer too large");
+        hipLaunchKernelGGL(k_zero_rest, dim3((unsigned)blocks), dim3(256), 0, st, (zero_f4 *)ptr, n16, (const unsigned *)zero_state);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && tail) e = zero_bytes((char *)ptr + n16 * 16, tail, st);
+    return e == hipSuccess ? HBVX_OK : hip_fail(e, "hbvx_zero_rest");
 }
 
 // Zero fill that leaves out what the adjoint overwrites (include/hbvx.h: hbvx_zero_except).

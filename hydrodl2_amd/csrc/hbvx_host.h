@@ -25,6 +25,10 @@ int hip_fail(hipError_t e, const char *what);
 // hbvx_last_dispatch (include/hbvx.h): the kernel family that took the call; dir 0 forward, 1 adjoint
 void note_dispatch(int dir, const char *family);
 int env_int(const char *name, int dflt);
+int device_cu_count();                   // compute units of the current device (cached per device)
+// hbvx_fwd_out.zero_ptr: set by the kernel family that carries fill workgroups in its own launch (the pipelined forward);
+// the entry points clear it before dispatch (hbvx_zero_in_launch reports it)
+bool &zero_taken();
 int lg_members(int M);
 int count_dyn(const hbvx_desc *d);
 bool use_tiled(const hbvx_desc *d);      // false under HBVX_KERNEL=simple

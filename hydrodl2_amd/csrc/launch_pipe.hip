@@ -59,6 +59,27 @@ bool hbvx_host::try_fwd_pipe(const hbvx_desc *d, const hbvx_fwd_out *out, void *
             pa.ckptK = ckpt_k;
             const int bpw_p = 64 >> pa.lgMp;
             dim3 grid_p((d->B + bpw_p - 1) / bpw_p);
+            // hbvx_fwd_out.zero_ptr: surplus workgroups of THIS launch write its zeros while the recurrence runs -- when the
+            // chain leaves at least an eighth of the chip idle (config 2: 168 workgroups, one per CU, 88 CUs free).
+            // HBVX_PIPE_FILL_WGS: 0 = never (everything is left to hbvx_zero_rest), n = that many fill workgroups;
+            // HBVX_PIPE_FILL_WAVES: waves of each that write (tools: the fill's share of HBM)
+            pa.fill_ptr = nullptr;
+            pa.fill_state = nullptr;
+            pa.fill_n16 = 0;
+            pa.nwg = (int)grid_p.x;
+            pa.fill_waves = env_int("HBVX_PIPE_FILL_WAVES", 16);
+            if (out->zero_ptr && out->zero_state && out->zero_bytes >= 16 && ((uintptr_t)out->zero_ptr & 15) == 0) {
+                const int n_cu = device_cu_count();
+                const int spare = n_cu - (int)grid_p.x;
+                const int nfill = env_int("HBVX_PIPE_FILL_WGS", spare >= n_cu / 8 ? spare : 0);
+                if (nfill > 0) {
+                    pa.fill_ptr = out->zero_ptr;
+                    pa.fill_state = (unsigned *)out->zero_state;
+                    pa.fill_n16 = out->zero_bytes / 16;     // a ragged tail (< 16 bytes) belongs to hbvx_zero_rest
+                    grid_p.x += (unsigned)nfill;
+                    zero_taken() = true;
+                }
+            }
             int pthreads = env_int("HBVX_PIPE_THREADS", 1024); // 3 steppers + filler + drainers (hbv_pipe.h)
             pthreads = pthreads < 512 ? 512 : (pthreads > 1024 ? 1024 : (pthreads / 64) * 64);
             if (nd > 0) pthreads = 1024;   // the dynamic-parameter roles assume all 16 waves

@@ -154,7 +154,16 @@ static int check_adj(const hbvx_desc *d)
     return HBVX_OK;
 }
 
+static int adj_forward_dispatch(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream);
+
 extern "C" int hbvx_adj_forward(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream)
+{
+    zero_taken() = false;
+    if (out && out->zero_ptr && !out->zero_state) return fail(HBVX_E_NULL, "zero_ptr needs zero_state");
+    return adj_forward_dispatch(d, out, stream);
+}
+
+static int adj_forward_dispatch(const hbvx_desc *d, const hbvx_fwd_out *out, void *stream)
 {
     int rc = check_adj(d);
     if (rc) return rc;

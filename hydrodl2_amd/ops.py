@@ -178,35 +178,62 @@ def _grad_like(lib, p: torch.Tensor, cfg: "StepConfig", tensor_idx: int) -> torc
     return out
 
 
-# Optional (HBVX_EARLY_ZERO=1): prepare the parameter-gradient buffers while the forward kernel runs.  The
-# zero fill of a [T,B,ny] gradient (3.8 GB, 0.57 ms at HBM speed for config 2) needs bandwidth, the pipelined
-# forward needs latency on 168 of 256 CUs; on a second HIP stream the fill hides behind it.  Measured at
-# config 2: step 3.47 -> 3.32 ms, but the forward kernel itself slows from 1.12 to 1.27 ms (its row drains
-# wait longer for memory) with a much wider spread (1.15-2.2 ms under the profiler).  Off by default: the gain
-# is small and the forward's time stops being a property of the forward.  The buffers are handed to
-# backward through the autograd context (first backward only; a second one over a retained graph fills
-# its own).  Re-measured in round 5 with today's kernels (profiles/r05_earlyzero.txt): the MEDIAN step drops
-# 2.40 -> 1.95 ms at config 2, but the buffers are allocated on the side stream and the caching allocator cannot
-# recycle a block another stream still owns: every other step pays a hipMalloc (region mean 2.44 ms, one multi-second
-# stall).  Two safer ownership schemes were tried (caller's pool + stream wait; buffers held until the fill's event):
-# no net gain / worse.  Stays off.
-_EARLY_ZERO = os.environ.get("HBVX_EARLY_ZERO", "0") not in ("", "0")
-_EARLY_ZERO_MIN = 1 << 26     # elements: below 256 MB the stream switch costs the host more than the fill costs the GPU
+# Part of the dense zero fill of a [T,B,ny] gradient (3.8 GB at config 2) INSIDE THE FORWARD LAUNCH (hbvx_fwd_out.zero_ptr,
+# ABI 10): the pipelined forward is a latency chain on 168 of 256 CUs; surplus workgroups of the same launch, on the CUs
+# it leaves idle, write zeros into the buffer front to back for as long as the recurrence runs.  The buffer is allocated
+# on the caller's stream in forward and handed to backward through the autograd context (first backward only: a second
+# one over a retained graph fills its own); backward fills what is missing (hbvx_zero_rest) on the second stream beside
+# the adjoint, as it fills the whole buffer without this.  One stream and one launch in forward: no cross-stream
+# ownership (round 5's second-stream fill beside the forward cost a hipMalloc every other step: the caching allocator
+# cannot recycle a block another stream still owns -- profiles/r05_earlyzero.txt).
+# WHERE IT PAYS (profiles/r05_inlaunch_fill.txt): the implicit scheme, whose 4.2 ms forward (575 ns per day) does not
+# notice the fill -- config 4: 6.75-6.84 -> 6.32-6.38 ms, the speed of grad_buffer='persistent' with a fresh gradient
+# tensor per step.  The explicit models' recurrence (115 ns per day, a tile of ten days in flight) is sensitive to ANY
+# concurrent HBM writes: 22 fill waves (1 TB/s) stretch config 2's forward from 0.90 to 1.08 ms, 88 waves to 1.25 --
+# what the adjoint gains (1.33 -> 0.92) the forward loses (2.37-2.55 -> 2.22-2.46 ms over three boxes, config 2 with two
+# dynamic parameters +-0).  So: "auto" = the implicit scheme only; HBVX_EARLY_ZERO=1 all models, 0 none.
+_EARLY_ZERO = os.environ.get("HBVX_EARLY_ZERO", "auto")
+_EARLY_ZERO_MIN = 1 << 26     # elements: below 256 MB the fill is not worth a special path
 _SIDE_STREAMS: dict = {}
 
 
-def _early_grad_buffers(lib, cfg: "StepConfig", ptensors, needs) -> Optional[tuple]:
-    dev = ptensors[0].device
-    main = torch.cuda.current_stream(dev)
-    side = _side_stream(dev)
-    with torch.cuda.stream(side):
-        bufs = [_grad_like(lib, p, cfg, i) if need else None for i, (p, need) in enumerate(zip(ptensors, needs))]
-        done = torch.cuda.Event()
-        done.record(side)
-    for b in bufs:
-        if b is not None:
-            b.record_stream(main)      # allocated on the side stream's pool, consumed on the caller's
-    return bufs, done
+def _row_split(p: torch.Tensor, cfg: "StepConfig", i: int):
+    """Whether parameter tensor i takes the big-buffer + separate-last-row form of its gradient: (ok, base, cols).
+    It does when it is large, [T,B,W]-shaped, every static / routing source of it lies in its last row, and at most half
+    of its columns belong to dynamic parameters of this call."""
+    base = (p.shape[0] - 1) * p[0].numel() if p.dim() == 3 else -1
+    offs = [ps.sta_off for ps in cfg.params if ps.tensor_idx == i]
+    if cfg.route is not None and cfg.route.tensor_idx == i:
+        offs += [cfg.route.a_off, cfg.route.b_off]
+    cols = _dyn_columns(p, cfg, i)
+    few_dyn = cols is not None and bin(cols[0]).count("1") * cfg.M * 2 <= p.shape[-1]
+    ok = (p.dim() == 3 and p.is_contiguous() and p.numel() >= _EARLY_ZERO_MIN and p.shape[0] > 1
+          and all(o >= base for o in offs) and cols is not None and (cols[0] == 0 or few_dyn))
+    return ok, base, cols
+
+
+def _early_zero_request(lib, cfg: "StepConfig", ptensors, needs, out) -> Optional[tuple]:
+    """Forward side: allocate the gradient buffer of the (one) qualifying parameter tensor and offer it to the forward
+    launch (out.zero_ptr / zero_bytes / zero_state).  Returns (tensor index, buffer, state words) for the autograd
+    context, or None.  A configuration whose forward carries no fill workgroups (another kernel family, no idle CUs)
+    stops offering after its first call: holding the buffer from forward to backward would buy nothing."""
+    wanted = _EARLY_ZERO == "1" or (_EARLY_ZERO not in ("", "0") and cfg.model == _abi.MODEL_HBVADJ)
+    if not (wanted and lib.is_device and not cfg.persistent_grad and _FILL_OVERLAP):
+        return None
+    if cfg.__dict__.get("_early_zero_useless"):
+        return None
+    for i, (p, need) in enumerate(zip(ptensors, needs)):
+        if need and _row_split(p, cfg, i)[0]:
+            big = torch.empty_like(p)
+            state = torch.zeros(2, dtype=torch.int32, device=p.device)
+            out.zero_ptr, out.zero_bytes, out.zero_state = big.data_ptr(), big.numel() * big.element_size(), state.data_ptr()
+            return i, big, state
+    return None
+
+
+def _early_zero_result(lib, cfg: "StepConfig", early) -> None:
+    if early is not None and not lib.zero_in_launch():
+        cfg.__dict__["_early_zero_useless"] = True
 
 
 # Default: the fill runs BESIDE the adjoint.  The adjoint kernels are bound by instruction issue (DESIGN.md §4), the
@@ -226,14 +253,13 @@ def _side_stream(dev) -> "torch.cuda.Stream":
     return side
 
 
-def _overlapped_grad_buffers(lib, cfg: "StepConfig", ptensors, needs):
+def _overlapped_grad_buffers(lib, cfg: "StepConfig", ptensors, needs, early=None):
     """(gp, rows, bases, start): gradient buffers, the separate last rows (None where a tensor keeps the
     plain path), their element offsets inside the big tensors, and `start()` -> event: begins the fills
     of the qualifying tensors on the side stream (call it when the caller's stream has nothing
     bandwidth-bound left in front of the adjoint) and returns the event that marks them complete;
-    `start.gated`: that event must reach the library as `store_gate`.
-    A tensor qualifies when it is large, [T,B,W]-shaped, every static / routing source of it lies in its last
-    row, and at most half of its columns belong to dynamic parameters of this call."""
+    `start.gated`: that event must reach the library as `store_gate`.  Which tensors qualify: _row_split.
+    `early`: (index, buffer) from the forward (_early_zero_request): that tensor's buffer is already zero."""
     dev = ptensors[0].device
     gp, rows, bases, todo = [], [], [], []
     gated = False
@@ -241,20 +267,22 @@ def _overlapped_grad_buffers(lib, cfg: "StepConfig", ptensors, needs):
         if not need:
             gp.append(None); rows.append(None); bases.append(0)
             continue
-        base = (p.shape[0] - 1) * p[0].numel() if p.dim() == 3 else -1
-        offs = [ps.sta_off for ps in cfg.params if ps.tensor_idx == i]
-        if cfg.route is not None and cfg.route.tensor_idx == i:
-            offs += [cfg.route.a_off, cfg.route.b_off]
-        cols = _dyn_columns(p, cfg, i)
         # A tensor with dynamic columns is filled DENSELY (the fastest fill) and the adjoint's stores into those
         # columns must land after it: the fill's event goes to the library as hbvx_bwd_io.store_gate, which holds
         # back the storing kernel only (the transfer-map and scan passes of the time-parallel adjoint run beside
         # the fill).  Without the gate the two race (measured: wrong gradients).  Worth it while few columns are
         # dynamic -- with most of them dynamic (config 3) hbvx_zero_except in front of the adjoint writes a
         # fraction of the bytes and stays.
-        few_dyn = cols is not None and bin(cols[0]).count("1") * cfg.M * 2 <= p.shape[-1]
-        ok = (p.dim() == 3 and p.is_contiguous() and p.numel() >= _EARLY_ZERO_MIN and p.shape[0] > 1
-              and all(o >= base for o in offs) and cols is not None and (cols[0] == 0 or few_dyn))
+        ok, base, cols = _row_split(p, cfg, i)
+        if early is not None and early[0] == i and ok:
+            # its front part was zeroed inside the forward's launch (_early_zero_request); what is missing is filled below,
+            # beside the adjoint, like a whole buffer
+            gp.append(early[1])
+            rows.append(torch.zeros_like(p[0]))
+            bases.append(base)
+            todo.append((early[1], early[2]))
+            gated = gated or cols[0] != 0
+            continue
         if not ok:
             gp.append(_grad_like(lib, p, cfg, i)); rows.append(None); bases.append(0)
             continue
@@ -285,7 +313,7 @@ def _overlapped_grad_buffers(lib, cfg: "StepConfig", ptensors, needs):
         gp.append(big)
         rows.append(torch.zeros_like(p[0]))
         bases.append(base)
-        todo.append(big)
+        todo.append((big, None))
         gated = gated or cols[0] != 0
 
     def start():
@@ -295,8 +323,12 @@ def _overlapped_grad_buffers(lib, cfg: "StepConfig", ptensors, needs):
         side = _side_stream(dev)
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            for big in todo:
-                _call(lib, 'hbvx_zero', lib.zero, big.data_ptr(), big.numel() * big.element_size(), _stream_of(lib, big))
+            for big, state in todo:
+                if state is None:
+                    _call(lib, 'hbvx_zero', lib.zero, big.data_ptr(), big.numel() * big.element_size(), _stream_of(lib, big))
+                else:
+                    _call(lib, 'hbvx_zero', lib.zero_rest, big.data_ptr(), big.numel() * big.element_size(), state.data_ptr(),
+                          _stream_of(lib, big))
             done = torch.cuda.Event()
             done.record(side)
         return done
@@ -506,10 +538,10 @@ def _hbv_forward(ctx, cfg: StepConfig, x, state_in, muwts, ac, elev, ptensors):
     out.traj, out.aux = _ptr(traj), _ptr(aux)
     out.n_flux, out.traj_layout = cfg.n_flux, layout
     ctx.early_gp = None
-    if (needs_grad and _EARLY_ZERO and lib.is_device and any(ctx.needs_input_grad[6:])
-            and sum(p.numel() for p in ptensors) >= _EARLY_ZERO_MIN):
-        ctx.early_gp = _early_grad_buffers(lib, cfg, ptensors, ctx.needs_input_grad[6:])
+    if needs_grad and cfg.want_flux and any(ctx.needs_input_grad[6:]):
+        ctx.early_gp = _early_zero_request(lib, cfg, ptensors, ctx.needs_input_grad[6:], out)
     _call(lib, 'hbvx_forward', lib.forward, desc, out, stream)
+    _early_zero_result(lib, cfg, ctx.early_gp)
 
     routed = uh = None
     if cfg.route is not None and cfg.want_flux:
@@ -608,11 +640,8 @@ class HbvPath(torch.autograd.Function):
         rows = [None] * len(ptensors)
         bases = [0] * len(ptensors)
         fill_done, start_fill = None, None
-        if early is not None:
-            gp, done = early
-            torch.cuda.current_stream(dev).wait_event(done)
-        elif _FILL_OVERLAP and lib.is_device:
-            gp, rows, bases, start_fill = _overlapped_grad_buffers(lib, cfg, ptensors, ctx.needs_input_grad[6:])
+        if _FILL_OVERLAP and lib.is_device:
+            gp, rows, bases, start_fill = _overlapped_grad_buffers(lib, cfg, ptensors, ctx.needs_input_grad[6:], early)
         else:
             gp = [_grad_like(lib, p, cfg, i) if ctx.needs_input_grad[6 + i] else None
                   for i, p in enumerate(ptensors)]
@@ -781,7 +810,11 @@ class HbvAdjPath(torch.autograd.Function):
         if state_in is not None:
             state_in = state_in.contiguous()
         desc = _fill_desc(cfg, x, state_in, None, None, None, ptensors)
+        ctx.early_gp = None
+        if needs_grad and any(ctx.needs_input_grad[3:]):
+            ctx.early_gp = _early_zero_request(lib, cfg, ptensors, ctx.needs_input_grad[3:], out)
         _call(lib, 'hbvx_adj_forward', lib.adj_forward, desc, out, stream)
+        _early_zero_result(lib, cfg, ctx.early_gp)
         routed = uh = None
         if cfg.route is not None and cfg.want_flux:
             r = _route_desc(cfg, ptensors, S=1)
@@ -811,8 +844,9 @@ class HbvAdjPath(torch.autograd.Function):
         rows = [None] * len(ptensors)
         bases = [0] * len(ptensors)
         start_fill = None
+        early, ctx.early_gp = ctx.early_gp, None
         if _FILL_OVERLAP and lib.is_device:
-            gp, rows, bases, start_fill = _overlapped_grad_buffers(lib, cfg, ptensors, ctx.needs_input_grad[3:])
+            gp, rows, bases, start_fill = _overlapped_grad_buffers(lib, cfg, ptensors, ctx.needs_input_grad[3:], early)
         else:
             gp = [_grad_like(lib, p, cfg, i) if ctx.needs_input_grad[3 + i] else None
                   for i, p in enumerate(ptensors)]

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define HBVX_ABI_VERSION 9
+#define HBVX_ABI_VERSION 10
 #define HBVX_MAX_PARAM 20
 #define HBVX_NSTATE 5   /* SNOWPACK, MELTWATER, SM, SUZ, SLZ  (hbv.py:61-67) */
 #define HBVX_MAX_FLUX 12
@@ -180,6 +180,18 @@ typedef struct hbvx_fwd_out {
     int32_t n_flux;   /* 11 (HBV 1.0) or 12 */
     int32_t traj_layout; /* enum hbvx_traj_layout: how traj / aux are laid out.  Must be what
                             hbvx_preferred_traj_layout() returns for this desc, or HBVX_TRAJ_ROWS */
+    void *zero_ptr;      /* ABI 10, optional: a caller-owned buffer (16-byte aligned) the caller needs ZEROED later -- its
+                            dense gradient tensor ([T,B,ny]: 3.8 GB at config 2).  The pipelined forward is a latency
+                            chain on 168 of 256 CUs; surplus workgroups of the SAME launch, on the CUs it leaves idle,
+                            write zeros into this buffer in 256 KB pieces, front to back, for as long as the recurrence
+                            runs, and stop with it (same stream, same launch: no cross-stream ownership of the buffer,
+                            and the forward is never longer than its recurrence).  How many pieces they wrote is left in
+                            zero_state[0]; hbvx_zero_rest() then fills what is missing -- all of it when another
+                            kernel family took the call (zero_state[0] stays 0).  NULL: nothing.  The CPU oracle
+                            leaves everything to hbvx_zero_rest. */
+    uint64_t zero_bytes; /* multiple of 16 */
+    void *zero_state;    /* device memory, two uint32 words, ZERO on entry ([0]: pieces claimed, [1]: workgroups of the
+                            recurrence that have finished); required with zero_ptr */
 } hbvx_fwd_out;
 
 typedef struct hbvx_bwd_io {
@@ -227,6 +239,13 @@ uint64_t hbvx_sizeof(int which);        /* 0 desc, 1 fwd_out, 2 bwd_io, 3 route_
  * "pipe", "stream2", "stream", "tiled", "simple", "chunked", "ckpt-block:<family>", "ckpt-lds"; "oracle" in the CPU
  * restatement.  The parity tests assert that the family they mean to pin against the reference is the one that ran. */
 const char *hbvx_last_dispatch(int direction);
+/* 1 when the last hbvx_forward / hbvx_adj_forward of this thread carried fill workgroups for hbvx_fwd_out.zero_ptr in its
+ * launch (the pipelined forward with idle CUs), else 0 (diagnostic, like hbvx_last_dispatch). */
+int hbvx_zero_in_launch(void);
+/* Zero what the forward's launch left of hbvx_fwd_out.zero_ptr: pieces zero_state[0] .. end (HBVX_ZERO_PIECE bytes each).
+ * Asynchronous on `stream`, which must be ordered behind the forward call. */
+#define HBVX_ZERO_PIECE (256u * 1024u)
+int hbvx_zero_rest(void *ptr, uint64_t bytes, const void *zero_state, void *stream);
 
 /* The trajectory layout this library wants for the problem (grid size, dynamic set): pass the
  * value in hbvx_fwd_out.traj_layout and hbvx_bwd_io.traj_layout.  HBVX_TRAJ_ROWS is always accepted. */

@@ -46,6 +46,15 @@ uint64_t hbvx_ckpt_workspace_bytes(const hbvx_desc *d, int32_t K) { (void)d; (vo
 int hbvx_preferred_traj_layout(const hbvx_desc *d) { (void)d; return HBVX_TRAJ_ROWS; }
 const char *hbvx_last_error(void) { return g_err; }
 const char *hbvx_last_dispatch(int direction) { (void)direction; return "oracle"; }
+int hbvx_zero_in_launch(void) { return 0; }
+/* include/hbvx.h, ABI 10: the CPU forward writes no zeros (zero_state[0] stays 0), so the rest is everything */
+int hbvx_zero_rest(void *ptr, uint64_t bytes, const void *zero_state, void *stream)
+{
+    (void)zero_state; (void)stream;
+    if (bytes && !ptr) return fail(HBVX_E_NULL, "hbvx_zero_rest: buffer is NULL");
+    if (bytes) memset(ptr, 0, (size_t)bytes);
+    return HBVX_OK;
+}
 const char *hbvx_backend(void) { return "cpu-oracle"; }
 
 uint64_t hbvx_sizeof(int which)

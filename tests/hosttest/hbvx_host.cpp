@@ -23,6 +23,12 @@ extern "C" int hbvx_preferred_traj_layout(const hbvx_desc *) { return HBVX_TRAJ_
 extern "C" uint64_t hbvx_ckpt_workspace_bytes(const hbvx_desc *, int32_t) { return 0; }
 extern "C" const char *hbvx_last_error(void) { return g_err; }
 extern "C" const char *hbvx_last_dispatch(int) { return "host-steptest"; }
+extern "C" int hbvx_zero_in_launch(void) { return 0; }
+extern "C" int hbvx_zero_rest(void *ptr, uint64_t bytes, const void *, void *)
+{
+    if (bytes) memset(ptr, 0, (size_t)bytes);
+    return 0;
+}
 extern "C" const char *hbvx_backend(void) { return "cpu-steptest"; }
 extern "C" uint64_t hbvx_sizeof(int w)
 {
