@@ -323,13 +323,21 @@ class HbvModule(torch.nn.Module):
         dyn_idx = [i for i, ps in enumerate(cfg.params) if ps.dyn_off >= 0]
         masks = self._draw_drop_masks(len(dyn_idx), ngrid, x.device)
         if any(m is not None for m in masks):
-            cfg = copy.copy(cfg)               # a config with masks belongs to this call (and its backward) alone
+            # a config with masks belongs to this call (and its backward) alone -- but not what is memoised on it (the
+            # library's size / layout answers, the descriptor plan, the persistent gradient buffer): functions of the
+            # shapes, shared with the cached original.  (Until round 5 a first call WITH masks left its memo on the copy:
+            # every later call rebuilt it, and grad_buffer='persistent' allocated and filled a new buffer per step.)
+            shared = cfg
+            shared.__dict__.setdefault("_memo", {})
+            cfg = copy.copy(cfg)
             cfg.params = [copy.copy(ps) for ps in cfg.params]
             for i, m in zip(dyn_idx, masks):
                 cfg.params[i].drop = m
         muwts = self._expand_muwts(self.muwts, T, T_total, ngrid)
         res = hbv_path(cfg, x, state_in, muwts, None, None, parameters)
         flux, routed, state_out = res.flux, res.routed, res.state_out
+        if any(m is not None for m in masks) and "_plan" in cfg.__dict__:
+            shared.__dict__.setdefault("_plan", cfg.__dict__["_plan"])      # the plan holds offsets, no pointers
 
         # hbv.py:356-359
         self.__dict__['_states_cache'] = list(state_out.detach().unbind(0))

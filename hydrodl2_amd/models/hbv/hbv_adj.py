@@ -60,6 +60,7 @@ class HbvAdj(torch.nn.Module):
         self.graph = False           # replay the call's launches as HIP graphs (hydrodl2_amd/graphed.py); opt-in
         self.grad_buffer = 'fresh'   # 'persistent': the [T,B,ny] gradient in a buffer kept per shape (core/hbv_module.py)
         self._cfg_cache = {}
+        self._memo_cache = {}
         self.parameter_bounds = {
             'parBETA': [1.0, 6.0], 'parFC': [50, 1000], 'parK0': [0.05, 0.9],
             'parK1': [0.01, 0.5], 'parK2': [0.001, 0.2], 'parLP': [0.2, 1],
@@ -194,6 +195,12 @@ class HbvAdj(torch.nn.Module):
                 if len(self._cfg_cache) > 8:
                     self._cfg_cache.clear()
                 self._cfg_cache[key] = (cfg_w, cfg)
+            else:
+                # configurations with dy_drop masks are built per call; what is memoised on them (the library's size
+                # answers, the persistent gradient buffer) is a function of the shapes and lives with the module
+                if len(self._memo_cache) > 8:
+                    self._memo_cache.clear()
+                cfg.__dict__["_memo"] = self._memo_cache.setdefault(key, {})
         state = None  # zeros (hbv_adj.py:254)
         if cfg_w is not None:
             _, _, state = HbvAdjPath.apply(cfg_w, x, None, parameters)

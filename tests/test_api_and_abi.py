@@ -219,3 +219,48 @@ def test_zero_length_record_on_oracle(oracle_backend):
 @pytest.mark.gpu
 def test_zero_length_record_on_gpu(hip_backend):
     _zero_length_record("cuda:0")
+
+
+def _memo_ids_over_three_dy_drop_calls(family, cls, device):
+    """A call with dy_drop masks runs on a per-call step configuration (the masks belong to that call and its backward);
+    what is memoised on a configuration -- the library's size / layout answers, the descriptor plan, the persistent
+    gradient buffer -- is a function of the shapes and must survive the call.  (Until round 5 a module whose FIRST call
+    carried masks left the memo on the copy: every later call rebuilt it, and grad_buffer='persistent' allocated and
+    zero-filled a new [T,B,ny] buffer per step.)"""
+    import torch
+    import hydrodl2_amd
+    from hydrodl2_amd import ops
+    T, B, M = 40, 3, 4
+    dyn = ["parBETA", "parBETAET"] if cls == "Hbv" else ["parBETAET"]
+    model = hydrodl2_amd.load_model(family, cls)({"nmul": M, "dy_drop": 0.5, "dynamic_params": {cls: dyn}}, device)
+    seen = []
+    real = ops._cached
+
+    def spy(cfg, key, fn):
+        seen.append(id(cfg.__dict__.setdefault("_memo", {})))
+        return real(cfg, key, fn)
+    ops._cached = spy
+    try:
+        for rnd in range(3):
+            g = torch.Generator().manual_seed(rnd)
+            x = torch.stack([torch.rand((T, B), generator=g) * 10, torch.randn((T, B), generator=g) * 5 + 3,
+                             torch.rand((T, B), generator=g) * 4], -1)
+            p = torch.randn((T, B, model.learnable_param_count), generator=g).to(device).requires_grad_(True)
+            torch.manual_seed(rnd)
+            out = model({"x_phy": x.to(device)}, p)
+            next(iter(out.values())).sum().backward()
+    finally:
+        ops._cached = real
+    return seen
+
+
+def test_dy_drop_calls_share_the_memo_of_their_configuration(oracle_backend):
+    seen = _memo_ids_over_three_dy_drop_calls("hbv", "Hbv", "cpu")
+    assert seen and len(set(seen)) == 1, seen
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("family,cls", [("hbv", "Hbv"), ("hbv_adj", "HbvAdj")])
+def test_dy_drop_calls_share_the_memo_on_gpu(family, cls, hip_backend):
+    seen = _memo_ids_over_three_dy_drop_calls(family, cls, "cuda:0")
+    assert seen and len(set(seen)) <= 2, seen        # main configuration (+ HbvAdj: none for warm-up here)

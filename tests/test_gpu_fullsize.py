@@ -446,9 +446,10 @@ def test_gated_fill_with_dynamic_columns_is_equivalent(dy_drop, hip_backend, mon
 def test_persistent_gradient_buffer_equals_fresh(dyn, dy_drop, warm_up, hip_backend):
     """Module key grad_buffer='persistent': the [T,B,ny] gradient is written into a buffer the module keeps (zero-filled
     once; every step rewrites the dynamic columns and the last row only).  Bit-identical to the default over three steps
-    with new inputs, new dy_drop masks and two loss patterns, out of the SAME storage (autograd adopts the tensor it is
-    handed when nothing else references it; on a step where it sees another reference it copies -- correct, slower --
-    so: the same storage on at least two of the three steps)."""
+    with new inputs, new dy_drop masks and two loss patterns, out of the SAME storage from the second step on (the
+    first step's tensor may be a copy autograd made).  With dy_drop masks the step configuration is a per-call copy:
+    the buffer lives in the memo it shares with the cached original (round 5: it used to be rebuilt -- and refilled --
+    every step, which this assertion caught as [A, B, A])."""
     import hydrodl2_amd
     from hydrodl2_amd import ops
     dev = torch.device("cuda:0")
@@ -473,7 +474,7 @@ def test_persistent_gradient_buffer_equals_fresh(dyn, dy_drop, warm_up, hip_back
                 ptrs.append(pl.grad.untyped_storage().data_ptr())
             del pl, out, loss
         assert torch.equal(res[0], res[1]), f"round {rnd}"
-    assert max(ptrs.count(q) for q in set(ptrs)) >= 2, ptrs
+    assert len(set(ptrs[1:])) == 1, ptrs
     with pytest.raises(ValueError, match="grad_buffer"):
         C(dict(conf, grad_buffer="sometimes"), dev)({"x_phy": x}, p)
 
