@@ -132,7 +132,11 @@ class Hbv_2(HbvModule):
             self._cfg_cache[key] = cfg
         # one Bernoulli draw per dynamic parameter, in the order of the config list (hbv_2.py:254-258)
         masks = self._draw_drop_masks(n_dy, ngrid, x.device)
+        shared = None
         if any(m is not None for m in masks):
+            # the masks belong to this call; the memo and the descriptor plan to the shape (core/hbv_module.py)
+            shared = cfg
+            shared.__dict__.setdefault("_memo", {})
             cfg = copy.copy(cfg)
             cfg.params = [copy.copy(ps) for ps in cfg.params]
             by_name = dict(zip(dy, masks))
@@ -156,6 +160,8 @@ class Hbv_2(HbvModule):
         muwts = self._expand_muwts(self.muwts, T, T, ngrid)
         res = hbv_path(cfg, x, state_in, muwts, ac, elev, p_dyn, p_sta)
         flux, routed, state_out, traj = res.flux, res.routed, res.state_out, res.traj
+        if shared is not None and "_plan" in cfg.__dict__:
+            shared.__dict__.setdefault("_plan", cfg.__dict__["_plan"])
 
         # hbv_2.py:385-388,628: the state cache is the full series [T,B,nmul] x 5 (views of the
         # saved trajectory: storages after day t = storages entering day t + 1)
