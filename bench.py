@@ -507,7 +507,10 @@ class DplWorkload:
         spec.loader.exec_module(mod)
         self.graph = graph
         self.name = "dplgraph" if graph else "dpl"
-        self.step, self.info = mod.make_trainer(dev, graph=graph, tune_gemm=graph)
+        # HBVX_BENCH_TUNE_GEMM=0: no TunableOp pass (profiling runs: the tuner's trial launches flood a kernel trace)
+        tune = graph and os.environ.get("HBVX_BENCH_TUNE_GEMM", "1") not in ("", "0")
+        self.tuned = tune
+        self.step, self.info = mod.make_trainer(dev, graph=graph, tune_gemm=tune)
 
     def entry(self, ms, kms):
         i = self.info
@@ -515,7 +518,8 @@ class DplWorkload:
         lstm = sum(v for k, v in kms.items() if "lstm" in k)
         e = {"config": self.name,
              "what": "examples/train_dpl.py step: LSTM-256 -> Hbv -> 1-NSE -> Adam (fused LSTM kernels)"
-                     + ("; the whole step replayed as ONE captured HIP graph with TunableOp's GEMM picks (--graph --tune-gemm)"
+                     + (("; the whole step replayed as ONE captured HIP graph" + (" with TunableOp's GEMM picks (--graph --tune-gemm)"
+                                                                                    if self.tuned else " (--graph)"))
                         if self.graph else ""),
              "T": i["T"], "B": i["B"], "M": i["M"], "steps": 5, "ms_per_step": round(ms, 4),
              "lane_steps_per_s": i["T"] * i["B"] * i["M"] / (ms * 1e-3),

@@ -260,7 +260,27 @@ def test_dy_drop_calls_share_the_memo_of_their_configuration(oracle_backend):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("family,cls", [("hbv", "Hbv"), ("hbv_adj", "HbvAdj")])
-def test_dy_drop_calls_share_the_memo_on_gpu(family, cls, hip_backend):
-    seen = _memo_ids_over_three_dy_drop_calls(family, cls, "cuda:0")
-    assert seen and len(set(seen)) <= 2, seen        # main configuration (+ HbvAdj: none for warm-up here)
+def test_dy_drop_calls_share_the_memo_on_gpu(hip_backend):
+    seen = _memo_ids_over_three_dy_drop_calls("hbv", "Hbv", "cuda:0")
+    assert seen and len(set(seen)) == 1, seen
+
+
+@pytest.mark.gpu
+def test_implicit_scheme_keeps_one_memo_per_shape_under_dy_drop(hip_backend):
+    """HbvAdj builds its masked step configurations per call; their memo (the persistent gradient buffer) is kept per
+    shape on the module and handed to every one of them."""
+    import torch
+    import hydrodl2_amd
+    T, B, M = 40, 3, 4
+    model = hydrodl2_amd.load_model("hbv_adj", "HbvAdj")({"nmul": M, "dy_drop": 0.5, "dynamic_params": {"HbvAdj": ["parBETAET"]}}, "cuda:0")
+    memos = []
+    for rnd in range(3):
+        g = torch.Generator().manual_seed(rnd)
+        x = torch.stack([torch.rand((T, B), generator=g) * 10, torch.randn((T, B), generator=g) * 5 + 3,
+                         torch.rand((T, B), generator=g) * 4], -1).to("cuda:0")
+        p = torch.randn((T, B, model.learnable_param_count), generator=g).to("cuda:0").requires_grad_(True)
+        out = model({"x_phy": x}, p)
+        next(iter(out.values())).sum().backward()
+        assert len(model._memo_cache) == 1
+        memos.append(id(next(iter(model._memo_cache.values()))))
+    assert len(model._memo_cache) == 1 and len(set(memos)) == 1, (memos, len(model._memo_cache))

@@ -9,6 +9,7 @@ set -e
 TAG=${1:-r02}
 R=$PWD
 export TMPDIR=/tmp
+export HBVX_BENCH_TUNE_GEMM=0   # the tuner's trial launches would flood the kernel trace
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG/kt -o kt -- python3 $R/bench.py --steps 5 --warmup 2 > $R/gpurun_out/prof_$TAG.bench.json 2> $R/gpurun_out/prof_$TAG.kt.log
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_$TAG/fetch -o fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-secondary --no-cpu-baseline > /dev/null 2> $R/gpurun_out/prof_$TAG.fetch.log
