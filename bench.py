@@ -529,6 +529,40 @@ class DplWorkload:
         return e
 
 
+def tuned_graph_entry_from_child():
+    """The `dplgraph` entry (whole training step as one HIP graph, TunableOp's GEMM picks) measured by tools/bench_one.py in a
+    child process; if the child fails, the workload runs here without the tuner."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_one.py"), "dplgraph", "--steps", str(SEC_STEPS), "--warmup", "3"]
+    env = dict(os.environ, HBVX_BENCH_TUNE_GEMM="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+        r = json.loads(line)
+        e = {"config": "dplgraph",
+             "what": "examples/train_dpl.py step: LSTM-256 -> Hbv -> 1-NSE -> Adam (fused LSTM kernels); the whole step replayed "
+                     "as ONE captured HIP graph with TunableOp's GEMM picks (--graph --tune-gemm); measured in a child process",
+             "T": 730, "B": 100, "M": 16, "ms_per_step": r["ms_median"], "lane_steps_per_s": 730 * 100 * 16 / (r["ms_median"] * 1e-3),
+             "steps": SEC_STEPS, "ms_per_step_is": "median of the per-step samples",
+             "step_samples": {"n": SEC_STEPS, "ms_median": r["ms_median"], "ms_min": r["ms_min"], "ms_max": r["ms_max"],
+                              "ms_mean_region": r["ms_mean_region"], "host_enqueue_ms_median": r["host_enqueue_ms_median"]},
+             "kernel_ms": {}, "kernel_sum_ms": 0, "device_mallocs_in_timed_steps": r.get("device_mallocs")}
+        e.update(limited_by("dplgraph"))
+        return e
+    except Exception as ex:  # noqa: BLE001 -- the child died or printed nothing: same workload, no tuner, in this process
+        import torch
+        os.environ["HBVX_BENCH_TUNE_GEMM"] = "0"
+        dev = torch.device("cuda", torch.cuda.current_device())
+        w = DplWorkload(dev, 7, graph=True)
+        dt, k = timed_steps(w, SEC_STEPS, 3, dev, 1)
+        smp = timed_steps.samples
+        e = w.entry(smp["ms_median"] if smp else 1e3 * dt / SEC_STEPS, k)
+        e.update({"steps": SEC_STEPS, "step_samples": smp, "tuner_child_failed": repr(ex)[:160]})
+        return e
+
+
 def make_workload(name, dev, seed=7):
     """Any named workload of the bench (tools/bench_one.py)."""
     if name == "lstm":
@@ -953,6 +987,13 @@ def main():
             if name == args.config:
                 continue
             try:
+                if name == "dplgraph" and os.environ.get("HBVX_BENCH_TUNE_GEMM", "1") not in ("", "0"):
+                    # torch's TunableOp times every library GEMM candidate of nine shapes on this device: third-party
+                    # kernels this process has never run.  In a child process, so that a fault in one of them costs this
+                    # entry, not the headline; the child times the workload with this file's own protocol
+                    sec.append(tuned_graph_entry_from_child())
+                    print(f"[bench] {name}: {sec[-1].get('ms_per_step', float('nan')):.3f} ms/step (child process)", file=sys.stderr, flush=True)
+                    continue
                 w2 = make_workload(name, dev, 7)
                 dt2, k2 = timed_steps(w2, SEC_STEPS, 3, dev, 1)
                 smp = timed_steps.samples
