@@ -60,3 +60,48 @@ def test_zero_rest_on_the_oracle_is_a_plain_fill(oracle_backend):
     state = torch.zeros(2, dtype=torch.int32)
     lib.zero_rest(buf.data_ptr(), 1000, state.data_ptr(), 0)
     assert int(buf[:1000].max()) == 0 and int(buf[1000:].min()) == 0x5A
+
+
+@pytest.mark.gpu
+def test_fill_workgroups_of_the_forward_launch_claim_whole_pieces_and_stop(hip_backend, monkeypatch):
+    """The contract of hbvx_fwd_out.zero_ptr at the ABI's level of detail: after the forward call zero_state[1] counts the
+    recurrence's workgroups (150 here), zero_state[0] the 256 KB pieces the fill waves claimed; every claimed piece is
+    zero, every byte behind them still holds what the caller put there (NaN)."""
+    import math
+    import hydrodl2_amd
+    from hydrodl2_amd import ops
+    dev = torch.device("cuda:0")
+    T, B, M = 640, 600, 16
+    monkeypatch.setattr(ops, "_EARLY_ZERO", "1")
+    real = ops._early_zero_request
+    seen = []
+
+    def spy(lib, cfg, ptensors, needs, out):
+        r = real(lib, cfg, ptensors, needs, out)
+        if r is not None:
+            r[1].fill_(float("nan"))      # on the launch stream, in front of the forward
+            seen.append(r)
+        return r
+    monkeypatch.setattr(ops, "_early_zero_request", spy)
+    model = hydrodl2_amd.load_model("hbv", "Hbv")({"nmul": M, "dynamic_params": {"Hbv": []}}, dev)
+    g = torch.Generator(device=dev).manual_seed(1)
+    x = torch.rand((T, B, 3), generator=g, device=dev) * torch.tensor([20.0, 30.0, 5.0], device=dev) - torch.tensor([12.0, 10.0, 0.0], device=dev)
+    x[..., 0].clamp_(min=0.0)
+    p = torch.randn((T, B, model.learnable_param_count), generator=g, device=dev, requires_grad=True)
+    out = model({"x_phy": x}, p)
+    torch.cuda.synchronize()
+    assert len(seen) == 1 and ops.get_library().zero_in_launch()
+    _, big, state = seen[0]
+    claimed, done = (int(v) for v in state.tolist())
+    nbytes = big.numel() * 4
+    npiece = math.ceil(nbytes / PIECE)
+    assert done == (B + 3) // 4                       # one count per workgroup of the recurrence (4 basins x 16 members per wave)
+    assert claimed > 0
+    flat = big.view(-1)
+    edge = min(claimed, npiece) * (PIECE // 4)
+    assert float(flat[:edge].abs().max()) == 0.0
+    if edge < flat.numel():
+        assert bool(torch.isnan(flat[edge:]).all())
+    # and backward completes the buffer: the gradient is finite and zero outside the last row
+    out["streamflow"].sum().backward()
+    assert bool(torch.isfinite(p.grad).all()) and float(p.grad[:-1].abs().max()) == 0.0 and float(p.grad[-1].abs().max()) > 0.0
