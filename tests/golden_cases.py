@@ -115,6 +115,14 @@ CASES = {
                            seed=45, loss="all"),
     "hbv2_long_routing": dict(model="Hbv_2", config=_cfg("Hbv_2", 4, ("parBETA", "parBETAET"), routing=True), T=300,
                               B=7, seed=46, loss="streamflow"),
+    # the hourly model's production adjoints (hbv_2_hourly.py:527-675 taped): 300 hours, three dynamic parameters; and
+    # with the lagged-UH gage routing, dy_drop and a 16-member ensemble
+    "hourly_long_dyn3": dict(model="Hbv_2_hourly",
+                             config=_cfg("Hbv_2_hourly", 4, ("parBETA", "parK0", "parBETAET")),
+                             T=300, B=7, G=3, seed=47, loss="all"),
+    "hourly_long_routing": dict(model="Hbv_2_hourly",
+                                config=_cfg("Hbv_2_hourly", 16, ("parBETA", "parF0"), routing=True, dy_drop=0.3),
+                                T=256, B=6, G=2, seed=48, loss="all", torch_seed=9),
 }
 
 LONG_CASES = [n for n, c in CASES.items() if "_long_" in n]
