@@ -115,6 +115,11 @@ CASES = {
                            seed=45, loss="all"),
     "hbv2_long_routing": dict(model="Hbv_2", config=_cfg("Hbv_2", 4, ("parBETA", "parBETAET"), routing=True), T=300,
                               B=7, seed=46, loss="streamflow"),
+    # learned ensemble weights over a long record: the pipelined forward's staged weight row and the `MU` instances of the
+    # time-parallel adjoint (static and slot-list modes) against hbv.py:508-511 taped
+    "hbv_long_muwts": dict(model="Hbv", config=_cfg("Hbv", 16), T=300, B=6, seed=49, loss="all", muwts=True),
+    "hbv_long_muwts_dyn2": dict(model="Hbv", config=_cfg("Hbv", 4, ("parBETA", "parBETAET")), T=256, B=9, seed=50,
+                                loss="all", muwts=True),
     # the hourly model's production adjoints (hbv_2_hourly.py:527-675 taped): 300 hours, three dynamic parameters; and
     # with the lagged-UH gage routing, dy_drop and a 16-member ensemble
     "hourly_long_dyn3": dict(model="Hbv_2_hourly",

@@ -324,6 +324,12 @@ LONG_ENVS = {
 }
 
 
+# learned ensemble weights: the streaming kernels do not carry them, so where the grid size is forced the pipelined / tiled
+# forward and the time-parallel adjoint still run; checkpoints: block-wise through the time-parallel adjoint
+MUWTS_BWD = {"stream2-packed": {"chunked"}, "stream2-8wave": {"chunked"}, "ckpt4-onchip": {"ckpt-block:chunked"},
+             "ckpt8-onchip": {"ckpt-block:chunked"}, "ckpt16-onchip": {"ckpt-block:chunked"}}
+
+
 @pytest.mark.parametrize("env_id", list(LONG_ENVS))
 @pytest.mark.parametrize("name", gc.LONG_CASES)
 def test_long_golden_case_under_every_adjoint(name, env_id, hip_backend, monkeypatch):
@@ -345,6 +351,8 @@ def test_long_golden_case_under_every_adjoint(name, env_id, hip_backend, monkeyp
         want_bwd = {"chunked", "stream"}     # no second-generation instance for this dynamic set
     if want_bwd == {"ckpt-stream2"} and not has_stream2:
         want_bwd = {"ckpt-block:chunked"}
+    if gc.CASES[name].get("muwts"):
+        want_bwd = MUWTS_BWD.get(env_id, want_bwd)
     if model == "Hbv_2_hourly" and "HBVX_CKPT_DAYS" in env:
         # the hourly class always keeps the state series (its routing and its state cache read them): no checkpoints,
         # the trajectory adjoints run -- the time-parallel one, or the streaming pair where the grid size is forced
