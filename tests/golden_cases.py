@@ -115,6 +115,12 @@ CASES = {
                            seed=45, loss="all"),
     "hbv2_long_routing": dict(model="Hbv_2", config=_cfg("Hbv_2", 4, ("parBETA", "parBETAET"), routing=True), T=300,
                               B=7, seed=46, loss="streamflow"),
+    # five dynamic parameters with dy_drop masks (the streaming kernels' six-slot run-time lists, the time-parallel
+    # adjoint's generic mode); forcing channels in another order with one dynamic parameter (channel picks + slot list)
+    "hbv_long_dyn5_drop": dict(model="Hbv", config=_cfg("Hbv", 16, ("parBETA", "parFC", "parK0", "parK1", "parLP"),
+                                                         dy_drop=0.3), T=256, B=7, seed=51, loss="all", torch_seed=13),
+    "hbv_long_variables": dict(model="Hbv", config=_cfg("Hbv", 8, ("parBETA",), variables=["tmean", "pet", "prcp"]),
+                               T=300, B=5, seed=52, loss="streamflow"),
     # learned ensemble weights over a long record: the pipelined forward's staged weight row and the `MU` instances of the
     # time-parallel adjoint (static and slot-list modes) against hbv.py:508-511 taped
     "hbv_long_muwts": dict(model="Hbv", config=_cfg("Hbv", 16), T=300, B=6, seed=49, loss="all", muwts=True),
