@@ -121,6 +121,12 @@ CASES = {
                                                          dy_drop=0.3), T=256, B=7, seed=51, loss="all", torch_seed=13),
     "hbv_long_variables": dict(model="Hbv", config=_cfg("Hbv", 8, ("parBETA",), variables=["tmean", "pet", "prcp"]),
                                T=300, B=5, seed=52, loss="streamflow"),
+    # a capillary model with a short dynamic list (slot lists outside the compiled sets), HBV 2.0 all static from a cold
+    # start, and the tie conventions (cold dry start, wide raw parameters) through the long adjoints
+    "hbv11p_long_dyn2": dict(model="Hbv_1_1p", config=_cfg("Hbv_1_1p", 16, ("parBETA", "parC")), T=256, B=6, seed=53,
+                             loss="all"),
+    "hbv2_long_static_cold": dict(model="Hbv_2", config=_cfg("Hbv_2", 8), T=256, B=7, seed=54, loss="all", cold=True),
+    "hbv_long_ties": dict(model="Hbv", config=_cfg("Hbv", 2), T=256, B=9, seed=55, loss="all", cold=True, raw_scale=2.5),
     # learned ensemble weights over a long record: the pipelined forward's staged weight row and the `MU` instances of the
     # time-parallel adjoint (static and slot-list modes) against hbv.py:508-511 taped
     "hbv_long_muwts": dict(model="Hbv", config=_cfg("Hbv", 16), T=300, B=6, seed=49, loss="all", muwts=True),
