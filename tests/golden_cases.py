@@ -64,6 +64,14 @@ CASES = {
     # return) -- so only shapes that broadcast over time ([B,nmul], [1,B,nmul]) run there.
     "hbv_muwts_warmup": dict(model="Hbv", config=_cfg("Hbv", 4, ("parBETA",), warm_up=12), T=60, B=5,
                              seed=32, loss="all", muwts="bcast"),
+    # comprout=True (hbv.py:516-518,540-546): route every member, then average.  Self-consistent upstream for one member
+    # only (the grouped convolution has `ngrid` groups): accepted here for nmul == 1, refused otherwise like the reference.
+    # grad_atol_rel: a one-member "group" is a single column, and its smallest entries are sums over T with cancellation
+    # -- in float64 (oracle/hbv_torch_eager.py) parK2's gradient of basin 2 is 0.00182629; the reference's float32 tape
+    # gives 0.00182280 (-1.4e-5 of the column's largest entry, 0.241), the GPU 0.00182910 (+1.2e-5): both sides of the
+    # truth, 2.6e-5 apart.  The stated 2e-6 of the group's largest holds for ensembles (every other fixture); here 2e-5.
+    "hbv_comprout_m1": dict(model="Hbv", config=_cfg("Hbv", 1, ("parBETA",), comprout=True), T=64, B=6, seed=56,
+                            loss="all", grad_atol_rel=2e-5),
     # cold dry start: melt = SNOWPACK = 0 ties, SM hitting FC, SUZ < PERC.
     "hbv_ties": dict(model="Hbv", config=_cfg("Hbv", 2), T=48, B=9, seed=20, loss="all",
                      cold=True, raw_scale=2.5),

@@ -284,3 +284,17 @@ def test_implicit_scheme_keeps_one_memo_per_shape_under_dy_drop(hip_backend):
         assert len(model._memo_cache) == 1
         memos.append(id(next(iter(model._memo_cache.values()))))
     assert len(model._memo_cache) == 1 and len(set(memos)) == 1, (memos, len(model._memo_cache))
+
+
+def test_comprout_with_an_ensemble_is_refused_like_the_reference(oracle_backend):
+    """comprout=True reshapes [T, B, nmul] to B * nmul routed channels while the unit hydrograph has B groups: the
+    reference's grouped convolution raises a RuntimeError for nmul > 1 (hbv.py:516-530; checked against it: "shape
+    '[12, 1, 15]' is invalid for input of size 45").  Same exception type here; nmul == 1 runs (golden case
+    hbv_comprout_m1)."""
+    import torch
+    import hydrodl2_amd
+    model = hydrodl2_amd.load_model("hbv", "Hbv")({"nmul": 4, "comprout": True, "dynamic_params": {"Hbv": []}}, "cpu")
+    x = torch.rand(30, 3, 3)
+    p = torch.randn(30, 3, model.learnable_param_count)
+    with pytest.raises(RuntimeError, match="comprout"):
+        model({"x_phy": x}, p)
