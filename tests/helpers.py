@@ -99,8 +99,11 @@ def run_case(name: str, device: str):
 
 
 def compare(name: str, res: dict, ref, report=None, flux_rtol=FLUX_RTOL, flux_atol=FLUX_ATOL,
-            grad_rtol=GRAD_RTOL, grad_atol_rel=GRAD_ATOL_REL):
-    """Assert `res` matches the golden record `ref` within the stated tolerances."""
+            grad_rtol=GRAD_RTOL, grad_atol_rel=GRAD_ATOL_REL, grad_outlier_frac=0.0, grad_outlier_atol_rel=0.0):
+    """Assert `res` matches the golden record `ref` within the stated tolerances.  `grad_outlier_*` (0 for every
+    committed fixture): at most that fraction of a gradient tensor's elements (or four) may miss the per-group tolerance, by no
+    more than that multiple of the tensor's largest entry -- for randomly drawn cases (tests/test_live_reference.py),
+    where an element can be a sum whose terms cancel four orders of magnitude deep."""
     bad = []
     nmul = (gc.CASES[name]["config"] or {}).get("nmul", 1) if name in gc.CASES else 1
     if name in gc.CASES:
@@ -118,7 +121,9 @@ def compare(name: str, res: dict, ref, report=None, flux_rtol=FLUX_RTOL, flux_at
             w = b.shape[-1]
             labels = np.arange(w) if key in ("grad/x_phy", "grad/p_distr") else column_groups(w, nmul)
             colmax = np.abs(b).reshape(-1, w).max(0)
-            floor = max(GROUP_FLOOR * colmax.max(), 1e-30)
+            # (absolute floor: a gradient tensor whose largest entry is below 1e-2 -- a record in which no water moves -- is
+            #  compared at 2e-11; every committed fixture's tensors are larger and unaffected)
+            floor = max(GROUP_FLOOR * colmax.max(), 1e-5)
             scale = np.array([max(colmax[labels == g].max(), floor) * (ROUTE_ATOL_REL / GRAD_ATOL_REL if g < 0 else 1.0)
                               for g in labels])
             tol = grad_atol_rel * scale + grad_rtol * np.abs(b)
@@ -126,6 +131,10 @@ def compare(name: str, res: dict, ref, report=None, flux_rtol=FLUX_RTOL, flux_at
             tol = flux_atol + flux_rtol * np.abs(b)
         err = np.abs(a - b)
         nbad = int((err > tol).sum())
+        if nbad and key.startswith("grad/") and grad_outlier_frac > 0.0:
+            out = err > tol
+            if out.sum() <= max(grad_outlier_frac * a.size, 4) and err[out].max() <= grad_outlier_atol_rel * np.abs(b).max():
+                nbad = 0
         REPORT.append((f"{name}:{key}", float(err.max()), float((err / tol).max()), nbad, a.size))
         if report is not None:
             report.append((key, float(err.max()), float((err / (np.abs(b) + 1e-12)).max()), nbad,
