@@ -104,3 +104,39 @@ def test_load_states_rejects_what_the_reference_rejects(bad, reference):
         m = mod.load_model("hbv", "Hbv")(None, dev)
         with pytest.raises(ValueError):
             m.load_states(bad)
+
+
+def test_multi_timescale_wrapper_has_the_references_surface(reference):
+    """Hbv_2_mts(low_freq_config, high_freq_config, device) (hbv_2_mts.py:31-75): every public data attribute the
+    reference's instance carries exists here with the same value; sub-models are the same classes in the same roles.
+    (The reference indexes high_freq_config for its chunk sizes: a config without them is a TypeError there and here.)"""
+    import warnings
+    import hydrodl2_amd
+    from . import golden_mts
+    dev = torch.device("cpu")
+    low, high = golden_mts.configs("mts_chunked")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = reference.load_model("hbv_2_mts", "Hbv_2_mts")(dict(low), dict(high), dev)
+        own = hydrodl2_amd.load_model("hbv_2_mts", "Hbv_2_mts")(dict(low), dict(high), dev)
+        for mod in (reference, hydrodl2_amd):
+            with pytest.raises(TypeError):
+                mod.load_model("hbv_2_mts", "Hbv_2_mts")(None, None, dev)
+    diffs = []
+    for a, rv in vars(ref).items():
+        if a.startswith("_") or a == "training":
+            continue
+        assert hasattr(own, a), f"Hbv_2_mts: attribute {a!r} of the reference is missing"
+        ov = getattr(own, a)
+        if isinstance(rv, torch.nn.Module):
+            if type(rv).__name__ != type(ov).__name__:
+                diffs.append(f"{a}: {type(rv).__name__} != {type(ov).__name__}")
+        elif _plain(rv) != _plain(ov):
+            diffs.append(f"{a}: reference {_plain(rv)!r} != {_plain(ov)!r}")
+    assert not diffs, diffs
+    assert ref.low_freq_model.initialize is True and own.low_freq_model.initialize is True
+    for sub in ("low_freq_model", "high_freq_model"):
+        r, o = getattr(ref, sub), getattr(own, sub)
+        for a in ATTRS:
+            if hasattr(r, a):
+                assert _plain(getattr(r, a)) == _plain(getattr(o, a)), (sub, a)
