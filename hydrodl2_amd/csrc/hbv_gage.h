@@ -111,9 +111,6 @@ __global__ void __launch_bounds__(128) k_gage_uh(const hbvx_gage_desc r, float *
 // fixed-order sums over a gage's / unit's pairs are separate, trivially parallel kernels.
 #define GAGE_TILE4 (4 * GAGE_TILE)
 #define GAGE_COLN (GAGE_TILE4 + GAGE_L + 8)
-// (k_gage_bwd_p keeps the one-word-per-32 padded column: its stride-4 scalar reads need distinct banks)
-#define GAGE_COLN_PAD (GAGE_TILE4 + GAGE_L + (GAGE_TILE4 + GAGE_L) / 32 + 1)
-__device__ __forceinline__ int gage_phys(int i) { return i + (i >> 5); }
 
 // The pair's tap weights, zero-padded to a multiple of four, staged in LDS once per block: a wave-uniform 16-byte LDS
 // read per four taps (a broadcast) instead of four dependent scalar loads from memory inside the tap loop.
@@ -228,22 +225,25 @@ __global__ void __launch_bounds__(256) k_gage_sum_bwd(const hbvx_gage_desc r, co
 // route_tau) in closed form: for the normalised gamma taps w_k,
 //   d w_k / d aa = w_k (ln t_k - sum_j w_j ln t_j),  d w_k / d theta = w_k (t_k - sum_j w_j t_j) / theta^2
 // (the lgamma / theta^aa factor cancels in the normalisation, so no digamma is needed).
-// Threads: 18 tap groups (4 taps each) x 14 contiguous time phases of a 1024-step tile.  Within its
-// phase a thread slides a 4-value window of the runoff through registers: per step one runoff value
-// and one gradient value from LDS for 4 FMAs (the 3 x 72 layout read two values per FMA).  Phase
+// Threads: 18 tap groups (4 taps each) x 14 contiguous time phases (76 steps) of a 1024-step tile.  Both columns live in
+// LDS as aligned 16-byte chunks: per FOUR steps a thread reads one chunk of the gradient and one new chunk of the runoff
+// (the previous one is kept) for 16 multiply-adds -- until round 5 one scalar read of each, an index computation and
+// three register moves per step for 4.  Every tap still adds its steps in ascending order within a phase; phase
 // partials are added in order (deterministic).
 #define GAGE_PH 14
-#define GAGE_PLEN ((GAGE_TILE4 + GAGE_PH - 1) / GAGE_PH)
+#define GAGE_PLEN 76                     // steps per phase: a multiple of 4, 14 x 76 >= 1024
 __global__ void __launch_bounds__(GAGE_TILE) k_gage_bwd_p(const hbvx_gage_desc r, const float *__restrict__ qsT,
                                                            const float *__restrict__ goT, float *__restrict__ gdp)
 {
-    __shared__ float qcol[GAGE_COLN_PAD];
-    __shared__ float gcol[GAGE_TILE4];
+    // qcol[x] = runoff at time t0 - HS + x with HS = H rounded up to a multiple of 4 (so that step j, tap 4 tg sits
+    // on a chunk boundary); gcol[j] = gradient at time t0 + j, zero beyond the tile (phase 13 runs past 1024)
+    __shared__ __align__(16) float qcol[GAGE_PH * GAGE_PLEN + GAGE_L + 8];
+    __shared__ __align__(16) float gcol[GAGE_PH * GAGE_PLEN];
     __shared__ float part[GAGE_PH][GAGE_L];
     __shared__ float w[GAGE_L];
     __shared__ float guh[GAGE_L];
     const int p = blockIdx.x, tid = threadIdx.x;
-    const int T = r.T, U = r.U, G = r.G, L = r.L, H = L - 1;
+    const int T = r.T, U = r.U, G = r.G, L = r.L, H = L - 1, HS = (H + 3) & ~3;
     const int u = clampi_(r.pair_unit[p], 0, U - 1), g = clampi_(r.pair_gage[p], 0, G - 1);
     const float ar = r.areas[u], inv = 1.0f / r.denom[g];
     const int tg = tid % 18, phase = tid / 18;   // taps 4 tg .. 4 tg + 3; threads >= 252 only stage
@@ -252,25 +252,28 @@ __global__ void __launch_bounds__(GAGE_TILE) k_gage_bwd_p(const hbvx_gage_desc r
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     for (int t0 = 0; t0 < T; t0 += GAGE_TILE4) {
         __syncthreads();
-        for (int i = tid; i < GAGE_TILE4 + H; i += GAGE_TILE) {
-            const int ts = t0 - H + i;
-            qcol[gage_phys(i)] = (ts >= 0 && ts < T) ? qsT[(int64_t)u * T + ts] * ar : 0.0f;
+        for (int x = tid; x < GAGE_PH * GAGE_PLEN + HS; x += GAGE_TILE) {
+            const int ts = t0 - HS + x;
+            qcol[x] = (ts >= 0 && ts < T && x < GAGE_TILE4 + HS) ? qsT[(int64_t)u * T + ts] * ar : 0.0f;
         }
-        for (int i = tid; i < GAGE_TILE4; i += GAGE_TILE)
-            gcol[i] = (t0 + i < T) ? goT[(int64_t)g * T + t0 + i] * inv : 0.0f;
+        for (int i = tid; i < GAGE_PH * GAGE_PLEN; i += GAGE_TILE)
+            gcol[i] = (i < GAGE_TILE4 && t0 + i < T) ? goT[(int64_t)g * T + t0 + i] * inv : 0.0f;
         __syncthreads();
-        if (worker) {
-            const int j0 = phase * GAGE_PLEN, j1 = min(j0 + GAGE_PLEN, GAGE_TILE4);
-            // window: qa[t - k] for k = k0 .. k0+3 at step j lives at column j + H - k (>= 0: H >= 71 >= k)
-            int c = j0 + H - k0;
-            float w0 = qcol[gage_phys(max(c, 0))], w1 = qcol[gage_phys(max(c - 1, 0))],
-                  w2 = qcol[gage_phys(max(c - 2, 0))], w3 = qcol[gage_phys(max(c - 3, 0))];
-            for (int j = j0; j < j1; j++) {
-                const float gj = gcol[j];
-                acc[0] += gj * w0; acc[1] += gj * w1; acc[2] += gj * w2; acc[3] += gj * w3;
-                w3 = w2; w2 = w1; w1 = w0;
-                c++;
-                w0 = qcol[gage_phys(min(max(c, 0), GAGE_TILE4 + H - 1))];   // (c < 0 only for unused taps >= L)
+        if (worker && k0 <= HS) {
+            // step j, tap k0 + q reads qa[t - k] at column j + HS - k0 - q: chunk (j + HS - k0) / 4 and the one before it
+            const int j0 = phase * GAGE_PLEN;
+            const float4 *q4 = reinterpret_cast<const float4 *>(qcol) + ((j0 + HS - k0) >> 2);
+            const float4 *g4 = reinterpret_cast<const float4 *>(gcol) + (j0 >> 2);
+            float4 prev = (j0 + HS - k0 >= 4) ? q4[-1] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll 2
+            for (int c = 0; c < GAGE_PLEN / 4; c++) {
+                const float4 cur = q4[c], gv = g4[c];
+                // acc[q] += g[j + jj] * col[4 c' + jj - q], jj ascending
+                acc[0] += gv.x * cur.x;  acc[0] += gv.y * cur.y;  acc[0] += gv.z * cur.z;  acc[0] += gv.w * cur.w;
+                acc[1] += gv.x * prev.w; acc[1] += gv.y * cur.x;  acc[1] += gv.z * cur.y;  acc[1] += gv.w * cur.z;
+                acc[2] += gv.x * prev.z; acc[2] += gv.y * prev.w; acc[2] += gv.z * cur.x;  acc[2] += gv.w * cur.y;
+                acc[3] += gv.x * prev.y; acc[3] += gv.y * prev.z; acc[3] += gv.z * prev.w; acc[3] += gv.w * cur.x;
+                prev = cur;
             }
         }
     }
