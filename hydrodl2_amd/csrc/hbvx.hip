@@ -547,35 +547,38 @@ __global__ void __launch_bounds__(256) k_route_bwd(int T, int B, int S, int L,
 }
 
 // stage 2: reduce the chunks (fixed order: deterministic) and go through the normalised
-// gamma UH to the routing inputs.  Block = 64 basins x 16 tap-threads: thread (bl, k) sums tap
-// k over all chunks (coalesced along basins), then the k == 0 threads finish per basin.
+// gamma UH to the routing inputs.  Block = 16 basins x 16 tap-threads x 4 parts: thread (bl, k, part) sums tap k over
+// the chunks c = part (mod 4) in ascending order (part 0 also the last nchunk mod 4 ones), the parts are combined as
+// (p0 + p1) + (p2 + p3) -- the association the one-thread-per-tap version used, on four times the threads and blocks
+// (11 blocks of 1 024 at config 2 were a 35 us latency chain of 229 dependent loads) -- then the k == 0 threads finish
+// per basin.
 // d w_k / d aa    = w_k (ln t_k - sum_j w_j ln t_j)      (Gamma(aa) and theta^aa cancel
 // d w_k / d theta = w_k (t_k - sum_j w_j t_j) / theta^2    in the normalisation)
+#define ROUTE_PB 16      // basins per block of k_route_bwd_params
 __global__ void __launch_bounds__(1024) k_route_bwd_params(const hbvx_route_desc r, int nchunk,
                                                            const float *__restrict__ uh,
                                                            const double *__restrict__ ws,
                                                            float *grad_ra, float *grad_rb)
 {
-    __shared__ double red[16][64];
-    const int bl = threadIdx.x & 63, k = threadIdx.x >> 6;
-    const int b = blockIdx.x * 64 + bl;
+    __shared__ double prt[4][16][ROUTE_PB];
+    __shared__ double red[16][ROUTE_PB];
+    const int bl = threadIdx.x & (ROUTE_PB - 1), k = (threadIdx.x >> 4) & 15, part = threadIdx.x >> 8;
+    const int b = blockIdx.x * ROUTE_PB + bl;
     const int B = r.B, L = r.L;
-    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+    double acc = 0.0;
     if (b < B && k < L) {
         const double *src = ws + (int64_t)k * B + b;
         const int64_t cs = (int64_t)L * B;
-        int c = 0;
-        for (; c + 3 < nchunk; c += 4) {
-            acc0 += src[(int64_t)c * cs];
-            acc1 += src[(int64_t)(c + 1) * cs];
-            acc2 += src[(int64_t)(c + 2) * cs];
-            acc3 += src[(int64_t)(c + 3) * cs];
-        }
-        for (; c < nchunk; c++) acc0 += src[(int64_t)c * cs];
+        const int n4 = nchunk & ~3;
+        for (int c = part; c < n4; c += 4) acc += src[(int64_t)c * cs];
+        if (part == 0)
+            for (int c = n4; c < nchunk; c++) acc += src[(int64_t)c * cs];
     }
-    red[k][bl] = (acc0 + acc1) + (acc2 + acc3);
+    prt[part][k][bl] = acc;
     __syncthreads();
-    if (k != 0 || b >= B) return;
+    if (part == 0) red[k][bl] = (prt[0][k][bl] + prt[1][k][bl]) + (prt[2][k][bl] + prt[3][k][bl]);
+    __syncthreads();
+    if (part != 0 || k != 0 || b >= B) return;
     float ua, ub, a, bb;
     route_ab(r, b, ua, ub, a, bb);
     const float theta = fmaxf(bb, 0.0f) + 0.5f;
@@ -890,7 +893,7 @@ extern "C" int hbvx_route_backward(const hbvx_route_desc *r, const float *q, con
     hipLaunchKernelGGL(k_route_bwd, dim3((r->B + 63) / 64, (nchunk + 3) / 4), dim3(256), 0, st, r->T,
                        r->B, r->S, r->L, q, uh, grad_q_rout, grad_q, want_p ? (double *)workspace : nullptr);
     if (want_p)
-        hipLaunchKernelGGL(k_route_bwd_params, dim3((r->B + 63) / 64), dim3(1024), 0, st, *r, nchunk,
+        hipLaunchKernelGGL(k_route_bwd_params, dim3((r->B + ROUTE_PB - 1) / ROUTE_PB), dim3(1024), 0, st, *r, nchunk,
                            uh, (const double *)workspace, grad_ra, grad_rb);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "hbvx_route_backward launch");
