@@ -431,6 +431,11 @@ __global__ void k_uh_gamma(const hbvx_route_desc r, float *__restrict__ uh)
 #ifndef ROUTE_CHUNK
 #define ROUTE_CHUNK 32
 #endif
+// The adjoint's chunk: its tap-gradient partials are per chunk, so longer chunks halve the second stage's input; measured at
+// the headline shape (round 5, whole-library variants): forward 32 / 16 / 64 days: 81 / 78 / 82 us; adjoint: 68 / 84 / 57 us.
+#ifndef ROUTE_CHUNK_BWD
+#define ROUTE_CHUNK_BWD 64
+#endif
 
 __device__ __forceinline__ void load_uh(const float *__restrict__ uh, int b, int L, float *w)
 {
@@ -490,9 +495,9 @@ __global__ void __launch_bounds__(256) k_route_bwd(int T, int B, int S, int L,
 {
     const int b = blockIdx.x * 64 + (threadIdx.x & 63);
     const int chunk = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int t0 = chunk * ROUTE_CHUNK;
+    const int t0 = chunk * ROUTE_CHUNK_BWD;
     if (b >= B || t0 >= T) return;
-    const int t1 = min(T, t0 + ROUTE_CHUNK);
+    const int t1 = min(T, t0 + ROUTE_CHUNK_BWD);
     // The tap gradients are summed in DOUBLE: what leaves this path is sum_k gw[k] w_k (ln t_k - <ln t>), whose weights
     // sum to zero (the hydrograph is normalised), so the common part of the gw[k] -- nearly all of them when the
     // inflow is smooth -- cancels and float32 sums (eps x ~1e+2) left 1e-6 where the result is 1e-4: 0.7 % off the
@@ -869,7 +874,7 @@ extern "C" int hbvx_route_forward(const hbvx_route_desc *r, const float *q, floa
     return HBVX_OK;
 }
 
-static int route_chunks(const hbvx_route_desc *r) { return (r->T + ROUTE_CHUNK - 1) / ROUTE_CHUNK; }
+static int route_chunks(const hbvx_route_desc *r) { return (r->T + ROUTE_CHUNK_BWD - 1) / ROUTE_CHUNK_BWD; }   // the adjoint's
 
 extern "C" uint64_t hbvx_route_workspace_bytes(const hbvx_route_desc *r)
 {
